@@ -1,0 +1,208 @@
+"""Columnar (struct-of-arrays) form of the two inputs of the evaluation path.
+
+The reference keeps both inputs as lists of Python dicts and indexes them with
+dict-of-list maps (reference: tao_amodal/evaluation/tao_amodal/tao.py:112-160,
+tao_amodal/evaluation/lvis_amodal/lvis.py:38-61).  Here each JSON table becomes
+a handful of contiguous numpy arrays so that every later stage (flatten, upload
+to HBM, kernels) is index arithmetic over arrays instead of dict lookups.
+
+Input contract (unchanged from the reference, README.md:107-116 and
+tao.py:4-60):
+
+* ground truth: ``{info, images, videos, tracks, annotations, categories}``
+* predictions : list of ``{image_id, category_id, bbox, score, track_id,
+  video_id}``
+
+Ragged ``neg_category_ids`` / ``not_exhaustive_category_ids`` lists are kept
+as CSR (offsets + values).
+"""
+import json
+
+import numpy as np
+
+
+def _csr(lists):
+    off = np.zeros(len(lists) + 1, dtype=np.int64)
+    if len(lists):
+        off[1:] = np.cumsum([len(x) for x in lists])
+    flat = [c for x in lists for c in x]
+    return off, np.asarray(flat, dtype=np.int64).reshape(-1)
+
+
+def _uncsr(off, val):
+    return [val[off[i]:off[i + 1]].tolist() for i in range(len(off) - 1)]
+
+
+class GTColumns:
+    """Ground-truth annotation file as arrays."""
+
+    FIELDS = (
+        "cat_id", "cat_freq", "cat_merged",
+        "vid_id", "vid_neg_off", "vid_neg", "vid_nel_off", "vid_nel",
+        "img_id", "img_vid", "img_frame",
+        "img_neg_off", "img_neg", "img_nel_off", "img_nel",
+        "trk_id", "trk_cat", "trk_vid", "trk_ignore",
+        "ann_id", "ann_img", "ann_trk", "ann_cat", "ann_bbox", "ann_area",
+        "ann_vis", "ann_oof", "ann_ignore",
+    )
+
+    def __init__(self, **kw):
+        for f in self.FIELDS:
+            setattr(self, f, kw[f])
+
+    # ------------------------------------------------------------------ json
+    @classmethod
+    def from_json(cls, dataset):
+        """dataset: parsed annotation dict (or a path)."""
+        if isinstance(dataset, str):
+            with open(dataset, "r") as f:
+                dataset = json.load(f)
+        assert type(dataset) == dict, (
+            "Annotation file format {} not supported.".format(type(dataset)))
+        cats = dataset["categories"]
+        vids = dataset["videos"]
+        imgs = dataset["images"]
+        trks = dataset["tracks"]
+        anns = dataset["annotations"]
+        merged = [(m["id"], c["id"]) for c in cats if "merged" in c
+                  for m in c["merged"]]
+        vneg = _csr([v["neg_category_ids"] for v in vids])
+        vnel = _csr([v["not_exhaustive_category_ids"] for v in vids])
+        ineg = _csr([i["neg_category_ids"] for i in imgs])
+        inel = _csr([i["not_exhaustive_category_ids"] for i in imgs])
+        i64 = np.int64
+        return cls(
+            cat_id=np.asarray([c["id"] for c in cats], dtype=i64),
+            cat_freq=np.asarray([ord(c.get("frequency", "?")[0])
+                                 for c in cats], dtype=np.uint8),
+            cat_merged=np.asarray(merged, dtype=i64).reshape(-1, 2),
+            vid_id=np.asarray([v["id"] for v in vids], dtype=i64),
+            vid_neg_off=vneg[0], vid_neg=vneg[1],
+            vid_nel_off=vnel[0], vid_nel=vnel[1],
+            img_id=np.asarray([i["id"] for i in imgs], dtype=i64),
+            img_vid=np.asarray([i["video_id"] for i in imgs], dtype=i64),
+            img_frame=np.asarray([i["frame_index"] for i in imgs],
+                                 dtype=np.float64),
+            img_neg_off=ineg[0], img_neg=ineg[1],
+            img_nel_off=inel[0], img_nel=inel[1],
+            trk_id=np.asarray([t["id"] for t in trks], dtype=i64),
+            trk_cat=np.asarray([t["category_id"] for t in trks], dtype=i64),
+            trk_vid=np.asarray([t["video_id"] for t in trks], dtype=i64),
+            trk_ignore=np.asarray([1 if t.get("ignore", 0) else 0
+                                   for t in trks], dtype=np.uint8),
+            ann_id=np.asarray([a["id"] for a in anns], dtype=i64),
+            ann_img=np.asarray([a["image_id"] for a in anns], dtype=i64),
+            ann_trk=np.asarray([a["track_id"] for a in anns], dtype=i64),
+            ann_cat=np.asarray([a["category_id"] for a in anns], dtype=i64),
+            ann_bbox=np.asarray([a["bbox"] for a in anns],
+                                dtype=np.float64).reshape(-1, 4),
+            ann_area=np.asarray([a["area"] for a in anns], dtype=np.float64),
+            ann_vis=np.asarray([a["visibility"] for a in anns],
+                               dtype=np.float64),
+            ann_oof=np.asarray([1 if a["out_of_frame"] else 0 for a in anns],
+                               dtype=np.uint8),
+            ann_ignore=np.asarray([1 if a.get("ignore", 0) else 0
+                                   for a in anns], dtype=np.uint8),
+        )
+
+    def to_json(self):
+        """Inverse of from_json (used by the synthetic generator and tests)."""
+        def num(x):
+            x = float(x)
+            return int(x) if x == int(x) else x
+        merged_by = {}
+        for src, dst in self.cat_merged.tolist():
+            merged_by.setdefault(dst, []).append({"id": src})
+        cats = []
+        for cid, fr in zip(self.cat_id.tolist(), self.cat_freq.tolist()):
+            c = {"id": cid, "name": "c%d" % cid, "frequency": chr(fr)}
+            if cid in merged_by:
+                c["merged"] = merged_by[cid]
+            cats.append(c)
+        vneg = _uncsr(self.vid_neg_off, self.vid_neg)
+        vnel = _uncsr(self.vid_nel_off, self.vid_nel)
+        vids = [{"id": v, "name": "v%d" % v, "neg_category_ids": vneg[k],
+                 "not_exhaustive_category_ids": vnel[k]}
+                for k, v in enumerate(self.vid_id.tolist())]
+        ineg = _uncsr(self.img_neg_off, self.img_neg)
+        inel = _uncsr(self.img_nel_off, self.img_nel)
+        imgs = [{"id": i, "video_id": v, "frame_index": num(fi),
+                 "neg_category_ids": ineg[k],
+                 "not_exhaustive_category_ids": inel[k]}
+                for k, (i, v, fi) in enumerate(zip(self.img_id.tolist(),
+                                                   self.img_vid.tolist(),
+                                                   self.img_frame.tolist()))]
+        trks = []
+        for t, c, v, ig in zip(self.trk_id.tolist(), self.trk_cat.tolist(),
+                               self.trk_vid.tolist(),
+                               self.trk_ignore.tolist()):
+            d = {"id": t, "category_id": c, "video_id": v}
+            if ig:
+                d["ignore"] = 1
+            trks.append(d)
+        anns = []
+        bb = self.ann_bbox.tolist()
+        for k in range(len(self.ann_id)):
+            d = {"id": int(self.ann_id[k]), "image_id": int(self.ann_img[k]),
+                 "track_id": int(self.ann_trk[k]),
+                 "category_id": int(self.ann_cat[k]),
+                 "bbox": [num(x) for x in bb[k]],
+                 "area": num(self.ann_area[k]),
+                 "visibility": num(self.ann_vis[k]),
+                 "out_of_frame": bool(self.ann_oof[k])}
+            if self.ann_ignore[k]:
+                d["ignore"] = 1
+            anns.append(d)
+        return {"info": {"description": "synthetic"}, "images": imgs,
+                "videos": vids, "tracks": trks, "annotations": anns,
+                "categories": cats}
+
+
+class DTColumns:
+    """Prediction list as arrays (file order preserved)."""
+
+    FIELDS = ("image_id", "category_id", "bbox", "score", "track_id",
+              "video_id")
+
+    def __init__(self, **kw):
+        for f in self.FIELDS:
+            setattr(self, f, kw[f])
+
+    def __len__(self):
+        return len(self.image_id)
+
+    @classmethod
+    def from_json(cls, results):
+        if isinstance(results, str):
+            with open(results, "r") as f:
+                results = json.load(f)
+        assert isinstance(results, list), "results is not a list."
+        i64 = np.int64
+        return cls(
+            image_id=np.asarray([r["image_id"] for r in results], dtype=i64),
+            category_id=np.asarray([r["category_id"] for r in results],
+                                   dtype=i64),
+            bbox=np.asarray([r["bbox"] for r in results],
+                            dtype=np.float64).reshape(-1, 4),
+            score=np.asarray([r["score"] for r in results], dtype=np.float64),
+            track_id=np.asarray([r.get("track_id", -1) for r in results],
+                                dtype=i64),
+            video_id=np.asarray([r.get("video_id", -1) for r in results],
+                                dtype=i64),
+        )
+
+    def to_json(self):
+        def num(x):
+            x = float(x)
+            return int(x) if x == int(x) else x
+        bb = self.bbox.tolist()
+        return [{"image_id": int(self.image_id[k]),
+                 "category_id": int(self.category_id[k]),
+                 "bbox": [num(x) for x in bb[k]],
+                 "score": float(self.score[k]),
+                 "track_id": int(self.track_id[k]),
+                 "video_id": int(self.video_id[k])}
+                for k in range(len(self.image_id))]
+
+    def take(self, idx):
+        return DTColumns(**{f: getattr(self, f)[idx] for f in self.FIELDS})
