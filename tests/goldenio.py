@@ -1,0 +1,41 @@
+"""Load the committed golden vectors (tests/golden/<name>/)."""
+import gzip
+import json
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+FIXTURES = ["f1", "f2", "f3", "f4", "f5"]
+INTEGER_FIXTURES = ["f1", "f2", "f3", "f5"]
+
+
+def path(name, fn):
+    return os.path.join(GOLDEN, name, fn)
+
+
+def load_inputs(name):
+    with open(path(name, "gt.json")) as f:
+        gt = json.load(f)
+    with open(path(name, "pred.json")) as f:
+        pred = json.load(f)
+    return gt, pred
+
+
+def load_json_gz(name, fn):
+    with gzip.open(path(name, fn), "rb") as f:
+        return json.loads(f.read().decode())
+
+
+def load_eval(name):
+    z = np.load(path(name, "eval.npz"))
+    out = {}
+    for side in ("lvis", "tao"):
+        shape = tuple(int(x) for x in z[side + "_shape"])
+        k = z[side + "_valid_k"]
+        p = -np.ones(shape)
+        p[:, :, k] = z[side + "_precision"]
+        r = -np.ones((shape[0],) + shape[2:])
+        r[:, k] = z[side + "_recall"]
+        out[side] = (p, r)
+    return out
