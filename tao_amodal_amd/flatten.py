@@ -1,0 +1,522 @@
+"""Host "flatten" stage: columnar inputs -> cell tables for the HIP kernels.
+
+The reference answers every ``(image, category)`` / ``(video, category)``
+query through dict-of-list maps and enumerates *all* I x C (resp. V x C) cells,
+most of them empty (reference L/eval.py:132-145, T/eval.py:264-276; SURVEY.md
+section 3.2).  Here only non-empty cells exist: detections, ground truths and
+tracks are laid out contiguously per cell (CSR offsets), in exactly the order
+the reference would visit them, so that the device kernels reproduce its
+tie-breaking without any dictionary.
+
+Order rules reproduced (L/ = tao_amodal/evaluation/lvis_amodal/, T/ =
+tao_amodal/evaluation/tao_amodal/):
+
+* top-300 per image by per-box score, stable, only when the image has more
+  than 300 boxes; ids = post-truncation position + 1 (L/results.py:39-52,73-84;
+  T/results.py:56-81,121-132)
+* strict ``0 < area < inf`` and known-category filter (L/lvis.py:90-96,
+  T/tao.py:247-253)
+* federated filter: keep a detection only if its category is in the
+  image's/video's ``neg_category_ids`` or has ground truth there
+  (L/eval.py:99-103, T/eval.py:228-233)
+* cells ordered by (sorted image id | sorted video id, sorted category id);
+  detections inside a cell by descending score, stable (L/eval.py:175,
+  T/eval.py:313); ground truth in visiting order
+* TAO visiting order = CPython iteration order of
+  ``set(video_images) & set(video_images)`` (T/tao.py:230) -- obtained here by
+  building that very set -- then first appearance of each track id
+  (T/tao.py:172-188)
+* category merge on the TAO side only (T/tao.py:115-118, T/results.py:47-50)
+* track score = ``np.mean`` of its boxes' scores when they differ
+  (T/results.py:88-98), computed with numpy itself (pairwise summation)
+* track area = left-to-right ``sum(area)/len`` over annotations sorted by
+  frame_index (T/tao.py:181-187)
+"""
+import numpy as np
+
+from .columns import DTColumns, GTColumns
+
+MAX_DETS = 300
+I32 = np.int32
+
+# flag bits shared with csrc/ (keep in sync with include/tao_amodal_hip.h)
+GT_IGNORE = 1       # annotation/track carries a truthy "ignore"
+GT_OOF = 2          # annotation is out of frame (LVIS side only)
+GT_ID_HIDDEN = 4    # id equals the evaluator's "unmatched" sentinel
+DT_IGNORE_UNMATCHED = 1   # unmatched detection is ignored (not exhaustive...)
+DT_NO_CONSUME = 2         # id <= 0: a match does not mark the GT as taken
+
+
+def _lookup(sorted_keys, values):
+    """index of each value in sorted_keys, -1 when absent"""
+    if len(sorted_keys) == 0:
+        return np.full(len(values), -1, dtype=np.int64)
+    pos = np.searchsorted(sorted_keys, values)
+    pos = np.minimum(pos, len(sorted_keys) - 1)
+    return np.where(sorted_keys[pos] == values, pos, -1)
+
+
+def _last_with_same_id(ids):
+    """The reference resolves annotations through a dict keyed by id, so a
+    duplicated id silently aliases the *last* annotation carrying it."""
+    if len(np.unique(ids)) == len(ids):
+        return np.arange(len(ids))
+    order = np.argsort(ids, kind="stable")
+    sid = ids[order]
+    last = np.flatnonzero(np.r_[sid[1:] != sid[:-1], True])
+    grp = np.cumsum(np.r_[0, (sid[1:] != sid[:-1]).astype(np.int64)])
+    out = np.empty(len(ids), dtype=np.int64)
+    out[order] = order[last[grp]]
+    return out
+
+
+def limit_dets_per_image(dt, max_dets=MAX_DETS):
+    """Permutation of kept detections in post-truncation list order."""
+    n = len(dt)
+    if n == 0:
+        return np.zeros(0, dtype=np.int64)
+    uniq, first, inv, cnt = np.unique(dt.image_id, return_index=True,
+                                      return_inverse=True, return_counts=True)
+    rank_of_img = np.empty(len(uniq), dtype=np.int64)
+    rank_of_img[np.argsort(first, kind="stable")] = np.arange(len(uniq))
+    img_rank = rank_of_img[inv]
+    big = (cnt > max_dets)[inv] if max_dets >= 0 else np.zeros(n, bool)
+    key = np.where(big, -dt.score, 0.0)
+    order = np.lexsort((np.arange(n), key, img_rank))
+    if max_dets >= 0 and big.any():
+        r = img_rank[order]
+        start = np.flatnonzero(np.r_[True, r[1:] != r[:-1]])
+        pos = np.arange(n) - np.repeat(start, np.diff(np.r_[start, n]))
+        order = order[pos < max_dets]
+    return order
+
+
+def make_track_ids_unique(dt):
+    """tools/eval_on_tao_amodal.py:44-66 on columns; returns (new track_id
+    array, number of ids that had to change)."""
+    n = len(dt)
+    tid, vid = dt.track_id, dt.video_id
+    if n == 0:
+        return tid.copy(), 0
+    uniq, first, inv = np.unique(tid, return_index=True, return_inverse=True)
+    clash_t = np.zeros(len(uniq), dtype=bool)
+    np.logical_or.at(clash_t, inv, vid != vid[first][inv])
+    if not clash_t.any():
+        return tid.copy(), 0
+    top = max(int(tid.max()), 0)
+    sel = np.flatnonzero(clash_t[inv])
+    pair = np.stack([tid[sel], vid[sel]], 1)
+    _, pfirst, pinv = np.unique(pair, axis=0, return_index=True,
+                                return_inverse=True)
+    pinv = pinv.reshape(-1)
+    new_of_pair = np.empty(len(pfirst), dtype=np.int64)
+    new_of_pair[np.argsort(pfirst, kind="stable")] = \
+        top + 1 + np.arange(len(pfirst))
+    out = tid.copy()
+    out[sel] = new_of_pair[pinv]
+    return out, int(clash_t.sum())
+
+
+class Flat(dict):
+    """A bag of arrays with attribute access."""
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+
+
+def _csr_member(off, val, row, item):
+    """item[k] in val[off[row[k]]:off[row[k]+1]] for every k (vectorised via a
+    sorted key table)."""
+    if len(val) == 0 or len(row) == 0:
+        return np.zeros(len(row), dtype=bool)
+    rows = np.repeat(np.arange(len(off) - 1), np.diff(off))
+    keys = np.stack([rows, val], 1)
+    q = np.stack([row, item], 1)
+    # encode pairs as structured scalars for isin
+    kd = np.ascontiguousarray(keys).view([("a", np.int64), ("b", np.int64)])
+    qd = np.ascontiguousarray(q).view([("a", np.int64), ("b", np.int64)])
+    return np.isin(qd.reshape(-1), kd.reshape(-1))
+
+
+def _cells(keys_gt, keys_dt):
+    cell_keys = np.union1d(keys_gt, keys_dt)
+    g_cell = np.searchsorted(cell_keys, keys_gt)
+    d_cell = np.searchsorted(cell_keys, keys_dt)
+    n = len(cell_keys)
+    g_off = np.zeros(n + 1, dtype=np.int64)
+    d_off = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(np.bincount(g_cell, minlength=n), out=g_off[1:])
+    np.cumsum(np.bincount(d_cell, minlength=n), out=d_off[1:])
+    return cell_keys, g_cell, d_cell, g_off, d_off
+
+
+# ---------------------------------------------------------------------------
+# image level (LVISEval)
+# ---------------------------------------------------------------------------
+def flatten_lvis(gt: GTColumns, dt: DTColumns, max_dets=MAX_DETS):
+    if len(dt) == 0:
+        raise IndexError("list index out of range")  # L/results.py:42
+    img_ids = np.unique(gt.img_id)
+    cat_ids = np.unique(gt.cat_id)
+    K = len(cat_ids)
+    # the reference keeps images in a dict keyed by id: last one wins
+    img_row = np.full(len(img_ids), -1, dtype=np.int64)
+    img_row[_lookup(img_ids, gt.img_id)] = np.arange(len(gt.img_id))
+
+    keep = limit_dets_per_image(dt, max_dets)
+    d = dt.take(keep)
+    d_id = np.arange(1, len(keep) + 1, dtype=np.int64)
+    d_img = _lookup(img_ids, d.image_id)
+    if (d_img < 0).any():
+        raise AssertionError("Results do not correspond to current LVIS set.")
+    d_area = d.bbox[:, 2] * d.bbox[:, 3]
+
+    # ---- ground truth selection (sorted image order, dataset order inside)
+    a_img = _lookup(img_ids, gt.ann_img)
+    a_cat = _lookup(cat_ids, gt.ann_cat)
+    alias = _last_with_same_id(gt.ann_id)
+    g_sel = np.flatnonzero(a_img >= 0)
+    g_sel = g_sel[np.argsort(a_img[g_sel], kind="stable")]
+    g_sel = g_sel[(a_cat[g_sel] >= 0) & (gt.ann_area[g_sel] > 0)
+                  & (gt.ann_area[g_sel] < np.inf)]
+    g_sel = alias[g_sel]
+    g_img, g_cat = a_img[g_sel], a_cat[g_sel]
+
+    # ---- detection selection + federated filter
+    d_cat = _lookup(cat_ids, d.category_id)
+    order = np.argsort(d_img, kind="stable")
+    order = order[(d_cat[order] >= 0) & (d_area[order] > 0)
+                  & (d_area[order] < np.inf)]
+    key_present = np.unique(g_img * K + g_cat)
+    k_of = d_img[order] * K + d_cat[order]
+    is_present = _lookup(key_present, k_of) >= 0
+    rows = img_row[d_img[order]]
+    is_neg = _csr_member(gt.img_neg_off, gt.img_neg, rows,
+                         d.category_id[order])
+    order = order[is_present | is_neg]
+
+    # ---- cells
+    keys_g = g_img * K + g_cat
+    keys_d = d_img[order] * K + d_cat[order]
+    # detections: by cell, then descending score, stable in visiting order
+    o2 = np.lexsort((np.arange(len(order)), -d.score[order], keys_d))
+    order = order[o2]
+    keys_d = keys_d[o2]
+    og = np.argsort(keys_g, kind="stable")
+    g_sel, keys_g = g_sel[og], keys_g[og]
+    cell_keys, g_cell, d_cell, g_off, d_off = _cells(keys_g, keys_d)
+
+    rows = img_row[d_img[order]]
+    nel = _csr_member(gt.img_nel_off, gt.img_nel, rows, d.category_id[order])
+    area = d_area[order]
+    d_flags = np.where((area < 0) | (area > 1e5 ** 2) | nel,
+                       DT_IGNORE_UNMATCHED, 0).astype(np.uint8)
+    g_flags = (np.where(gt.ann_ignore[g_sel] != 0, GT_IGNORE, 0)
+               | np.where(gt.ann_oof[g_sel] != 0, GT_OOF, 0)
+               | np.where(gt.ann_id[g_sel] == 0, GT_ID_HIDDEN, 0)
+               ).astype(np.uint8)
+
+    f = Flat()
+    f.kind = "lvis"
+    f.img_ids, f.cat_ids = img_ids, cat_ids
+    f.cat_freq = _freq_of(gt, cat_ids)
+    f.n_cells = len(cell_keys)
+    f.cell_unit = (cell_keys // K).astype(I32)      # image index
+    f.cell_cat = (cell_keys % K).astype(I32)
+    f.cell_dt_off = d_off.astype(I32)
+    f.cell_gt_off = g_off.astype(I32)
+    f.dt_box = np.ascontiguousarray(d.bbox[order])
+    f.dt_score = np.ascontiguousarray(d.score[order])
+    f.dt_flags = d_flags
+    f.dt_id = d_id[order]
+    f.dt_cat = (keys_d % K).astype(I32)
+    f.dt_cell = d_cell.astype(I32)
+    f.gt_box = np.ascontiguousarray(gt.ann_bbox[g_sel])
+    f.gt_vis = np.ascontiguousarray(gt.ann_vis[g_sel])
+    f.gt_flags = g_flags
+    f.gt_id = gt.ann_id[g_sel]
+    f.gt_cat = (keys_g % K).astype(I32)
+    f.gt_cell = g_cell.astype(I32)
+    f.n_pairs = int(np.sum(np.diff(d_off) * np.diff(g_off)))
+    return f
+
+
+def _freq_of(gt, cat_ids):
+    # categories live in a dict keyed by id: last one wins
+    row = np.full(len(cat_ids), -1, dtype=np.int64)
+    row[_lookup(cat_ids, gt.cat_id)] = np.arange(len(gt.cat_id))
+    return gt.cat_freq[row]
+
+
+# ---------------------------------------------------------------------------
+# track level (TaoEval)
+# ---------------------------------------------------------------------------
+def _seq_track_mean(vals, off):
+    """left-to-right sum(vals)/len per CSR segment, the arithmetic of
+    ``sum(x['area'] ...) / len(...)`` (T/tao.py:186-187)."""
+    lens = np.diff(off)
+    acc = np.zeros(len(lens))
+    if len(lens) == 0:
+        return acc
+    for s in range(int(lens.max())):
+        live = np.flatnonzero(lens > s)
+        acc[live] = acc[live] + vals[off[live] + s]
+    return acc / lens
+
+
+def _group_tracks(sel_trk, sel_frame_index):
+    """Group selected annotations (in visiting order) into tracks.
+
+    Returns (track order = first appearance, per-annotation permutation that
+    lists every track's annotations contiguously sorted by frame_index
+    (stable), CSR offsets)."""
+    uniq, first, inv = np.unique(sel_trk, return_index=True,
+                                 return_inverse=True)
+    t_rank = np.empty(len(uniq), dtype=np.int64)
+    t_rank[np.argsort(first, kind="stable")] = np.arange(len(uniq))
+    trk_of_ann = t_rank[inv]
+    perm = np.lexsort((np.arange(len(sel_trk)), sel_frame_index, trk_of_ann))
+    off = np.zeros(len(uniq) + 1, dtype=np.int64)
+    np.cumsum(np.bincount(trk_of_ann, minlength=len(uniq)), out=off[1:])
+    ids = np.empty(len(uniq), dtype=np.int64)
+    ids[t_rank] = uniq
+    return ids, perm, off
+
+
+def _unique_frames(trk_of, pos_of, n_trk):
+    """Per track: one box per image (the *last* annotation in frame_index
+    order wins, T/eval.py:322-325), listed by ascending timeline position.
+    Inputs are per-annotation arrays already grouped by track.  Returns
+    (selection into the annotations, CSR offsets)."""
+    n = len(trk_of)
+    order = np.lexsort((np.arange(n), pos_of, trk_of))
+    t, p = trk_of[order], pos_of[order]
+    last = np.r_[(t[1:] != t[:-1]) | (p[1:] != p[:-1]), True] if n else \
+        np.zeros(0, bool)
+    sel = order[last]
+    off = np.zeros(n_trk + 1, dtype=np.int64)
+    np.cumsum(np.bincount(trk_of[sel], minlength=n_trk), out=off[1:])
+    return sel, off
+
+
+def flatten_tao(gt: GTColumns, dt: DTColumns, max_dets=MAX_DETS):
+    """``dt.track_id`` must already be unique per video (the CLI runs
+    make_track_ids_unique first; T/results.py:111-119 asserts it)."""
+    if len(dt) == 0:
+        raise IndexError("list index out of range")  # T/results.py:61
+    # ---- category merge (GT annotations + tracks + predictions)
+    merge_src = gt.cat_merged[:, 0] if len(gt.cat_merged) else \
+        np.zeros(0, np.int64)
+    merge_dst = gt.cat_merged[:, 1] if len(gt.cat_merged) else \
+        np.zeros(0, np.int64)
+    # later "merged" entries overwrite earlier ones for the same source id
+    m_order = np.argsort(merge_src, kind="stable")
+    ms, md = merge_src[m_order], merge_dst[m_order]
+    keep_last = np.r_[ms[1:] != ms[:-1], True] if len(ms) else np.zeros(0, bool)
+    ms, md = ms[keep_last], md[keep_last]
+
+    def merged(c):
+        j = _lookup(ms, c)
+        return np.where(j >= 0, md[np.maximum(j, 0)], c) if len(ms) else c
+
+    ann_cat = merged(gt.ann_cat)
+    trk_cat = merged(gt.trk_cat)
+    pred_cat = merged(dt.category_id)
+
+    vid_ids = np.unique(gt.vid_id)
+    cat_ids = np.unique(gt.cat_id)
+    img_ids = np.unique(gt.img_id)
+    K = len(cat_ids)
+    vid_row = np.full(len(vid_ids), -1, dtype=np.int64)
+    vid_row[_lookup(vid_ids, gt.vid_id)] = np.arange(len(gt.vid_id))
+    img_row = np.full(len(img_ids), -1, dtype=np.int64)
+    img_row[_lookup(img_ids, gt.img_id)] = np.arange(len(gt.img_id))
+    # T/tao.py:148-149
+    trow = np.full(len(gt.trk_id), -1, dtype=np.int64)
+    t_sorted = np.argsort(gt.trk_id, kind="stable")
+    t_keys = gt.trk_id[t_sorted]
+    # dict semantics: last track with an id wins
+    t_last = np.r_[t_keys[1:] != t_keys[:-1], True] if len(t_keys) else \
+        np.zeros(0, bool)
+    t_keys_u, t_rows_u = t_keys[t_last], t_sorted[t_last]
+    a_trow = _lookup(t_keys_u, gt.ann_trk)
+    if (a_trow < 0).any():
+        raise KeyError(int(gt.ann_trk[np.flatnonzero(a_trow < 0)[0]]))
+    a_trow = t_rows_u[a_trow]
+    assert np.array_equal(ann_cat, trk_cat[a_trow]), \
+        "annotation/track category mismatch"
+
+    # ---- per-video timeline position of every image: (frame_index, id)
+    img_vid_idx = _lookup(vid_ids, gt.img_vid[img_row])
+    img_frame = gt.img_frame[img_row]
+    tl_order = np.lexsort((img_ids, img_frame, img_vid_idx))
+    tl_pos = np.empty(len(img_ids), dtype=np.int64)
+    v_sorted = img_vid_idx[tl_order]
+    start = np.flatnonzero(np.r_[True, v_sorted[1:] != v_sorted[:-1]])
+    tl_pos[tl_order] = np.arange(len(img_ids)) - np.repeat(
+        start, np.diff(np.r_[start, len(img_ids)]))
+
+    # ---- visiting order of images: CPython set iteration (T/tao.py:224-230)
+    vid_of_image_row = _lookup(vid_ids, gt.img_vid)
+    by_vid = np.argsort(vid_of_image_row, kind="stable")
+    by_vid = by_vid[vid_of_image_row[by_vid] >= 0]
+    video_images = gt.img_id[by_vid].tolist()
+    visit = list(set(video_images) & set(video_images))
+    visit_rank = np.full(len(img_ids), -1, dtype=np.int64)
+    visit_rank[_lookup(img_ids, np.asarray(visit, dtype=np.int64))] = \
+        np.arange(len(visit))
+
+    # ---- predictions: TaoResults
+    tid = dt.track_id
+    u, first, inv = np.unique(tid, return_index=True, return_inverse=True)
+    if (dt.video_id != dt.video_id[first][inv]).any():
+        bad = tid[np.flatnonzero(dt.video_id != dt.video_id[first][inv])[0]]
+        raise AssertionError(
+            "Track id {} appears in more than one video".format(int(bad)))
+    keep = limit_dets_per_image(dt, max_dets)
+    d = dt.take(keep)
+    d_cat_id = pred_cat[keep]
+    u, first, inv = np.unique(d.track_id, return_index=True,
+                              return_inverse=True)
+    if (d_cat_id != d_cat_id[first][inv]).any():
+        bad = d.track_id[np.flatnonzero(d_cat_id != d_cat_id[first][inv])[0]]
+        raise AssertionError(
+            "Annotations for track {} have multiple categories".format(
+                int(bad)))
+    d_img = _lookup(img_ids, d.image_id)
+    if (d_img < 0).any():
+        raise AssertionError("Results do not correspond to current Tao set.")
+    d_area = d.bbox[:, 2] * d.bbox[:, 3]
+    # track score over *all* kept boxes of the track (T/results.py:88-98)
+    trk_score = np.empty(len(u))
+    by_trk = np.argsort(inv, kind="stable")
+    t_off = np.zeros(len(u) + 1, dtype=np.int64)
+    np.cumsum(np.bincount(inv, minlength=len(u)), out=t_off[1:])
+    sc = d.score[by_trk]
+    seg_min = np.minimum.reduceat(sc, t_off[:-1])
+    seg_max = np.maximum.reduceat(sc, t_off[:-1])
+    trk_score[:] = sc[t_off[:-1]]
+    required_average = False
+    for k in np.flatnonzero(seg_min != seg_max):
+        required_average = True
+        trk_score[k] = np.mean(sc[t_off[k]:t_off[k + 1]])
+    dt_trk_vid = d.video_id[first]
+    dt_trk_cat = d_cat_id[first]
+
+    def select(a_img_idx, a_cat_idx, a_area, a_ids):
+        """get_ann_ids(vid_ids, cat_ids) + load_anns (T/tao.py:203-254)"""
+        sel = np.flatnonzero(a_img_idx >= 0)
+        sel = sel[visit_rank[a_img_idx[sel]] >= 0]
+        sel = sel[np.argsort(visit_rank[a_img_idx[sel]], kind="stable")]
+        sel = sel[(a_cat_idx[sel] >= 0) & (a_area[sel] > 0)
+                  & (a_area[sel] < np.inf)]
+        return _last_with_same_id(a_ids)[sel]
+
+    a_img = _lookup(img_ids, gt.ann_img)
+    g_sel = select(a_img, _lookup(cat_ids, ann_cat), gt.ann_area, gt.ann_id)
+    d_sel = select(d_img, _lookup(cat_ids, d_cat_id), d_area,
+                   np.arange(1, len(keep) + 1, dtype=np.int64))
+    if len(g_sel) == 0:
+        raise ValueError("Found no groundtruth annotations for given params")
+    if len(d_sel) == 0:
+        raise ValueError("Found no predicted annotations for given params")
+
+    # ---- group into tracks
+    g_ids, g_perm, g_aoff = _group_tracks(
+        gt.ann_trk[g_sel], gt.img_frame[img_row[a_img[g_sel]]])
+    g_ann = g_sel[g_perm]                          # annotations, track-major
+    g_trk_of_ann = np.repeat(np.arange(len(g_ids)), np.diff(g_aoff))
+    d_ids, d_perm, d_aoff = _group_tracks(
+        d.track_id[d_sel], gt.img_frame[img_row[d_img[d_sel]]])
+    d_ann = d_sel[d_perm]
+    d_trk_of_ann = np.repeat(np.arange(len(d_ids)), np.diff(d_aoff))
+
+    g_area = _seq_track_mean(gt.ann_area[g_ann], g_aoff)
+    d_area_t = _seq_track_mean(d_area[d_ann], d_aoff)
+    g_len = np.diff(g_aoff)
+    d_len = np.diff(d_aoff)
+    g_nhp = np.bincount(g_trk_of_ann, weights=(gt.ann_vis[g_ann] < 0.8),
+                        minlength=len(g_ids)).astype(np.int64)
+
+    g_row = t_rows_u[_lookup(t_keys_u, g_ids)]
+    g_vid = _lookup(vid_ids, gt.trk_vid[g_row])
+    g_cat = _lookup(cat_ids, trk_cat[g_row])
+    g_ign = gt.trk_ignore[g_row]
+    d_trow = _lookup(u, d_ids)
+    d_vid_id = dt_trk_vid[d_trow]
+    d_vid = _lookup(vid_ids, d_vid_id)
+    d_catid = dt_trk_cat[d_trow]
+    d_cat = _lookup(cat_ids, d_catid)
+    d_score = trk_score[d_trow]
+    if (g_vid < 0).any() or (d_vid < 0).any():
+        raise KeyError("track refers to an unknown video")
+
+    # ---- federated filter on the video lists (T/eval.py:214-233)
+    key_present = np.unique(g_vid * K + g_cat)
+    is_present = _lookup(key_present, d_vid * K + d_cat) >= 0
+    is_neg = _csr_member(gt.vid_neg_off, gt.vid_neg, vid_row[d_vid], d_catid)
+    d_keep = np.flatnonzero(is_present | is_neg)
+
+    keys_g = g_vid * K + g_cat
+    keys_d = d_vid[d_keep] * K + d_cat[d_keep]
+    o2 = np.lexsort((np.arange(len(d_keep)), -d_score[d_keep], keys_d))
+    d_keep, keys_d = d_keep[o2], keys_d[o2]
+    og = np.argsort(keys_g, kind="stable")
+    keys_g = keys_g[og]
+    cell_keys, g_cell, d_cell, g_off, d_off = _cells(keys_g, keys_d)
+
+    # ---- frames per track (unique images, timeline order)
+    def frames(trk_order, trk_of_ann, ann_rows, img_idx_of_ann, boxes):
+        # renumber tracks to their final (cell) position
+        new_of_old = np.full(int(trk_of_ann.max()) + 1 if len(trk_of_ann)
+                             else 0, -1, dtype=np.int64)
+        new_of_old[trk_order] = np.arange(len(trk_order))
+        nt = new_of_old[trk_of_ann]
+        live = np.flatnonzero(nt >= 0)
+        sel, off = _unique_frames(nt[live], tl_pos[img_idx_of_ann[live]],
+                                  len(trk_order))
+        rows = live[sel]
+        return (tl_pos[img_idx_of_ann[rows]].astype(I32),
+                np.ascontiguousarray(boxes[ann_rows[rows]]), off.astype(I32))
+
+    g_fpos, g_fbox, g_foff = frames(og, g_trk_of_ann, g_ann, a_img[g_ann],
+                                    gt.ann_bbox)
+    d_fpos, d_fbox, d_foff = frames(d_keep, d_trk_of_ann, d_ann, d_img[d_ann],
+                                    d.bbox)
+
+    nel = _csr_member(gt.vid_nel_off, gt.vid_nel, vid_row[d_vid[d_keep]],
+                      d_catid[d_keep])
+    f = Flat()
+    f.kind = "tao"
+    f.vid_ids, f.cat_ids = vid_ids, cat_ids
+    f.required_average = required_average
+    f.n_cells = len(cell_keys)
+    f.cell_unit = (cell_keys // K).astype(I32)      # video index
+    f.cell_cat = (cell_keys % K).astype(I32)
+    f.cell_dt_off = d_off.astype(I32)
+    f.cell_gt_off = g_off.astype(I32)
+    iou_off = np.zeros(f.n_cells + 1, dtype=np.int64)
+    np.cumsum(np.diff(d_off) * np.diff(g_off), out=iou_off[1:])
+    f.cell_iou_off = iou_off
+    f.dt_score = np.ascontiguousarray(d_score[d_keep])
+    f.dt_area = np.ascontiguousarray(d_area_t[d_keep])
+    f.dt_len = d_len[d_keep].astype(I32)
+    f.dt_flags = (np.where(nel, DT_IGNORE_UNMATCHED, 0)
+                  | np.where(d_ids[d_keep] <= 0, DT_NO_CONSUME, 0)
+                  ).astype(np.uint8)
+    f.dt_id = d_ids[d_keep]
+    f.dt_cat = (keys_d % K).astype(I32)
+    f.dt_cell = d_cell.astype(I32)
+    f.dt_frame_off, f.dt_frame_pos, f.dt_frame_box = d_foff, d_fpos, d_fbox
+    f.gt_area = np.ascontiguousarray(g_area[og])
+    f.gt_len = g_len[og].astype(I32)
+    f.gt_nhp = g_nhp[og].astype(I32)
+    f.gt_flags = (np.where(g_ign[og] != 0, GT_IGNORE, 0)
+                  | np.where(g_ids[og] == -1, GT_ID_HIDDEN, 0)
+                  ).astype(np.uint8)
+    f.gt_id = g_ids[og]
+    f.gt_cat = (keys_g % K).astype(I32)
+    f.gt_cell = g_cell.astype(I32)
+    f.gt_frame_off, f.gt_frame_pos, f.gt_frame_box = g_foff, g_fpos, g_fbox
+    f.n_pairs = int(iou_off[-1])
+    f.track_scores = dict(zip(u.tolist(), trk_score.tolist()))
+    return f

@@ -1,0 +1,147 @@
+"""ctypes access to the C oracle (oracle/_build/liboracle.so) for the tests
+and bench.py's cpu_baseline leg.  TEST INFRASTRUCTURE ONLY."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SO = os.path.join(ROOT, "oracle", "_build", "liboracle.so")
+REF_SO = os.path.join(ROOT, "oracle", "_ref", "libmaskapi_ref.so")
+N_THR, N_REC = 10, 101
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        src = os.path.join(ROOT, "oracle", "tao_oracle.c")
+        if (not os.path.exists(SO)
+                or os.path.getmtime(SO) < os.path.getmtime(src)):
+            subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"),
+                            "_build/liboracle.so"], check=True,
+                           stdout=subprocess.DEVNULL)
+        _lib = C.CDLL(SO)
+        _lib.orc_track_iou.restype = C.c_int64
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _c(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+def thresholds():
+    a, b = np.zeros(N_THR), np.zeros(N_REC)
+    lib().orc_thresholds(_p(a), _p(b))
+    return a, b
+
+
+def bb_iou(dt, gt):
+    dt, gt = _c(dt, np.float64).reshape(-1, 4), _c(gt, np.float64).reshape(-1, 4)
+    m, n = len(dt), len(gt)
+    o = np.zeros(m * n)
+    lib().orc_bb_iou(_p(dt), _p(gt), C.c_size_t(m), C.c_size_t(n), _p(o))
+    return o.reshape((m, n), order="F")
+
+
+def ref_bb_iou(dt, gt):
+    """The reference's own compiled bbIou (oracle/_ref), iscrowd = 0."""
+    r = C.CDLL(REF_SO)
+    dt, gt = _c(dt, np.float64).reshape(-1, 4), _c(gt, np.float64).reshape(-1, 4)
+    m, n = len(dt), len(gt)
+    o = np.zeros(m * n)
+    crowd = np.zeros(max(n, 1), dtype=np.uint8)
+    r.bbIou(_p(dt), _p(gt), C.c_ulong(m), C.c_ulong(n), _p(crowd), _p(o))
+    return o.reshape((m, n), order="F")
+
+
+def ranges(f):
+    ng, nd = len(f.gt_flags), len(f.dt_flags)
+    g, d = np.zeros(ng, np.uint32), np.zeros(nd, np.uint32)
+    if f.kind == "lvis":
+        lib().orc_lvis_ranges(C.c_int64(ng), _p(f.gt_vis), _p(f.gt_flags),
+                              C.c_int64(nd), _p(f.dt_flags), _p(g), _p(d))
+    else:
+        lib().orc_tao_ranges(C.c_int64(ng), _p(f.gt_area), _p(f.gt_len),
+                             _p(f.gt_nhp), _p(f.gt_flags), C.c_int64(nd),
+                             _p(f.dt_area), _p(f.dt_len), _p(f.dt_flags),
+                             _p(g), _p(d))
+    return g, d
+
+
+def iou_offsets(f):
+    off = np.zeros(f.n_cells + 1, dtype=np.int64)
+    np.cumsum(np.diff(f.cell_dt_off).astype(np.int64)
+              * np.diff(f.cell_gt_off), out=off[1:])
+    return off
+
+
+def track_iou(f):
+    iou = np.zeros(int(f.cell_iou_off[-1]))
+    pairs = lib().orc_track_iou(
+        C.c_int64(f.n_cells), _p(f.cell_dt_off), _p(f.cell_gt_off),
+        _p(f.cell_iou_off), _p(f.dt_frame_off), _p(f.dt_frame_pos),
+        _p(f.dt_frame_box), _p(f.gt_frame_off), _p(f.gt_frame_pos),
+        _p(f.gt_frame_box), _p(iou))
+    return iou, int(pairs)
+
+
+def match(f, gt_rng, dt_rng, iou=None, detail=True):
+    n_rng = 6 if f.kind == "lvis" else 20
+    n_combo = n_rng * N_THR
+    n_words = (n_combo + 63) // 64
+    nd = len(f.dt_flags)
+    matched = np.zeros((nd, n_words), np.uint64)
+    ignored = np.zeros((nd, n_words), np.uint64)
+    mg = np.zeros((nd, n_combo), np.int32) if detail else None
+    off = iou_offsets(f)
+    ious_out = None
+    if f.kind == "lvis":
+        ious_out = np.zeros(int(off[-1])) if detail else None
+        lib().orc_match(C.c_int64(f.n_cells), _p(f.cell_dt_off),
+                        _p(f.cell_gt_off), _p(off), _p(f.dt_box), _p(f.gt_box),
+                        None, C.c_int(n_rng), _p(gt_rng), _p(dt_rng),
+                        _p(f.gt_flags), _p(f.dt_flags), _p(matched),
+                        _p(ignored), _p(mg), _p(ious_out))
+    else:
+        lib().orc_match(C.c_int64(f.n_cells), _p(f.cell_dt_off),
+                        _p(f.cell_gt_off), _p(off), None, None, _p(iou),
+                        C.c_int(n_rng), _p(gt_rng), _p(dt_rng),
+                        _p(f.gt_flags), _p(f.dt_flags), _p(matched),
+                        _p(ignored), _p(mg), None)
+    return matched, ignored, mg, ious_out
+
+
+def accumulate(f, gt_rng, matched, ignored):
+    n_rng = 6 if f.kind == "lvis" else 20
+    K = len(f.cat_ids)
+    nd = len(f.dt_flags)
+    prec = np.zeros((N_THR, N_REC, K, n_rng))
+    rec = np.zeros((N_THR, K, n_rng))
+    order = np.zeros(nd, np.int64)
+    num_gt = np.zeros((K, n_rng), np.int32)
+    lib().orc_accumulate(C.c_int64(nd), C.c_int32(K), C.c_int(n_rng),
+                         _p(f.dt_cat), _p(f.dt_score), _p(matched),
+                         _p(ignored), C.c_int64(len(f.gt_flags)),
+                         _p(f.gt_cat), _p(gt_rng), _p(prec), _p(rec),
+                         _p(order), _p(num_gt))
+    return prec, rec, order, num_gt
+
+
+def run_flat(f):
+    """Whole per-evaluator oracle pipeline on a flattened problem."""
+    gt_rng, dt_rng = ranges(f)
+    iou = pairs = None
+    if f.kind == "tao":
+        iou, pairs = track_iou(f)
+    matched, ignored, mg, ious_out = match(f, gt_rng, dt_rng, iou)
+    prec, rec, order, num_gt = accumulate(f, gt_rng, matched, ignored)
+    return dict(gt_rng=gt_rng, dt_rng=dt_rng,
+                iou=iou if f.kind == "tao" else ious_out, pairs=pairs,
+                matched=matched, ignored=ignored, match_gt=mg,
+                precision=prec, recall=rec, order=order, num_gt=num_gt)
