@@ -1,0 +1,184 @@
+/*
+ * tao_amodal_hip.h -- C ABI of the MI355X (gfx950) evaluation hot path.
+ *
+ * This is the drop-in boundary for the path the reference runs in
+ * tools/eval_on_tao_amodal.py (LVISEval + TaoEval).  The reference has exactly
+ * one native seam on that path, pycocotools' bbIou; everything else is Python
+ * that this library replaces with batched device kernels over flattened cell
+ * tables.  Every entry point is extern "C", takes plain pointers and sizes,
+ * returns an int status (0 = ok, see taoamd_strerror) and never throws.  All
+ * pointers are DEVICE pointers unless the name ends in _host; the caller owns
+ * every buffer; `stream` is a hipStream_t passed as void* (NULL = default
+ * stream).  Calls are asynchronous on `stream` unless stated otherwise.  One
+ * host thread per device.
+ *
+ * Reference interfaces replaced (paths relative to /root/reference;
+ * L/ = tao_amodal/evaluation/lvis_amodal/, T/ = tao_amodal/evaluation/
+ * tao_amodal/, C/ = visualization/tao/third_party/pysot/training_dataset/
+ * coco/pycocotools/common/):
+ *
+ *   taoamd_bb_iou[_host]   void bbIou(BB dt, BB gt, siz m, siz n, byte
+ *                          *iscrowd, double *o)            C/maskApi.h:41-42,
+ *                          C/maskApi.c:109-120, called at L/eval.py:191
+ *   taoamd_lvis_ranges     LVISEval.evaluate_img, GT _ignore per visibility
+ *                          range + dt_ig_mask              L/eval.py:202-217,
+ *                                                          281-288
+ *   taoamd_tao_ranges      TaoEval.evaluate_vid, the same for 5 area x 4
+ *                          duration ranges                 T/eval.py:348-368,
+ *                                                          432-441
+ *   taoamd_track_iou       TaoEval.compute_iou / compute_track_box_iou /
+ *                          bb_intersect_union              T/eval.py:15-48,
+ *                                                          73-96,306-335
+ *   taoamd_match           LVISEval.compute_iou + evaluate_img greedy loop,
+ *                          TaoEval.evaluate_vid greedy loop
+ *                                                          L/eval.py:168-192,
+ *                                                          219-290;
+ *                                                          T/eval.py:370-443
+ *   taoamd_sort_by_cat_score  np.argsort(-dt_scores, kind="mergesort") per
+ *                          category                        L/eval.py:353-361,
+ *                                                          T/eval.py:508-518
+ *   taoamd_accumulate      LVISEval.accumulate / TaoEval.accumulate
+ *                                                          L/eval.py:339-426,
+ *                                                          T/eval.py:496-584
+ *
+ * Data model ("cell tables", built by tao_amodal_amd/flatten.py):
+ *   a cell = one (image, category) [LVIS] or (video, category) [TAO] pair that
+ *   has at least one detection or ground truth.  Detections (LVIS) / detection
+ *   tracks (TAO) of a cell are contiguous and sorted by descending score
+ *   (stable); ground truths are contiguous in the reference's visiting order.
+ *   cell_dt_off / cell_gt_off are CSR offsets (int32, n_cells + 1 entries).
+ *
+ *   A "combo" is one (range r, IoU threshold t) pair, combo = r*10 + t;
+ *   n_rng = 6 (LVIS visibility ranges) or 20 (TAO area x duration, r = a*4+t_).
+ *   Per detection the kernels emit n_words = ceil(n_rng*10/64) 64-bit words
+ *   of `matched` bits and of `ignored` bits (bit combo%64 of word combo/64):
+ *     TP = matched & ~ignored, FP = ~matched & ~ignored.
+ */
+#ifndef TAO_AMODAL_HIP_H
+#define TAO_AMODAL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TAOAMD_N_THR 10   /* IoU thresholds 0.50:0.05:0.95 */
+#define TAOAMD_N_REC 101  /* recall thresholds 0:0.01:1 */
+#define TAOAMD_LVIS_RNG 6
+#define TAOAMD_TAO_RNG 20
+
+/* per-ground-truth flag bits */
+#define TAOAMD_GT_IGNORE 1     /* truthy "ignore" field */
+#define TAOAMD_GT_OOF 2        /* annotation is out_of_frame (LVIS side) */
+#define TAOAMD_GT_ID_HIDDEN 4  /* id equals the "unmatched" sentinel (0 / -1) */
+/* per-detection flag bits */
+#define TAOAMD_DT_IGNORE_UNMATCHED 1 /* not-exhaustive category / area window */
+#define TAOAMD_DT_NO_CONSUME 2       /* id <= 0: a match leaves the GT free */
+
+/* status codes */
+#define TAOAMD_OK 0
+#define TAOAMD_ERR_HIP 1         /* a HIP runtime call failed */
+#define TAOAMD_ERR_ARG 2         /* bad argument */
+#define TAOAMD_ERR_TOO_LARGE 3   /* a cell exceeds a kernel limit */
+#define TAOAMD_ERR_WORKSPACE 4   /* workspace too small */
+
+const char *taoamd_strerror(int status);
+/* text of the last failing HIP call on this thread ("" if none) */
+const char *taoamd_last_error(void);
+int taoamd_version(void);
+
+/* Exact bit patterns of np.linspace(.5,.95,10) / np.linspace(0,1,101)
+ * (L/eval.py:560-565).  Host pointers. */
+int taoamd_thresholds_host(double *iou_thrs, double *rec_thrs);
+
+/* ---- bbIou ---------------------------------------------------------------
+ * o[g*m + d] = IoU(dt[d], gt[g]); boxes are x,y,w,h doubles.  iscrowd may be
+ * NULL (all zero); a non-zero entry selects u = area(dt) as in bbIou. */
+int taoamd_bb_iou(const double *dt, const double *gt, size_t m, size_t n,
+                  const unsigned char *iscrowd, double *o, void *stream);
+/* same, host pointers in and out (allocates, copies, synchronises) */
+int taoamd_bb_iou_host(const double *dt, const double *gt, size_t m, size_t n,
+                       const unsigned char *iscrowd, double *o);
+
+/* ---- range masks ------------------------------------------------------------
+ * gt_rng[g] bit r: GT g is ignored in range r.  dt_rng[d] bit r: detection d
+ * is ignored in range r when it ends up unmatched.  num_gt[k*n_rng + r]
+ * (int32, zeroed by the call) counts the evaluated GTs of category k. */
+int taoamd_lvis_ranges(int64_t n_gt, const double *gt_vis,
+                       const uint8_t *gt_flags, const int32_t *gt_cat,
+                       int64_t n_dt, const uint8_t *dt_flags, int32_t n_cat,
+                       uint32_t *gt_rng, uint32_t *dt_rng, int32_t *num_gt,
+                       void *stream);
+int taoamd_tao_ranges(int64_t n_gt, const double *gt_area,
+                      const int32_t *gt_len, const int32_t *gt_nhp,
+                      const uint8_t *gt_flags, const int32_t *gt_cat,
+                      int64_t n_dt, const double *dt_area,
+                      const int32_t *dt_len, const uint8_t *dt_flags,
+                      int32_t n_cat, uint32_t *gt_rng, uint32_t *dt_rng,
+                      int32_t *num_gt, void *stream);
+
+/* ---- 3D IoU of track pairs --------------------------------------------------
+ * iou[cell_iou_off[c] + d*G + g] for every cell c (G = its GT track count).
+ * Tracks are CSR lists of (timeline position, box) sorted by position.
+ * pair_frames (optional, int64[1], zeroed by the call) receives the number of
+ * same-frame box pairs evaluated (the unit of BASELINE.json's metric). */
+int taoamd_track_iou(int64_t n_cells, const int32_t *cell_dt_off,
+                     const int32_t *cell_gt_off, const int64_t *cell_iou_off,
+                     int64_t n_pairs, const int32_t *dt_frame_off,
+                     const int32_t *dt_frame_pos, const double *dt_frame_box,
+                     const int32_t *gt_frame_off, const int32_t *gt_frame_pos,
+                     const double *gt_frame_box, double *iou,
+                     int64_t *pair_frames, void *stream);
+
+/* ---- greedy assignment --------------------------------------------------------
+ * If dt_box/gt_box are non-NULL the IoU matrix of each cell is computed on the
+ * fly from the boxes (LVIS, fused); otherwise it is read from `iou` at
+ * cell_iou_off (TAO).  dst (optional, int32 per detection) redirects the
+ * output row of detection d to dst[d] (used to write in (category, score)
+ * order); NULL = identity.
+ *   matched, ignored : uint64[n_dt * n_words]
+ *   match_gt (opt.)  : int32[n_dt * n_rng*10], in-cell GT index or -1
+ *                      (always in identity order)
+ *   ious_out (opt.)  : LVIS only, double at cell_iou_off like `iou`
+ * max_gt_per_cell must be >= the largest GT count of a cell (host knows it
+ * from the CSR table); cells with more than 64 GTs take a slower kernel and
+ * more than TAOAMD_MAX_GT_PER_CELL is an error. */
+#define TAOAMD_MAX_GT_PER_CELL 3072
+int taoamd_match(int64_t n_cells, const int32_t *cell_dt_off,
+                 const int32_t *cell_gt_off, const int64_t *cell_iou_off,
+                 int32_t max_gt_per_cell, const double *dt_box,
+                 const double *gt_box, const double *iou, int32_t n_rng,
+                 const uint32_t *gt_rng, const uint32_t *dt_rng,
+                 const uint8_t *gt_flags, const uint8_t *dt_flags,
+                 const int32_t *dst, uint64_t *matched, uint64_t *ignored,
+                 int32_t *match_gt, double *ious_out, void *stream);
+
+/* ---- stable sort by (category asc, score desc) ---------------------------------
+ * order[p] = detection at sorted position p; dst[d] = sorted position of
+ * detection d (either may be NULL).  Ties keep input order, i.e. the
+ * reference's concatenation order.  Workspace: taoamd_sort_workspace(n). */
+size_t taoamd_sort_workspace(int64_t n);
+int taoamd_sort_by_cat_score(int64_t n, const int32_t *dt_cat,
+                             const double *dt_score, int32_t *order,
+                             int32_t *dst, void *workspace,
+                             size_t workspace_bytes, void *stream);
+
+/* ---- accumulate -------------------------------------------------------------------
+ * matched/ignored are in sorted order (row p = sorted position p); cat_off
+ * (int32[n_cat+1], device) delimits the categories in that order.  Outputs, C
+ * order, -1 where the category has no evaluated GT in the range:
+ *   precision[T][R][n_cat][n_rng], recall[T][n_cat][n_rng]
+ * Workspace: taoamd_accumulate_workspace(n_dt, n_cat, n_rng). */
+size_t taoamd_accumulate_workspace(int64_t n_dt, int32_t n_cat, int32_t n_rng);
+int taoamd_accumulate(int64_t n_dt, int32_t n_cat, int32_t n_rng,
+                      const int32_t *cat_off, const uint64_t *matched,
+                      const uint64_t *ignored,
+                      const int32_t *num_gt, double *precision, double *recall,
+                      void *workspace, size_t workspace_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,76 @@
+"""ctypes binding of the C ABI declared in include/tao_amodal_hip.h.
+
+The shared library is built in-tree by ``tao_amodal_amd/csrc/build.sh`` (or
+``__graft_entry__.build()``).  There is NO fallback: if the library is missing
+or fails to load, importing the product path raises -- results never come
+from a CPU path.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(HERE, "libtao_amodal_hip.so")
+
+OK = 0
+N_THR, N_REC = 10, 101
+LVIS_RNG, TAO_RNG = 6, 20
+MAX_GT_PER_CELL = 3072
+
+_vp, _i64, _i32, _sz = C.c_void_p, C.c_int64, C.c_int32, C.c_size_t
+
+SIGNATURES = {
+    "taoamd_strerror": (C.c_char_p, [C.c_int]),
+    "taoamd_last_error": (C.c_char_p, []),
+    "taoamd_version": (C.c_int, []),
+    "taoamd_thresholds_host": (C.c_int, [_vp, _vp]),
+    "taoamd_bb_iou": (C.c_int, [_vp, _vp, _sz, _sz, _vp, _vp, _vp]),
+    "taoamd_bb_iou_host": (C.c_int, [_vp, _vp, _sz, _sz, _vp, _vp]),
+    "taoamd_lvis_ranges": (C.c_int, [_i64, _vp, _vp, _vp, _i64, _vp, _i32,
+                                     _vp, _vp, _vp, _vp]),
+    "taoamd_tao_ranges": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp,
+                                    _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "taoamd_track_iou": (C.c_int, [_i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp,
+                                   _vp, _vp, _vp, _vp, _vp, _vp]),
+    "taoamd_match": (C.c_int, [_i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32,
+                               _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                               _vp]),
+    "taoamd_sort_workspace": (_sz, [_i64]),
+    "taoamd_sort_by_cat_score": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _sz,
+                                           _vp]),
+    "taoamd_accumulate_workspace": (_sz, [_i64, _i32, _i32]),
+    "taoamd_accumulate": (C.c_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp,
+                                    _vp, _vp, _sz, _vp]),
+}
+
+_lib = None
+
+
+class TaoAmdError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise TaoAmdError(
+            "HIP extension not built: %s is missing.  Run "
+            "tao_amodal_amd/csrc/build.sh (or __graft_entry__.build()).  "
+            "There is no CPU fallback." % SO_PATH)
+    lib = C.CDLL(SO_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)     # AttributeError if a symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != OK:
+        lib = load()
+        raise TaoAmdError("%s failed: %s [%s]" % (
+            what, lib.taoamd_strerror(status).decode(),
+            lib.taoamd_last_error().decode()))

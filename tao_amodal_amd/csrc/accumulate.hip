@@ -1,0 +1,345 @@
+// accumulate(): TP/FP sweep over the score-sorted detections of every
+// category, precision envelope and 101-point recall sampling (gfx950).
+// Reference: lvis_amodal/eval.py:339-417 == tao_amodal/eval.py:496-573.
+//
+// Input rows are already in (category, descending score, concatenation) order
+// (sort.hip + the scatter of match_kernel), so a category is a contiguous row
+// range [cat_off[k], cat_off[k+1]).  Lane = one (range, IoU threshold) combo,
+// exactly as in match_kernel, so a detection's two 64-bit words are consumed
+// with wave-uniform (scalar) loads and one bit test per lane.
+//
+// A category is cut into chunks of ACC_CH rows so that long categories
+// (e.g. "person") spread over the whole chip:
+//
+//   acc_chunks     chunk table from cat_off (block scan)
+//   acc_count      per chunk: #TP, #FP per combo
+//   acc_prefix     per category: exclusive prefix of the chunk counts; recall
+//   acc_chunkmax   per chunk: max precision at a TP row (needs the prefix)
+//   acc_sufmax     per category: reverse exclusive max over chunks
+//   acc_emit       per chunk, walking backwards: running max = precision
+//                  envelope; each recall threshold is written by the chunk
+//                  holding the TP that first reaches it  -> val[k][r][t][j]
+//   acc_transpose  val -> precision[T][R][K][A] (reference layout), -1 fill,
+//                  LDS-tiled so that both sides are coalesced
+//
+// Precision at a TP row is tp / (fp + tp + eps) in fp64, the very expression
+// of the reference; the envelope is a max of those values, so the order in
+// which chunks are combined cannot change a bit of the result.
+#include "common.hpp"
+
+using namespace taoamd;
+
+#define ACC_CH 256
+#define ACC_EPS 2.220446049250313e-16  // np.spacing(1)
+
+struct AccArgs {
+    int64_t n_dt;
+    int32_t n_cat, n_rng, n_words, n_chunks_max;
+    const int32_t *cat_off;
+    const uint64_t *matched;
+    const uint64_t *ignored;
+    const int32_t *num_gt;
+    int32_t *cat_chunk_off;  // [n_cat + 1]
+    uint32_t *cnt_tp, *cnt_fp;   // [chunk][word][64] counts inside the chunk
+    uint32_t *pre_tp, *pre_fp;   // exclusive prefix inside the category
+    double *cmax;                // chunk max, then reverse-exclusive max
+    double *val;                 // [n_cat][n_rng][N_THR][N_REC]
+    double *precision, *recall;
+};
+
+__global__ __launch_bounds__(256) void acc_chunks_kernel(AccArgs a)
+{
+    __shared__ int32_t part[256];
+    const int per = (a.n_cat + 255) / 256;
+    const int lo = threadIdx.x * per, hi = min(lo + per, a.n_cat);
+    int32_t s = 0;
+    for (int k = lo; k < hi; k++)
+        s += (a.cat_off[k + 1] - a.cat_off[k] + ACC_CH - 1) / ACC_CH;
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        int32_t v = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int32_t run = part[threadIdx.x] - s;
+    for (int k = lo; k < hi; k++) {
+        a.cat_chunk_off[k] = run;
+        run += (a.cat_off[k + 1] - a.cat_off[k] + ACC_CH - 1) / ACC_CH;
+    }
+    if (threadIdx.x == 255) a.cat_chunk_off[a.n_cat] = part[255];
+}
+
+// category owning chunk c: last k with cat_chunk_off[k] <= c (uniform)
+__device__ __forceinline__ int32_t chunk_cat(const int32_t *__restrict__ off,
+                                             int32_t n_cat, int32_t c)
+{
+    int32_t lo = 0, hi = n_cat;
+    while (hi - lo > 1) {
+        int32_t mid = (lo + hi) >> 1;
+        if (off[mid] <= c) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+struct ChunkInfo {
+    int32_t k, first, last;  // category, is first / last chunk of it
+    int64_t start;
+    int32_t len, c, word;
+    bool valid;
+};
+
+__device__ __forceinline__ ChunkInfo chunk_info(const AccArgs &a)
+{
+    ChunkInfo ci;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t item = (int64_t)blockIdx.x * 4 + wave;
+    ci.c = (int32_t)(item / a.n_words);
+    ci.word = (int32_t)(item - (int64_t)ci.c * a.n_words);
+    const int32_t total = a.cat_chunk_off[a.n_cat];
+    ci.valid = ci.c < total;
+    if (!ci.valid) return ci;
+    ci.k = chunk_cat(a.cat_chunk_off, a.n_cat, ci.c);
+    const int32_t j = ci.c - a.cat_chunk_off[ci.k];
+    ci.start = (int64_t)a.cat_off[ci.k] + (int64_t)j * ACC_CH;
+    const int64_t end = a.cat_off[ci.k + 1];
+    ci.len = (int32_t)min((int64_t)ACC_CH, end - ci.start);
+    ci.first = j == 0;
+    ci.last = ci.c + 1 == a.cat_chunk_off[ci.k + 1];
+    return ci;
+}
+
+__global__ __launch_bounds__(256) void acc_count_kernel(AccArgs a)
+{
+    const ChunkInfo ci = chunk_info(a);
+    if (!ci.valid) return;
+    const int lane = lane_id();
+    uint32_t tp = 0, fp = 0;
+    const uint64_t *__restrict__ M = a.matched + ci.start * a.n_words + ci.word;
+    const uint64_t *__restrict__ I = a.ignored + ci.start * a.n_words + ci.word;
+    for (int p = 0; p < ci.len; p++) {
+        const uint64_t m = M[(int64_t)p * a.n_words];
+        const uint64_t i = I[(int64_t)p * a.n_words];
+        tp += (uint32_t)(((m & ~i) >> lane) & 1);
+        fp += (uint32_t)(((~m & ~i) >> lane) & 1);
+    }
+    const int64_t o = ((int64_t)ci.c * a.n_words + ci.word) * WAVE + lane;
+    a.cnt_tp[o] = tp;
+    a.cnt_fp[o] = fp;
+}
+
+// one wavefront per (category, word)
+__global__ __launch_bounds__(256) void acc_prefix_kernel(AccArgs a)
+{
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t item = (int64_t)blockIdx.x * 4 + wave;
+    if (item >= (int64_t)a.n_cat * a.n_words) return;
+    const int32_t k = (int32_t)(item / a.n_words);
+    const int word = (int)(item - (int64_t)k * a.n_words);
+    const int lane = lane_id();
+    const int32_t c0 = a.cat_chunk_off[k], c1 = a.cat_chunk_off[k + 1];
+    uint32_t tp = 0, fp = 0;
+    for (int32_t c = c0; c < c1; c++) {
+        const int64_t o = ((int64_t)c * a.n_words + word) * WAVE + lane;
+        const uint32_t t_ = a.cnt_tp[o], f_ = a.cnt_fp[o];
+        a.pre_tp[o] = tp;
+        a.pre_fp[o] = fp;
+        tp += t_;
+        fp += f_;
+    }
+    const int combo = word * WAVE + lane;
+    if (combo < a.n_rng * N_THR) {
+        const int r = combo / N_THR, t = combo - r * N_THR;
+        const int32_t ng = a.num_gt[(int64_t)k * a.n_rng + r];
+        a.recall[((int64_t)t * a.n_cat + k) * a.n_rng + r] =
+            ng > 0 ? (double)tp / (double)ng : -1.0;
+    }
+}
+
+__global__ __launch_bounds__(256) void acc_chunkmax_kernel(AccArgs a)
+{
+    const ChunkInfo ci = chunk_info(a);
+    if (!ci.valid) return;
+    const int lane = lane_id();
+    const int64_t o = ((int64_t)ci.c * a.n_words + ci.word) * WAVE + lane;
+    double tp = (double)a.pre_tp[o], fp = (double)a.pre_fp[o];
+    double best = 0.0;
+    const uint64_t *__restrict__ M = a.matched + ci.start * a.n_words + ci.word;
+    const uint64_t *__restrict__ I = a.ignored + ci.start * a.n_words + ci.word;
+    for (int p = 0; p < ci.len; p++) {
+        const uint64_t m = M[(int64_t)p * a.n_words];
+        const uint64_t i = I[(int64_t)p * a.n_words];
+        const bool is_tp = ((m & ~i) >> lane) & 1;
+        const bool is_fp = ((~m & ~i) >> lane) & 1;
+        if (is_tp) {
+            tp += 1.0;
+            const double pr = tp / (fp + tp + ACC_EPS);
+            best = pr > best ? pr : best;
+        }
+        if (is_fp) fp += 1.0;
+    }
+    a.cmax[o] = best;
+}
+
+__global__ __launch_bounds__(256) void acc_sufmax_kernel(AccArgs a)
+{
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t item = (int64_t)blockIdx.x * 4 + wave;
+    if (item >= (int64_t)a.n_cat * a.n_words) return;
+    const int32_t k = (int32_t)(item / a.n_words);
+    const int word = (int)(item - (int64_t)k * a.n_words);
+    const int lane = lane_id();
+    const int32_t c0 = a.cat_chunk_off[k], c1 = a.cat_chunk_off[k + 1];
+    double run = 0.0;
+    for (int32_t c = c1 - 1; c >= c0; c--) {
+        const int64_t o = ((int64_t)c * a.n_words + word) * WAVE + lane;
+        const double v = a.cmax[o];
+        a.cmax[o] = run;
+        run = v > run ? v : run;
+    }
+}
+
+__global__ __launch_bounds__(256) void acc_emit_kernel(AccArgs a, RecThr rec_in)
+{
+    __shared__ double rec[N_REC];
+    if (threadIdx.x < N_REC) rec[threadIdx.x] = rec_in.v[threadIdx.x];
+    __syncthreads();
+    const ChunkInfo ci = chunk_info(a);
+    if (!ci.valid) return;
+    const int lane = lane_id();
+    const int combo = ci.word * WAVE + lane;
+    const bool active = combo < a.n_rng * N_THR;
+    const int r = active ? combo / N_THR : 0;
+    const int t = active ? combo - r * N_THR : 0;
+    const int32_t ng = active ? a.num_gt[(int64_t)ci.k * a.n_rng + r] : 0;
+    const bool live = active && ng > 0;
+    const int64_t o = ((int64_t)ci.c * a.n_words + ci.word) * WAVE + lane;
+    double tp = (double)(a.pre_tp[o] + a.cnt_tp[o]);
+    double fp = (double)(a.pre_fp[o] + a.cnt_fp[o]);
+    double run = a.cmax[o];
+    const double dng = (double)(live ? ng : 1);
+    double *__restrict__ out =
+        a.val + (((int64_t)ci.k * a.n_rng + r) * N_THR + t) * N_REC;
+    // thresholds already reached by the TP count at the end of this chunk
+    int jcur = 0;
+    if (live) {
+        const double x = tp / dng;
+        jcur = (int)(x * 100.0);
+        jcur = jcur < 0 ? 0 : (jcur > N_REC ? N_REC : jcur);
+        while (jcur < N_REC && rec[jcur] <= x) jcur++;
+        while (jcur > 0 && rec[jcur - 1] > x) jcur--;
+        if (ci.last)
+            for (int j = jcur; j < N_REC; j++) out[j] = 0.0;
+    }
+    const uint64_t *__restrict__ M = a.matched + ci.start * a.n_words + ci.word;
+    const uint64_t *__restrict__ I = a.ignored + ci.start * a.n_words + ci.word;
+    for (int p = ci.len - 1; p >= 0; p--) {
+        const uint64_t m = M[(int64_t)p * a.n_words];
+        const uint64_t i = I[(int64_t)p * a.n_words];
+        const bool is_tp = live && (((m & ~i) >> lane) & 1);
+        const bool is_fp = live && (((~m & ~i) >> lane) & 1);
+        if (is_tp) {
+            const double pr = tp / (fp + tp + ACC_EPS);
+            run = pr > run ? pr : run;
+            tp -= 1.0;
+            const double x_prev = tp / dng;
+            while (jcur > 0 && rec[jcur - 1] > x_prev) {
+                out[jcur - 1] = run;
+                jcur--;
+            }
+        }
+        if (is_fp) fp -= 1.0;
+    }
+    if (live && ci.first)
+        while (jcur > 0) {
+            out[jcur - 1] = run;
+            jcur--;
+        }
+}
+
+// val[KR][T*R] -> precision[T*R][KR] with -1 / 0 fill
+__global__ __launch_bounds__(256) void acc_transpose_kernel(AccArgs a)
+{
+    __shared__ double tile[32][33];
+    const int64_t KR = (int64_t)a.n_cat * a.n_rng;
+    const int64_t COLS = (int64_t)N_THR * N_REC;
+    const int64_t row0 = (int64_t)blockIdx.x * 32;   // (k, r) rows of val
+    const int64_t col0 = (int64_t)blockIdx.y * 32;   // (t, j) columns of val
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        const int64_t row = row0 + i, col = col0 + tx;
+        double v = -1.0;
+        if (row < KR && col < COLS) {
+            const int32_t k = (int32_t)(row / a.n_rng);
+            if (a.num_gt[row] > 0)
+                v = (a.cat_off[k + 1] > a.cat_off[k]) ? a.val[row * COLS + col] : 0.0;
+        }
+        tile[i][tx] = v;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int64_t col = col0 + i, row = row0 + tx;
+        if (row < KR && col < COLS) a.precision[col * KR + row] = tile[tx][i];
+    }
+}
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static int32_t max_chunks(int64_t n_dt, int32_t n_cat)
+{
+    return (int32_t)((n_dt + ACC_CH - 1) / ACC_CH + n_cat);
+}
+
+extern "C" size_t taoamd_accumulate_workspace(int64_t n_dt, int32_t n_cat,
+                                              int32_t n_rng)
+{
+    const size_t nw = (size_t)(n_rng * N_THR + 63) / 64;
+    const size_t nc = (size_t)max_chunks(n_dt, n_cat);
+    return align256(((size_t)n_cat + 1) * 4) + 4 * align256(nc * nw * WAVE * 4) +
+           align256(nc * nw * WAVE * 8) +
+           align256((size_t)n_cat * n_rng * N_THR * N_REC * 8) + 4096;
+}
+
+extern "C" int taoamd_accumulate(int64_t n_dt, int32_t n_cat, int32_t n_rng,
+                                 const int32_t *cat_off,
+                                 const uint64_t *matched,
+                                 const uint64_t *ignored, const int32_t *num_gt,
+                                 double *precision, double *recall,
+                                 void *workspace, size_t workspace_bytes,
+                                 void *stream)
+{
+    if (n_cat <= 0 || n_rng < 1 || n_rng > 32) return TAOAMD_ERR_ARG;
+    if (!cat_off || !num_gt || !precision || !recall || !workspace) return TAOAMD_ERR_ARG;
+    if (workspace_bytes < taoamd_accumulate_workspace(n_dt, n_cat, n_rng))
+        return TAOAMD_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    AccArgs a;
+    a.n_dt = n_dt; a.n_cat = n_cat; a.n_rng = n_rng;
+    a.n_words = (n_rng * N_THR + 63) / 64;
+    a.n_chunks_max = max_chunks(n_dt, n_cat);
+    a.cat_off = cat_off; a.matched = matched; a.ignored = ignored;
+    a.num_gt = num_gt; a.precision = precision; a.recall = recall;
+    unsigned char *w = (unsigned char *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    const size_t nc = (size_t)a.n_chunks_max, nw = (size_t)a.n_words;
+    a.cat_chunk_off = (int32_t *)w; w += align256(((size_t)n_cat + 1) * 4);
+    a.cnt_tp = (uint32_t *)w; w += align256(nc * nw * WAVE * 4);
+    a.cnt_fp = (uint32_t *)w; w += align256(nc * nw * WAVE * 4);
+    a.pre_tp = (uint32_t *)w; w += align256(nc * nw * WAVE * 4);
+    a.pre_fp = (uint32_t *)w; w += align256(nc * nw * WAVE * 4);
+    a.cmax = (double *)w; w += align256(nc * nw * WAVE * 8);
+    a.val = (double *)w;
+    const unsigned chunk_blocks = (unsigned)((nc * nw + 3) / 4);
+    const unsigned cat_blocks = (unsigned)(((size_t)n_cat * nw + 3) / 4);
+    acc_chunks_kernel<<<1, 256, 0, s>>>(a);
+    acc_count_kernel<<<chunk_blocks, 256, 0, s>>>(a);
+    acc_prefix_kernel<<<cat_blocks, 256, 0, s>>>(a);
+    acc_chunkmax_kernel<<<chunk_blocks, 256, 0, s>>>(a);
+    acc_sufmax_kernel<<<cat_blocks, 256, 0, s>>>(a);
+    acc_emit_kernel<<<chunk_blocks, 256, 0, s>>>(a, rec_thr());
+    const int64_t KR = (int64_t)n_cat * n_rng;
+    dim3 grid((unsigned)((KR + 31) / 32), (unsigned)((N_THR * N_REC + 31) / 32));
+    acc_transpose_kernel<<<grid, 256, 0, s>>>(a);
+    TAO_LAUNCH_CHECK();
+    return TAOAMD_OK;
+}

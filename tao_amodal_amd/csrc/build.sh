@@ -1,0 +1,12 @@
+#!/bin/bash
+# Build the C-ABI library for gfx950 (cross-compiles without a GPU).
+# -ffp-contract=off: fp64 IoU must not be fused into fma (bit parity with the
+# CPU result); no fast-math anywhere.
+set -e
+cd "$(dirname "$0")"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+OUT=../libtao_amodal_hip.so
+$HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared \
+    -ffp-contract=off -fno-fast-math -Wall -Wno-unused-result \
+    api.hip iou_match.hip sort.hip accumulate.hip -o $OUT "$@"
+echo "built $(realpath $OUT)"

@@ -1,0 +1,71 @@
+// Shared declarations of the gfx950 evaluation kernels.  CDNA4 only: 64-lane
+// wavefronts are assumed everywhere (no warp-size abstraction, no CUDA path).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/tao_amodal_hip.h"
+
+#define WAVE 64
+#define N_THR TAOAMD_N_THR
+#define N_REC TAOAMD_N_REC
+
+// IoU / recall thresholds travel as kernel arguments (uniform -> SGPRs).
+struct IouThr {
+    double v[N_THR];
+};
+struct RecThr {
+    double v[N_REC];
+};
+
+namespace taoamd {
+
+void set_error(hipError_t e, const char *what);
+const IouThr &iou_thr();
+const RecThr &rec_thr();
+
+#define TAO_HIP(call)                                     \
+    do {                                                  \
+        hipError_t e_ = (call);                           \
+        if (e_ != hipSuccess) {                           \
+            taoamd::set_error(e_, #call);                 \
+            return TAOAMD_ERR_HIP;                        \
+        }                                                 \
+    } while (0)
+
+#define TAO_LAUNCH_CHECK()                                \
+    do {                                                  \
+        hipError_t e_ = hipGetLastError();                \
+        if (e_ != hipSuccess) {                           \
+            taoamd::set_error(e_, "kernel launch");       \
+            return TAOAMD_ERR_HIP;                        \
+        }                                                 \
+    } while (0)
+
+// One box pair of bbIou with iscrowd == 0 (reference maskApi.c:109-120).
+// Compiled with -ffp-contract=off: da + ga - w*h must NOT become an fma, or
+// the last bit of the union differs from the CPU result.
+__device__ __forceinline__ double box_iou(double dx, double dy, double dw,
+                                          double dh, double gx, double gy,
+                                          double gw, double gh)
+{
+    double da = dw * dh, ga = gw * gh;
+    double w = fmin(dw + dx, gw + gx) - fmax(dx, gx);
+    if (w <= 0) return 0.0;
+    double h = fmin(dh + dy, gh + gy) - fmax(dy, gy);
+    if (h <= 0) return 0.0;
+    double i = w * h;
+    double u = da + ga - i;
+    return i / u;
+}
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
+
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+}  // namespace taoamd

@@ -1,0 +1,533 @@
+// IoU and greedy-assignment kernels (gfx950).
+//
+//   bb_iou_kernel       one thread per (d, g) entry of a single bbIou matrix
+//   *_ranges_kernel     per-GT / per-detection range masks + num_gt histogram
+//   track_iou_kernel    one lane per (dt track, gt track) pair, two-pointer
+//                       merge over the tracks' frame lists
+//   match_kernel        one wavefront per (cell, 64-combo word): lane = one
+//                       (range, IoU threshold) combo running the sequential
+//                       greedy of the reference; the IoU tile of the cell
+//                       lives in one VGPR pair spread across the wave and is
+//                       broadcast with v_readlane (no LDS, no HBM round trip
+//                       for the LVIS matrix); the per-detection result of the
+//                       64 combos is packed with one ballot
+//   match_big_kernel    cells with more than 64 ground truths: IoU row and
+//                       per-lane "taken" bitsets staged in LDS
+//
+// HBM-bound integer/compare work: nothing here is shaped into a GEMM.
+#include "common.hpp"
+
+using namespace taoamd;
+
+// --------------------------------------------------------------------- bbIou
+__global__ void bb_iou_kernel(const double *__restrict__ dt,
+                              const double *__restrict__ gt, size_t m,
+                              size_t n, const unsigned char *__restrict__ crowd,
+                              double *__restrict__ o)
+{
+    size_t total = m * n;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        size_t g = i / m, d = i - g * m;
+        const double4 D = reinterpret_cast<const double4 *>(dt)[d];
+        const double4 G = reinterpret_cast<const double4 *>(gt)[g];
+        double v;
+        if (crowd != nullptr && crowd[g]) {
+            double da = D.z * D.w;
+            double w = fmin(D.z + D.x, G.z + G.x) - fmax(D.x, G.x);
+            double h = fmin(D.w + D.y, G.w + G.y) - fmax(D.y, G.y);
+            v = (w <= 0 || h <= 0) ? 0.0 : (w * h) / da;
+        } else {
+            v = box_iou(D.x, D.y, D.z, D.w, G.x, G.y, G.z, G.w);
+        }
+        o[i] = v;
+    }
+}
+
+// -------------------------------------------------------------------- ranges
+__global__ void lvis_ranges_kernel(int64_t n_gt, const double *__restrict__ vis,
+                                   const uint8_t *__restrict__ gflags,
+                                   const int32_t *__restrict__ gcat,
+                                   int64_t n_dt,
+                                   const uint8_t *__restrict__ dflags,
+                                   uint32_t *__restrict__ gt_rng,
+                                   uint32_t *__restrict__ dt_rng,
+                                   int32_t *__restrict__ num_gt)
+{
+    // visibility ranges of reference lvis_amodal/eval.py:567-574
+    const double lo[5] = {0, 0, 0.1, 0.8, 0};
+    const double hi[5] = {1.0, 0.1, 0.8, 1.0, 0.8};
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < n_gt) {
+        uint32_t m = 0;
+        bool ign = gflags[i] & TAOAMD_GT_IGNORE;
+        double v = vis[i];
+#pragma unroll
+        for (int r = 0; r < 5; r++)
+            if (ign || v < lo[r] || v > hi[r]) m |= 1u << r;
+        if (ign || !(gflags[i] & TAOAMD_GT_OOF)) m |= 1u << 5;
+        gt_rng[i] = m;
+        int32_t *row = num_gt + (int64_t)gcat[i] * TAOAMD_LVIS_RNG;
+#pragma unroll
+        for (int r = 0; r < TAOAMD_LVIS_RNG; r++)
+            if (!((m >> r) & 1u)) atomicAdd(row + r, 1);
+    }
+    if (i < n_dt)
+        dt_rng[i] = (dflags[i] & TAOAMD_DT_IGNORE_UNMATCHED) ? 0x3fu : 0u;
+}
+
+__global__ void tao_ranges_kernel(
+    int64_t n_gt, const double *__restrict__ garea,
+    const int32_t *__restrict__ glen, const int32_t *__restrict__ gnhp,
+    const uint8_t *__restrict__ gflags, const int32_t *__restrict__ gcat,
+    int64_t n_dt, const double *__restrict__ darea,
+    const int32_t *__restrict__ dlen, const uint8_t *__restrict__ dflags,
+    uint32_t *__restrict__ gt_rng, uint32_t *__restrict__ dt_rng,
+    int32_t *__restrict__ num_gt)
+{
+    // area / duration ranges of reference tao_amodal/eval.py:735-744
+    const double alo[5] = {0, 0, 1024, 9216, 0};
+    const double ahi[5] = {1e10, 1024, 9216, 1e10, 1e10};
+    const double tlo[4] = {0, 0, 3, 10};
+    const double thi[4] = {1e5, 3, 10, 1e5};
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < n_gt) {
+        uint32_t m = 0;
+        bool ign = gflags[i] & TAOAMD_GT_IGNORE;
+        double a_ = garea[i], len = (double)glen[i];
+        bool few_hp = gnhp[i] <= 5;
+#pragma unroll
+        for (int a = 0; a < 5; a++)
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                bool bad = ign || a_ < alo[a] || a_ > ahi[a] || len < tlo[t] ||
+                           len > thi[t] || (a == 4 && few_hp);
+                if (bad) m |= 1u << (a * 4 + t);
+            }
+        gt_rng[i] = m;
+        int32_t *row = num_gt + (int64_t)gcat[i] * TAOAMD_TAO_RNG;
+        for (int r = 0; r < TAOAMD_TAO_RNG; r++)
+            if (!((m >> r) & 1u)) atomicAdd(row + r, 1);
+    }
+    if (i < n_dt) {
+        uint32_t m = 0;
+        bool nel = dflags[i] & TAOAMD_DT_IGNORE_UNMATCHED;
+        double a_ = darea[i], len = (double)dlen[i];
+#pragma unroll
+        for (int a = 0; a < 5; a++)
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+                if (nel || a_ < alo[a] || a_ > ahi[a] || len < tlo[t] ||
+                    len > thi[t])
+                    m |= 1u << (a * 4 + t);
+        dt_rng[i] = m;
+    }
+}
+
+// ------------------------------------------------------------------ 3D IoU
+// upper_bound(off, n+1 entries, p) - 1: the cell whose pair range holds p
+__device__ __forceinline__ int64_t find_cell(const int64_t *__restrict__ off,
+                                             int64_t n_cells, int64_t p)
+{
+    int64_t lo = 0, hi = n_cells;  // invariant: off[lo] <= p < off[hi]
+    while (hi - lo > 1) {
+        int64_t mid = (lo + hi) >> 1;
+        if (off[mid] <= p) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ void track_iou_kernel(
+    int64_t n_cells, const int32_t *__restrict__ cell_dt_off,
+    const int32_t *__restrict__ cell_gt_off,
+    const int64_t *__restrict__ cell_iou_off, int64_t n_pairs,
+    const int32_t *__restrict__ dfoff, const int32_t *__restrict__ dfpos,
+    const double *__restrict__ dfbox, const int32_t *__restrict__ gfoff,
+    const int32_t *__restrict__ gfpos, const double *__restrict__ gfbox,
+    double *__restrict__ iou, unsigned long long *__restrict__ pair_frames)
+{
+    int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    unsigned long long common = 0;
+    if (p < n_pairs) {
+        int64_t c = find_cell(cell_iou_off, n_cells, p);
+        int32_t G = cell_gt_off[c + 1] - cell_gt_off[c];
+        int64_t local = p - cell_iou_off[c];
+        int32_t d = (int32_t)(local / G), g = (int32_t)(local - (int64_t)d * G);
+        int32_t td = cell_dt_off[c] + d, tg = cell_gt_off[c] + g;
+        int32_t pd = dfoff[td], ed = dfoff[td + 1];
+        int32_t pg = gfoff[tg], eg = gfoff[tg + 1];
+        double i = 0.0, u = 0.0;
+        // ascending timeline order; per frame exactly the arithmetic of
+        // reference tao_amodal/eval.py:32-48 and :87-94
+        int32_t fd = pd < ed ? dfpos[pd] : INT32_MAX;
+        int32_t fg = pg < eg ? gfpos[pg] : INT32_MAX;
+        while (pd < ed || pg < eg) {
+            if (fd == fg) {
+                const double4 B = reinterpret_cast<const double4 *>(dfbox)[pd];
+                const double4 A = reinterpret_cast<const double4 *>(gfbox)[pg];
+                double w = fmin(B.x + B.z, A.x + A.z) - fmax(B.x, A.x);
+                double h = fmin(B.y + B.w, A.y + A.w) - fmax(B.y, A.y);
+                w = w > 0 ? w : 0.0;
+                h = h > 0 ? h : 0.0;
+                double i_ = w * h;
+                double u_ = B.z * B.w + A.z * A.w - i_;
+                i += i_;
+                u += u_;
+                common++;
+                pd++; pg++;
+                fd = pd < ed ? dfpos[pd] : INT32_MAX;
+                fg = pg < eg ? gfpos[pg] : INT32_MAX;
+            } else if (fg < fd) {
+                const double4 A = reinterpret_cast<const double4 *>(gfbox)[pg];
+                u += A.z * A.w;
+                pg++;
+                fg = pg < eg ? gfpos[pg] : INT32_MAX;
+            } else {
+                const double4 B = reinterpret_cast<const double4 *>(dfbox)[pd];
+                u += B.z * B.w;
+                pd++;
+                fd = pd < ed ? dfpos[pd] : INT32_MAX;
+            }
+        }
+        iou[p] = u > 0 ? i / u : 0.0;
+    }
+    if (pair_frames != nullptr) {
+        // wave reduction with DPP-free shuffles, one atomic per wavefront
+        for (int s = WAVE / 2; s > 0; s >>= 1)
+            common += __shfl_down(common, s, WAVE);
+        if (lane_id() == 0 && common) atomicAdd(pair_frames, common);
+    }
+}
+
+// ------------------------------------------------------------------- greedy
+struct MatchArgs {
+    int64_t n_cells;
+    const int32_t *cell_dt_off;
+    const int32_t *cell_gt_off;
+    const int64_t *cell_iou_off;
+    const double *dt_box;   // fused LVIS IoU when non-null
+    const double *gt_box;
+    const double *iou;      // precomputed (TAO) otherwise
+    const uint32_t *gt_rng;
+    const uint32_t *dt_rng;
+    const uint8_t *gt_flags;
+    const uint8_t *dt_flags;
+    const int32_t *dst;
+    uint64_t *matched;
+    uint64_t *ignored;
+    int32_t *match_gt;
+    double *ious_out;
+    int32_t n_rng;
+    int32_t n_words;
+    int32_t big_only;  // 1: handle only cells with G > 64 (big kernel)
+};
+
+// Fast path: G <= 64.  One wavefront per (cell, word).
+template <bool FUSED>
+__global__ __launch_bounds__(256) void match_kernel(MatchArgs a, IouThr thr)
+{
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t item = (int64_t)blockIdx.x * 4 + wave;
+    if (item >= a.n_cells * a.n_words) return;
+    const int64_t cell = item / a.n_words;
+    const int word = (int)(item - cell * a.n_words);
+    const int32_t d0 = __builtin_amdgcn_readfirstlane(a.cell_dt_off[cell]);
+    const int32_t D = __builtin_amdgcn_readfirstlane(a.cell_dt_off[cell + 1]) - d0;
+    const int32_t g0 = __builtin_amdgcn_readfirstlane(a.cell_gt_off[cell]);
+    const int32_t G = __builtin_amdgcn_readfirstlane(a.cell_gt_off[cell + 1]) - g0;
+    if (D == 0 || G > WAVE) return;
+    const int n_combo = a.n_rng * N_THR;
+    const int combo = word * WAVE + lane;
+    const bool active = combo < n_combo;
+    const int r = active ? combo / N_THR : 0;
+    const int t = active ? combo - r * N_THR : 0;
+    const double thr0 = fmin(thr.v[t], 1 - 1e-10);
+    const int64_t ioff = (FUSED && a.ious_out == nullptr && a.iou == nullptr)
+                             ? 0 : a.cell_iou_off[cell];
+
+    // per-lane set of GTs ignored in this lane's range; wave-uniform set of
+    // GTs whose id equals the "unmatched" sentinel
+    uint64_t IG = 0, HID = 0;
+    for (int g = 0; g < G; g++) {
+        uint32_t m = a.gt_rng[g0 + g];
+        IG |= (uint64_t)((m >> r) & 1u) << g;
+        HID |= (uint64_t)((a.gt_flags[g0 + g] & TAOAMD_GT_ID_HIDDEN) ? 1 : 0) << g;
+    }
+    // this lane's GT box when it holds column (lane % G) of the IoU tile
+    const int TD = G > 0 ? WAVE / G : WAVE;  // detections per register tile
+    double gx = 0, gy = 0, gw = 0, gh = 0;
+    const int my_dd = G > 0 ? lane / G : 0;
+    const int my_g = G > 0 ? lane - my_dd * G : 0;
+    if (FUSED && G > 0 && my_dd < TD) {
+        const double4 B = reinterpret_cast<const double4 *>(a.gt_box)[g0 + my_g];
+        gx = B.x; gy = B.y; gw = B.z; gh = B.w;
+    }
+
+    uint64_t taken = 0;
+    for (int32_t base = 0; base < D; base += TD) {
+        const int nd = min(TD, D - base);
+        // ---- IoU tile: lane l holds entry (dd = l / G, g = l % G)
+        double v_tile = 0.0;
+        if (G > 0 && my_dd < nd) {
+            if (FUSED) {
+                const double4 B =
+                    reinterpret_cast<const double4 *>(a.dt_box)[d0 + base + my_dd];
+                v_tile = box_iou(B.x, B.y, B.z, B.w, gx, gy, gw, gh);
+                if (a.ious_out != nullptr && word == 0)
+                    a.ious_out[ioff + (int64_t)(base + my_dd) * G + my_g] = v_tile;
+            } else {
+                v_tile = a.iou[ioff + (int64_t)(base + my_dd) * G + my_g];
+            }
+        }
+        uint64_t my_m = 0, my_i = 0;
+        for (int dd = 0; dd < nd; dd++) {
+            const int32_t d = d0 + base + dd;
+            double best1 = thr0, best2 = thr0;
+            int m1 = -1, m2 = -1;
+            const uint64_t free1 = ~taken & ~IG, free2 = ~taken & IG;
+            for (int g = 0; g < G; g++) {
+                const double v = readlane_f64(v_tile, dd * G + g);
+                const bool ok1 = ((free1 >> g) & 1) && !(v < best1);
+                const bool ok2 = ((free2 >> g) & 1) && !(v < best2);
+                best1 = ok1 ? v : best1;  m1 = ok1 ? g : m1;
+                best2 = ok2 ? v : best2;  m2 = ok2 ? g : m2;
+            }
+            const int m = m1 >= 0 ? m1 : m2;
+            const uint8_t df = a.dt_flags[d];
+            if (m >= 0 && !(df & TAOAMD_DT_NO_CONSUME)) taken |= 1ull << m;
+            const bool vis = m >= 0 && !((HID >> m) & 1);
+            bool ig = m >= 0 && ((IG >> m) & 1);
+            if (!vis && ((a.dt_rng[d] >> r) & 1u)) ig = true;
+            const uint64_t mw = __ballot(active && vis);
+            const uint64_t iw = __ballot(active && ig);
+            if (lane == dd) { my_m = mw; my_i = iw; }
+            if (a.match_gt != nullptr && active)
+                a.match_gt[(int64_t)d * n_combo + combo] = m;
+        }
+        if (lane < nd) {
+            const int32_t d = d0 + base + lane;
+            const int64_t row = a.dst != nullptr ? a.dst[d] : d;
+            a.matched[row * a.n_words + word] = my_m;
+            a.ignored[row * a.n_words + word] = my_i;
+        }
+    }
+}
+
+// Slow path: cells with more than 64 ground truths.  One wavefront (one
+// 64-thread block) per (cell, word); dynamic LDS = IoU row [Gmax] doubles +
+// taken bitsets [ceil(Gmax/32)][64] words (lane-minor: conflict free).
+template <bool FUSED>
+__global__ __launch_bounds__(64) void match_big_kernel(MatchArgs a, IouThr thr,
+                                                       int32_t g_cap)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *row = reinterpret_cast<double *>(smem);
+    uint32_t *takenw = reinterpret_cast<uint32_t *>(smem + (size_t)g_cap * 8);
+    const int lane = lane_id();
+    const int64_t item = blockIdx.x;
+    const int64_t cell = item / a.n_words;
+    const int word = (int)(item - cell * a.n_words);
+    const int32_t d0 = a.cell_dt_off[cell], D = a.cell_dt_off[cell + 1] - d0;
+    const int32_t g0 = a.cell_gt_off[cell], G = a.cell_gt_off[cell + 1] - g0;
+    if (D == 0 || G <= WAVE) return;
+    const int n_combo = a.n_rng * N_THR;
+    const int combo = word * WAVE + lane;
+    const bool active = combo < n_combo;
+    const int r = active ? combo / N_THR : 0;
+    const int t = active ? combo - r * N_THR : 0;
+    const double thr0 = fmin(thr.v[t], 1 - 1e-10);
+    const int64_t ioff = a.cell_iou_off != nullptr ? a.cell_iou_off[cell] : 0;
+    const int n_tw = (G + 31) / 32;
+    for (int w = 0; w < n_tw; w++) takenw[w * WAVE + lane] = 0;
+    for (int32_t dd = 0; dd < D; dd++) {
+        const int32_t d = d0 + dd;
+        __syncthreads();  // single-wave block: orders the LDS row reuse
+        if (FUSED) {
+            const double4 B = reinterpret_cast<const double4 *>(a.dt_box)[d];
+            for (int g = lane; g < G; g += WAVE) {
+                const double4 A = reinterpret_cast<const double4 *>(a.gt_box)[g0 + g];
+                const double v = box_iou(B.x, B.y, B.z, B.w, A.x, A.y, A.z, A.w);
+                row[g] = v;
+                if (a.ious_out != nullptr && word == 0)
+                    a.ious_out[ioff + (int64_t)dd * G + g] = v;
+            }
+        } else {
+            for (int g = lane; g < G; g += WAVE)
+                row[g] = a.iou[ioff + (int64_t)dd * G + g];
+        }
+        __syncthreads();
+        double best1 = thr0, best2 = thr0;
+        int m1 = -1, m2 = -1;
+        uint32_t tw = 0;
+        for (int g = 0; g < G; g++) {
+            if ((g & 31) == 0) tw = takenw[(g >> 5) * WAVE + lane];
+            const double v = row[g];
+            const bool ign = (a.gt_rng[g0 + g] >> r) & 1u;
+            const bool fr = !((tw >> (g & 31)) & 1u);
+            const bool ok1 = fr && !ign && !(v < best1);
+            const bool ok2 = fr && ign && !(v < best2);
+            best1 = ok1 ? v : best1;  m1 = ok1 ? g : m1;
+            best2 = ok2 ? v : best2;  m2 = ok2 ? g : m2;
+        }
+        const int m = m1 >= 0 ? m1 : m2;
+        const uint8_t df = a.dt_flags[d];
+        if (m >= 0 && !(df & TAOAMD_DT_NO_CONSUME))
+            takenw[(m >> 5) * WAVE + lane] |= 1u << (m & 31);
+        const bool vis = m >= 0 && !(a.gt_flags[g0 + max(m, 0)] & TAOAMD_GT_ID_HIDDEN);
+        bool ig = m >= 0 && ((a.gt_rng[g0 + max(m, 0)] >> r) & 1u);
+        if (!vis && ((a.dt_rng[d] >> r) & 1u)) ig = true;
+        const uint64_t mw = __ballot(active && vis);
+        const uint64_t iw = __ballot(active && ig);
+        if (lane == 0) {
+            const int64_t rowi = a.dst != nullptr ? a.dst[d] : d;
+            a.matched[rowi * a.n_words + word] = mw;
+            a.ignored[rowi * a.n_words + word] = iw;
+        }
+        if (a.match_gt != nullptr && active)
+            a.match_gt[(int64_t)d * n_combo + combo] = m;
+    }
+}
+
+// ---------------------------------------------------------------- host side
+extern "C" int taoamd_bb_iou(const double *dt, const double *gt, size_t m,
+                             size_t n, const unsigned char *iscrowd, double *o,
+                             void *stream)
+{
+    if (m == 0 || n == 0) return TAOAMD_OK;
+    if (!dt || !gt || !o) return TAOAMD_ERR_ARG;
+    size_t total = m * n;
+    unsigned blocks = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    bb_iou_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(dt, gt, m, n, iscrowd, o);
+    TAO_LAUNCH_CHECK();
+    return TAOAMD_OK;
+}
+
+extern "C" int taoamd_bb_iou_host(const double *dt, const double *gt, size_t m,
+                                  size_t n, const unsigned char *iscrowd,
+                                  double *o)
+{
+    if (m == 0 || n == 0) return TAOAMD_OK;
+    if (!dt || !gt || !o) return TAOAMD_ERR_ARG;
+    double *d_dt = nullptr, *d_gt = nullptr, *d_o = nullptr;
+    unsigned char *d_c = nullptr;
+    TAO_HIP(hipMalloc(&d_dt, m * 32));
+    TAO_HIP(hipMalloc(&d_gt, n * 32));
+    TAO_HIP(hipMalloc(&d_o, m * n * 8));
+    TAO_HIP(hipMemcpy(d_dt, dt, m * 32, hipMemcpyHostToDevice));
+    TAO_HIP(hipMemcpy(d_gt, gt, n * 32, hipMemcpyHostToDevice));
+    if (iscrowd) {
+        TAO_HIP(hipMalloc(&d_c, n));
+        TAO_HIP(hipMemcpy(d_c, iscrowd, n, hipMemcpyHostToDevice));
+    }
+    int st = taoamd_bb_iou(d_dt, d_gt, m, n, d_c, d_o, nullptr);
+    if (st == TAOAMD_OK) {
+        TAO_HIP(hipMemcpy(o, d_o, m * n * 8, hipMemcpyDeviceToHost));
+    }
+    (void)hipFree(d_dt); (void)hipFree(d_gt); (void)hipFree(d_o);
+    if (d_c) (void)hipFree(d_c);
+    return st;
+}
+
+extern "C" int taoamd_lvis_ranges(int64_t n_gt, const double *gt_vis,
+                                  const uint8_t *gt_flags,
+                                  const int32_t *gt_cat, int64_t n_dt,
+                                  const uint8_t *dt_flags, int32_t n_cat,
+                                  uint32_t *gt_rng, uint32_t *dt_rng,
+                                  int32_t *num_gt, void *stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    TAO_HIP(hipMemsetAsync(num_gt, 0, sizeof(int32_t) * (size_t)n_cat * TAOAMD_LVIS_RNG, s));
+    int64_t n = n_gt > n_dt ? n_gt : n_dt;
+    if (n == 0) return TAOAMD_OK;
+    lvis_ranges_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(
+        n_gt, gt_vis, gt_flags, gt_cat, n_dt, dt_flags, gt_rng, dt_rng, num_gt);
+    TAO_LAUNCH_CHECK();
+    return TAOAMD_OK;
+}
+
+extern "C" int taoamd_tao_ranges(int64_t n_gt, const double *gt_area,
+                                 const int32_t *gt_len, const int32_t *gt_nhp,
+                                 const uint8_t *gt_flags, const int32_t *gt_cat,
+                                 int64_t n_dt, const double *dt_area,
+                                 const int32_t *dt_len, const uint8_t *dt_flags,
+                                 int32_t n_cat, uint32_t *gt_rng,
+                                 uint32_t *dt_rng, int32_t *num_gt,
+                                 void *stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    TAO_HIP(hipMemsetAsync(num_gt, 0, sizeof(int32_t) * (size_t)n_cat * TAOAMD_TAO_RNG, s));
+    int64_t n = n_gt > n_dt ? n_gt : n_dt;
+    if (n == 0) return TAOAMD_OK;
+    tao_ranges_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(
+        n_gt, gt_area, gt_len, gt_nhp, gt_flags, gt_cat, n_dt, dt_area, dt_len,
+        dt_flags, gt_rng, dt_rng, num_gt);
+    TAO_LAUNCH_CHECK();
+    return TAOAMD_OK;
+}
+
+extern "C" int taoamd_track_iou(int64_t n_cells, const int32_t *cell_dt_off,
+                                const int32_t *cell_gt_off,
+                                const int64_t *cell_iou_off, int64_t n_pairs,
+                                const int32_t *dt_frame_off,
+                                const int32_t *dt_frame_pos,
+                                const double *dt_frame_box,
+                                const int32_t *gt_frame_off,
+                                const int32_t *gt_frame_pos,
+                                const double *gt_frame_box, double *iou,
+                                int64_t *pair_frames, void *stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (pair_frames) TAO_HIP(hipMemsetAsync(pair_frames, 0, 8, s));
+    if (n_pairs == 0) return TAOAMD_OK;
+    track_iou_kernel<<<(unsigned)((n_pairs + 255) / 256), 256, 0, s>>>(
+        n_cells, cell_dt_off, cell_gt_off, cell_iou_off, n_pairs, dt_frame_off,
+        dt_frame_pos, dt_frame_box, gt_frame_off, gt_frame_pos, gt_frame_box,
+        iou, (unsigned long long *)pair_frames);
+    TAO_LAUNCH_CHECK();
+    return TAOAMD_OK;
+}
+
+extern "C" int taoamd_match(int64_t n_cells, const int32_t *cell_dt_off,
+                            const int32_t *cell_gt_off,
+                            const int64_t *cell_iou_off,
+                            int32_t max_gt_per_cell, const double *dt_box,
+                            const double *gt_box, const double *iou,
+                            int32_t n_rng, const uint32_t *gt_rng,
+                            const uint32_t *dt_rng, const uint8_t *gt_flags,
+                            const uint8_t *dt_flags, const int32_t *dst,
+                            uint64_t *matched, uint64_t *ignored,
+                            int32_t *match_gt, double *ious_out, void *stream)
+{
+    if (n_cells == 0) return TAOAMD_OK;
+    if (n_rng < 1 || n_rng > 32) return TAOAMD_ERR_ARG;
+    const bool fused = dt_box != nullptr;
+    if (fused ? (gt_box == nullptr) : (iou == nullptr)) return TAOAMD_ERR_ARG;
+    if (max_gt_per_cell > TAOAMD_MAX_GT_PER_CELL) return TAOAMD_ERR_TOO_LARGE;
+    if ((!fused || ious_out) && cell_iou_off == nullptr) return TAOAMD_ERR_ARG;
+    MatchArgs a;
+    a.n_cells = n_cells; a.cell_dt_off = cell_dt_off; a.cell_gt_off = cell_gt_off;
+    a.cell_iou_off = cell_iou_off; a.dt_box = dt_box; a.gt_box = gt_box;
+    a.iou = iou; a.gt_rng = gt_rng; a.dt_rng = dt_rng; a.gt_flags = gt_flags;
+    a.dt_flags = dt_flags; a.dst = dst; a.matched = matched; a.ignored = ignored;
+    a.match_gt = match_gt; a.ious_out = ious_out; a.n_rng = n_rng;
+    a.n_words = (n_rng * N_THR + 63) / 64; a.big_only = 0;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t items = n_cells * a.n_words;
+    const unsigned blocks = (unsigned)((items + 3) / 4);
+    if (fused)
+        match_kernel<true><<<blocks, 256, 0, s>>>(a, iou_thr());
+    else
+        match_kernel<false><<<blocks, 256, 0, s>>>(a, iou_thr());
+    TAO_LAUNCH_CHECK();
+    if (max_gt_per_cell > WAVE) {
+        const int32_t cap = (max_gt_per_cell + 31) / 32 * 32;
+        const size_t lds = (size_t)cap * 8 + (size_t)(cap / 32) * WAVE * 4;
+        if (fused)
+            match_big_kernel<true><<<(unsigned)items, 64, lds, s>>>(a, iou_thr(), cap);
+        else
+            match_big_kernel<false><<<(unsigned)items, 64, lds, s>>>(a, iou_thr(), cap);
+        TAO_LAUNCH_CHECK();
+    }
+    return TAOAMD_OK;
+}

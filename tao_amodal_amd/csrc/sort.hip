@@ -1,0 +1,275 @@
+// Stable LSD radix sort of detections by (category asc, score desc) (gfx950).
+//
+// The reference orders the detections of a category with
+// np.argsort(-dt_scores, kind="mergesort") over the concatenation of the
+// category's cells (lvis_amodal/eval.py:353-361, tao_amodal/eval.py:508-518):
+// ties keep concatenation order.  The input of this sort IS in concatenation
+// order, so any stable sort on the key (category, -score) reproduces it.
+//
+// Key digits, least significant first: 8 x 8 bits of the order-preserving
+// transform of -score (descending), then 2 x 8 bits of the category index.
+// A pass whose digit is the same for every element (e.g. the sign/exponent
+// byte of scores in (0,1)) is detected from the global digit histograms and
+// skipped on the device without host involvement.
+//
+// Per pass: (1) per-block digit histogram, (2) one block per digit scans its
+// row of block counts, (3) scatter with wave-level match-any ranking
+// (8 ballots per 64 elements) so that equal digits keep their order.
+#include "common.hpp"
+
+using namespace taoamd;
+
+#define RS_THREADS 256
+#define RS_WAVES (RS_THREADS / WAVE)
+#define RS_ITEMS 8                           // rounds of 64 per wave
+#define RS_TILE (RS_THREADS * RS_ITEMS)      // 2048 elements per block
+#define RS_BINS 256
+#define RS_PASSES 10
+
+struct SortBufs {
+    uint64_t *key[2];
+    int32_t *idx[2];
+    const int32_t *cat;
+    uint32_t *block_hist;   // [RS_BINS][n_blocks]
+    uint32_t *digit_total;  // [RS_PASSES][RS_BINS] global totals
+    int32_t *skip;          // [RS_PASSES]
+    int32_t *sel;           // [RS_PASSES + 1] which buffer holds the data
+    int64_t n;
+    int32_t n_blocks;
+};
+
+__device__ __forceinline__ uint64_t desc_key(double s)
+{
+    s = s + 0.0;  // -0.0 -> +0.0: argsort(-score) sees them as equal
+    uint64_t u = (uint64_t)__double_as_longlong(s);
+    uint64_t asc = (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+    return ~asc;
+}
+
+__device__ __forceinline__ uint32_t digit_of(int pass, uint64_t key, int32_t idx,
+                                             const int32_t *__restrict__ cat)
+{
+    if (pass < 8) return (uint32_t)(key >> (8 * pass)) & 255u;
+    return ((uint32_t)cat[idx] >> (8 * (pass - 8))) & 255u;
+}
+
+// keys, identity payload and the global histograms of all 10 digits
+__global__ __launch_bounds__(RS_THREADS) void rs_init_kernel(
+    SortBufs b, const double *__restrict__ score)
+{
+    __shared__ uint32_t h[RS_PASSES][RS_BINS];
+    for (int i = threadIdx.x; i < RS_PASSES * RS_BINS; i += RS_THREADS)
+        (&h[0][0])[i] = 0;
+    __syncthreads();
+    for (int64_t i = blockIdx.x * (int64_t)RS_THREADS + threadIdx.x; i < b.n;
+         i += (int64_t)gridDim.x * RS_THREADS) {
+        uint64_t k = desc_key(score[i]);
+        b.key[0][i] = k;
+        b.idx[0][i] = (int32_t)i;
+#pragma unroll
+        for (int p = 0; p < RS_PASSES; p++)
+            atomicAdd(&h[p][digit_of(p, k, (int32_t)i, b.cat)], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < RS_PASSES * RS_BINS; i += RS_THREADS) {
+        uint32_t v = (&h[0][0])[i];
+        if (v) atomicAdd(&b.digit_total[i], v);
+    }
+}
+
+__global__ void rs_plan_kernel(SortBufs b)
+{
+    // one wave: a pass is skippable iff a single bin holds everything
+    if (threadIdx.x == 0) {
+        int cur = 0;
+        b.sel[0] = 0;
+        for (int p = 0; p < RS_PASSES; p++) {
+            bool single = false;
+            for (int d = 0; d < RS_BINS; d++)
+                if (b.digit_total[p * RS_BINS + d] == (uint32_t)b.n) single = true;
+            b.skip[p] = single ? 1 : 0;
+            if (!single) cur ^= 1;
+            b.sel[p + 1] = cur;
+        }
+    }
+}
+
+__global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(SortBufs b, int pass)
+{
+    if (b.skip[pass]) return;
+    __shared__ uint32_t h[RS_BINS];
+    const int s = b.sel[pass];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * RS_TILE;
+    for (int k = 0; k < RS_ITEMS; k++) {
+        int64_t i = base + k * RS_THREADS + threadIdx.x;
+        if (i < b.n)
+            atomicAdd(&h[digit_of(pass, b.key[s][i], b.idx[s][i], b.cat)], 1u);
+    }
+    __syncthreads();
+    b.block_hist[(int64_t)threadIdx.x * b.n_blocks + blockIdx.x] = h[threadIdx.x];
+}
+
+// one block per digit: exclusive scan of that digit's per-block counts
+__global__ __launch_bounds__(RS_THREADS) void rs_scan_kernel(SortBufs b, int pass)
+{
+    if (b.skip[pass]) return;
+    __shared__ uint32_t part[RS_THREADS];
+    uint32_t *row = b.block_hist + (int64_t)blockIdx.x * b.n_blocks;
+    const int per = (b.n_blocks + RS_THREADS - 1) / RS_THREADS;
+    const int lo = threadIdx.x * per, hi = min(lo + per, b.n_blocks);
+    uint32_t s = 0;
+    for (int i = lo; i < hi; i++) s += row[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    // Hillis-Steele inclusive scan of the 256 partial sums
+    for (int off = 1; off < RS_THREADS; off <<= 1) {
+        uint32_t v = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - s;
+    for (int i = lo; i < hi; i++) {
+        uint32_t c = row[i];
+        row[i] = run;
+        run += c;
+    }
+}
+
+__global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(SortBufs b, int pass)
+{
+    if (b.skip[pass]) return;
+    __shared__ uint32_t wave_cnt[RS_WAVES][RS_BINS];
+    __shared__ uint32_t digit_base[RS_BINS];
+    const int s = b.sel[pass];
+    const uint64_t *__restrict__ kin = b.key[s];
+    const int32_t *__restrict__ iin = b.idx[s];
+    uint64_t *__restrict__ kout = b.key[s ^ 1];
+    int32_t *__restrict__ iout = b.idx[s ^ 1];
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < RS_WAVES * RS_BINS; i += RS_THREADS)
+        (&wave_cnt[0][0])[i] = 0;
+    // exclusive prefix of the global digit totals: where each digit starts
+    {
+        uint32_t v = b.digit_total[pass * RS_BINS + threadIdx.x];
+        digit_base[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < RS_BINS; off <<= 1) {
+            uint32_t w = threadIdx.x >= off ? digit_base[threadIdx.x - off] : 0;
+            __syncthreads();
+            digit_base[threadIdx.x] += w;
+            __syncthreads();
+        }
+        uint32_t incl = digit_base[threadIdx.x];
+        __syncthreads();
+        digit_base[threadIdx.x] = incl - v +
+            b.block_hist[(int64_t)threadIdx.x * b.n_blocks + blockIdx.x];
+    }
+    __syncthreads();
+    // wave w owns elements [base + w*512, base + (w+1)*512): 8 rounds of 64
+    const int64_t base = (int64_t)blockIdx.x * RS_TILE + (int64_t)wave * (WAVE * RS_ITEMS);
+    uint64_t key[RS_ITEMS];
+    int32_t idx[RS_ITEMS];
+    uint32_t dig[RS_ITEMS], rank[RS_ITEMS];
+#pragma unroll
+    for (int k = 0; k < RS_ITEMS; k++) {
+        const int64_t i = base + k * WAVE + lane;
+        const bool ok = i < b.n;
+        key[k] = ok ? kin[i] : 0;
+        idx[k] = ok ? iin[i] : 0;
+        dig[k] = ok ? digit_of(pass, key[k], idx[k], b.cat) : 0xffffffffu;
+    }
+#pragma unroll
+    for (int k = 0; k < RS_ITEMS; k++) {
+        const bool ok = dig[k] != 0xffffffffu;
+        // match-any: lanes holding the same digit
+        uint64_t peers = __ballot(ok);
+#pragma unroll
+        for (int bit = 0; bit < 8; bit++) {
+            const bool one = (dig[k] >> bit) & 1u;
+            const uint64_t m = __ballot(one);
+            peers &= one ? m : ~m;
+        }
+        const uint32_t below = (uint32_t)__popcll(peers & ((1ull << lane) - 1));
+        uint32_t old = 0;
+        if (ok) old = wave_cnt[wave][dig[k]];
+        rank[k] = old + below;
+        // the highest peer lane publishes the new count (LDS ops of one
+        // wave execute in program order)
+        if (ok && (peers >> lane) == 1ull)
+            wave_cnt[wave][dig[k]] = old + below + 1;
+    }
+    __syncthreads();
+    // offsets of this wave inside the block, per digit
+#pragma unroll
+    for (int k = 0; k < RS_ITEMS; k++) {
+        if (dig[k] == 0xffffffffu) continue;
+        uint32_t off = digit_base[dig[k]] + rank[k];
+        for (int w = 0; w < wave; w++) off += wave_cnt[w][dig[k]];
+        kout[off] = key[k];
+        iout[off] = idx[k];
+    }
+}
+
+// order[p] = idx[p]; dst[idx[p]] = p
+__global__ void rs_finish_kernel(SortBufs b, int32_t *__restrict__ order,
+                                 int32_t *__restrict__ dst)
+{
+    const int s = b.sel[RS_PASSES];
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < b.n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        int32_t d = b.idx[s][i];
+        if (order) order[i] = d;
+        if (dst) dst[d] = (int32_t)i;
+    }
+}
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+extern "C" size_t taoamd_sort_workspace(int64_t n)
+{
+    if (n < 1) n = 1;
+    size_t nb = (size_t)((n + RS_TILE - 1) / RS_TILE);
+    return 2 * align256((size_t)n * 8) + 2 * align256((size_t)n * 4) +
+           align256(nb * RS_BINS * 4) + align256(RS_PASSES * RS_BINS * 4) +
+           align256(256) + 4096;
+}
+
+extern "C" int taoamd_sort_by_cat_score(int64_t n, const int32_t *dt_cat,
+                                        const double *dt_score, int32_t *order,
+                                        int32_t *dst, void *workspace,
+                                        size_t workspace_bytes, void *stream)
+{
+    if (n == 0) return TAOAMD_OK;
+    if (n > 0x7fffffff) return TAOAMD_ERR_TOO_LARGE;
+    if (!dt_cat || !dt_score || !workspace) return TAOAMD_ERR_ARG;
+    if (workspace_bytes < taoamd_sort_workspace(n)) return TAOAMD_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    unsigned char *w = (unsigned char *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    SortBufs b;
+    b.n = n;
+    b.n_blocks = (int32_t)((n + RS_TILE - 1) / RS_TILE);
+    b.cat = dt_cat;
+    b.key[0] = (uint64_t *)w; w += align256((size_t)n * 8);
+    b.key[1] = (uint64_t *)w; w += align256((size_t)n * 8);
+    b.idx[0] = (int32_t *)w;  w += align256((size_t)n * 4);
+    b.idx[1] = (int32_t *)w;  w += align256((size_t)n * 4);
+    b.block_hist = (uint32_t *)w; w += align256((size_t)b.n_blocks * RS_BINS * 4);
+    b.digit_total = (uint32_t *)w; w += align256(RS_PASSES * RS_BINS * 4);
+    b.skip = (int32_t *)w;
+    b.sel = b.skip + RS_PASSES;
+    TAO_HIP(hipMemsetAsync(b.digit_total, 0, RS_PASSES * RS_BINS * 4, s));
+    unsigned init_blocks = (unsigned)(b.n_blocks < 2048 ? b.n_blocks : 2048);
+    rs_init_kernel<<<init_blocks, RS_THREADS, 0, s>>>(b, dt_score);
+    rs_plan_kernel<<<1, 64, 0, s>>>(b);
+    for (int p = 0; p < RS_PASSES; p++) {
+        rs_hist_kernel<<<b.n_blocks, RS_THREADS, 0, s>>>(b, p);
+        rs_scan_kernel<<<RS_BINS, RS_THREADS, 0, s>>>(b, p);
+        rs_scatter_kernel<<<b.n_blocks, RS_THREADS, 0, s>>>(b, p);
+    }
+    rs_finish_kernel<<<init_blocks, 256, 0, s>>>(b, order, dst);
+    TAO_LAUNCH_CHECK();
+    return TAOAMD_OK;
+}

@@ -1,0 +1,197 @@
+"""Device pipeline: flattened cell tables -> precision / recall on the GPU.
+
+PyTorch is used only as the allocator/stream provider (device tensors,
+``data_ptr()``, ``torch.cuda.current_stream()``); every arithmetic step is a
+hand-written HIP kernel behind the C ABI of ``include/tao_amodal_hip.h``.
+
+One evaluator pass ("step" of bench.py) =
+
+    ranges  ->  sort (category, -score)  ->  [track 3D IoU]  ->
+    IoU + greedy match (writes rows in sorted order)  ->  accumulate
+
+which covers reference LVISEval.evaluate()+accumulate() (lvis_amodal/eval.py:
+115-145,305-426) or TaoEval.evaluate()+accumulate() (tao_amodal/eval.py:
+246-276,459-584) for the non-empty cells.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+
+N_THR, N_REC = _lib.N_THR, _lib.N_REC
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class DeviceProblem:
+    """A flattened problem (flatten.Flat) resident in HBM."""
+
+    def __init__(self, flat, device="cuda"):
+        self.kind = flat.kind
+        self.device = torch.device(device)
+        self.n_rng = _lib.LVIS_RNG if self.kind == "lvis" else _lib.TAO_RNG
+        self.n_words = (self.n_rng * N_THR + 63) // 64
+        self.n_cells = int(flat.n_cells)
+        self.n_cat = len(flat.cat_ids)
+        self.n_dt = len(flat.dt_flags)
+        self.n_gt = len(flat.gt_flags)
+        self.n_pairs = int(flat.n_pairs)
+        d_cnt = np.diff(flat.cell_dt_off).astype(np.int64)
+        g_cnt = np.diff(flat.cell_gt_off).astype(np.int64)
+        self.max_g = int(g_cnt.max()) if self.n_cells else 0
+        if self.max_g > _lib.MAX_GT_PER_CELL:
+            raise _lib.TaoAmdError(
+                "a cell holds %d ground truths; the kernels support up to %d"
+                % (self.max_g, _lib.MAX_GT_PER_CELL))
+        iou_off = np.zeros(self.n_cells + 1, dtype=np.int64)
+        np.cumsum(d_cnt * g_cnt, out=iou_off[1:])
+        self.n_iou = int(iou_off[-1])
+        cat_off = np.zeros(self.n_cat + 1, dtype=np.int32)
+        np.cumsum(np.bincount(flat.dt_cat, minlength=self.n_cat),
+                  out=cat_off[1:])
+        names = ["cell_dt_off", "cell_gt_off", "dt_score", "dt_flags",
+                 "dt_cat", "gt_flags", "gt_cat"]
+        if self.kind == "lvis":
+            names += ["dt_box", "gt_box", "gt_vis"]
+        else:
+            names += ["dt_area", "dt_len", "gt_area", "gt_len", "gt_nhp",
+                      "dt_frame_off", "dt_frame_pos", "dt_frame_box",
+                      "gt_frame_off", "gt_frame_pos", "gt_frame_box"]
+        self.t = {}
+        for n in names:
+            self.t[n] = torch.from_numpy(np.ascontiguousarray(flat[n])).to(
+                self.device)
+        self.t["cell_iou_off"] = torch.from_numpy(iou_off).to(self.device)
+        self.t["cat_off"] = torch.from_numpy(cat_off).to(self.device)
+        self.cat_off_host = cat_off
+
+    def input_bytes(self):
+        return sum(v.numel() * v.element_size() for v in self.t.values())
+
+
+class Workspace:
+    """Output and scratch buffers of one evaluator pass, allocated once."""
+
+    def __init__(self, dp, detail=False):
+        lib = _lib.load()
+        dev = dp.device
+        u8 = torch.uint8
+
+        def buf(nbytes):
+            return torch.empty(max(int(nbytes), 256), dtype=u8, device=dev)
+        self.gt_rng = torch.empty(max(dp.n_gt, 1), dtype=torch.int32, device=dev)
+        self.dt_rng = torch.empty(max(dp.n_dt, 1), dtype=torch.int32, device=dev)
+        self.num_gt = torch.empty((dp.n_cat, dp.n_rng), dtype=torch.int32,
+                                  device=dev)
+        self.order = torch.empty(max(dp.n_dt, 1), dtype=torch.int32, device=dev)
+        self.dst = torch.empty(max(dp.n_dt, 1), dtype=torch.int32, device=dev)
+        self.sort_bytes = lib.taoamd_sort_workspace(dp.n_dt)
+        self.sort_ws = buf(self.sort_bytes)
+        self.matched = torch.empty((max(dp.n_dt, 1), dp.n_words),
+                                   dtype=torch.int64, device=dev)
+        self.ignored = torch.empty_like(self.matched)
+        self.acc_bytes = lib.taoamd_accumulate_workspace(dp.n_dt, dp.n_cat,
+                                                         dp.n_rng)
+        self.acc_ws = buf(self.acc_bytes)
+        self.precision = torch.empty((N_THR, N_REC, dp.n_cat, dp.n_rng),
+                                     dtype=torch.float64, device=dev)
+        self.recall = torch.empty((N_THR, dp.n_cat, dp.n_rng),
+                                  dtype=torch.float64, device=dev)
+        self.iou = None
+        self.pair_frames = None
+        if dp.kind == "tao":
+            self.iou = torch.empty(max(dp.n_iou, 1), dtype=torch.float64,
+                                   device=dev)
+            self.pair_frames = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.match_gt = None
+        self.ious_out = None
+        if detail:
+            self.match_gt = torch.empty((max(dp.n_dt, 1), dp.n_rng * N_THR),
+                                        dtype=torch.int32, device=dev)
+            if dp.kind == "lvis":
+                self.ious_out = torch.empty(max(dp.n_iou, 1),
+                                            dtype=torch.float64, device=dev)
+
+
+def run(dp, ws):
+    """Launch one evaluator pass on the current stream (asynchronous)."""
+    lib = _lib.load()
+    t = dp.t
+    s = _stream()
+    if dp.kind == "lvis":
+        _lib.check(lib.taoamd_lvis_ranges(
+            dp.n_gt, _ptr(t["gt_vis"]), _ptr(t["gt_flags"]), _ptr(t["gt_cat"]),
+            dp.n_dt, _ptr(t["dt_flags"]), dp.n_cat, _ptr(ws.gt_rng),
+            _ptr(ws.dt_rng), _ptr(ws.num_gt), s), "taoamd_lvis_ranges")
+    else:
+        _lib.check(lib.taoamd_tao_ranges(
+            dp.n_gt, _ptr(t["gt_area"]), _ptr(t["gt_len"]), _ptr(t["gt_nhp"]),
+            _ptr(t["gt_flags"]), _ptr(t["gt_cat"]), dp.n_dt,
+            _ptr(t["dt_area"]), _ptr(t["dt_len"]), _ptr(t["dt_flags"]),
+            dp.n_cat, _ptr(ws.gt_rng), _ptr(ws.dt_rng), _ptr(ws.num_gt), s),
+            "taoamd_tao_ranges")
+    _lib.check(lib.taoamd_sort_by_cat_score(
+        dp.n_dt, _ptr(t["dt_cat"]), _ptr(t["dt_score"]), _ptr(ws.order),
+        _ptr(ws.dst), _ptr(ws.sort_ws), ws.sort_bytes, s),
+        "taoamd_sort_by_cat_score")
+    if dp.kind == "tao":
+        _lib.check(lib.taoamd_track_iou(
+            dp.n_cells, _ptr(t["cell_dt_off"]), _ptr(t["cell_gt_off"]),
+            _ptr(t["cell_iou_off"]), dp.n_iou, _ptr(t["dt_frame_off"]),
+            _ptr(t["dt_frame_pos"]), _ptr(t["dt_frame_box"]),
+            _ptr(t["gt_frame_off"]), _ptr(t["gt_frame_pos"]),
+            _ptr(t["gt_frame_box"]), _ptr(ws.iou), _ptr(ws.pair_frames), s),
+            "taoamd_track_iou")
+    fused = dp.kind == "lvis"
+    _lib.check(lib.taoamd_match(
+        dp.n_cells, _ptr(t["cell_dt_off"]), _ptr(t["cell_gt_off"]),
+        _ptr(t["cell_iou_off"]), dp.max_g,
+        _ptr(t["dt_box"]) if fused else None,
+        _ptr(t["gt_box"]) if fused else None,
+        None if fused else _ptr(ws.iou), dp.n_rng, _ptr(ws.gt_rng),
+        _ptr(ws.dt_rng), _ptr(t["gt_flags"]), _ptr(t["dt_flags"]),
+        _ptr(ws.dst), _ptr(ws.matched), _ptr(ws.ignored), _ptr(ws.match_gt),
+        _ptr(ws.ious_out), s), "taoamd_match")
+    _lib.check(lib.taoamd_accumulate(
+        dp.n_dt, dp.n_cat, dp.n_rng, _ptr(t["cat_off"]), _ptr(ws.matched),
+        _ptr(ws.ignored), _ptr(ws.num_gt), _ptr(ws.precision),
+        _ptr(ws.recall), _ptr(ws.acc_ws), ws.acc_bytes, s),
+        "taoamd_accumulate")
+
+
+def evaluate_flat(flat, device="cuda", detail=False):
+    """Upload, run, download.  Returns a dict of numpy arrays shaped like the
+    C oracle's outputs (tests compare the two field by field)."""
+    dp = DeviceProblem(flat, device)
+    ws = Workspace(dp, detail=detail)
+    run(dp, ws)
+    torch.cuda.synchronize(dp.device)
+    n = dp.n_dt
+    out = {
+        "precision": ws.precision.cpu().numpy(),
+        "recall": ws.recall.cpu().numpy(),
+        "num_gt": ws.num_gt.cpu().numpy(),
+        "gt_rng": ws.gt_rng[:dp.n_gt].cpu().numpy().view(np.uint32),
+        "dt_rng": ws.dt_rng[:n].cpu().numpy().view(np.uint32),
+        "order": ws.order[:n].cpu().numpy().astype(np.int64),
+        "dst": ws.dst[:n].cpu().numpy().astype(np.int64),
+        # rows are in sorted order on the device; give them back per detection
+        "matched_sorted": ws.matched[:n].cpu().numpy().view(np.uint64),
+        "ignored_sorted": ws.ignored[:n].cpu().numpy().view(np.uint64),
+    }
+    out["matched"] = out["matched_sorted"][out["dst"]] if n else out["matched_sorted"]
+    out["ignored"] = out["ignored_sorted"][out["dst"]] if n else out["ignored_sorted"]
+    if dp.kind == "tao":
+        out["iou"] = ws.iou[:dp.n_iou].cpu().numpy()
+        out["pairs"] = int(ws.pair_frames.item())
+    if detail:
+        out["match_gt"] = ws.match_gt[:n].cpu().numpy()
+        if dp.kind == "lvis":
+            out["iou"] = ws.ious_out[:dp.n_iou].cpu().numpy()
+    return out

@@ -1,0 +1,117 @@
+"""-m gpu: the HIP path (through the C ABI) against the golden vectors of the
+reference and against the C oracle on seeded synthetic inputs.  Bit-exact:
+integer match decisions, IoUs, precision and recall are compared with ==."""
+import numpy as np
+import pytest
+
+import orclib
+from goldenio import FIXTURES, INTEGER_FIXTURES, load_eval, load_inputs, load_json_gz
+from test_flat_oracle_golden import _check_side
+from tao_amodal_amd import flatten as fl
+from tao_amodal_amd.columns import DTColumns, GTColumns
+from tao_amodal_amd.synth import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine():
+    from tao_amodal_amd import engine
+    return engine
+
+
+def _compare_with_oracle(f, got, detail=True):
+    want = orclib.run_flat(f)
+    assert np.array_equal(got["gt_rng"], want["gt_rng"])
+    assert np.array_equal(got["dt_rng"], want["dt_rng"])
+    assert np.array_equal(got["num_gt"], want["num_gt"])
+    assert np.array_equal(got["order"], want["order"])
+    if f.kind == "tao" or detail:
+        assert np.array_equal(got["iou"], want["iou"])
+    if f.kind == "tao":
+        assert got["pairs"] == want["pairs"]
+    assert np.array_equal(got["matched"], want["matched"])
+    assert np.array_equal(got["ignored"], want["ignored"])
+    if detail:
+        assert np.array_equal(got["match_gt"], want["match_gt"])
+    assert np.array_equal(got["precision"], want["precision"])
+    assert np.array_equal(got["recall"], want["recall"])
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_lvis_hip_matches_reference_golden(name):
+    gtj, predj = load_inputs(name)
+    want = load_json_gz(name, "lvis.json.gz")
+    f = fl.flatten_lvis(GTColumns.from_json(gtj), DTColumns.from_json(predj))
+    got = _engine().evaluate_flat(f, detail=True)
+    _check_side(f, got, want, f.img_ids, 0)
+    p, r = load_eval(name)["lvis"]
+    assert np.array_equal(got["precision"], p)
+    assert np.array_equal(got["recall"], r)
+    _compare_with_oracle(f, got)
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_tao_hip_matches_reference_golden(name):
+    gtj, predj = load_inputs(name)
+    want = load_json_gz(name, "tao.json.gz")
+    dt = DTColumns.from_json(predj)
+    dt.track_id, _ = fl.make_track_ids_unique(dt)
+    f = fl.flatten_tao(GTColumns.from_json(gtj), dt)
+    got = _engine().evaluate_flat(f, detail=True)
+    _check_side(f, got, want, f.vid_ids, -1, exact_iou=name in INTEGER_FIXTURES)
+    p, r = load_eval(name)["tao"]
+    assert np.array_equal(got["precision"].reshape(p.shape), p)
+    assert np.array_equal(got["recall"].reshape(r.shape), r)
+    _compare_with_oracle(f, got)
+
+
+@pytest.mark.parametrize("seed,V,F,C,dpf", [(1, 6, 30, 40, 25), (2, 3, 8, 1203, 60),
+                                            (3, 10, 50, 7, 340)])
+def test_synthetic_hip_vs_c_oracle(seed, V, F, C, dpf):
+    gt, dt = synth(seed=seed, V=V, F=F, C=C, dets_per_frame=dpf,
+                   n_present=min(5, C - 3))
+    f = fl.flatten_lvis(gt, dt)
+    _compare_with_oracle(f, _engine().evaluate_flat(f, detail=True))
+    _compare_with_oracle(f, _engine().evaluate_flat(f, detail=False), detail=False)
+    dt.track_id, _ = fl.make_track_ids_unique(dt)
+    f = fl.flatten_tao(gt, dt)
+    _compare_with_oracle(f, _engine().evaluate_flat(f, detail=True))
+
+
+def test_cells_with_more_than_64_ground_truths():
+    """Crowded cells take match_big_kernel (LDS row + LDS bitsets)."""
+    gt, dt = synth(seed=9, V=2, F=3, C=4, dets_per_frame=200,
+                   gt_tracks_per_video=150, n_present=1, n_neg=1)
+    f = fl.flatten_lvis(gt, dt)
+    assert np.diff(f.cell_gt_off).max() > 64
+    _compare_with_oracle(f, _engine().evaluate_flat(f, detail=True))
+    dt.track_id, _ = fl.make_track_ids_unique(dt)
+    f = fl.flatten_tao(gt, dt)
+    assert np.diff(f.cell_gt_off).max() > 64
+    _compare_with_oracle(f, _engine().evaluate_flat(f, detail=True))
+
+
+def test_bb_iou_entry_points_match_reference_bbiou():
+    """taoamd_bb_iou[_host] against the C oracle and (when present) the
+    reference's own bbIou compiled from its source (oracle/_ref)."""
+    import ctypes, os
+    import torch
+    from tao_amodal_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(3)
+    dt = np.c_[rng.integers(-50, 500, (300, 2)), rng.integers(0, 300, (300, 2))] * 0.37
+    gt = np.c_[rng.integers(-50, 500, (77, 2)), rng.integers(0, 300, (77, 2))] * 0.37
+    dt, gt = np.ascontiguousarray(dt), np.ascontiguousarray(gt)
+    o = np.zeros(300 * 77)
+    _lib.check(lib.taoamd_bb_iou_host(dt.ctypes.data, gt.ctypes.data, 300, 77, None,
+                                      o.ctypes.data), "bb_iou_host")
+    got = o.reshape((300, 77), order="F")
+    assert np.array_equal(got, orclib.bb_iou(dt, gt))
+    if os.path.exists(orclib.REF_SO):
+        assert np.array_equal(got, orclib.ref_bb_iou(dt, gt))
+    d_dt, d_gt = torch.from_numpy(dt).cuda(), torch.from_numpy(gt).cuda()
+    d_o = torch.empty(300 * 77, dtype=torch.float64, device="cuda")
+    _lib.check(lib.taoamd_bb_iou(d_dt.data_ptr(), d_gt.data_ptr(), 300, 77, None,
+                                 d_o.data_ptr(), None), "bb_iou")
+    torch.cuda.synchronize()
+    assert np.array_equal(d_o.cpu().numpy().reshape((300, 77), order="F"), got)
