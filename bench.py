@@ -1,0 +1,207 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the MI355X evaluation hot path.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic input that
+is already resident in HBM: for BOTH evaluators (image-level LVISEval and
+track-level TaoEval) range masks -> (category, -score) sort -> [3D track IoU]
+-> IoU + greedy match at 10 thresholds x {6 | 20} ranges -> accumulate
+(precision[T,R,K,A] and recall materialised in the reference layout).
+
+Workload at N=1: BASELINE.json configs[1], "Synthetic 200 videos x 300 frames
+x 50 dets" with 1203 categories (SURVEY.md 8(d) Config 2).  For N>1 every
+rank evaluates its own 200-video shard (weak scaling): match runs per rank,
+then one RCCL exchange routes each category's records to its owner rank,
+which sorts and accumulates them; an all-reduce(max) assembles the tensors.
+
+Prints ONE JSON line on rank 0 (see the driver contract in the task text).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--videos", type=int, default=200)
+    p.add_argument("--frames", type=int, default=300)
+    p.add_argument("--dets", type=int, default=50)
+    p.add_argument("--cats", type=int, default=1203)
+    p.add_argument("--seed", type=int, default=20240807)
+    p.add_argument("--cpu-sample-videos", type=int, default=200,
+                   help="videos of the same workload timed through the C "
+                        "oracle for cpu_baseline (rank 0, N=1 only)")
+    p.add_argument("--no-cpu", action="store_true")
+    p.add_argument("--no-verify", action="store_true")
+    return p.parse_args()
+
+
+def algorithmic_bytes_match(dp):
+    """Compulsory HBM traffic of ONE launch of the fused LVIS IoU+match
+    kernel (DESIGN.md 'Kernels'): boxes 32 B, range masks 4 B, flags 1 B per
+    detection and GT; scatter index 4 B and 2 x 8 B output words per
+    detection; 2 x 4 B CSR entries per cell."""
+    return (dp.n_dt * (32 + 4 + 1 + 4 + 16 * dp.n_words)
+            + dp.n_gt * (32 + 4 + 1) + dp.n_cells * 8)
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from tao_amodal_amd import engine, flatten
+    from tao_amodal_amd.synth import synth
+
+    t0 = time.time()
+    gt, dt = synth(seed=args.seed + rank, V=args.videos, F=args.frames,
+                   C=args.cats, dets_per_frame=args.dets,
+                   video_id_base=rank * args.videos)
+    t_gen = time.time() - t0
+    t0 = time.time()
+    fl = flatten.flatten_lvis(gt, dt)
+    dt.track_id, _ = flatten.make_track_ids_unique(dt)
+    ft = flatten.flatten_tao(gt, dt)
+    t_flat = time.time() - t0
+    t0 = time.time()
+    dpl, dpt = engine.DeviceProblem(fl, dev), engine.DeviceProblem(ft, dev)
+    wsl, wst = engine.Workspace(dpl), engine.Workspace(dpt)
+    torch.cuda.synchronize()
+    t_h2d = time.time() - t0
+
+    if world > 1:
+        from tao_amodal_amd import dist as tdist
+        plan = tdist.ExchangePlan(dpl, dpt, rank, world, dev)
+
+        def step():
+            tdist.step(plan)
+    else:
+        def step():
+            engine.run(dpl, wsl)
+            engine.run(dpt, wst)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # ---- pairs: exact counts from the cell tables / the kernel's counter
+    p_l = dpl.n_pairs
+    p_t = int(wst.pair_frames.item()) if world == 1 else int(plan.pair_frames())
+    pairs = torch.tensor([p_l + p_t], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(pairs)
+    total_pairs = int(pairs.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = total_pairs * args.steps / elapsed / 1e6
+
+    # ---- stage breakdown + dominant-kernel roofline (HIP events on the
+    # stream the kernels run on), measured outside the timed region
+    stages, roof = None, None
+    if world == 1:
+        stages = engine.time_stages(dpl, wsl, dpt, wst, reps=max(args.steps, 10))
+        k_ms = stages["lvis"]["match"]
+        alg = algorithmic_bytes_match(dpl)
+        ach = alg / (k_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": "match_kernel<fused> (LVIS IoU+greedy match)",
+                "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                "alg_bytes_per_launch": int(alg), "kernel_ms": round(k_ms, 4)}
+
+    # ---- verification + CPU baseline (C oracle = "port"), rank 0, N=1
+    cpu, verified = None, None
+    if world == 1 and rank == 0 and not args.no_cpu:
+        import orclib
+        nv = min(args.cpu_sample_videos, args.videos)
+        sgt, sdt = synth(seed=args.seed, V=nv, F=args.frames, C=args.cats,
+                         dets_per_frame=args.dets)
+        sfl = flatten.flatten_lvis(sgt, sdt)
+        sdt.track_id, _ = flatten.make_track_ids_unique(sdt)
+        sft = flatten.flatten_tao(sgt, sdt)
+        t0 = time.perf_counter()
+        ol = orclib.run_flat(sfl, detail=False)
+        ot = orclib.run_flat(sft, detail=False)
+        t_cpu = time.perf_counter() - t0
+        sp = sfl.n_pairs + ot["pairs"]
+        cpu = {"value": round(sp / t_cpu / 1e6, 4), "unit": "Mpair/s", "cores": 1,
+               "kind": "port",
+               "sample": "%d of the %d videos of the same workload (%d box pairs, "
+                         "%.1f s) through oracle/tao_oracle.c, single thread"
+                         % (nv, args.videos, sp, t_cpu)}
+        if not args.no_verify:
+            gl = engine.evaluate_flat(sfl, dev)
+            gtt = engine.evaluate_flat(sft, dev)
+            verified = bool(
+                np.array_equal(gl["matched"], ol["matched"])
+                and np.array_equal(gl["ignored"], ol["ignored"])
+                and np.array_equal(gl["precision"], ol["precision"])
+                and np.array_equal(gl["recall"], ol["recall"])
+                and np.array_equal(gtt["iou"], ot["iou"])
+                and np.array_equal(gtt["matched"], ot["matched"])
+                and np.array_equal(gtt["precision"], ot["precision"])
+                and np.array_equal(gtt["recall"], ot["recall"]))
+
+    if rank == 0:
+        out = {
+            "metric": "box-pair IoU+match throughput", "value": round(value, 3),
+            "unit": "Mpair/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "SYNTH Config 2: %d videos x %d frames x %d "
+                                   "dets/frame, %d categories per GPU; LVISEval + "
+                                   "TaoEval passes" % (args.videos, args.frames,
+                                                       args.dets, args.cats),
+                       "pairs_per_step": total_pairs,
+                       "lvis_pairs_rank0": p_l, "tao_pairs_rank0": p_t,
+                       "detections_rank0": dpl.n_dt, "tracks_rank0": dpt.n_dt,
+                       "cells_rank0": [dpl.n_cells, dpt.n_cells],
+                       "parallelism": "video-sharded x%d" % world},
+            "roofline": roof, "cpu_baseline": cpu,
+            "stages_ms": stages, "bit_exact_vs_oracle": verified,
+            "host_s": {"generate": round(t_gen, 2), "flatten": round(t_flat, 2),
+                       "upload": round(t_h2d, 2)},
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

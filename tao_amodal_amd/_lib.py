@@ -54,6 +54,11 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own libamdhip64/libhsa-runtime64.  It must be the HIP
+    # runtime of the process: loading ours first would map a second runtime
+    # (the system one named in our DT_NEEDED) that cannot see torch's device
+    # allocations ("no ROCm-capable device is detected").
+    import torch  # noqa: F401
     if not os.path.exists(SO_PATH):
         raise TaoAmdError(
             "HIP extension not built: %s is missing.  Run "

@@ -83,6 +83,30 @@ __device__ __forceinline__ int32_t chunk_cat(const int32_t *__restrict__ off,
     return lo;
 }
 
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int lane)
+{
+    uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, lane);
+    uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// Rows [base, base+n) of a chunk: lane q loads row q (coalesced), returning
+// the TP and FP words of that row; the sequential loops then broadcast row q
+// with v_readlane, so there is no memory access inside them.
+__device__ __forceinline__ void load_rows(const uint64_t *__restrict__ M,
+                                          const uint64_t *__restrict__ I,
+                                          int n_words, int base, int n, int lane,
+                                          uint64_t &tpw, uint64_t &fpw)
+{
+    uint64_t m = 0, i = ~0ull;
+    if (lane < n) {
+        m = M[(int64_t)(base + lane) * n_words];
+        i = I[(int64_t)(base + lane) * n_words];
+    }
+    tpw = m & ~i;
+    fpw = ~m & ~i;
+}
+
 struct ChunkInfo {
     int32_t k, first, last;  // category, is first / last chunk of it
     int64_t start;
@@ -118,11 +142,14 @@ __global__ __launch_bounds__(256) void acc_count_kernel(AccArgs a)
     uint32_t tp = 0, fp = 0;
     const uint64_t *__restrict__ M = a.matched + ci.start * a.n_words + ci.word;
     const uint64_t *__restrict__ I = a.ignored + ci.start * a.n_words + ci.word;
-    for (int p = 0; p < ci.len; p++) {
-        const uint64_t m = M[(int64_t)p * a.n_words];
-        const uint64_t i = I[(int64_t)p * a.n_words];
-        tp += (uint32_t)(((m & ~i) >> lane) & 1);
-        fp += (uint32_t)(((~m & ~i) >> lane) & 1);
+    for (int base = 0; base < ci.len; base += WAVE) {
+        const int n = min(WAVE, ci.len - base);
+        uint64_t tpw, fpw;
+        load_rows(M, I, a.n_words, base, n, lane, tpw, fpw);
+        for (int q = 0; q < n; q++) {
+            tp += (uint32_t)((readlane_u64(tpw, q) >> lane) & 1);
+            fp += (uint32_t)((readlane_u64(fpw, q) >> lane) & 1);
+        }
     }
     const int64_t o = ((int64_t)ci.c * a.n_words + ci.word) * WAVE + lane;
     a.cnt_tp[o] = tp;
@@ -167,17 +194,20 @@ __global__ __launch_bounds__(256) void acc_chunkmax_kernel(AccArgs a)
     double best = 0.0;
     const uint64_t *__restrict__ M = a.matched + ci.start * a.n_words + ci.word;
     const uint64_t *__restrict__ I = a.ignored + ci.start * a.n_words + ci.word;
-    for (int p = 0; p < ci.len; p++) {
-        const uint64_t m = M[(int64_t)p * a.n_words];
-        const uint64_t i = I[(int64_t)p * a.n_words];
-        const bool is_tp = ((m & ~i) >> lane) & 1;
-        const bool is_fp = ((~m & ~i) >> lane) & 1;
-        if (is_tp) {
-            tp += 1.0;
-            const double pr = tp / (fp + tp + ACC_EPS);
-            best = pr > best ? pr : best;
+    for (int base = 0; base < ci.len; base += WAVE) {
+        const int n = min(WAVE, ci.len - base);
+        uint64_t tpw, fpw;
+        load_rows(M, I, a.n_words, base, n, lane, tpw, fpw);
+        for (int q = 0; q < n; q++) {
+            const bool is_tp = (readlane_u64(tpw, q) >> lane) & 1;
+            const bool is_fp = (readlane_u64(fpw, q) >> lane) & 1;
+            if (is_tp) {
+                tp += 1.0;
+                const double pr = tp / (fp + tp + ACC_EPS);
+                best = pr > best ? pr : best;
+            }
+            if (is_fp) fp += 1.0;
         }
-        if (is_fp) fp += 1.0;
     }
     a.cmax[o] = best;
 }
@@ -234,22 +264,25 @@ __global__ __launch_bounds__(256) void acc_emit_kernel(AccArgs a, RecThr rec_in)
     }
     const uint64_t *__restrict__ M = a.matched + ci.start * a.n_words + ci.word;
     const uint64_t *__restrict__ I = a.ignored + ci.start * a.n_words + ci.word;
-    for (int p = ci.len - 1; p >= 0; p--) {
-        const uint64_t m = M[(int64_t)p * a.n_words];
-        const uint64_t i = I[(int64_t)p * a.n_words];
-        const bool is_tp = live && (((m & ~i) >> lane) & 1);
-        const bool is_fp = live && (((~m & ~i) >> lane) & 1);
-        if (is_tp) {
-            const double pr = tp / (fp + tp + ACC_EPS);
-            run = pr > run ? pr : run;
-            tp -= 1.0;
-            const double x_prev = tp / dng;
-            while (jcur > 0 && rec[jcur - 1] > x_prev) {
-                out[jcur - 1] = run;
-                jcur--;
+    for (int base = (ci.len - 1) / WAVE * WAVE; base >= 0; base -= WAVE) {
+        const int n = min(WAVE, ci.len - base);
+        uint64_t tpw, fpw;
+        load_rows(M, I, a.n_words, base, n, lane, tpw, fpw);
+        for (int q = n - 1; q >= 0; q--) {
+            const bool is_tp = live && ((readlane_u64(tpw, q) >> lane) & 1);
+            const bool is_fp = live && ((readlane_u64(fpw, q) >> lane) & 1);
+            if (is_tp) {
+                const double pr = tp / (fp + tp + ACC_EPS);
+                run = pr > run ? pr : run;
+                tp -= 1.0;
+                const double x_prev = tp / dng;
+                while (jcur > 0 && rec[jcur - 1] > x_prev) {
+                    out[jcur - 1] = run;
+                    jcur--;
+                }
             }
+            if (is_fp) fp -= 1.0;
         }
-        if (is_fp) fp -= 1.0;
     }
     if (live && ci.first)
         while (jcur > 0) {

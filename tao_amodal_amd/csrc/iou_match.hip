@@ -280,6 +280,16 @@ __global__ __launch_bounds__(256) void match_kernel(MatchArgs a, IouThr thr)
                 v_tile = a.iou[ioff + (int64_t)(base + my_dd) * G + my_g];
             }
         }
+        // per-detection inputs of the tile: one coalesced load, then
+        // v_readlane inside the sequential loop (no memory in the loop)
+        int32_t t_flags = 0, t_rng = 0;
+        int64_t t_row = 0;
+        if (lane < nd) {
+            const int32_t d = d0 + base + lane;
+            t_flags = a.dt_flags[d];
+            t_rng = (int32_t)a.dt_rng[d];
+            t_row = a.dst != nullptr ? a.dst[d] : d;
+        }
         uint64_t my_m = 0, my_i = 0;
         for (int dd = 0; dd < nd; dd++) {
             const int32_t d = d0 + base + dd;
@@ -294,11 +304,12 @@ __global__ __launch_bounds__(256) void match_kernel(MatchArgs a, IouThr thr)
                 best2 = ok2 ? v : best2;  m2 = ok2 ? g : m2;
             }
             const int m = m1 >= 0 ? m1 : m2;
-            const uint8_t df = a.dt_flags[d];
+            const uint32_t df = (uint32_t)__builtin_amdgcn_readlane(t_flags, dd);
+            const uint32_t drng = (uint32_t)__builtin_amdgcn_readlane(t_rng, dd);
             if (m >= 0 && !(df & TAOAMD_DT_NO_CONSUME)) taken |= 1ull << m;
             const bool vis = m >= 0 && !((HID >> m) & 1);
             bool ig = m >= 0 && ((IG >> m) & 1);
-            if (!vis && ((a.dt_rng[d] >> r) & 1u)) ig = true;
+            if (!vis && ((drng >> r) & 1u)) ig = true;
             const uint64_t mw = __ballot(active && vis);
             const uint64_t iw = __ballot(active && ig);
             if (lane == dd) { my_m = mw; my_i = iw; }
@@ -306,10 +317,8 @@ __global__ __launch_bounds__(256) void match_kernel(MatchArgs a, IouThr thr)
                 a.match_gt[(int64_t)d * n_combo + combo] = m;
         }
         if (lane < nd) {
-            const int32_t d = d0 + base + lane;
-            const int64_t row = a.dst != nullptr ? a.dst[d] : d;
-            a.matched[row * a.n_words + word] = my_m;
-            a.ignored[row * a.n_words + word] = my_i;
+            a.matched[t_row * a.n_words + word] = my_m;
+            a.ignored[t_row * a.n_words + word] = my_i;
         }
     }
 }

@@ -77,18 +77,23 @@ __global__ __launch_bounds__(RS_THREADS) void rs_init_kernel(
     }
 }
 
-__global__ void rs_plan_kernel(SortBufs b)
+__global__ __launch_bounds__(RS_BINS) void rs_plan_kernel(SortBufs b)
 {
-    // one wave: a pass is skippable iff a single bin holds everything
+    // a pass is skippable iff a single bin holds everything: thread d tests
+    // bin d of every pass
+    __shared__ int32_t single[RS_PASSES];
+    if (threadIdx.x < RS_PASSES) single[threadIdx.x] = 0;
+    __syncthreads();
+    for (int p = 0; p < RS_PASSES; p++)
+        if (b.digit_total[p * RS_BINS + threadIdx.x] == (uint32_t)b.n)
+            single[p] = 1;
+    __syncthreads();
     if (threadIdx.x == 0) {
         int cur = 0;
         b.sel[0] = 0;
         for (int p = 0; p < RS_PASSES; p++) {
-            bool single = false;
-            for (int d = 0; d < RS_BINS; d++)
-                if (b.digit_total[p * RS_BINS + d] == (uint32_t)b.n) single = true;
-            b.skip[p] = single ? 1 : 0;
-            if (!single) cur ^= 1;
+            b.skip[p] = single[p];
+            if (!single[p]) cur ^= 1;
             b.sel[p + 1] = cur;
         }
     }
@@ -263,7 +268,7 @@ extern "C" int taoamd_sort_by_cat_score(int64_t n, const int32_t *dt_cat,
     TAO_HIP(hipMemsetAsync(b.digit_total, 0, RS_PASSES * RS_BINS * 4, s));
     unsigned init_blocks = (unsigned)(b.n_blocks < 2048 ? b.n_blocks : 2048);
     rs_init_kernel<<<init_blocks, RS_THREADS, 0, s>>>(b, dt_score);
-    rs_plan_kernel<<<1, 64, 0, s>>>(b);
+    rs_plan_kernel<<<1, RS_BINS, 0, s>>>(b);
     for (int p = 0; p < RS_PASSES; p++) {
         rs_hist_kernel<<<b.n_blocks, RS_THREADS, 0, s>>>(b, p);
         rs_scan_kernel<<<RS_BINS, RS_THREADS, 0, s>>>(b, p);

@@ -119,11 +119,8 @@ class Workspace:
                                             dtype=torch.float64, device=dev)
 
 
-def run(dp, ws):
-    """Launch one evaluator pass on the current stream (asynchronous)."""
-    lib = _lib.load()
-    t = dp.t
-    s = _stream()
+def stage_ranges(dp, ws):
+    lib, t, s = _lib.load(), dp.t, _stream()
     if dp.kind == "lvis":
         _lib.check(lib.taoamd_lvis_ranges(
             dp.n_gt, _ptr(t["gt_vis"]), _ptr(t["gt_flags"]), _ptr(t["gt_cat"]),
@@ -136,18 +133,31 @@ def run(dp, ws):
             _ptr(t["dt_area"]), _ptr(t["dt_len"]), _ptr(t["dt_flags"]),
             dp.n_cat, _ptr(ws.gt_rng), _ptr(ws.dt_rng), _ptr(ws.num_gt), s),
             "taoamd_tao_ranges")
+
+
+def stage_sort(dp, ws):
+    lib, t, s = _lib.load(), dp.t, _stream()
     _lib.check(lib.taoamd_sort_by_cat_score(
         dp.n_dt, _ptr(t["dt_cat"]), _ptr(t["dt_score"]), _ptr(ws.order),
         _ptr(ws.dst), _ptr(ws.sort_ws), ws.sort_bytes, s),
         "taoamd_sort_by_cat_score")
-    if dp.kind == "tao":
-        _lib.check(lib.taoamd_track_iou(
-            dp.n_cells, _ptr(t["cell_dt_off"]), _ptr(t["cell_gt_off"]),
-            _ptr(t["cell_iou_off"]), dp.n_iou, _ptr(t["dt_frame_off"]),
-            _ptr(t["dt_frame_pos"]), _ptr(t["dt_frame_box"]),
-            _ptr(t["gt_frame_off"]), _ptr(t["gt_frame_pos"]),
-            _ptr(t["gt_frame_box"]), _ptr(ws.iou), _ptr(ws.pair_frames), s),
-            "taoamd_track_iou")
+
+
+def stage_track_iou(dp, ws):
+    if dp.kind != "tao":
+        return
+    lib, t, s = _lib.load(), dp.t, _stream()
+    _lib.check(lib.taoamd_track_iou(
+        dp.n_cells, _ptr(t["cell_dt_off"]), _ptr(t["cell_gt_off"]),
+        _ptr(t["cell_iou_off"]), dp.n_iou, _ptr(t["dt_frame_off"]),
+        _ptr(t["dt_frame_pos"]), _ptr(t["dt_frame_box"]),
+        _ptr(t["gt_frame_off"]), _ptr(t["gt_frame_pos"]),
+        _ptr(t["gt_frame_box"]), _ptr(ws.iou), _ptr(ws.pair_frames), s),
+        "taoamd_track_iou")
+
+
+def stage_match(dp, ws, scatter=True):
+    lib, t, s = _lib.load(), dp.t, _stream()
     fused = dp.kind == "lvis"
     _lib.check(lib.taoamd_match(
         dp.n_cells, _ptr(t["cell_dt_off"]), _ptr(t["cell_gt_off"]),
@@ -156,13 +166,51 @@ def run(dp, ws):
         _ptr(t["gt_box"]) if fused else None,
         None if fused else _ptr(ws.iou), dp.n_rng, _ptr(ws.gt_rng),
         _ptr(ws.dt_rng), _ptr(t["gt_flags"]), _ptr(t["dt_flags"]),
-        _ptr(ws.dst), _ptr(ws.matched), _ptr(ws.ignored), _ptr(ws.match_gt),
-        _ptr(ws.ious_out), s), "taoamd_match")
+        _ptr(ws.dst) if scatter else None, _ptr(ws.matched),
+        _ptr(ws.ignored), _ptr(ws.match_gt), _ptr(ws.ious_out), s),
+        "taoamd_match")
+
+
+def stage_accumulate(dp, ws):
+    lib, t, s = _lib.load(), dp.t, _stream()
     _lib.check(lib.taoamd_accumulate(
         dp.n_dt, dp.n_cat, dp.n_rng, _ptr(t["cat_off"]), _ptr(ws.matched),
         _ptr(ws.ignored), _ptr(ws.num_gt), _ptr(ws.precision),
         _ptr(ws.recall), _ptr(ws.acc_ws), ws.acc_bytes, s),
         "taoamd_accumulate")
+
+
+STAGES = (("ranges", stage_ranges), ("sort", stage_sort),
+          ("track_iou", stage_track_iou), ("match", stage_match),
+          ("accumulate", stage_accumulate))
+
+
+def run(dp, ws):
+    """Launch one evaluator pass on the current stream (asynchronous)."""
+    for _, fn in STAGES:
+        fn(dp, ws)
+
+
+def time_stages(dpl, wsl, dpt, wst, reps=10):
+    """Average duration (ms) of every stage of both evaluators, measured with
+    HIP events recorded on the stream the kernels are launched on."""
+    out = {}
+    for side, dp, ws in (("lvis", dpl, wsl), ("tao", dpt, wst)):
+        acc = {name: 0.0 for name, _ in STAGES}
+        for _ in range(reps):
+            evs = []
+            for name, fn in STAGES:
+                a = torch.cuda.Event(enable_timing=True)
+                b = torch.cuda.Event(enable_timing=True)
+                a.record()
+                fn(dp, ws)
+                b.record()
+                evs.append((name, a, b))
+            torch.cuda.synchronize(dp.device)
+            for name, a, b in evs:
+                acc[name] += a.elapsed_time(b)
+        out[side] = {k: round(v / reps, 4) for k, v in acc.items()}
+    return out
 
 
 def evaluate_flat(flat, device="cuda", detail=False):

@@ -1,0 +1,206 @@
+"""Shared machinery of the two evaluator classes: running a flattened problem
+on the GPU, the numpy-side summaries (kept in numpy so that the means are
+computed by the very same pairwise summation as the reference), and the lazy
+views that expose the reference's bulky per-cell state (``ious``,
+``eval_imgs`` / ``eval_vids``, ``dt_pointers``) without materialising it.
+"""
+import datetime
+from collections.abc import Mapping, Sequence
+
+import numpy as np
+
+N_THR, N_REC = 10, 101
+
+
+def masked_mean(s):
+    """``np.mean(s[s > -1])`` or -1 (reference lvis_amodal/eval.py:453-457,
+    tao_amodal/eval.py:619-623)."""
+    sel = s[s > -1]
+    if len(sel) == 0:
+        return -1
+    return np.mean(sel)
+
+
+class GpuRun:
+    """One evaluator pass on the device, split like the reference's API:
+    evaluate() = ranges + sort + [track IoU] + match, accumulate() = sweep."""
+
+    def __init__(self, flat, device=None):
+        import torch
+        from .. import engine
+        if not torch.cuda.is_available():
+            raise RuntimeError(
+                "tao_amodal_amd evaluates on an AMD GPU through its HIP "
+                "extension; no GPU is visible and there is no CPU fallback.")
+        self.engine = engine
+        self.torch = torch
+        self.flat = flat
+        self.device = torch.device(device or "cuda")
+        self.dp = engine.DeviceProblem(flat, self.device)
+        self.ws = engine.Workspace(self.dp)
+        self._detail = None
+        self.precision = self.recall = None
+
+    def evaluate(self):
+        e = self.engine
+        e.stage_ranges(self.dp, self.ws)
+        e.stage_sort(self.dp, self.ws)
+        e.stage_track_iou(self.dp, self.ws)
+        e.stage_match(self.dp, self.ws)
+
+    def accumulate(self):
+        self.engine.stage_accumulate(self.dp, self.ws)
+        self.torch.cuda.synchronize(self.device)
+        self.precision = self.ws.precision.cpu().numpy()
+        self.recall = self.ws.recall.cpu().numpy()
+
+    # ------------------------------------------------------ lazy detail
+    def detail(self):
+        """Per-detection match indices / IoUs (a second, detail-mode pass,
+        only when the per-cell views are actually inspected)."""
+        if self._detail is None:
+            self._detail = self.engine.evaluate_flat(self.flat, self.device,
+                                                     detail=True)
+        return self._detail
+
+    def sorted_rows(self):
+        n = self.dp.n_dt
+        ws = self.ws
+        return (ws.order[:n].cpu().numpy().astype(np.int64),
+                ws.matched[:n].cpu().numpy().view(np.uint64),
+                ws.ignored[:n].cpu().numpy().view(np.uint64),
+                ws.num_gt.cpu().numpy())
+
+
+def _bit(words, combo):
+    return ((words[..., combo // 64] >> np.uint64(combo % 64))
+            & np.uint64(1)).astype(bool)
+
+
+class CellView:
+    """What the reference stores per (unit, category, range) in eval_imgs /
+    eval_vids, rebuilt on demand from the device results."""
+
+    def __init__(self, run, unit_ids, sentinel, unit_key, rng_key, rng_values):
+        self.run = run
+        self.flat = run.flat
+        self.unit_ids = unit_ids
+        self.sentinel = sentinel
+        self.unit_key, self.rng_key, self.rng_values = unit_key, rng_key, rng_values
+        f = self.flat
+        K = len(f.cat_ids)
+        self.index = {int(u) * K + int(c): k for k, (u, c) in
+                      enumerate(zip(f.cell_unit, f.cell_cat))}
+        self.K = K
+
+    def cell_of(self, unit_idx, cat_idx):
+        return self.index.get(int(unit_idx) * self.K + int(cat_idx))
+
+    def iou(self, k):
+        f, d = self.flat, self.run.detail()
+        off = np.zeros(f.n_cells + 1, dtype=np.int64)
+        np.cumsum(np.diff(f.cell_dt_off).astype(np.int64)
+                  * np.diff(f.cell_gt_off), out=off[1:])
+        D = f.cell_dt_off[k + 1] - f.cell_dt_off[k]
+        G = f.cell_gt_off[k + 1] - f.cell_gt_off[k]
+        if self.flat.kind == "lvis" and (D == 0 or G == 0):
+            return []           # mask_utils.iou returns [] (_mask.pyx:203-204)
+        return d["iou"][off[k]:off[k + 1]].reshape(D, G).copy()
+
+    def entry(self, k, r):
+        f, d = self.flat, self.run.detail()
+        d0, d1 = f.cell_dt_off[k], f.cell_dt_off[k + 1]
+        g0, g1 = f.cell_gt_off[k], f.cell_gt_off[k + 1]
+        D, G = d1 - d0, g1 - g0
+        gid = f.gt_id[g0:g1]
+        ig = ((d["gt_rng"][g0:g1] >> np.uint32(r)) & np.uint32(1)).astype(np.int64)
+        perm = np.argsort(ig, kind="mergesort")
+        dt_m = np.full((N_THR, D), float(self.sentinel))
+        gt_m = np.full((N_THR, G), float(self.sentinel))
+        dt_ig = np.zeros((N_THR, D), dtype=bool)
+        for t in range(N_THR):
+            combo = r * N_THR + t
+            m = d["match_gt"][d0:d1, combo]
+            hit = m >= 0
+            if G:
+                dt_m[t, hit] = gid[m[hit]]
+                for j in np.flatnonzero(hit):
+                    gt_m[t, m[j]] = f.dt_id[d0 + j]
+            dt_ig[t] = _bit(d["ignored"][d0:d1], combo)
+        return {
+            self.unit_key: int(self.unit_ids[f.cell_unit[k]]),
+            "category_id": int(f.cat_ids[f.cell_cat[k]]),
+            self.rng_key: self.rng_values[r],
+            "dt_ids": f.dt_id[d0:d1].tolist(),
+            "gt_ids": gid[perm].tolist(),
+            "dt_matches": dt_m,
+            "gt_matches": gt_m[:, perm],
+            "dt_scores": f.dt_score[d0:d1].tolist(),
+            "gt_ignore": ig[perm],
+            "dt_ignore": dt_ig,
+        }
+
+
+class LazyIous(Mapping):
+    """``self.ious``: {(unit_id, cat_id): (D, G) array or []} over ALL unit x
+    category pairs, like the reference, but computed on access."""
+
+    def __init__(self, view, unit_list, cat_list):
+        self.view, self.units, self.cats = view, unit_list, cat_list
+        self.upos = {int(u): i for i, u in enumerate(view.unit_ids)}
+        self.cpos = {int(c): i for i, c in enumerate(view.flat.cat_ids)}
+
+    def __getitem__(self, key):
+        u, c = key
+        if u not in self.upos or c not in self.cpos:
+            raise KeyError(key)
+        k = self.view.cell_of(self.upos[u], self.cpos[c])
+        return [] if k is None else self.view.iou(k)
+
+    def __iter__(self):
+        return ((int(u), int(c)) for u in self.units for c in self.cats)
+
+    def __len__(self):
+        return len(self.units) * len(self.cats)
+
+
+class LazyPointers(Mapping):
+    """eval['dt_pointers'][cat_idx][range...] = {dt_ids, tps, fps}."""
+
+    def __init__(self, run, n_rng, shape):
+        self.run, self.n_rng, self.shape = run, n_rng, shape
+        self._rows = None
+
+    def _data(self):
+        if self._rows is None:
+            self._rows = self.run.sorted_rows()
+        return self._rows
+
+    def leaf(self, k, r):
+        order, matched, ignored, num_gt = self._data()
+        if num_gt[k, r] == 0:
+            return {}
+        lo, hi = self.run.dp.cat_off_host[k], self.run.dp.cat_off_host[k + 1]
+        m = np.stack([_bit(matched[lo:hi], r * N_THR + t) for t in range(N_THR)])
+        i = np.stack([_bit(ignored[lo:hi], r * N_THR + t) for t in range(N_THR)])
+        return {"dt_ids": self.run.flat.dt_id[order[lo:hi]],
+                "tps": m & ~i, "fps": ~m & ~i}
+
+    def __getitem__(self, k):
+        if not 0 <= k < len(self):
+            raise KeyError(k)
+        if len(self.shape) == 1:
+            return {r: self.leaf(k, r) for r in range(self.shape[0])}
+        A, T = self.shape
+        return {a: {t: self.leaf(k, a * T + t) for t in range(T)}
+                for a in range(A)}
+
+    def __iter__(self):
+        return iter(range(len(self)))
+
+    def __len__(self):
+        return self.run.dp.n_cat
+
+
+def now():
+    return datetime.datetime.now().strftime("%Y-%m-%d %H:%M:%S")

@@ -133,13 +133,13 @@ def accumulate(f, gt_rng, matched, ignored):
     return prec, rec, order, num_gt
 
 
-def run_flat(f):
+def run_flat(f, detail=True):
     """Whole per-evaluator oracle pipeline on a flattened problem."""
     gt_rng, dt_rng = ranges(f)
     iou = pairs = None
     if f.kind == "tao":
         iou, pairs = track_iou(f)
-    matched, ignored, mg, ious_out = match(f, gt_rng, dt_rng, iou)
+    matched, ignored, mg, ious_out = match(f, gt_rng, dt_rng, iou, detail)
     prec, rec, order, num_gt = accumulate(f, gt_rng, matched, ignored)
     return dict(gt_rng=gt_rng, dt_rng=dt_rng,
                 iou=iou if f.kind == "tao" else ious_out, pairs=pairs,
