@@ -1,0 +1,105 @@
+"""``LVIS``: the annotation file of the image-level evaluator.
+
+Mirror of the reference class (tao_amodal/evaluation/lvis_amodal/lvis.py:18-153)
+for the part the bbox evaluation path uses.  The file is parsed once into
+``GTColumns`` (struct of arrays); the dict indexes of the reference
+(``anns``, ``imgs``, ``cats``, ``img_ann_map``, ``cat_img_map``) are built
+lazily, only if somebody asks for them -- the evaluation itself never does.
+"""
+import json
+import logging
+from collections import defaultdict
+
+from ...columns import GTColumns
+
+
+class LVIS:
+    def __init__(self, annotation_path):
+        """annotation_path: location of the annotation file (the reference
+        accepts a path only; an already parsed dict is accepted as well)."""
+        self.logger = logging.getLogger(__name__)
+        self.logger.info("Loading annotations.")
+        if isinstance(annotation_path, dict):
+            self.dataset = annotation_path
+        else:
+            self.dataset = self._load_json(annotation_path)
+        assert type(self.dataset) == dict, (
+            "Annotation file format {} not supported.".format(type(self.dataset)))
+        self._columns = None
+        self._index = None
+
+    def _load_json(self, path):
+        with open(path, "r") as f:
+            return json.load(f)
+
+    @property
+    def columns(self):
+        if self._columns is None:
+            self._columns = GTColumns.from_json(self.dataset)
+        return self._columns
+
+    # ------------------------------------------------- lazy dict indexes
+    def _create_index(self):
+        if self._index is None:
+            self.logger.info("Creating index.")
+            idx = {"anns": {}, "cats": {}, "imgs": {},
+                   "img_ann_map": defaultdict(list),
+                   "cat_img_map": defaultdict(list)}
+            for ann in self.dataset["annotations"]:
+                idx["img_ann_map"][ann["image_id"]].append(ann)
+                idx["anns"][ann["id"]] = ann
+                idx["cat_img_map"][ann["category_id"]].append(ann["image_id"])
+            for img in self.dataset["images"]:
+                idx["imgs"][img["id"]] = img
+            for cat in self.dataset["categories"]:
+                idx["cats"][cat["id"]] = cat
+            self._index = idx
+            self.logger.info("Index created.")
+        return self._index
+
+    anns = property(lambda self: self._create_index()["anns"])
+    cats = property(lambda self: self._create_index()["cats"])
+    imgs = property(lambda self: self._create_index()["imgs"])
+    img_ann_map = property(lambda self: self._create_index()["img_ann_map"])
+    cat_img_map = property(lambda self: self._create_index()["cat_img_map"])
+
+    def get_ann_ids(self, img_ids=None, cat_ids=None, area_rng=None):
+        """Same filter as the reference (lvis.py:63-97): strict area window."""
+        anns = []
+        if img_ids is not None:
+            for img_id in img_ids:
+                anns.extend(self.img_ann_map[img_id])
+        else:
+            anns = self.dataset["annotations"]
+        if cat_ids is None and area_rng is None:
+            return [a["id"] for a in anns]
+        cat_ids = set(cat_ids)
+        lo, hi = area_rng if area_rng is not None else (0, float("inf"))
+        return [a["id"] for a in anns
+                if a["category_id"] in cat_ids and lo < a["area"] < hi]
+
+    def get_cat_ids(self):
+        return [c["id"] for c in self.dataset["categories"]]
+
+    def get_img_ids(self):
+        return [i["id"] for i in self.dataset["images"]]
+
+    def _load_helper(self, _dict, ids):
+        return list(_dict.values()) if ids is None else [_dict[i] for i in ids]
+
+    def load_anns(self, ids=None):
+        return self._load_helper(self.anns, ids)
+
+    def load_cats(self, ids):
+        return self._load_helper(self.cats, ids)
+
+    def load_imgs(self, ids):
+        return self._load_helper(self.imgs, ids)
+
+    # segmentation / download helpers of the reference (lvis.py:155-205) are
+    # outside the bbox evaluation path
+    def ann_to_rle(self, ann):
+        raise NotImplementedError("segm evaluation is out of scope")
+
+    def ann_to_mask(self, ann):
+        raise NotImplementedError("segm evaluation is out of scope")

@@ -1,0 +1,64 @@
+"""``LVISResults``: the prediction list seen by the image-level evaluator
+(reference tao_amodal/evaluation/lvis_amodal/results.py:9-84).
+
+The reference deep-copies the whole ground truth and rewrites every
+prediction dict (area, id, polygon).  Here predictions are parsed once into
+``DTColumns``; the top-300-per-image cut, ``area = w*h`` and
+``id = position + 1`` are applied by ``flatten.flatten_lvis`` on arrays.
+"""
+import logging
+
+import numpy as np
+
+from ...columns import DTColumns
+from ...flatten import limit_dets_per_image
+from .lvis import LVIS
+
+
+class LVISResults(LVIS):
+    def __init__(self, lvis_gt, results, max_dets=300):
+        if isinstance(lvis_gt, LVIS):
+            self.gt = lvis_gt
+        elif isinstance(lvis_gt, str):
+            self.gt = LVIS(lvis_gt)
+        else:
+            raise TypeError("Unsupported type {} of lvis_gt.".format(lvis_gt))
+        self.logger = logging.getLogger(__name__)
+        self.logger.info("Loading and preparing results.")
+        if isinstance(results, DTColumns):
+            self.columns_dt = results
+        elif isinstance(results, str):
+            self.columns_dt = DTColumns.from_json(results)
+        else:
+            self.logger.warning(
+                "Assuming user provided the results in correct format.")
+            assert isinstance(results, list), "results is not a list."
+            self.columns_dt = DTColumns.from_json(results)
+        self.max_dets = max_dets
+        if len(self.columns_dt) == 0:
+            raise IndexError("list index out of range")  # results.py:42
+        assert np.isin(self.columns_dt.image_id, self.gt.columns.img_id).all(), \
+            "Results do not correspond to current LVIS set."
+        self._index = None
+        self._columns = None
+        self._dataset = None
+
+    @property
+    def dataset(self):
+        """GT dataset with ``annotations`` replaced by the kept predictions
+        (built on demand; the evaluation does not use it)."""
+        if self._dataset is None:
+            keep = limit_dets_per_image(self.columns_dt, self.max_dets)
+            anns = self.columns_dt.take(keep).to_json()
+            for k, a in enumerate(anns):
+                x, y, w, h = a["bbox"]
+                a["segmentation"] = [[x, y, x, y + h, x + w, y + h, x + w, y]]
+                a["area"] = w * h
+                a["id"] = k + 1
+            self._dataset = dict(self.gt.dataset)
+            self._dataset["annotations"] = anns
+        return self._dataset
+
+    def get_top_results(self, img_id, score_thrs):
+        anns = self.load_anns(self.get_ann_ids(img_ids=[img_id]))
+        return [a for a in anns if a["score"] > score_thrs]

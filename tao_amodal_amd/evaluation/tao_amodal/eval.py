@@ -1,0 +1,224 @@
+"""``TaoEval``: track-level federated mAP (3D IoU) on the GPU.  Same
+constructor, methods, public state and logged lines as the reference class
+(tao_amodal/evaluation/tao_amodal/eval.py:120-717); the per-(video, category)
+Python loops are replaced by the HIP pipeline over the non-empty cells.
+"""
+import logging
+from collections import OrderedDict
+from collections.abc import Mapping
+
+import numpy as np
+
+from .._core import (N_REC, N_THR, CellView, GpuRun, LazyIous, LazyPointers,
+                     masked_mean, now)
+from .results import TaoResults
+from .tao import Tao
+
+
+class Params:
+    def __init__(self, iou_type, iou_3d_type="3d_iou"):
+        """Params of the Tao evaluation (reference eval.py:720-757)."""
+        self.vid_ids = []
+        self.cat_ids = []
+        self.iou_thrs = np.linspace(
+            0.5, 0.95, int(np.round((0.95 - 0.5) / 0.05)) + 1, endpoint=True)
+        self.rec_thrs = np.linspace(
+            0.0, 1.00, int(np.round((1.00 - 0.0) / 0.01) + 1), endpoint=True)
+        self.max_dets = 300
+        self.area_rng = [[0 ** 2, 1e5 ** 2], [0 ** 2, 32 ** 2],
+                         [32 ** 2, 96 ** 2], [96 ** 2, 1e5 ** 2],
+                         [0 ** 2, 1e5 ** 2]]
+        self.area_rng_lbl = ["all", "small", "medium", "large",
+                             "highly-and-partially-occluded"]
+        self.time_rng = [[0, 1e5], [0, 3], [3, 10], [10, 1e5]]
+        self.time_rng_lbl = ["all", "short", "medium", "long"]
+        self.use_cats = 1
+        self.vid_count_lbl = ["r", "c", "f"]
+        self.iou_type = iou_type
+        self.iou_3d_type = iou_3d_type
+
+
+class _EvalVids(Mapping):
+    """``eval_vids[(v, c, a, t)]`` of the reference, rebuilt when read."""
+
+    def __init__(self, view, n_vid, n_cat, n_area, n_time):
+        self.view = view
+        self.shape = (n_vid, n_cat, n_area, n_time)
+
+    def __len__(self):
+        return int(np.prod(self.shape))
+
+    def __iter__(self):
+        V, C, A, T = self.shape
+        return ((v, c, a, t) for c in range(C) for a in range(A)
+                for t in range(T) for v in range(V))
+
+    def __getitem__(self, key):
+        v, c, a, t = key
+        V, C, A, T = self.shape
+        if not (0 <= v < V and 0 <= c < C and 0 <= a < A and 0 <= t < T):
+            raise KeyError(key)
+        k = self.view.cell_of(v, c)
+        if k is None:
+            return None
+        e = self.view.entry(k, a * T + t)
+        e["area_rng"], e["time_rng"] = e.pop("rng")
+        return e
+
+
+class TaoEval:
+    def __init__(self, tao_gt, tao_dt, logger=None, iou_type="bbox",
+                 iou_3d_type="3d_iou", device=None):
+        if not logger:
+            self.logger = logging.getLogger("tao.eval")
+        elif isinstance(logger, str):
+            self.logger = logging.getLogger(logger)
+        else:
+            self.logger = logger
+        if iou_type not in ["bbox", "segm"]:
+            raise ValueError("iou_type: {} is not supported.".format(iou_type))
+        if isinstance(tao_gt, Tao):
+            self.tao_gt = tao_gt
+        elif isinstance(tao_gt, str):
+            self.tao_gt = Tao(tao_gt)
+        else:
+            raise TypeError("Unsupported type {} of tao_gt.".format(tao_gt))
+        if isinstance(tao_dt, TaoResults):
+            self.tao_dt = tao_dt
+        elif isinstance(tao_dt, (str, list)):
+            self.tao_dt = TaoResults(self.tao_gt, tao_dt)
+        else:
+            raise TypeError("Unsupported type {} of tao_dt.".format(tao_dt))
+        self.device = device
+        self.eval_vids = {}
+        self.eval = {}
+        self.params = Params(iou_type=iou_type, iou_3d_type=iou_3d_type)
+        self.results = OrderedDict()
+        self.ious = {}
+        self.params.vid_ids = sorted(self.tao_gt.get_vid_ids())
+        self.params.cat_ids = sorted(self.tao_gt.get_cat_ids())
+        self.flat = self.tao_dt.flat
+        self._run = None
+
+    # ------------------------------------------------------------ stages
+    def evaluate(self, show_progress=False):
+        self.logger.info("Running per video evaluation.")
+        self.logger.info("Evaluate annotation type *{}*".format(self.params.iou_type))
+        if self.params.iou_type != "bbox":
+            raise NotImplementedError("only iou_type='bbox' runs on the HIP path")
+        if self.params.iou_3d_type != "3d_iou":
+            raise NotImplementedError(
+                "iou_3d_type %r is SURVEY.md 8(f) rank 2 (not on the CLI path)"
+                % self.params.iou_3d_type)
+        if not self.params.use_cats:
+            raise NotImplementedError("use_cats=0 is SURVEY.md 8(f) rank 2")
+        self.params.vid_ids = list(np.unique(self.params.vid_ids))
+        flat = self.flat
+        self._run = GpuRun(flat, self.device)
+        self._run.evaluate()
+        P = self.params
+        rngs = [(a, t) for a in P.area_rng for t in P.time_rng]
+        view = CellView(self._run, flat.vid_ids, -1, "video_id", "rng", rngs)
+        self.ious = LazyIous(view, P.vid_ids, P.cat_ids)
+        self.eval_vids = _EvalVids(view, len(P.vid_ids), len(P.cat_ids),
+                                   len(P.area_rng), len(P.time_rng))
+
+    def accumulate(self):
+        self.logger.info("Accumulating evaluation results.")
+        if self._run is None:
+            self.logger.warning("Please run evaluate first.")
+            return
+        self._run.accumulate()
+        P = self.params
+        A, T = len(P.area_rng), len(P.time_rng)
+        K = len(P.cat_ids)
+        self.eval = {
+            "params": P,
+            "counts": [N_THR, N_REC, K, A, T],
+            "date": now(),
+            "precision": self._run.precision.reshape(N_THR, N_REC, K, A, T),
+            "recall": self._run.recall.reshape(N_THR, K, A, T),
+            "dt_pointers": LazyPointers(self._run, A * T, (A, T)),
+        }
+
+    def _summarize(self, summary_type, iou_thr=None, area_rng="all",
+                   time_rng="all", freq_group_idx=None):
+        aidx = [i for i, lbl in enumerate(self.params.area_rng_lbl)
+                if lbl == area_rng]
+        tidx_ = [i for i, lbl in enumerate(self.params.time_rng_lbl)
+                 if lbl == time_rng]
+        if summary_type == "ap":
+            s = self.eval["precision"]
+            if iou_thr is not None:
+                s = s[np.where(iou_thr == self.params.iou_thrs)[0]]
+            s = s[:, :, :, aidx, tidx_]
+        else:
+            s = self.eval["recall"]
+            if iou_thr is not None:
+                s = s[np.where(iou_thr == self.params.iou_thrs)[0]]
+            s = s[:, :, aidx, tidx_]
+        return masked_mean(s)
+
+    def summarize(self):
+        if not self.eval:
+            raise RuntimeError("Please run accumulate() first.")
+        max_dets = self.params.max_dets
+        R = self.results
+        hp = "highly-and-partially-occluded"
+        R["AP"] = self._summarize("ap")
+        R["AP50"] = self._summarize("ap", iou_thr=0.50)
+        R["AP75"] = self._summarize("ap", iou_thr=0.75)
+        R["AP-HP"] = self._summarize("ap", area_rng=hp)
+        R["AP50-HP"] = self._summarize("ap", area_rng=hp, iou_thr=0.50)
+        R["AP75-HP"] = self._summarize("ap", area_rng=hp, iou_thr=0.75)
+        for rng in ["small", "medium", "large"]:
+            R[("AP", "area", rng, max_dets)] = self._summarize("ap", area_rng=rng)
+        for rng in ["short", "medium", "long"]:
+            R[("AP", "time", rng, max_dets)] = self._summarize("ap", time_rng=rng)
+        R["AR@{}".format(max_dets)] = self._summarize("ar")
+        for rng in ["small", "medium", "large"]:
+            R[("AR", "area", rng, max_dets)] = self._summarize("ar", area_rng=rng)
+        for rng in ["short", "medium", "long"]:
+            R[("AR", "time", rng, max_dets)] = self._summarize("ar", time_rng=rng)
+
+    def run(self, show_progress=False):
+        self.evaluate(show_progress=show_progress)
+        self.accumulate()
+        self.summarize()
+
+    def result_lines(self):
+        template = (" {:<18} {} @[ IoU={:<9} | area={:>6s} | dur={:>6s} | "
+                    "maxDets={:>3d} catIds={:>3s}] = {:0.3f}")
+        lines = []
+        for key, value in self.results.items():
+            max_dets = self.params.max_dets
+            is_ap = "AP" in key
+            area = time = "all"
+            if isinstance(key, tuple):
+                kind, rng, max_dets = key[1:]
+                if kind == "time":
+                    time = rng[0]
+                elif kind == "area":
+                    area = rng[0]
+                else:
+                    raise ValueError("This should not happen")
+            if len(key) > 2 and key[2].isdigit():
+                iou = "{:0.2f}".format(float(key[2:4]) / 100)
+            else:
+                iou = "{:0.2f}:{:0.2f}".format(self.params.iou_thrs[0],
+                                               self.params.iou_thrs[-1])
+            group = key[2] if len(key) > 2 and key[2] in ["r", "c", "f"] else "all"
+            lines.append(template.format(
+                "Average Precision" if is_ap else "Average Recall",
+                "(AP)" if is_ap else "(AR)", iou, area, time, max_dets, group,
+                value))
+        return lines
+
+    def print_results(self):
+        for line in self.result_lines():
+            self.logger.info(line)
+
+    def get_results(self):
+        if not self.results:
+            self.logger.warning("results is empty. Call run().")
+        return self.results

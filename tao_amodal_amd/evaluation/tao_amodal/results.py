@@ -1,0 +1,80 @@
+"""``TaoResults``: the prediction list seen by the track-level evaluator
+(reference tao_amodal/evaluation/tao_amodal/results.py:11-132).
+
+Predictions live in ``DTColumns``.  The checks the reference performs while
+building its dicts are performed on arrays: one video per track id
+(results.py:111-119), one category per track (:77-79), image ids known
+(:105-109).  Per-image top-300, track scores (mean of the boxes' scores when
+they differ, :88-98) and ``area = w*h`` happen in ``flatten.flatten_tao``.
+"""
+import logging
+
+import numpy as np
+
+from ... import flatten
+from ...columns import DTColumns
+from .tao import Tao
+
+
+class TaoResults(Tao):
+    def __init__(self, tao_gt, results, max_dets=300):
+        if isinstance(tao_gt, Tao):
+            self.gt = tao_gt
+        elif isinstance(tao_gt, str):
+            self.gt = Tao(tao_gt)
+        else:
+            raise TypeError("Unsupported type {} of tao_gt.".format(type(tao_gt)))
+        self.logger = logging.getLogger("tao.results")
+        self.logger.info("Loading and preparing results.")
+        if isinstance(results, DTColumns):
+            self.columns_dt = results
+        elif isinstance(results, str):
+            self.columns_dt = DTColumns.from_json(results)
+        else:
+            self.logger.warning(
+                "Assuming user provided the results in correct format.")
+            assert isinstance(results, list), "results is not a list."
+            self.columns_dt = DTColumns.from_json(results)
+        self.max_dets = max_dets
+        self.ensure_unique_track_ids(self.columns_dt)
+        if len(self.columns_dt) == 0:
+            raise IndexError("list index out of range")  # results.py:61
+        if len(self.gt.columns.cat_merged) == 0:
+            # TaoResults rebuilds the merge map twice (results.py:47 and, via
+            # _create_index, tao.py:115): two more root-logger records
+            logging.error("Did not merge any categories.")
+            logging.error("Did not merge any categories.")
+        # cell tables of the track-level problem; this is where the track
+        # scores are formed, as in the reference constructor
+        self.flat = flatten.flatten_tao(self.gt.columns, self.columns_dt,
+                                        max_dets)
+        keep = flatten.limit_dets_per_image(self.columns_dt, max_dets)
+        b = self.columns_dt.bbox[keep]
+        neg = int(np.count_nonzero((b[:, 0] < 0) | (b[:, 1] < 0)
+                                   | (b[:, 2] <= 0) | (b[:, 3] <= 0)))
+        if neg:
+            self.logger.warning(
+                f"{neg} annotations had negative values in coordinates!")
+        if self.flat.required_average:
+            self.logger.warning(
+                "At least one track had annotations with different scores; "
+                "using average of individual annotation scores as track "
+                "scores.")
+
+    @staticmethod
+    def ensure_unique_track_ids(dt):
+        if len(dt) == 0:
+            return
+        u, first, inv = np.unique(dt.track_id, return_index=True,
+                                  return_inverse=True)
+        bad = np.flatnonzero(dt.video_id != dt.video_id[first][inv])
+        if len(bad):
+            t = int(dt.track_id[bad[0]])
+            raise AssertionError(
+                f"Track id {t} appears in more than one video: "
+                f"{int(dt.video_id[first][inv][bad[0]])} and "
+                f"{int(dt.video_id[bad[0]])}")
+
+    def get_top_results(self, img_id, score_thrs):
+        raise NotImplementedError(
+            "Unclear if this should be per image or per video")

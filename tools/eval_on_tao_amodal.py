@@ -1,0 +1,138 @@
+#!/usr/bin/env python
+"""Drop-in for the reference's ``tools/eval_on_tao_amodal.py``: same three
+flags, same stdout / log-file text, evaluation on an MI355X.
+
+    python tools/eval_on_tao_amodal.py --track_result prediction.json \
+        --output_log out/eval.log --annotation validation_lvis_v1.json
+
+Flow (reference tools/eval_on_tao_amodal.py:155-165): image-level LVISEval on
+the pair, its 25 lines on stdout and the 21-metric table + two ``copypaste:``
+lines in the log; then ``make_track_ids_unique`` and the track-level TaoEval,
+its 19 lines and the four ``TAO 3DmAP...`` lines in the log.  Both JSON files
+are parsed once and shared by the two evaluators (the reference parses each of
+them twice and deep-copies the ground truth twice).
+"""
+import argparse
+import logging
+import os
+import sys
+from pathlib import Path
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
+import json  # noqa: E402
+
+from tao_amodal_amd import flatten  # noqa: E402
+from tao_amodal_amd.columns import DTColumns  # noqa: E402
+from tao_amodal_amd.evaluation.lvis_amodal import LVIS, LVISEval, LVISResults  # noqa: E402
+from tao_amodal_amd.evaluation.tao_amodal import Tao, TaoEval, TaoResults  # noqa: E402
+
+DEFAULT_ANNOTATION = (
+    "/compute/trinity-1-38/chengyeh/TAO/amodal_annotations/"
+    "validation_with_freeform_amodal_boxes_Aug10_2022_oof_visibility_GTR_"
+    "lvis_v1.json")
+
+LVIS_METRICS = ["AP", "AP50", "AP75",
+                "AP-HO", "AP50-HO", "AP75-HO",
+                "AP-PO", "AP50-PO", "AP75-PO",
+                "AP-HV", "AP50-HV", "AP75-HV",
+                "AP-OOF", "AP50-OOF", "AP75-OOF",
+                "AP-HP", "AP50-HP", "AP75-HP", "APr", "APc", "APf"]
+
+
+def default_arg_parser(argv=None):
+    parser = argparse.ArgumentParser(
+        description=__doc__.split("\n")[0],
+        formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    parser.add_argument("--track_result", type=str, required=True)
+    parser.add_argument("--output_log", type=str, required=True)
+    parser.add_argument("--annotation", type=str, default=None)
+    return parser.parse_args(argv)
+
+
+def create_small_table(small_dict):
+    """The one-row pipe table the reference gets from
+    ``detectron2.utils.logger.create_small_table`` (tabulate, tablefmt="pipe",
+    floatfmt=".3f", centred): header padded by two, ``str.center`` cells."""
+    keys = list(small_dict.keys())
+    vals = ["{:.3f}".format(v) for v in small_dict.values()]
+    widths = [max(len(k) + 2, len(v)) for k, v in zip(keys, vals)]
+    row = lambda cells: "|" + "|".join(  # noqa: E731
+        " {:^{w}s} ".format(c, w=w) for c, w in zip(cells, widths)) + "|"
+    sep = "|" + "|".join(":" + "-" * w + ":" for w in widths) + "|"
+    return "\n".join([row(keys), sep, row(vals)])
+
+
+def make_track_ids_unique(dt):
+    """reference tools/eval_on_tao_amodal.py:44-66, on columns (in place)."""
+    dt.track_id, n = flatten.make_track_ids_unique(dt)
+    return n
+
+
+def evaluate_predictions_on_lvis(lvis_gt, track_result, dt_columns, iou_type,
+                                 logger):
+    logger.info("Evaluating {} on LVIS...".format(track_result))
+    lvis_eval = LVISEval(lvis_gt, LVISResults(lvis_gt, dt_columns), iou_type)
+    lvis_eval.run()
+    lvis_eval.print_results()
+    results = lvis_eval.get_results()
+    results = {m: float(results[m] * 100) for m in LVIS_METRICS}
+    logger.info("Evaluation results for {}: \n".format(iou_type)
+                + create_small_table(results))
+    logger.info("copypaste: " + ",".join(LVIS_METRICS))
+    logger.info("copypaste: " + ",".join(
+        "{0:.4f}".format(results[m]) for m in LVIS_METRICS))
+    return results
+
+
+def eval_tao_track(ann_path, gt_dataset, dt_columns, logger):
+    logger.setLevel(logging.INFO)
+    results = {}
+    logger.info("Loading gt {}...".format(ann_path))
+    tao_gt = Tao(gt_dataset)
+    logger.info("Done")
+    logger.info("Loading results...")
+    make_track_ids_unique(dt_columns)
+    logger.info("Done")
+    logger.info("Building")
+    tao_eval = TaoEval(tao_gt, TaoResults(tao_gt, dt_columns), logger=logger)
+    logger.info("Done")
+    tao_eval.run()
+    tao_eval.print_results()
+    res = tao_eval.get_results()
+    results["TAO 3DmAP50"] = res["AP50"] * 100
+    results["TAO 3DmAP50-HP"] = res["AP50-HP"] * 100
+    results["TAO 3DmAP"] = res["AP"] * 100
+    results["TAO 3DmAP-HP"] = res["AP-HP"] * 100
+    keys = ["TAO 3DmAP50", "TAO 3DmAP50-HP", "TAO 3DmAP", "TAO 3DmAP-HP"]
+    for k in keys:
+        logger.info("{}:{:.4f}".format(k, results[k]))
+    logger.info("copypaste: " + ",".join(keys))
+    logger.info("copypaste: " + ",".join("{:.4f}".format(results[k]) for k in keys))
+    return results
+
+
+def main(argv=None):
+    args = default_arg_parser(argv)
+    annotation = args.annotation if args.annotation else DEFAULT_ANNOTATION
+    output_log = Path(args.output_log)
+    logger = logging.getLogger("__main__")
+    logger.setLevel(logging.INFO)
+    output_log.parent.mkdir(parents=True, exist_ok=True)
+    handler = logging.FileHandler(output_log, mode="w")
+    logger.addHandler(handler)
+    try:
+        with open(annotation, "r") as f:
+            gt_dataset = json.load(f)
+        lvis_gt = LVIS(gt_dataset)
+        dt_columns = DTColumns.from_json(args.track_result)
+        evaluate_predictions_on_lvis(lvis_gt, args.track_result, dt_columns,
+                                     "bbox", logger)
+        eval_tao_track(annotation, gt_dataset, dt_columns, logger)
+    finally:
+        logger.removeHandler(handler)
+        handler.close()
+
+
+if __name__ == "__main__":
+    main()
