@@ -142,6 +142,9 @@ int taoamd_track_iou(int64_t n_cells, const int32_t *cell_dt_off,
  *   match_gt (opt.)  : int32[n_dt * n_rng*10], in-cell GT index or -1
  *                      (always in identity order)
  *   ious_out (opt.)  : LVIS only, double at cell_iou_off like `iou`
+ * out_stride: distance, in 64-bit words, between consecutive output rows of
+ * matched / ignored (0 = n_words, i.e. dense); lets the kernel write straight
+ * into an interleaved exchange record.
  * max_gt_per_cell must be >= the largest GT count of a cell (host knows it
  * from the CSR table); cells with more than 64 GTs take a slower kernel and
  * more than TAOAMD_MAX_GT_PER_CELL is an error. */
@@ -152,8 +155,9 @@ int taoamd_match(int64_t n_cells, const int32_t *cell_dt_off,
                  const double *gt_box, const double *iou, int32_t n_rng,
                  const uint32_t *gt_rng, const uint32_t *dt_rng,
                  const uint8_t *gt_flags, const uint8_t *dt_flags,
-                 const int32_t *dst, uint64_t *matched, uint64_t *ignored,
-                 int32_t *match_gt, double *ious_out, void *stream);
+                 const int32_t *dst, int64_t out_stride, uint64_t *matched,
+                 uint64_t *ignored, int32_t *match_gt, double *ious_out,
+                 void *stream);
 
 /* ---- stable sort by (category asc, score desc) ---------------------------------
  * order[p] = detection at sorted position p; dst[d] = sorted position of
@@ -165,6 +169,14 @@ int taoamd_sort_by_cat_score(int64_t n, const int32_t *dt_cat,
                              int32_t *dst, void *workspace,
                              size_t workspace_bytes, void *stream);
 
+/* ---- row gather -----------------------------------------------------------------
+ * dst_*[p*n_words + w] = src_*[order[p]*src_stride + w]: brings exchanged
+ * records (multi-GPU path) into sorted order. */
+int taoamd_gather_rows(int64_t n, int32_t n_words, const uint64_t *src_matched,
+                       const uint64_t *src_ignored, int64_t src_stride,
+                       const int32_t *order, uint64_t *dst_matched,
+                       uint64_t *dst_ignored, void *stream);
+
 /* ---- accumulate -------------------------------------------------------------------
  * matched/ignored are in sorted order (row p = sorted position p); cat_off
  * (int32[n_cat+1], device) delimits the categories in that order.  Outputs, C
@@ -172,6 +184,26 @@ int taoamd_sort_by_cat_score(int64_t n, const int32_t *dt_cat,
  *   precision[T][R][n_cat][n_rng], recall[T][n_cat][n_rng]
  * Workspace: taoamd_accumulate_workspace(n_dt, n_cat, n_rng). */
 size_t taoamd_accumulate_workspace(int64_t n_dt, int32_t n_cat, int32_t n_rng);
+/* The two halves of taoamd_accumulate, used separately by the multi-GPU path:
+ *  _compact  sweeps the categories [k_begin, k_end) (rows of other categories
+ *            must be absent) and writes the category-major tables
+ *              val[n_cat][n_rng][T][R]   precision at the recall thresholds
+ *              rec[n_cat][n_rng][T]      recall
+ *            for every (k, range) with num_gt > 0 in that category range;
+ *  _finalize turns complete tables into the reference layout (-1 fill).
+ * Category-major tables make a rank's share one contiguous block, so ranks
+ * exchange them with a single all-gather.
+ * Workspace of _compact: taoamd_accumulate_workspace (val/rec excluded). */
+size_t taoamd_compact_elems(int32_t n_cat, int32_t n_rng); /* doubles in val */
+int taoamd_accumulate_compact(int64_t n_dt, int32_t n_cat, int32_t n_rng,
+                              const int32_t *cat_off, const uint64_t *matched,
+                              const uint64_t *ignored, const int32_t *num_gt,
+                              int32_t k_begin, int32_t k_end, double *val,
+                              double *rec, void *workspace,
+                              size_t workspace_bytes, void *stream);
+int taoamd_finalize(int32_t n_cat, int32_t n_rng, const int32_t *num_gt,
+                    const double *val, const double *rec, double *precision,
+                    double *recall, void *stream);
 int taoamd_accumulate(int64_t n_dt, int32_t n_cat, int32_t n_rng,
                       const int32_t *cat_off, const uint64_t *matched,
                       const uint64_t *ignored,

@@ -32,8 +32,15 @@ SIGNATURES = {
     "taoamd_track_iou": (C.c_int, [_i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp,
                                    _vp, _vp, _vp, _vp, _vp, _vp]),
     "taoamd_match": (C.c_int, [_i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32,
-                               _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                               _vp]),
+                               _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp,
+                               _vp, _vp]),
+    "taoamd_gather_rows": (C.c_int, [_i64, _i32, _vp, _vp, _i64, _vp, _vp,
+                                     _vp, _vp]),
+    "taoamd_compact_elems": (_sz, [_i32, _i32]),
+    "taoamd_accumulate_compact": (C.c_int, [_i64, _i32, _i32, _vp, _vp, _vp,
+                                            _vp, _i32, _i32, _vp, _vp, _vp,
+                                            _sz, _vp]),
+    "taoamd_finalize": (C.c_int, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "taoamd_sort_workspace": (_sz, [_i64]),
     "taoamd_sort_by_cat_score": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _sz,
                                            _vp]),

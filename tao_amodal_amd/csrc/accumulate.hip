@@ -44,7 +44,8 @@ struct AccArgs {
     uint32_t *pre_tp, *pre_fp;   // exclusive prefix inside the category
     double *cmax;                // chunk max, then reverse-exclusive max
     double *val;                 // [n_cat][n_rng][N_THR][N_REC]
-    double *precision, *recall;
+    double *rec;                 // [n_cat][n_rng][N_THR]
+    int32_t k_begin, k_end;      // categories swept by this call
 };
 
 __global__ __launch_bounds__(256) void acc_chunks_kernel(AccArgs a)
@@ -161,9 +162,9 @@ __global__ __launch_bounds__(256) void acc_prefix_kernel(AccArgs a)
 {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t item = (int64_t)blockIdx.x * 4 + wave;
-    if (item >= (int64_t)a.n_cat * a.n_words) return;
-    const int32_t k = (int32_t)(item / a.n_words);
-    const int word = (int)(item - (int64_t)k * a.n_words);
+    if (item >= (int64_t)(a.k_end - a.k_begin) * a.n_words) return;
+    const int32_t k = a.k_begin + (int32_t)(item / a.n_words);
+    const int word = (int)(item % a.n_words);
     const int lane = lane_id();
     const int32_t c0 = a.cat_chunk_off[k], c1 = a.cat_chunk_off[k + 1];
     uint32_t tp = 0, fp = 0;
@@ -179,8 +180,16 @@ __global__ __launch_bounds__(256) void acc_prefix_kernel(AccArgs a)
     if (combo < a.n_rng * N_THR) {
         const int r = combo / N_THR, t = combo - r * N_THR;
         const int32_t ng = a.num_gt[(int64_t)k * a.n_rng + r];
-        a.recall[((int64_t)t * a.n_cat + k) * a.n_rng + r] =
-            ng > 0 ? (double)tp / (double)ng : -1.0;
+        if (ng > 0) {
+            const int64_t kr = (int64_t)k * a.n_rng + r;
+            a.rec[kr * N_THR + t] = (double)tp / (double)ng;
+            // a category without detections still has precision 0 / recall 0
+            // where it has evaluated GT (reference lvis_amodal/eval.py:412-417)
+            if (c0 == c1) {
+                double *out = a.val + (kr * N_THR + t) * N_REC;
+                for (int j = 0; j < N_REC; j++) out[j] = 0.0;
+            }
+        }
     }
 }
 
@@ -216,9 +225,9 @@ __global__ __launch_bounds__(256) void acc_sufmax_kernel(AccArgs a)
 {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t item = (int64_t)blockIdx.x * 4 + wave;
-    if (item >= (int64_t)a.n_cat * a.n_words) return;
-    const int32_t k = (int32_t)(item / a.n_words);
-    const int word = (int)(item - (int64_t)k * a.n_words);
+    if (item >= (int64_t)(a.k_end - a.k_begin) * a.n_words) return;
+    const int32_t k = a.k_begin + (int32_t)(item / a.n_words);
+    const int word = (int)(item % a.n_words);
     const int lane = lane_id();
     const int32_t c0 = a.cat_chunk_off[k], c1 = a.cat_chunk_off[k + 1];
     double run = 0.0;
@@ -291,8 +300,15 @@ __global__ __launch_bounds__(256) void acc_emit_kernel(AccArgs a, RecThr rec_in)
         }
 }
 
-// val[KR][T*R] -> precision[T*R][KR] with -1 / 0 fill
-__global__ __launch_bounds__(256) void acc_transpose_kernel(AccArgs a)
+// val[KR][T*R] -> precision[T*R][KR], rec[KR][T] -> recall[T][KR], -1 fill
+struct FinArgs {
+    int32_t n_cat, n_rng;
+    const int32_t *num_gt;
+    const double *val, *rec;
+    double *precision, *recall;
+};
+
+__global__ __launch_bounds__(256) void acc_finalize_kernel(FinArgs a)
 {
     __shared__ double tile[32][33];
     const int64_t KR = (int64_t)a.n_cat * a.n_rng;
@@ -303,17 +319,23 @@ __global__ __launch_bounds__(256) void acc_transpose_kernel(AccArgs a)
     for (int i = ty; i < 32; i += 8) {
         const int64_t row = row0 + i, col = col0 + tx;
         double v = -1.0;
-        if (row < KR && col < COLS) {
-            const int32_t k = (int32_t)(row / a.n_rng);
-            if (a.num_gt[row] > 0)
-                v = (a.cat_off[k + 1] > a.cat_off[k]) ? a.val[row * COLS + col] : 0.0;
-        }
+        if (row < KR && col < COLS && a.num_gt[row] > 0) v = a.val[row * COLS + col];
         tile[i][tx] = v;
     }
     __syncthreads();
     for (int i = ty; i < 32; i += 8) {
         const int64_t col = col0 + i, row = row0 + tx;
         if (row < KR && col < COLS) a.precision[col * KR + row] = tile[tx][i];
+    }
+    // recall: the first column-block also transposes rec[KR][T]
+    if (blockIdx.y == 0) {
+        for (int i = threadIdx.x; i < 32 * N_THR; i += 256) {
+            const int64_t row = row0 + i / N_THR;
+            const int t = i % N_THR;
+            if (row < KR)
+                a.recall[(int64_t)t * KR + row] =
+                    a.num_gt[row] > 0 ? a.rec[row * N_THR + t] : -1.0;
+        }
     }
 }
 
@@ -324,14 +346,85 @@ static int32_t max_chunks(int64_t n_dt, int32_t n_cat)
     return (int32_t)((n_dt + ACC_CH - 1) / ACC_CH + n_cat);
 }
 
-extern "C" size_t taoamd_accumulate_workspace(int64_t n_dt, int32_t n_cat,
-                                              int32_t n_rng)
+static size_t base_workspace(int64_t n_dt, int32_t n_cat, int32_t n_rng)
 {
     const size_t nw = (size_t)(n_rng * N_THR + 63) / 64;
     const size_t nc = (size_t)max_chunks(n_dt, n_cat);
     return align256(((size_t)n_cat + 1) * 4) + 4 * align256(nc * nw * WAVE * 4) +
-           align256(nc * nw * WAVE * 8) +
-           align256((size_t)n_cat * n_rng * N_THR * N_REC * 8) + 4096;
+           align256(nc * nw * WAVE * 8) + 4096;
+}
+
+extern "C" size_t taoamd_compact_elems(int32_t n_cat, int32_t n_rng)
+{
+    return (size_t)n_cat * n_rng * N_THR * N_REC;
+}
+
+extern "C" size_t taoamd_accumulate_workspace(int64_t n_dt, int32_t n_cat,
+                                              int32_t n_rng)
+{
+    return base_workspace(n_dt, n_cat, n_rng) +
+           align256(taoamd_compact_elems(n_cat, n_rng) * 8) +
+           align256((size_t)n_cat * n_rng * N_THR * 8);
+}
+
+extern "C" int taoamd_accumulate_compact(int64_t n_dt, int32_t n_cat,
+                                         int32_t n_rng, const int32_t *cat_off,
+                                         const uint64_t *matched,
+                                         const uint64_t *ignored,
+                                         const int32_t *num_gt, int32_t k_begin,
+                                         int32_t k_end, double *val, double *rec,
+                                         void *workspace, size_t workspace_bytes,
+                                         void *stream)
+{
+    if (n_cat <= 0 || n_rng < 1 || n_rng > 32) return TAOAMD_ERR_ARG;
+    if (k_begin < 0 || k_end > n_cat || k_begin > k_end) return TAOAMD_ERR_ARG;
+    if (!cat_off || !num_gt || !val || !rec || !workspace) return TAOAMD_ERR_ARG;
+    if (workspace_bytes < base_workspace(n_dt, n_cat, n_rng))
+        return TAOAMD_ERR_WORKSPACE;
+    if (k_begin == k_end) return TAOAMD_OK;
+    hipStream_t s = (hipStream_t)stream;
+    AccArgs a;
+    a.n_dt = n_dt; a.n_cat = n_cat; a.n_rng = n_rng;
+    a.n_words = (n_rng * N_THR + 63) / 64;
+    a.n_chunks_max = max_chunks(n_dt, n_cat);
+    a.cat_off = cat_off; a.matched = matched; a.ignored = ignored;
+    a.num_gt = num_gt; a.val = val; a.rec = rec;
+    a.k_begin = k_begin; a.k_end = k_end;
+    unsigned char *w = (unsigned char *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    const size_t nc = (size_t)a.n_chunks_max, nw = (size_t)a.n_words;
+    a.cat_chunk_off = (int32_t *)w; w += align256(((size_t)n_cat + 1) * 4);
+    a.cnt_tp = (uint32_t *)w; w += align256(nc * nw * WAVE * 4);
+    a.cnt_fp = (uint32_t *)w; w += align256(nc * nw * WAVE * 4);
+    a.pre_tp = (uint32_t *)w; w += align256(nc * nw * WAVE * 4);
+    a.pre_fp = (uint32_t *)w; w += align256(nc * nw * WAVE * 4);
+    a.cmax = (double *)w;
+    const unsigned chunk_blocks = (unsigned)((nc * nw + 3) / 4);
+    const unsigned cat_blocks = (unsigned)(((size_t)(k_end - k_begin) * nw + 3) / 4);
+    acc_chunks_kernel<<<1, 256, 0, s>>>(a);
+    acc_count_kernel<<<chunk_blocks, 256, 0, s>>>(a);
+    acc_prefix_kernel<<<cat_blocks, 256, 0, s>>>(a);
+    acc_chunkmax_kernel<<<chunk_blocks, 256, 0, s>>>(a);
+    acc_sufmax_kernel<<<cat_blocks, 256, 0, s>>>(a);
+    acc_emit_kernel<<<chunk_blocks, 256, 0, s>>>(a, rec_thr());
+    TAO_LAUNCH_CHECK();
+    return TAOAMD_OK;
+}
+
+extern "C" int taoamd_finalize(int32_t n_cat, int32_t n_rng,
+                               const int32_t *num_gt, const double *val,
+                               const double *rec, double *precision,
+                               double *recall, void *stream)
+{
+    if (n_cat <= 0 || n_rng < 1 || n_rng > 32) return TAOAMD_ERR_ARG;
+    if (!num_gt || !val || !rec || !precision || !recall) return TAOAMD_ERR_ARG;
+    FinArgs f;
+    f.n_cat = n_cat; f.n_rng = n_rng; f.num_gt = num_gt; f.val = val; f.rec = rec;
+    f.precision = precision; f.recall = recall;
+    const int64_t KR = (int64_t)n_cat * n_rng;
+    dim3 grid((unsigned)((KR + 31) / 32), (unsigned)((N_THR * N_REC + 31) / 32));
+    acc_finalize_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(f);
+    TAO_LAUNCH_CHECK();
+    return TAOAMD_OK;
 }
 
 extern "C" int taoamd_accumulate(int64_t n_dt, int32_t n_cat, int32_t n_rng,
@@ -343,36 +436,16 @@ extern "C" int taoamd_accumulate(int64_t n_dt, int32_t n_cat, int32_t n_rng,
                                  void *stream)
 {
     if (n_cat <= 0 || n_rng < 1 || n_rng > 32) return TAOAMD_ERR_ARG;
-    if (!cat_off || !num_gt || !precision || !recall || !workspace) return TAOAMD_ERR_ARG;
+    if (!workspace) return TAOAMD_ERR_ARG;
     if (workspace_bytes < taoamd_accumulate_workspace(n_dt, n_cat, n_rng))
         return TAOAMD_ERR_WORKSPACE;
-    hipStream_t s = (hipStream_t)stream;
-    AccArgs a;
-    a.n_dt = n_dt; a.n_cat = n_cat; a.n_rng = n_rng;
-    a.n_words = (n_rng * N_THR + 63) / 64;
-    a.n_chunks_max = max_chunks(n_dt, n_cat);
-    a.cat_off = cat_off; a.matched = matched; a.ignored = ignored;
-    a.num_gt = num_gt; a.precision = precision; a.recall = recall;
     unsigned char *w = (unsigned char *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
-    const size_t nc = (size_t)a.n_chunks_max, nw = (size_t)a.n_words;
-    a.cat_chunk_off = (int32_t *)w; w += align256(((size_t)n_cat + 1) * 4);
-    a.cnt_tp = (uint32_t *)w; w += align256(nc * nw * WAVE * 4);
-    a.cnt_fp = (uint32_t *)w; w += align256(nc * nw * WAVE * 4);
-    a.pre_tp = (uint32_t *)w; w += align256(nc * nw * WAVE * 4);
-    a.pre_fp = (uint32_t *)w; w += align256(nc * nw * WAVE * 4);
-    a.cmax = (double *)w; w += align256(nc * nw * WAVE * 8);
-    a.val = (double *)w;
-    const unsigned chunk_blocks = (unsigned)((nc * nw + 3) / 4);
-    const unsigned cat_blocks = (unsigned)(((size_t)n_cat * nw + 3) / 4);
-    acc_chunks_kernel<<<1, 256, 0, s>>>(a);
-    acc_count_kernel<<<chunk_blocks, 256, 0, s>>>(a);
-    acc_prefix_kernel<<<cat_blocks, 256, 0, s>>>(a);
-    acc_chunkmax_kernel<<<chunk_blocks, 256, 0, s>>>(a);
-    acc_sufmax_kernel<<<cat_blocks, 256, 0, s>>>(a);
-    acc_emit_kernel<<<chunk_blocks, 256, 0, s>>>(a, rec_thr());
-    const int64_t KR = (int64_t)n_cat * n_rng;
-    dim3 grid((unsigned)((KR + 31) / 32), (unsigned)((N_THR * N_REC + 31) / 32));
-    acc_transpose_kernel<<<grid, 256, 0, s>>>(a);
-    TAO_LAUNCH_CHECK();
-    return TAOAMD_OK;
+    const size_t base = base_workspace(n_dt, n_cat, n_rng);
+    double *val = (double *)(w + base);
+    double *rec = val + (align256(taoamd_compact_elems(n_cat, n_rng) * 8) / 8);
+    int st = taoamd_accumulate_compact(n_dt, n_cat, n_rng, cat_off, matched,
+                                       ignored, num_gt, 0, n_cat, val, rec, w,
+                                       base, stream);
+    if (st != TAOAMD_OK) return st;
+    return taoamd_finalize(n_cat, n_rng, num_gt, val, rec, precision, recall, stream);
 }

@@ -219,7 +219,7 @@ struct MatchArgs {
     double *ious_out;
     int32_t n_rng;
     int32_t n_words;
-    int32_t big_only;  // 1: handle only cells with G > 64 (big kernel)
+    int64_t out_stride;  // words between consecutive output rows
 };
 
 // Fast path: G <= 64.  One wavefront per (cell, word).
@@ -317,8 +317,8 @@ __global__ __launch_bounds__(256) void match_kernel(MatchArgs a, IouThr thr)
                 a.match_gt[(int64_t)d * n_combo + combo] = m;
         }
         if (lane < nd) {
-            a.matched[t_row * a.n_words + word] = my_m;
-            a.ignored[t_row * a.n_words + word] = my_i;
+            a.matched[t_row * a.out_stride + word] = my_m;
+            a.ignored[t_row * a.out_stride + word] = my_i;
         }
     }
 }
@@ -390,8 +390,8 @@ __global__ __launch_bounds__(64) void match_big_kernel(MatchArgs a, IouThr thr,
         const uint64_t iw = __ballot(active && ig);
         if (lane == 0) {
             const int64_t rowi = a.dst != nullptr ? a.dst[d] : d;
-            a.matched[rowi * a.n_words + word] = mw;
-            a.ignored[rowi * a.n_words + word] = iw;
+            a.matched[rowi * a.out_stride + word] = mw;
+            a.ignored[rowi * a.out_stride + word] = iw;
         }
         if (a.match_gt != nullptr && active)
             a.match_gt[(int64_t)d * n_combo + combo] = m;
@@ -505,8 +505,9 @@ extern "C" int taoamd_match(int64_t n_cells, const int32_t *cell_dt_off,
                             int32_t n_rng, const uint32_t *gt_rng,
                             const uint32_t *dt_rng, const uint8_t *gt_flags,
                             const uint8_t *dt_flags, const int32_t *dst,
-                            uint64_t *matched, uint64_t *ignored,
-                            int32_t *match_gt, double *ious_out, void *stream)
+                            int64_t out_stride, uint64_t *matched,
+                            uint64_t *ignored, int32_t *match_gt,
+                            double *ious_out, void *stream)
 {
     if (n_cells == 0) return TAOAMD_OK;
     if (n_rng < 1 || n_rng > 32) return TAOAMD_ERR_ARG;
@@ -520,7 +521,9 @@ extern "C" int taoamd_match(int64_t n_cells, const int32_t *cell_dt_off,
     a.iou = iou; a.gt_rng = gt_rng; a.dt_rng = dt_rng; a.gt_flags = gt_flags;
     a.dt_flags = dt_flags; a.dst = dst; a.matched = matched; a.ignored = ignored;
     a.match_gt = match_gt; a.ious_out = ious_out; a.n_rng = n_rng;
-    a.n_words = (n_rng * N_THR + 63) / 64; a.big_only = 0;
+    a.n_words = (n_rng * N_THR + 63) / 64;
+    a.out_stride = out_stride > 0 ? out_stride : a.n_words;
+    if (a.out_stride < a.n_words) return TAOAMD_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     const int64_t items = n_cells * a.n_words;
     const unsigned blocks = (unsigned)((items + 3) / 4);
@@ -538,5 +541,43 @@ extern "C" int taoamd_match(int64_t n_cells, const int32_t *cell_dt_off,
             match_big_kernel<false><<<(unsigned)items, 64, lds, s>>>(a, iou_thr(), cap);
         TAO_LAUNCH_CHECK();
     }
+    return TAOAMD_OK;
+}
+
+// ------------------------------------------------------------- row gather
+__global__ void gather_rows_kernel(int64_t n, int32_t n_words,
+                                   const uint64_t *__restrict__ sm,
+                                   const uint64_t *__restrict__ si,
+                                   int64_t stride,
+                                   const int32_t *__restrict__ order,
+                                   uint64_t *__restrict__ dm,
+                                   uint64_t *__restrict__ di)
+{
+    const int64_t total = n * n_words;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = i / n_words;
+        const int w = (int)(i - p * n_words);
+        const int64_t src = (int64_t)order[p] * stride + w;
+        dm[i] = sm[src];
+        di[i] = si[src];
+    }
+}
+
+extern "C" int taoamd_gather_rows(int64_t n, int32_t n_words,
+                                  const uint64_t *src_matched,
+                                  const uint64_t *src_ignored,
+                                  int64_t src_stride, const int32_t *order,
+                                  uint64_t *dst_matched, uint64_t *dst_ignored,
+                                  void *stream)
+{
+    if (n == 0) return TAOAMD_OK;
+    if (n_words < 1 || src_stride < n_words) return TAOAMD_ERR_ARG;
+    const int64_t total = n * n_words;
+    unsigned blocks = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    gather_rows_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(
+        n, n_words, src_matched, src_ignored, src_stride, order, dst_matched,
+        dst_ignored);
+    TAO_LAUNCH_CHECK();
     return TAOAMD_OK;
 }

@@ -166,7 +166,7 @@ def stage_match(dp, ws, scatter=True):
         _ptr(t["gt_box"]) if fused else None,
         None if fused else _ptr(ws.iou), dp.n_rng, _ptr(ws.gt_rng),
         _ptr(ws.dt_rng), _ptr(t["gt_flags"]), _ptr(t["dt_flags"]),
-        _ptr(ws.dst) if scatter else None, _ptr(ws.matched),
+        _ptr(ws.dst) if scatter else None, 0, _ptr(ws.matched),
         _ptr(ws.ignored), _ptr(ws.match_gt), _ptr(ws.ious_out), s),
         "taoamd_match")
 

@@ -1,0 +1,196 @@
+"""world_size-2 run of tao_amodal_amd.dist over gloo on CPU tensors.
+
+The collective plumbing (owner partition, all_to_all of records, received
+order == concatenation order, category-block all_gather, finalize) is the
+product code; the kernels are replaced by an oracle-backed stand-in, which is
+allowed here because this is a test.  Both ranks must end with exactly the
+tensors a single process computes on the whole problem."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import orclib
+
+N_THR, N_REC = 10, 101
+
+
+class OracleBackend:
+    def __init__(self, flats):
+        self.flats = flats          # id(dp) -> Flat
+
+    def _f(self, dp):
+        return self.flats[id(dp)]
+
+    def ranges(self, dp, ws):
+        f = self._f(dp)
+        g, d = orclib.ranges(f)
+        ws.gt_rng[:len(g)] = torch.from_numpy(g.view(np.int32))
+        ws.dt_rng[:len(d)] = torch.from_numpy(d.view(np.int32))
+        num = np.zeros((dp.n_cat, dp.n_rng), np.int32)
+        for r in range(dp.n_rng):
+            np.add.at(num[:, r], f.gt_cat[((g >> np.uint32(r)) & 1) == 0], 1)
+        ws.num_gt.copy_(torch.from_numpy(num))
+
+    def track_iou(self, dp, ws):
+        if dp.kind == "tao":
+            iou, pairs = orclib.track_iou(self._f(dp))
+            ws.iou[:len(iou)] = torch.from_numpy(iou)
+            ws.pair_frames[0] = pairs
+
+    def match_into(self, dp, ws, dst, records, width):
+        f = self._f(dp)
+        g = ws.gt_rng[:dp.n_gt].numpy().view(np.uint32)
+        d = ws.dt_rng[:dp.n_dt].numpy().view(np.uint32)
+        iou = ws.iou[:dp.n_iou].numpy() if dp.kind == "tao" else None
+        m, i, _, _ = orclib.match(f, g, d, iou, detail=False)
+        nw = dp.n_words
+        slot = dst.numpy().astype(np.int64)
+        rec = records.numpy()
+        rec[slot, 2:2 + nw] = m.view(np.int64)
+        rec[slot, 2 + nw:2 + 2 * nw] = i.view(np.int64)
+
+    def sort(self, n, cat, score, order, ws_buf, ws_bytes):
+        c, s = cat[:n].numpy(), score[:n].numpy()
+        order[:n] = torch.from_numpy(
+            np.lexsort((np.arange(n), -(s + 0.0), c)).astype(np.int32))
+
+    def gather_rows(self, n, n_words, records, width, order, matched, ignored):
+        o = order[:n].numpy().astype(np.int64)
+        rec = records.numpy()
+        matched[:n] = torch.from_numpy(rec[o, 2:2 + n_words].copy())
+        ignored[:n] = torch.from_numpy(rec[o, 2 + n_words:2 + 2 * n_words].copy())
+
+    def accumulate_compact(self, n, n_cat, n_rng, cat_off, matched, ignored,
+                           num_gt, k0, k1, val, rec, ws_buf, ws_bytes):
+        import ctypes as C
+        co = cat_off.numpy().astype(np.int64)
+        cat = np.repeat(np.arange(n_cat, dtype=np.int32), np.diff(co))
+        score = -np.arange(n, dtype=np.float64)     # rows are already sorted
+        ng = num_gt.numpy()
+        # feed the C oracle GT tables that reproduce num_gt exactly
+        gcat, grng = [], []
+        for k in range(n_cat):
+            for r in range(n_rng):
+                gcat += [k] * int(ng[k, r])
+                grng += [(~(1 << r)) & 0xffffffff] * int(ng[k, r])
+        gcat = np.asarray(gcat, np.int32)
+        grng = np.asarray(grng, np.uint32)
+        prec = np.zeros((N_THR, N_REC, n_cat, n_rng))
+        rc = np.zeros((N_THR, n_cat, n_rng))
+        m = np.ascontiguousarray(matched[:max(n, 1)].numpy().view(np.uint64))
+        i = np.ascontiguousarray(ignored[:max(n, 1)].numpy().view(np.uint64))
+        p = orclib._p
+        orclib.lib().orc_accumulate(
+            C.c_int64(n), C.c_int32(n_cat), C.c_int(n_rng), p(cat), p(score), p(m),
+            p(i), C.c_int64(len(gcat)), p(gcat), p(grng), p(prec), p(rc), None, None)
+        v, rr = val.numpy(), rec.numpy()
+        for k in range(k0, k1):
+            for r in range(n_rng):
+                if ng[k, r] > 0:
+                    v[k, r] = prec[:, :, k, r]
+                    rr[k, r] = rc[:, k, r]
+
+    def finalize(self, n_cat, n_rng, num_gt, val, rec, precision, recall):
+        ng = num_gt.numpy() > 0
+        v = val.numpy()[:n_cat]
+        p = np.where(ng[None, None], v.transpose(2, 3, 0, 1), -1.0)
+        r = np.where(ng[None], rec.numpy()[:n_cat].transpose(2, 0, 1), -1.0)
+        precision.copy_(torch.from_numpy(np.ascontiguousarray(p)))
+        recall.copy_(torch.from_numpy(np.ascontiguousarray(r)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, out):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "tests")]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tao_amodal_amd import dist as tdist, engine, flatten
+    from tao_amodal_amd.synth import synth
+    gt, dt = synth(seed=17, V=6, F=12, C=23, dets_per_frame=30, n_present=4)
+    fl = flatten.flatten_lvis(gt, dt)
+    dt.track_id, _ = flatten.make_track_ids_unique(dt)
+    ft = flatten.flatten_tao(gt, dt)
+    res = {}
+    for name, flat in (("lvis", fl), ("tao", ft)):
+        b = tdist.shard_bounds(flat, world)
+        shard = tdist.shard_flat(flat, b[rank], b[rank + 1])
+        dp = engine.DeviceProblem(shard, "cpu")
+        ws = engine.Workspace(dp)
+        be = OracleBackend({id(dp): shard})
+        ev = tdist.ShardedEval(dp, ws, rank, world, be)
+        ev.step()
+        ev.step()          # a second step must reproduce the first
+        res[name] = (ev.precision.numpy().copy(), ev.recall.numpy().copy(),
+                     ev.num_gt.numpy().copy(), b)
+    torch.save(res, os.path.join(out, "rank%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_reproduce_the_single_process_result(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world,
+             join=True)
+    from tao_amodal_amd import flatten
+    from tao_amodal_amd.synth import synth
+    gt, dt = synth(seed=17, V=6, F=12, C=23, dets_per_frame=30, n_present=4)
+    fl = flatten.flatten_lvis(gt, dt)
+    dt.track_id, _ = flatten.make_track_ids_unique(dt)
+    ft = flatten.flatten_tao(gt, dt)
+    want = {"lvis": orclib.run_flat(fl, detail=False),
+            "tao": orclib.run_flat(ft, detail=False)}
+    for rank in range(world):
+        got = torch.load(os.path.join(str(tmp_path), "rank%d.pt" % rank),
+                         weights_only=False)
+        for name in ("lvis", "tao"):
+            p, r, ng, b = got[name]
+            assert 0 < b[1] < b[2], "both ranks must own cells"
+            assert np.array_equal(ng, want[name]["num_gt"])
+            assert np.array_equal(p, want[name]["precision"]), (rank, name)
+            assert np.array_equal(r, want[name]["recall"]), (rank, name)
+    assert (want["lvis"]["precision"] > 0).any()
+
+
+def test_shard_flat_partitions_the_problem():
+    from tao_amodal_amd import dist as tdist, flatten
+    from tao_amodal_amd.synth import synth
+    gt, dt = synth(seed=5, V=5, F=6, C=9, dets_per_frame=15, n_present=3)
+    fl = flatten.flatten_lvis(gt, dt)
+    dt.track_id, _ = flatten.make_track_ids_unique(dt)
+    ft = flatten.flatten_tao(gt, dt)
+    for flat in (fl, ft):
+        b = tdist.shard_bounds(flat, 3)
+        assert b[0] == 0 and b[-1] == flat.n_cells and b == sorted(b)
+        parts = [tdist.shard_flat(flat, b[i], b[i + 1]) for i in range(3)]
+        assert sum(p.n_pairs for p in parts) == flat.n_pairs
+        assert np.array_equal(np.concatenate([p.dt_id for p in parts]), flat.dt_id)
+        assert np.array_equal(np.concatenate([p.gt_id for p in parts]), flat.gt_id)
+        # a unit (image / video) never straddles two shards
+        for i in range(1, 3):
+            if 0 < b[i] < flat.n_cells:
+                assert flat.cell_unit[b[i]] != flat.cell_unit[b[i] - 1]
+        whole = orclib.run_flat(flat, detail=False)
+        # matches of a shard equal the matching slice of the whole problem
+        d_off = 0
+        for p in parts:
+            if len(p.dt_flags):
+                o = orclib.run_flat(p, detail=False)
+                n = len(p.dt_flags)
+                assert np.array_equal(o["matched"], whole["matched"][d_off:d_off + n])
+                assert np.array_equal(o["ignored"], whole["ignored"][d_off:d_off + n])
+                d_off += n
