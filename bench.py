@@ -47,6 +47,8 @@ def parse():
                         "oracle for cpu_baseline (rank 0, N=1 only)")
     p.add_argument("--no-cpu", action="store_true")
     p.add_argument("--no-verify", action="store_true")
+    p.add_argument("--force-dist", action="store_true",
+                   help="take the multi-GPU code path even with one rank")
     return p.parse_args()
 
 
@@ -66,9 +68,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -91,7 +96,7 @@ def main():
     torch.cuda.synchronize()
     t_h2d = time.time() - t0
 
-    if world > 1:
+    if use_dist:
         from tao_amodal_amd import dist as tdist
         plan = tdist.ExchangePlan(dpl, dpt, rank, world, dev)
 
@@ -105,27 +110,27 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
     # ---- pairs: exact counts from the cell tables / the kernel's counter
     p_l = dpl.n_pairs
-    p_t = int(wst.pair_frames.item()) if world == 1 else int(plan.pair_frames())
+    p_t = int(plan.pair_frames()) if use_dist else int(wst.pair_frames.item())
     pairs = torch.tensor([p_l + p_t], dtype=torch.int64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(pairs)
     total_pairs = int(pairs.item())
     ms_per_step = elapsed / args.steps * 1e3
@@ -134,7 +139,7 @@ def main():
     # ---- stage breakdown + dominant-kernel roofline (HIP events on the
     # stream the kernels run on), measured outside the timed region
     stages, roof = None, None
-    if world == 1:
+    if not use_dist:
         stages = engine.time_stages(dpl, wsl, dpt, wst, reps=max(args.steps, 10))
         k_ms = stages["lvis"]["match"]
         alg = algorithmic_bytes_match(dpl)
@@ -146,7 +151,7 @@ def main():
 
     # ---- verification + CPU baseline (C oracle = "port"), rank 0, N=1
     cpu, verified = None, None
-    if world == 1 and rank == 0 and not args.no_cpu:
+    if not use_dist and rank == 0 and not args.no_cpu:
         import orclib
         nv = min(args.cpu_sample_videos, args.videos)
         sgt, sdt = synth(seed=args.seed, V=nv, F=args.frames, C=args.cats,
@@ -199,7 +204,7 @@ def main():
                        "upload": round(t_h2d, 2)},
         }
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -115,3 +115,36 @@ def test_bb_iou_entry_points_match_reference_bbiou():
                                  d_o.data_ptr(), None), "bb_iou")
     torch.cuda.synchronize()
     assert np.array_equal(d_o.cpu().numpy().reshape((300, 77), order="F"), got)
+
+
+def test_sharded_path_on_one_gpu_equals_plain_path():
+    """The multi-GPU code path (records written with a row stride, RCCL
+    all_to_all / all_gather, gather_rows, compact + finalize) run with a
+    one-rank RCCL group must reproduce the single-process pipeline."""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    from tao_amodal_amd import dist as tdist, engine
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        gt, dt = synth(seed=21, V=5, F=25, C=50, dets_per_frame=40)
+        fl_ = fl.flatten_lvis(gt, dt)
+        dt.track_id, _ = fl.make_track_ids_unique(dt)
+        ft_ = fl.flatten_tao(gt, dt)
+        for flat in (fl_, ft_):
+            want = orclib.run_flat(flat, detail=False)
+            dp = engine.DeviceProblem(flat, "cuda:0")
+            ev = tdist.ShardedEval(dp, engine.Workspace(dp), 0, 1, tdist.HipBackend())
+            ev.step()
+            ev.step()
+            torch.cuda.synchronize()
+            assert np.array_equal(ev.num_gt.cpu().numpy(), want["num_gt"])
+            assert np.array_equal(ev.precision.cpu().numpy(), want["precision"])
+            assert np.array_equal(ev.recall.cpu().numpy(), want["recall"])
+    finally:
+        dist.destroy_process_group()
