@@ -105,32 +105,45 @@ int taoamd_bb_iou_host(const double *dt, const double *gt, size_t m, size_t n,
 /* ---- range masks ------------------------------------------------------------
  * gt_rng[g] bit r: GT g is ignored in range r.  dt_rng[d] bit r: detection d
  * is ignored in range r when it ends up unmatched.  num_gt[k*n_rng + r]
- * (int32, zeroed by the call) counts the evaluated GTs of category k. */
+ * (int32, written by the call) counts the evaluated GTs of category k.
+ * gt_cat_off (optional, int32[n_cat+1], device): when the GTs are grouped by
+ * category (category-major cell tables) the counts are formed by one
+ * wavefront per category with ballots -- no atomics; NULL selects the
+ * atomicAdd histogram over gt_cat. */
 int taoamd_lvis_ranges(int64_t n_gt, const double *gt_vis,
                        const uint8_t *gt_flags, const int32_t *gt_cat,
-                       int64_t n_dt, const uint8_t *dt_flags, int32_t n_cat,
+                       const int32_t *gt_cat_off, int64_t n_dt,
+                       const uint8_t *dt_flags, int32_t n_cat,
                        uint32_t *gt_rng, uint32_t *dt_rng, int32_t *num_gt,
                        void *stream);
 int taoamd_tao_ranges(int64_t n_gt, const double *gt_area,
                       const int32_t *gt_len, const int32_t *gt_nhp,
                       const uint8_t *gt_flags, const int32_t *gt_cat,
-                      int64_t n_dt, const double *dt_area,
-                      const int32_t *dt_len, const uint8_t *dt_flags,
-                      int32_t n_cat, uint32_t *gt_rng, uint32_t *dt_rng,
-                      int32_t *num_gt, void *stream);
+                      const int32_t *gt_cat_off, int64_t n_dt,
+                      const double *dt_area, const int32_t *dt_len,
+                      const uint8_t *dt_flags, int32_t n_cat,
+                      uint32_t *gt_rng, uint32_t *dt_rng, int32_t *num_gt,
+                      void *stream);
 
 /* ---- 3D IoU of track pairs --------------------------------------------------
  * iou[cell_iou_off[c] + d*G + g] for every cell c (G = its GT track count).
  * Tracks are CSR lists of (timeline position, box) sorted by position.
  * pair_frames (optional, int64[1], zeroed by the call) receives the number of
- * same-frame box pairs evaluated (the unit of BASELINE.json's metric). */
+ * same-frame box pairs evaluated (the unit of BASELINE.json's metric).
+ * cell_span (optional, int32[n_cells], device) = 1 + the largest timeline
+ * position used by the cell.  Cells with (G + 1) * span <= 12288 take the
+ * dense-timeline kernel (track rows in LDS, lane = track pair, no data-
+ * dependent control flow); the others the two-pointer merge kernel.
+ * all_dense: non-zero when the host knows every non-empty cell qualifies, so
+ * the merge kernel launch is skipped. */
 int taoamd_track_iou(int64_t n_cells, const int32_t *cell_dt_off,
                      const int32_t *cell_gt_off, const int64_t *cell_iou_off,
                      int64_t n_pairs, const int32_t *dt_frame_off,
                      const int32_t *dt_frame_pos, const double *dt_frame_box,
                      const int32_t *gt_frame_off, const int32_t *gt_frame_pos,
-                     const double *gt_frame_box, double *iou,
-                     int64_t *pair_frames, void *stream);
+                     const double *gt_frame_box, const int32_t *cell_span,
+                     int32_t all_dense, double *iou, int64_t *pair_frames,
+                     void *stream);
 
 /* ---- greedy assignment --------------------------------------------------------
  * If dt_box/gt_box are non-NULL the IoU matrix of each cell is computed on the
@@ -168,6 +181,21 @@ int taoamd_sort_by_cat_score(int64_t n, const int32_t *dt_cat,
                              const double *dt_score, int32_t *order,
                              int32_t *dst, void *workspace,
                              size_t workspace_bytes, void *stream);
+
+/* Same result for detections that are already grouped by category (the
+ * category-major cell tables).  cat_off (int32[n_cat+1], device) delimits the
+ * runs; every run is cut into tiles of TAOAMD_SEGMENT_TILE elements,
+ * tile_off (int32[n_cat+1], device) = exclusive prefix of ceil(len/TILE),
+ * n_tiles its total; max_segment = host value of the longest run.  Tiles are
+ * sorted in LDS, longer runs finished by rank-merge passes.
+ * Workspace: taoamd_sort_segments_workspace(n). */
+#define TAOAMD_SEGMENT_TILE 4096
+size_t taoamd_sort_segments_workspace(int64_t n);
+int taoamd_sort_segments(int64_t n, int32_t n_cat, const int32_t *cat_off,
+                         const int32_t *tile_off, int32_t n_tiles,
+                         int32_t max_segment, const int32_t *dt_cat,
+                         const double *dt_score, int32_t *order, int32_t *dst,
+                         void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- row gather -----------------------------------------------------------------
  * dst_*[p*n_words + w] = src_*[order[p]*src_stride + w]: brings exchanged

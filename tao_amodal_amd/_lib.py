@@ -15,6 +15,7 @@ OK = 0
 N_THR, N_REC = 10, 101
 LVIS_RNG, TAO_RNG = 6, 20
 MAX_GT_PER_CELL = 3072
+SEGMENT_TILE = 4096
 
 _vp, _i64, _i32, _sz = C.c_void_p, C.c_int64, C.c_int32, C.c_size_t
 
@@ -25,12 +26,15 @@ SIGNATURES = {
     "taoamd_thresholds_host": (C.c_int, [_vp, _vp]),
     "taoamd_bb_iou": (C.c_int, [_vp, _vp, _sz, _sz, _vp, _vp, _vp]),
     "taoamd_bb_iou_host": (C.c_int, [_vp, _vp, _sz, _sz, _vp, _vp]),
-    "taoamd_lvis_ranges": (C.c_int, [_i64, _vp, _vp, _vp, _i64, _vp, _i32,
-                                     _vp, _vp, _vp, _vp]),
-    "taoamd_tao_ranges": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp,
-                                    _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "taoamd_lvis_ranges": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _i64, _vp,
+                                     _i32, _vp, _vp, _vp, _vp]),
+    "taoamd_tao_ranges": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64,
+                                    _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "taoamd_sort_segments_workspace": (_sz, [_i64]),
+    "taoamd_sort_segments": (C.c_int, [_i64, _i32, _vp, _vp, _i32, _i32, _vp,
+                                       _vp, _vp, _vp, _vp, _sz, _vp]),
     "taoamd_track_iou": (C.c_int, [_i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp,
-                                   _vp, _vp, _vp, _vp, _vp, _vp]),
+                                   _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
     "taoamd_match": (C.c_int, [_i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32,
                                _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp,
                                _vp, _vp]),

@@ -67,10 +67,12 @@ __global__ void lvis_ranges_kernel(int64_t n_gt, const double *__restrict__ vis,
             if (ign || v < lo[r] || v > hi[r]) m |= 1u << r;
         if (ign || !(gflags[i] & TAOAMD_GT_OOF)) m |= 1u << 5;
         gt_rng[i] = m;
-        int32_t *row = num_gt + (int64_t)gcat[i] * TAOAMD_LVIS_RNG;
+        if (num_gt != nullptr) {
+            int32_t *row = num_gt + (int64_t)gcat[i] * TAOAMD_LVIS_RNG;
 #pragma unroll
-        for (int r = 0; r < TAOAMD_LVIS_RNG; r++)
-            if (!((m >> r) & 1u)) atomicAdd(row + r, 1);
+            for (int r = 0; r < TAOAMD_LVIS_RNG; r++)
+                if (!((m >> r) & 1u)) atomicAdd(row + r, 1);
+        }
     }
     if (i < n_dt)
         dt_rng[i] = (dflags[i] & TAOAMD_DT_IGNORE_UNMATCHED) ? 0x3fu : 0u;
@@ -105,9 +107,11 @@ __global__ void tao_ranges_kernel(
                 if (bad) m |= 1u << (a * 4 + t);
             }
         gt_rng[i] = m;
-        int32_t *row = num_gt + (int64_t)gcat[i] * TAOAMD_TAO_RNG;
-        for (int r = 0; r < TAOAMD_TAO_RNG; r++)
-            if (!((m >> r) & 1u)) atomicAdd(row + r, 1);
+        if (num_gt != nullptr) {
+            int32_t *row = num_gt + (int64_t)gcat[i] * TAOAMD_TAO_RNG;
+            for (int r = 0; r < TAOAMD_TAO_RNG; r++)
+                if (!((m >> r) & 1u)) atomicAdd(row + r, 1);
+        }
     }
     if (i < n_dt) {
         uint32_t m = 0;
@@ -124,6 +128,28 @@ __global__ void tao_ranges_kernel(
     }
 }
 
+// num_gt without atomics: GTs grouped by category, one wavefront per category,
+// lane r < n_rng ends up owning the count of range r
+__global__ __launch_bounds__(256) void count_gt_kernel(
+    int32_t n_cat, int32_t n_rng, const int32_t *__restrict__ gt_cat_off,
+    const uint32_t *__restrict__ gt_rng, int32_t *__restrict__ num_gt)
+{
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int32_t k = blockIdx.x * 4 + wave;
+    if (k >= n_cat) return;
+    const int lane = lane_id();
+    const int32_t b = gt_cat_off[k], e = gt_cat_off[k + 1];
+    int32_t mine = 0;
+    for (int32_t base = b; base < e; base += WAVE) {
+        const uint32_t m = base + lane < e ? gt_rng[base + lane] : 0xffffffffu;
+        for (int r = 0; r < n_rng; r++) {
+            const int c = __popcll(__ballot(!((m >> r) & 1u)));
+            if (lane == r) mine += c;
+        }
+    }
+    if (lane < n_rng) num_gt[(int64_t)k * n_rng + lane] = mine;
+}
+
 // ------------------------------------------------------------------ 3D IoU
 // upper_bound(off, n+1 entries, p) - 1: the cell whose pair range holds p
 __device__ __forceinline__ int64_t find_cell(const int64_t *__restrict__ off,
@@ -137,64 +163,215 @@ __device__ __forceinline__ int64_t find_cell(const int64_t *__restrict__ off,
     return lo;
 }
 
-__global__ void track_iou_kernel(
+__device__ __forceinline__ bool dense_cell(int32_t span, int32_t D, int32_t G);
+
+// A track's frame list read through a 3-deep register queue: the loads of
+// frame p+2 are issued when frame p becomes current, so the two-pointer merge
+// below never waits on a load it has just issued (the merge is a chain of
+// data-dependent steps; without the queue every step pays two serialized
+// memory round trips).
+struct FrameQueue {
+    const int32_t *__restrict__ pos;
+    const double4 *__restrict__ box;
+    int32_t p, e;
+    int32_t f0, f1, f2;
+    double4 b0, b1, b2;
+
+    __device__ __forceinline__ void load(int32_t q, int32_t &f, double4 &b) const
+    {
+        if (q < e) { f = pos[q]; b = box[q]; } else { f = INT32_MAX; }
+    }
+    __device__ __forceinline__ void init(const int32_t *pos_, const double *box_,
+                                         int32_t start, int32_t end)
+    {
+        pos = pos_; box = reinterpret_cast<const double4 *>(box_);
+        p = start; e = end;
+        b0 = b1 = b2 = make_double4(0, 0, 0, 0);
+        load(p, f0, b0); load(p + 1, f1, b1); load(p + 2, f2, b2);
+    }
+    __device__ __forceinline__ void advance()
+    {
+        p++;
+        f0 = f1; b0 = b1;
+        f1 = f2; b1 = b2;
+        load(p + 2, f2, b2);
+    }
+};
+
+__global__ __launch_bounds__(256) void track_iou_kernel(
     int64_t n_cells, const int32_t *__restrict__ cell_dt_off,
     const int32_t *__restrict__ cell_gt_off,
     const int64_t *__restrict__ cell_iou_off, int64_t n_pairs,
     const int32_t *__restrict__ dfoff, const int32_t *__restrict__ dfpos,
     const double *__restrict__ dfbox, const int32_t *__restrict__ gfoff,
     const int32_t *__restrict__ gfpos, const double *__restrict__ gfbox,
-    double *__restrict__ iou, unsigned long long *__restrict__ pair_frames)
+    double *__restrict__ iou, unsigned long long *__restrict__ pair_frames,
+    const int32_t *__restrict__ cell_span)
 {
     int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     unsigned long long common = 0;
-    if (p < n_pairs) {
-        int64_t c = find_cell(cell_iou_off, n_cells, p);
-        int32_t G = cell_gt_off[c + 1] - cell_gt_off[c];
-        int64_t local = p - cell_iou_off[c];
-        int32_t d = (int32_t)(local / G), g = (int32_t)(local - (int64_t)d * G);
-        int32_t td = cell_dt_off[c] + d, tg = cell_gt_off[c] + g;
-        int32_t pd = dfoff[td], ed = dfoff[td + 1];
-        int32_t pg = gfoff[tg], eg = gfoff[tg + 1];
+    bool mine = p < n_pairs;
+    int64_t c = 0;
+    if (mine) {
+        c = find_cell(cell_iou_off, n_cells, p);
+        // cells with a short timeline are done by track_iou_dense_kernel
+        if (cell_span != nullptr &&
+            dense_cell(cell_span[c], cell_dt_off[c + 1] - cell_dt_off[c],
+                       cell_gt_off[c + 1] - cell_gt_off[c]))
+            mine = false;
+    }
+    if (mine) {
+        const int32_t G = cell_gt_off[c + 1] - cell_gt_off[c];
+        const int64_t local = p - cell_iou_off[c];
+        const int32_t d = (int32_t)(local / G), g = (int32_t)(local - (int64_t)d * G);
+        const int32_t td = cell_dt_off[c] + d, tg = cell_gt_off[c] + g;
+        FrameQueue qd, qg;
+        qd.init(dfpos, dfbox, dfoff[td], dfoff[td + 1]);
+        qg.init(gfpos, gfbox, gfoff[tg], gfoff[tg + 1]);
         double i = 0.0, u = 0.0;
         // ascending timeline order; per frame exactly the arithmetic of
         // reference tao_amodal/eval.py:32-48 and :87-94
-        int32_t fd = pd < ed ? dfpos[pd] : INT32_MAX;
-        int32_t fg = pg < eg ? gfpos[pg] : INT32_MAX;
-        while (pd < ed || pg < eg) {
-            if (fd == fg) {
-                const double4 B = reinterpret_cast<const double4 *>(dfbox)[pd];
-                const double4 A = reinterpret_cast<const double4 *>(gfbox)[pg];
+        while (qd.f0 != INT32_MAX || qg.f0 != INT32_MAX) {
+            const double4 B = qd.b0, A = qg.b0;
+            if (qd.f0 == qg.f0) {
                 double w = fmin(B.x + B.z, A.x + A.z) - fmax(B.x, A.x);
                 double h = fmin(B.y + B.w, A.y + A.w) - fmax(B.y, A.y);
                 w = w > 0 ? w : 0.0;
                 h = h > 0 ? h : 0.0;
-                double i_ = w * h;
-                double u_ = B.z * B.w + A.z * A.w - i_;
+                const double i_ = w * h;
+                const double u_ = B.z * B.w + A.z * A.w - i_;
                 i += i_;
                 u += u_;
                 common++;
-                pd++; pg++;
-                fd = pd < ed ? dfpos[pd] : INT32_MAX;
-                fg = pg < eg ? gfpos[pg] : INT32_MAX;
-            } else if (fg < fd) {
-                const double4 A = reinterpret_cast<const double4 *>(gfbox)[pg];
+                qd.advance();
+                qg.advance();
+            } else if (qg.f0 < qd.f0) {
                 u += A.z * A.w;
-                pg++;
-                fg = pg < eg ? gfpos[pg] : INT32_MAX;
+                qg.advance();
             } else {
-                const double4 B = reinterpret_cast<const double4 *>(dfbox)[pd];
                 u += B.z * B.w;
-                pd++;
-                fd = pd < ed ? dfpos[pd] : INT32_MAX;
+                qd.advance();
             }
         }
         iou[p] = u > 0 ? i / u : 0.0;
     }
     if (pair_frames != nullptr) {
-        // wave reduction with DPP-free shuffles, one atomic per wavefront
         for (int s = WAVE / 2; s > 0; s >>= 1)
             common += __shfl_down(common, s, WAVE);
+        if (lane_id() == 0 && common) atomicAdd(pair_frames, common);
+    }
+}
+
+// Dense-timeline variant (the common case: videos with a few hundred frames).
+// One workgroup per cell.  LDS holds one row per track -- the GT tracks of the
+// cell and a group of its detection tracks -- mapping timeline position ->
+// frame index (-1 = absent).  Then lane = (detection track, GT track) pair and
+// all lanes walk the timeline together: every step fetches the two frames that
+// live at this position (addresses do not depend on earlier steps, so the
+// loads pipeline), forms the term
+//     both: (da + ga - i_, i_)   dt only: (da, 0)   gt only: (ga, 0)
+//     neither: (0, 0)
+// with the reference's per-frame arithmetic (tao_amodal/eval.py:32-48,87-94)
+// and adds it to the lane's running sums.  Adding (0, 0) for an empty position
+// is exact (u, i >= +0), so the sequence of roundings equals the two-pointer
+// merge over the union of frames: same result bit for bit, no data-dependent
+// control flow, no serialized memory round trips.
+#define TD_ENTRIES 12288   // int32 entries of LDS: rows * span <= TD_ENTRIES
+#define TD_UN 8            // positions per software-pipelined block
+
+__device__ __forceinline__ bool dense_cell(int32_t span, int32_t D, int32_t G)
+{
+    return D > 0 && G > 0 && G <= 256 && (int64_t)(G + 1) * span <= TD_ENTRIES;
+}
+
+__global__ __launch_bounds__(256) void track_iou_dense_kernel(
+    const int32_t *__restrict__ cell_dt_off,
+    const int32_t *__restrict__ cell_gt_off,
+    const int64_t *__restrict__ cell_iou_off,
+    const int32_t *__restrict__ cell_span,
+    const int32_t *__restrict__ dfoff, const int32_t *__restrict__ dfpos,
+    const double *__restrict__ dfbox, const int32_t *__restrict__ gfoff,
+    const int32_t *__restrict__ gfpos, const double *__restrict__ gfbox,
+    double *__restrict__ iou, unsigned long long *__restrict__ pair_frames)
+{
+    __shared__ int32_t map[TD_ENTRIES];
+    const int64_t c = blockIdx.x;
+    const int32_t d0 = cell_dt_off[c], D = cell_dt_off[c + 1] - d0;
+    const int32_t g0 = cell_gt_off[c], G = cell_gt_off[c + 1] - g0;
+    const int32_t span = cell_span[c];
+    if (!dense_cell(span, D, G)) return;
+    const int64_t ioff = cell_iou_off[c];
+    const int rows = TD_ENTRIES / span;
+    const int DG = min(min(D, rows - G), 256 / G);
+    int32_t *__restrict__ gmap = map;
+    int32_t *__restrict__ dmap = map + G * span;
+    for (int t = threadIdx.x; t < G * span; t += 256) gmap[t] = -1;
+    __syncthreads();
+    for (int g = 0; g < G; g++) {
+        const int32_t js = gfoff[g0 + g], je = gfoff[g0 + g + 1];
+        for (int32_t j = js + (int32_t)threadIdx.x; j < je; j += 256)
+            gmap[g * span + gfpos[j]] = j;
+    }
+    unsigned long long common = 0;
+    const double4 *__restrict__ DB = reinterpret_cast<const double4 *>(dfbox);
+    const double4 *__restrict__ GB = reinterpret_cast<const double4 *>(gfbox);
+    for (int32_t db = 0; db < D; db += DG) {
+        const int nd = min(DG, D - db);
+        __syncthreads();
+        for (int t = threadIdx.x; t < nd * span; t += 256) dmap[t] = -1;
+        __syncthreads();
+        // one wavefront per detection track of the group, lanes over frames
+        for (int dl = threadIdx.x >> 6; dl < nd; dl += 4) {
+            const int32_t ks = dfoff[d0 + db + dl], ke = dfoff[d0 + db + dl + 1];
+            for (int32_t k = ks + lane_id(); k < ke; k += WAVE)
+                dmap[dl * span + dfpos[k]] = k;
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < nd * G) {
+            const int dl = threadIdx.x / G, g = threadIdx.x - dl * G;
+            const int32_t *__restrict__ dr = dmap + dl * span;
+            const int32_t *__restrict__ gr = gmap + g * span;
+            double u = 0.0, i = 0.0;
+            // blocks of TD_UN positions: all index reads, then all box loads
+            // (absent frames read a dummy box, so nothing is conditional and
+            // the loads of a block are in flight together), then the adds
+            for (int32_t p0 = 0; p0 < span; p0 += TD_UN) {
+                int32_t dk[TD_UN], gj[TD_UN];
+                double4 B[TD_UN], A[TD_UN];
+#pragma unroll
+                for (int q = 0; q < TD_UN; q++) {
+                    const bool in = p0 + q < span;
+                    dk[q] = in ? dr[p0 + q] : -1;
+                    gj[q] = in ? gr[p0 + q] : -1;
+                }
+#pragma unroll
+                for (int q = 0; q < TD_UN; q++) {
+                    B[q] = DB[max(dk[q], 0)];
+                    A[q] = GB[max(gj[q], 0)];
+                }
+#pragma unroll
+                for (int q = 0; q < TD_UN; q++) {
+                    const bool hd = dk[q] >= 0, hg = gj[q] >= 0;
+                    double w = fmin(B[q].x + B[q].z, A[q].x + A[q].z) - fmax(B[q].x, A[q].x);
+                    double h = fmin(B[q].y + B[q].w, A[q].y + A[q].w) - fmax(B[q].y, A[q].y);
+                    w = w > 0 ? w : 0.0;
+                    h = h > 0 ? h : 0.0;
+                    const double i_ = w * h;
+                    const double da = B[q].z * B[q].w, ga = A[q].z * A[q].w;
+                    const double both = da + ga - i_;
+                    const double tu = hd ? (hg ? both : da) : (hg ? ga : 0.0);
+                    const double ti = (hd && hg) ? i_ : 0.0;
+                    common += (hd && hg) ? 1 : 0;
+                    u += tu;
+                    i += ti;
+                }
+            }
+            iou[ioff + (int64_t)(db + dl) * G + g] = u > 0 ? i / u : 0.0;
+        }
+    }
+    if (pair_frames != nullptr) {
+        for (int s_ = WAVE / 2; s_ > 0; s_ >>= 1)
+            common += __shfl_down(common, s_, WAVE);
         if (lane_id() == 0 && common) atomicAdd(pair_frames, common);
     }
 }
@@ -440,17 +617,25 @@ extern "C" int taoamd_bb_iou_host(const double *dt, const double *gt, size_t m,
 
 extern "C" int taoamd_lvis_ranges(int64_t n_gt, const double *gt_vis,
                                   const uint8_t *gt_flags,
-                                  const int32_t *gt_cat, int64_t n_dt,
+                                  const int32_t *gt_cat,
+                                  const int32_t *gt_cat_off, int64_t n_dt,
                                   const uint8_t *dt_flags, int32_t n_cat,
                                   uint32_t *gt_rng, uint32_t *dt_rng,
                                   int32_t *num_gt, void *stream)
 {
     hipStream_t s = (hipStream_t)stream;
-    TAO_HIP(hipMemsetAsync(num_gt, 0, sizeof(int32_t) * (size_t)n_cat * TAOAMD_LVIS_RNG, s));
+    const bool grouped = gt_cat_off != nullptr;
+    if (!grouped)
+        TAO_HIP(hipMemsetAsync(num_gt, 0, sizeof(int32_t) * (size_t)n_cat * TAOAMD_LVIS_RNG, s));
     int64_t n = n_gt > n_dt ? n_gt : n_dt;
-    if (n == 0) return TAOAMD_OK;
-    lvis_ranges_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(
-        n_gt, gt_vis, gt_flags, gt_cat, n_dt, dt_flags, gt_rng, dt_rng, num_gt);
+    if (n > 0) {
+        lvis_ranges_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(
+            n_gt, gt_vis, gt_flags, gt_cat, n_dt, dt_flags, gt_rng, dt_rng,
+            grouped ? nullptr : num_gt);
+    }
+    if (grouped)
+        count_gt_kernel<<<(unsigned)((n_cat + 3) / 4), 256, 0, s>>>(
+            n_cat, TAOAMD_LVIS_RNG, gt_cat_off, gt_rng, num_gt);
     TAO_LAUNCH_CHECK();
     return TAOAMD_OK;
 }
@@ -458,19 +643,25 @@ extern "C" int taoamd_lvis_ranges(int64_t n_gt, const double *gt_vis,
 extern "C" int taoamd_tao_ranges(int64_t n_gt, const double *gt_area,
                                  const int32_t *gt_len, const int32_t *gt_nhp,
                                  const uint8_t *gt_flags, const int32_t *gt_cat,
-                                 int64_t n_dt, const double *dt_area,
-                                 const int32_t *dt_len, const uint8_t *dt_flags,
-                                 int32_t n_cat, uint32_t *gt_rng,
-                                 uint32_t *dt_rng, int32_t *num_gt,
-                                 void *stream)
+                                 const int32_t *gt_cat_off, int64_t n_dt,
+                                 const double *dt_area, const int32_t *dt_len,
+                                 const uint8_t *dt_flags, int32_t n_cat,
+                                 uint32_t *gt_rng, uint32_t *dt_rng,
+                                 int32_t *num_gt, void *stream)
 {
     hipStream_t s = (hipStream_t)stream;
-    TAO_HIP(hipMemsetAsync(num_gt, 0, sizeof(int32_t) * (size_t)n_cat * TAOAMD_TAO_RNG, s));
+    const bool grouped = gt_cat_off != nullptr;
+    if (!grouped)
+        TAO_HIP(hipMemsetAsync(num_gt, 0, sizeof(int32_t) * (size_t)n_cat * TAOAMD_TAO_RNG, s));
     int64_t n = n_gt > n_dt ? n_gt : n_dt;
-    if (n == 0) return TAOAMD_OK;
-    tao_ranges_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(
-        n_gt, gt_area, gt_len, gt_nhp, gt_flags, gt_cat, n_dt, dt_area, dt_len,
-        dt_flags, gt_rng, dt_rng, num_gt);
+    if (n > 0) {
+        tao_ranges_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(
+            n_gt, gt_area, gt_len, gt_nhp, gt_flags, gt_cat, n_dt, dt_area,
+            dt_len, dt_flags, gt_rng, dt_rng, grouped ? nullptr : num_gt);
+    }
+    if (grouped)
+        count_gt_kernel<<<(unsigned)((n_cat + 3) / 4), 256, 0, s>>>(
+            n_cat, TAOAMD_TAO_RNG, gt_cat_off, gt_rng, num_gt);
     TAO_LAUNCH_CHECK();
     return TAOAMD_OK;
 }
@@ -483,16 +674,24 @@ extern "C" int taoamd_track_iou(int64_t n_cells, const int32_t *cell_dt_off,
                                 const double *dt_frame_box,
                                 const int32_t *gt_frame_off,
                                 const int32_t *gt_frame_pos,
-                                const double *gt_frame_box, double *iou,
-                                int64_t *pair_frames, void *stream)
+                                const double *gt_frame_box,
+                                const int32_t *cell_span, int32_t all_dense,
+                                double *iou, int64_t *pair_frames, void *stream)
 {
     hipStream_t s = (hipStream_t)stream;
     if (pair_frames) TAO_HIP(hipMemsetAsync(pair_frames, 0, 8, s));
     if (n_pairs == 0) return TAOAMD_OK;
-    track_iou_kernel<<<(unsigned)((n_pairs + 255) / 256), 256, 0, s>>>(
-        n_cells, cell_dt_off, cell_gt_off, cell_iou_off, n_pairs, dt_frame_off,
-        dt_frame_pos, dt_frame_box, gt_frame_off, gt_frame_pos, gt_frame_box,
-        iou, (unsigned long long *)pair_frames);
+    if (cell_span != nullptr)
+        track_iou_dense_kernel<<<(unsigned)n_cells, 256, 0, s>>>(
+            cell_dt_off, cell_gt_off, cell_iou_off, cell_span, dt_frame_off,
+            dt_frame_pos, dt_frame_box, gt_frame_off, gt_frame_pos,
+            gt_frame_box, iou, (unsigned long long *)pair_frames);
+    if (cell_span == nullptr || !all_dense)
+        track_iou_kernel<<<(unsigned)((n_pairs + 255) / 256), 256, 0, s>>>(
+            n_cells, cell_dt_off, cell_gt_off, cell_iou_off, n_pairs,
+            dt_frame_off, dt_frame_pos, dt_frame_box, gt_frame_off,
+            gt_frame_pos, gt_frame_box, iou, (unsigned long long *)pair_frames,
+            cell_span);
     TAO_LAUNCH_CHECK();
     return TAOAMD_OK;
 }

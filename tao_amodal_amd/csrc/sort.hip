@@ -278,3 +278,181 @@ extern "C" int taoamd_sort_by_cat_score(int64_t n, const int32_t *dt_cat,
     TAO_LAUNCH_CHECK();
     return TAOAMD_OK;
 }
+
+
+// ---------------------------------------------------------------------------
+// Segment-local sort: when the detections are laid out category-major (the
+// cell tables of flatten.py are), a category is a contiguous run and only the
+// score order inside it is missing.
+//   seg_tile_kernel   one workgroup sorts one tile (<= SEG_TILE elements of one
+//                     category) in LDS with a bitonic network over
+//                     (descending-score key, input position): the position
+//                     makes every key unique, so the result is THE stable order
+//   seg_merge_kernel  categories longer than one tile: log2(#tiles) passes of
+//                     pairwise run merging; every element finds its output
+//                     slot by one binary search in the partner run (merge by
+//                     rank -- no serial merge loop)
+//   seg_finish_kernel order / dst of the multi-tile categories
+// ---------------------------------------------------------------------------
+#define SEG_TILE 4096
+#define SEG_THREADS 256
+
+struct SegArgs {
+    const int32_t *cat_off;    // [n_cat + 1] element offsets
+    const int32_t *tile_off;   // [n_cat + 1] tile offsets
+    const int32_t *cat;        // [n] category of every element
+    const double *score;
+    uint64_t *key[2];
+    int32_t *idx[2];
+    int32_t *order, *dst;
+    int64_t n;
+    int32_t n_cat, n_tiles;
+};
+
+__global__ __launch_bounds__(SEG_THREADS) void seg_tile_kernel(SegArgs a)
+{
+    __shared__ uint64_t key[SEG_TILE];
+    __shared__ uint16_t pos[SEG_TILE];
+    // category owning this tile: last k with tile_off[k] <= blockIdx.x
+    int32_t lo = 0, hi = a.n_cat;
+    while (hi - lo > 1) {
+        const int32_t mid = (lo + hi) >> 1;
+        if (a.tile_off[mid] <= (int32_t)blockIdx.x) lo = mid; else hi = mid;
+    }
+    const int32_t k = lo, t = blockIdx.x - a.tile_off[k];
+    const int32_t sb = a.cat_off[k], se = a.cat_off[k + 1];
+    const int32_t b = sb + t * SEG_TILE;
+    const int32_t n = min(SEG_TILE, se - b);
+    if (n <= 0) return;
+    int N = 64;
+    while (N < n) N <<= 1;
+    for (int i = threadIdx.x; i < N; i += SEG_THREADS) {
+        key[i] = i < n ? desc_key(a.score[b + i]) : ~0ull;
+        pos[i] = (uint16_t)i;
+    }
+    __syncthreads();
+    for (int kk = 2; kk <= N; kk <<= 1) {
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            for (int p = threadIdx.x; p < (N >> 1); p += SEG_THREADS) {
+                const int i = ((p / j) * 2 * j) + (p % j);
+                const int l = i + j;
+                const bool up = (i & kk) == 0;
+                const uint64_t ki = key[i], kl = key[l];
+                const uint16_t pi = pos[i], pl = pos[l];
+                const bool gt = ki > kl || (ki == kl && pi > pl);
+                if (gt == up) {
+                    key[i] = kl; key[l] = ki;
+                    pos[i] = pl; pos[l] = pi;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const bool single = se - sb <= SEG_TILE;
+    for (int i = threadIdx.x; i < n; i += SEG_THREADS) {
+        const int32_t d = b + pos[i];
+        if (single) {
+            if (a.order) a.order[b + i] = d;
+            if (a.dst) a.dst[d] = b + i;
+        } else {
+            a.key[0][b + i] = key[i];
+            a.idx[0][b + i] = d;
+        }
+    }
+}
+
+// number of elements of run [b, e) that precede (k, i) in the unique order
+__device__ __forceinline__ int32_t rank_in(const uint64_t *__restrict__ key,
+                                           const int32_t *__restrict__ idx,
+                                           int32_t b, int32_t e, uint64_t k,
+                                           int32_t i)
+{
+    int32_t lo = b, hi = e;
+    while (lo < hi) {
+        const int32_t mid = (lo + hi) >> 1;
+        const uint64_t km = key[mid];
+        const bool less = km < k || (km == k && idx[mid] < i);
+        if (less) lo = mid + 1; else hi = mid;
+    }
+    return lo - b;
+}
+
+__global__ __launch_bounds__(256) void seg_merge_kernel(SegArgs a, int pass)
+{
+    const int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (p >= a.n) return;
+    const int32_t k = a.cat[p];
+    const int32_t sb = a.cat_off[k], se = a.cat_off[k + 1];
+    if (se - sb <= SEG_TILE) return;
+    const int s = pass & 1;
+    const uint64_t *__restrict__ kin = a.key[s];
+    const int32_t *__restrict__ iin = a.idx[s];
+    const int64_t L = (int64_t)SEG_TILE << pass;
+    const uint64_t kx = kin[p];
+    const int32_t ix = iin[p];
+    const int64_t local = p - sb;
+    const int64_t base = sb + (local / (2 * L)) * (2 * L);
+    const int64_t a_end = min(base + L, (int64_t)se);
+    const int64_t b_end = min(a_end + L, (int64_t)se);
+    int64_t out = p;
+    if (a_end < b_end) {
+        if (p < a_end)
+            out = p + rank_in(kin, iin, (int32_t)a_end, (int32_t)b_end, kx, ix);
+        else
+            out = base + (p - a_end) +
+                  rank_in(kin, iin, (int32_t)base, (int32_t)a_end, kx, ix);
+    }
+    a.key[s ^ 1][out] = kx;
+    a.idx[s ^ 1][out] = ix;
+}
+
+__global__ __launch_bounds__(256) void seg_finish_kernel(SegArgs a, int sel)
+{
+    const int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (p >= a.n) return;
+    const int32_t k = a.cat[p];
+    if (a.cat_off[k + 1] - a.cat_off[k] <= SEG_TILE) return;
+    const int32_t d = a.idx[sel][p];
+    if (a.order) a.order[p] = d;
+    if (a.dst) a.dst[d] = (int32_t)p;
+}
+
+extern "C" size_t taoamd_sort_segments_workspace(int64_t n)
+{
+    if (n < 1) n = 1;
+    return 2 * align256((size_t)n * 8) + 2 * align256((size_t)n * 4) + 4096;
+}
+
+extern "C" int taoamd_sort_segments(int64_t n, int32_t n_cat,
+                                    const int32_t *cat_off,
+                                    const int32_t *tile_off, int32_t n_tiles,
+                                    int32_t max_segment, const int32_t *dt_cat,
+                                    const double *dt_score, int32_t *order,
+                                    int32_t *dst, void *workspace,
+                                    size_t workspace_bytes, void *stream)
+{
+    if (n == 0 || n_cat == 0 || n_tiles == 0) return TAOAMD_OK;
+    if (n > 0x7fffffff) return TAOAMD_ERR_TOO_LARGE;
+    if (!cat_off || !tile_off || !dt_cat || !dt_score || !workspace) return TAOAMD_ERR_ARG;
+    if (workspace_bytes < taoamd_sort_segments_workspace(n)) return TAOAMD_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    unsigned char *w = (unsigned char *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    SegArgs a;
+    a.cat_off = cat_off; a.tile_off = tile_off; a.cat = dt_cat; a.score = dt_score;
+    a.order = order; a.dst = dst; a.n = n; a.n_cat = n_cat; a.n_tiles = n_tiles;
+    a.key[0] = (uint64_t *)w; w += align256((size_t)n * 8);
+    a.key[1] = (uint64_t *)w; w += align256((size_t)n * 8);
+    a.idx[0] = (int32_t *)w;  w += align256((size_t)n * 4);
+    a.idx[1] = (int32_t *)w;
+    seg_tile_kernel<<<(unsigned)n_tiles, SEG_THREADS, 0, s>>>(a);
+    if (max_segment > SEG_TILE) {
+        int passes = 0;
+        for (int64_t L = SEG_TILE; L < max_segment; L <<= 1) passes++;
+        const unsigned blocks = (unsigned)((n + 255) / 256);
+        for (int p = 0; p < passes; p++)
+            seg_merge_kernel<<<blocks, 256, 0, s>>>(a, p);
+        seg_finish_kernel<<<blocks, 256, 0, s>>>(a, passes & 1);
+    }
+    TAO_LAUNCH_CHECK();
+    return TAOAMD_OK;
+}

@@ -256,7 +256,7 @@ def shard_flat(flat, c0, c1):
             f[k] = v[d0:d1]
         elif k in per_gt:
             f[k] = v[g0:g1]
-        elif k in ("cell_unit", "cell_cat"):
+        elif k in ("cell_unit", "cell_cat", "cell_span"):
             f[k] = v[c0:c1]
         elif k in ("cell_dt_off", "cell_gt_off", "cell_iou_off"):
             f[k] = (v[c0:c1 + 1] - v[c0]).astype(v.dtype)

@@ -62,13 +62,31 @@ class DeviceProblem:
         else:
             names += ["dt_area", "dt_len", "gt_area", "gt_len", "gt_nhp",
                       "dt_frame_off", "dt_frame_pos", "dt_frame_box",
-                      "gt_frame_off", "gt_frame_pos", "gt_frame_box"]
+                      "gt_frame_off", "gt_frame_pos", "gt_frame_box",
+                      "cell_span"]
+            live = (d_cnt > 0) & (g_cnt > 0)
+            fits = (g_cnt <= 256) & ((g_cnt + 1) * flat.cell_span.astype(np.int64)
+                                     <= 12288)
+            self.all_dense = int(bool(np.all(fits[live])))
         self.t = {}
         for n in names:
             self.t[n] = torch.from_numpy(np.ascontiguousarray(flat[n])).to(
                 self.device)
+        gt_cat_off = np.zeros(self.n_cat + 1, dtype=np.int32)
+        np.cumsum(np.bincount(flat.gt_cat, minlength=self.n_cat),
+                  out=gt_cat_off[1:])
+        # category-major tables (flatten.py): every category is one run
+        self.grouped = bool(np.all(np.diff(flat.dt_cat) >= 0)
+                            and np.all(np.diff(flat.gt_cat) >= 0))
+        self.max_segment = int(np.diff(cat_off).max()) if self.n_cat else 0
+        tiles = (np.diff(cat_off) + _lib.SEGMENT_TILE - 1) // _lib.SEGMENT_TILE
+        tile_off = np.zeros(self.n_cat + 1, dtype=np.int32)
+        np.cumsum(tiles, out=tile_off[1:])
+        self.n_tiles = int(tile_off[-1])
         self.t["cell_iou_off"] = torch.from_numpy(iou_off).to(self.device)
         self.t["cat_off"] = torch.from_numpy(cat_off).to(self.device)
+        self.t["gt_cat_off"] = torch.from_numpy(gt_cat_off).to(self.device)
+        self.t["tile_off"] = torch.from_numpy(tile_off).to(self.device)
         self.cat_off_host = cat_off
 
     def input_bytes(self):
@@ -91,7 +109,8 @@ class Workspace:
                                   device=dev)
         self.order = torch.empty(max(dp.n_dt, 1), dtype=torch.int32, device=dev)
         self.dst = torch.empty(max(dp.n_dt, 1), dtype=torch.int32, device=dev)
-        self.sort_bytes = lib.taoamd_sort_workspace(dp.n_dt)
+        self.sort_bytes = max(lib.taoamd_sort_workspace(dp.n_dt),
+                              lib.taoamd_sort_segments_workspace(dp.n_dt))
         self.sort_ws = buf(self.sort_bytes)
         self.matched = torch.empty((max(dp.n_dt, 1), dp.n_words),
                                    dtype=torch.int64, device=dev)
@@ -124,12 +143,14 @@ def stage_ranges(dp, ws):
     if dp.kind == "lvis":
         _lib.check(lib.taoamd_lvis_ranges(
             dp.n_gt, _ptr(t["gt_vis"]), _ptr(t["gt_flags"]), _ptr(t["gt_cat"]),
+            _ptr(t["gt_cat_off"]) if dp.grouped else None,
             dp.n_dt, _ptr(t["dt_flags"]), dp.n_cat, _ptr(ws.gt_rng),
             _ptr(ws.dt_rng), _ptr(ws.num_gt), s), "taoamd_lvis_ranges")
     else:
         _lib.check(lib.taoamd_tao_ranges(
             dp.n_gt, _ptr(t["gt_area"]), _ptr(t["gt_len"]), _ptr(t["gt_nhp"]),
-            _ptr(t["gt_flags"]), _ptr(t["gt_cat"]), dp.n_dt,
+            _ptr(t["gt_flags"]), _ptr(t["gt_cat"]),
+            _ptr(t["gt_cat_off"]) if dp.grouped else None, dp.n_dt,
             _ptr(t["dt_area"]), _ptr(t["dt_len"]), _ptr(t["dt_flags"]),
             dp.n_cat, _ptr(ws.gt_rng), _ptr(ws.dt_rng), _ptr(ws.num_gt), s),
             "taoamd_tao_ranges")
@@ -137,6 +158,13 @@ def stage_ranges(dp, ws):
 
 def stage_sort(dp, ws):
     lib, t, s = _lib.load(), dp.t, _stream()
+    if dp.grouped:
+        _lib.check(lib.taoamd_sort_segments(
+            dp.n_dt, dp.n_cat, _ptr(t["cat_off"]), _ptr(t["tile_off"]),
+            dp.n_tiles, dp.max_segment, _ptr(t["dt_cat"]), _ptr(t["dt_score"]),
+            _ptr(ws.order), _ptr(ws.dst), _ptr(ws.sort_ws), ws.sort_bytes, s),
+            "taoamd_sort_segments")
+        return
     _lib.check(lib.taoamd_sort_by_cat_score(
         dp.n_dt, _ptr(t["dt_cat"]), _ptr(t["dt_score"]), _ptr(ws.order),
         _ptr(ws.dst), _ptr(ws.sort_ws), ws.sort_bytes, s),
@@ -152,7 +180,8 @@ def stage_track_iou(dp, ws):
         _ptr(t["cell_iou_off"]), dp.n_iou, _ptr(t["dt_frame_off"]),
         _ptr(t["dt_frame_pos"]), _ptr(t["dt_frame_box"]),
         _ptr(t["gt_frame_off"]), _ptr(t["gt_frame_pos"]),
-        _ptr(t["gt_frame_box"]), _ptr(ws.iou), _ptr(ws.pair_frames), s),
+        _ptr(t["gt_frame_box"]), _ptr(t["cell_span"]), dp.all_dense,
+        _ptr(ws.iou), _ptr(ws.pair_frames), s),
         "taoamd_track_iou")
 
 

@@ -19,9 +19,13 @@ tao_amodal/evaluation/tao_amodal/):
 * federated filter: keep a detection only if its category is in the
   image's/video's ``neg_category_ids`` or has ground truth there
   (L/eval.py:99-103, T/eval.py:228-233)
-* cells ordered by (sorted image id | sorted video id, sorted category id);
-  detections inside a cell by descending score, stable (L/eval.py:175,
-  T/eval.py:313); ground truth in visiting order
+* cells ordered CATEGORY-MAJOR: (sorted category id, sorted image id | sorted
+  video id).  The reference walks cells unit-major while matching and
+  category-major while accumulating (L/eval.py:339-346); only the second
+  order is observable (it fixes the tie order of equal scores), and laying the
+  cells out that way makes every category a contiguous run of detections and
+  of ground truths.  Detections inside a cell by descending score, stable
+  (L/eval.py:175, T/eval.py:313); ground truth in visiting order
 * TAO visiting order = CPython iteration order of
   ``set(video_images) & set(video_images)`` (T/tao.py:230) -- obtained here by
   building that very set -- then first appearance of each track id
@@ -186,8 +190,9 @@ def flatten_lvis(gt: GTColumns, dt: DTColumns, max_dets=MAX_DETS):
     order = np.argsort(d_img, kind="stable")
     order = order[(d_cat[order] >= 0) & (d_area[order] > 0)
                   & (d_area[order] < np.inf)]
-    key_present = np.unique(g_img * K + g_cat)
-    k_of = d_img[order] * K + d_cat[order]
+    U = len(img_ids)
+    key_present = np.unique(g_cat * U + g_img)
+    k_of = d_cat[order] * U + d_img[order]
     is_present = _lookup(key_present, k_of) >= 0
     rows = img_row[d_img[order]]
     is_neg = _csr_member(gt.img_neg_off, gt.img_neg, rows,
@@ -195,8 +200,8 @@ def flatten_lvis(gt: GTColumns, dt: DTColumns, max_dets=MAX_DETS):
     order = order[is_present | is_neg]
 
     # ---- cells
-    keys_g = g_img * K + g_cat
-    keys_d = d_img[order] * K + d_cat[order]
+    keys_g = g_cat * U + g_img
+    keys_d = d_cat[order] * U + d_img[order]
     # detections: by cell, then descending score, stable in visiting order
     o2 = np.lexsort((np.arange(len(order)), -d.score[order], keys_d))
     order = order[o2]
@@ -220,21 +225,21 @@ def flatten_lvis(gt: GTColumns, dt: DTColumns, max_dets=MAX_DETS):
     f.img_ids, f.cat_ids = img_ids, cat_ids
     f.cat_freq = _freq_of(gt, cat_ids)
     f.n_cells = len(cell_keys)
-    f.cell_unit = (cell_keys // K).astype(I32)      # image index
-    f.cell_cat = (cell_keys % K).astype(I32)
+    f.cell_unit = (cell_keys % U).astype(I32)       # image index
+    f.cell_cat = (cell_keys // U).astype(I32)
     f.cell_dt_off = d_off.astype(I32)
     f.cell_gt_off = g_off.astype(I32)
     f.dt_box = np.ascontiguousarray(d.bbox[order])
     f.dt_score = np.ascontiguousarray(d.score[order])
     f.dt_flags = d_flags
     f.dt_id = d_id[order]
-    f.dt_cat = (keys_d % K).astype(I32)
+    f.dt_cat = (keys_d // U).astype(I32)
     f.dt_cell = d_cell.astype(I32)
     f.gt_box = np.ascontiguousarray(gt.ann_bbox[g_sel])
     f.gt_vis = np.ascontiguousarray(gt.ann_vis[g_sel])
     f.gt_flags = g_flags
     f.gt_id = gt.ann_id[g_sel]
-    f.gt_cat = (keys_g % K).astype(I32)
+    f.gt_cat = (keys_g // U).astype(I32)
     f.gt_cell = g_cell.astype(I32)
     f.n_pairs = int(np.sum(np.diff(d_off) * np.diff(g_off)))
     return f
@@ -451,13 +456,14 @@ def flatten_tao(gt: GTColumns, dt: DTColumns, max_dets=MAX_DETS):
         raise KeyError("track refers to an unknown video")
 
     # ---- federated filter on the video lists (T/eval.py:214-233)
-    key_present = np.unique(g_vid * K + g_cat)
-    is_present = _lookup(key_present, d_vid * K + d_cat) >= 0
+    U = len(vid_ids)
+    key_present = np.unique(g_cat * U + g_vid)
+    is_present = _lookup(key_present, d_cat * U + d_vid) >= 0
     is_neg = _csr_member(gt.vid_neg_off, gt.vid_neg, vid_row[d_vid], d_catid)
     d_keep = np.flatnonzero(is_present | is_neg)
 
-    keys_g = g_vid * K + g_cat
-    keys_d = d_vid[d_keep] * K + d_cat[d_keep]
+    keys_g = g_cat * U + g_vid
+    keys_d = d_cat[d_keep] * U + d_vid[d_keep]
     o2 = np.lexsort((np.arange(len(d_keep)), -d_score[d_keep], keys_d))
     d_keep, keys_d = d_keep[o2], keys_d[o2]
     og = np.argsort(keys_g, kind="stable")
@@ -483,6 +489,13 @@ def flatten_tao(gt: GTColumns, dt: DTColumns, max_dets=MAX_DETS):
     d_fpos, d_fbox, d_foff = frames(d_keep, d_trk_of_ann, d_ann, d_img[d_ann],
                                     d.bbox)
 
+    # 1 + largest timeline position used by a cell (sizes the LDS tables of
+    # the dense-timeline 3D-IoU kernel)
+    span = np.zeros(len(cell_keys), dtype=np.int64)
+    if len(g_fpos):
+        np.maximum.at(span, np.repeat(g_cell, np.diff(g_foff)), g_fpos + 1)
+    if len(d_fpos):
+        np.maximum.at(span, np.repeat(d_cell, np.diff(d_foff)), d_fpos + 1)
     nel = _csr_member(gt.vid_nel_off, gt.vid_nel, vid_row[d_vid[d_keep]],
                       d_catid[d_keep])
     f = Flat()
@@ -490,13 +503,14 @@ def flatten_tao(gt: GTColumns, dt: DTColumns, max_dets=MAX_DETS):
     f.vid_ids, f.cat_ids = vid_ids, cat_ids
     f.required_average = required_average
     f.n_cells = len(cell_keys)
-    f.cell_unit = (cell_keys // K).astype(I32)      # video index
-    f.cell_cat = (cell_keys % K).astype(I32)
+    f.cell_unit = (cell_keys % U).astype(I32)       # video index
+    f.cell_cat = (cell_keys // U).astype(I32)
     f.cell_dt_off = d_off.astype(I32)
     f.cell_gt_off = g_off.astype(I32)
     iou_off = np.zeros(f.n_cells + 1, dtype=np.int64)
     np.cumsum(np.diff(d_off) * np.diff(g_off), out=iou_off[1:])
     f.cell_iou_off = iou_off
+    f.cell_span = span.astype(I32)
     f.dt_score = np.ascontiguousarray(d_score[d_keep])
     f.dt_area = np.ascontiguousarray(d_area_t[d_keep])
     f.dt_len = d_len[d_keep].astype(I32)
@@ -504,7 +518,7 @@ def flatten_tao(gt: GTColumns, dt: DTColumns, max_dets=MAX_DETS):
                   | np.where(d_ids[d_keep] <= 0, DT_NO_CONSUME, 0)
                   ).astype(np.uint8)
     f.dt_id = d_ids[d_keep]
-    f.dt_cat = (keys_d % K).astype(I32)
+    f.dt_cat = (keys_d // U).astype(I32)
     f.dt_cell = d_cell.astype(I32)
     f.dt_frame_off, f.dt_frame_pos, f.dt_frame_box = d_foff, d_fpos, d_fbox
     f.gt_area = np.ascontiguousarray(g_area[og])
@@ -514,7 +528,7 @@ def flatten_tao(gt: GTColumns, dt: DTColumns, max_dets=MAX_DETS):
                   | np.where(g_ids[og] == -1, GT_ID_HIDDEN, 0)
                   ).astype(np.uint8)
     f.gt_id = g_ids[og]
-    f.gt_cat = (keys_g % K).astype(I32)
+    f.gt_cat = (keys_g // U).astype(I32)
     f.gt_cell = g_cell.astype(I32)
     f.gt_frame_off, f.gt_frame_pos, f.gt_frame_box = g_foff, g_fpos, g_fbox
     f.n_pairs = int(iou_off[-1])

@@ -78,6 +78,21 @@ def test_synthetic_hip_vs_c_oracle(seed, V, F, C, dpf):
     _compare_with_oracle(f, _engine().evaluate_flat(f, detail=True))
 
 
+def test_long_timelines_take_the_merge_kernel_and_gt_groups():
+    """(G + 1) * span > 12288 -> two-pointer merge kernel; otherwise the
+    dense-timeline kernel, with detection tracks staged in several groups
+    when the cell has many of them."""
+    from tao_amodal_amd import engine
+    for seed, V, F, G, dense in ((31, 2, 700, 40, False), (32, 2, 200, 40, True),
+                                 (33, 1, 300, 8, True)):
+        gt, dt = synth(seed=seed, V=V, F=F, C=6, dets_per_frame=60,
+                       gt_tracks_per_video=G, n_present=2, n_neg=1)
+        dt.track_id, _ = fl.make_track_ids_unique(dt)
+        f = fl.flatten_tao(gt, dt)
+        assert bool(engine.DeviceProblem(f).all_dense) == dense
+        _compare_with_oracle(f, _engine().evaluate_flat(f, detail=True))
+
+
 def test_cells_with_more_than_64_ground_truths():
     """Crowded cells take match_big_kernel (LDS row + LDS bitsets)."""
     gt, dt = synth(seed=9, V=2, F=3, C=4, dets_per_frame=200,
@@ -148,3 +163,46 @@ def test_sharded_path_on_one_gpu_equals_plain_path():
             assert np.array_equal(ev.recall.cpu().numpy(), want["recall"])
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,n_cat,quant", [(50000, 7, 50), (200000, 3, 0), (3000, 500, 5),
+                                            (70000, 1, 3)])
+def test_both_sorts_are_the_stable_mergesort_order(n, n_cat, quant):
+    """Radix sort and tile+merge sort against numpy's stable argsort, with
+    heavy score ties and categories far longer than one LDS tile."""
+    import torch
+    from tao_amodal_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(n + n_cat)
+    cat = np.sort(rng.integers(0, n_cat, n)).astype(np.int32)
+    score = rng.random(n)
+    if quant:
+        score = np.round(score * quant) / quant
+    score[rng.integers(0, n, 5)] = -0.0
+    score[rng.integers(0, n, 5)] = 0.0
+    want = np.lexsort((np.arange(n), -score, cat))
+    d_cat, d_score = torch.from_numpy(cat).cuda(), torch.from_numpy(score).cuda()
+    order = torch.empty(n, dtype=torch.int32, device="cuda")
+    dst = torch.empty(n, dtype=torch.int32, device="cuda")
+    nb = max(lib.taoamd_sort_workspace(n), lib.taoamd_sort_segments_workspace(n))
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    _lib.check(lib.taoamd_sort_by_cat_score(n, d_cat.data_ptr(), d_score.data_ptr(),
+                                            order.data_ptr(), dst.data_ptr(),
+                                            ws.data_ptr(), nb, None), "radix")
+    torch.cuda.synchronize()
+    assert np.array_equal(order.cpu().numpy(), want)
+    assert np.array_equal(dst.cpu().numpy()[want], np.arange(n))
+    cat_off = np.zeros(n_cat + 1, np.int32)
+    np.cumsum(np.bincount(cat, minlength=n_cat), out=cat_off[1:])
+    tiles = (np.diff(cat_off) + _lib.SEGMENT_TILE - 1) // _lib.SEGMENT_TILE
+    tile_off = np.zeros(n_cat + 1, np.int32)
+    np.cumsum(tiles, out=tile_off[1:])
+    order.zero_(); dst.zero_()
+    d_co, d_to = torch.from_numpy(cat_off).cuda(), torch.from_numpy(tile_off).cuda()
+    _lib.check(lib.taoamd_sort_segments(
+        n, n_cat, d_co.data_ptr(), d_to.data_ptr(), int(tile_off[-1]),
+        int(np.diff(cat_off).max()), d_cat.data_ptr(), d_score.data_ptr(),
+        order.data_ptr(), dst.data_ptr(), ws.data_ptr(), nb, None), "segments")
+    torch.cuda.synchronize()
+    assert np.array_equal(order.cpu().numpy(), want)
+    assert np.array_equal(dst.cpu().numpy()[want], np.arange(n))
