@@ -61,6 +61,23 @@ def algorithmic_bytes_match(dp):
             + dp.n_gt * (32 + 4 + 1) + dp.n_cells * 8)
 
 
+def pmc_traffic(kernel_substr):
+    """HBM bytes per launch of the dominant kernel from the newest committed
+    PMC summary (profiles/*_pmc.json, written by tools/prof_summary.py from
+    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this very
+    command); None when no profile is present."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        ks = json.load(f)["kernels"]
+    for name, v in ks.items():
+        if kernel_substr in name:
+            return v["hbm_bytes_corrected"]
+    return None
+
+
 def main():
     args = parse()
     import torch
@@ -146,7 +163,8 @@ def main():
         ach = alg / (k_ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": "match_kernel<fused> (LVIS IoU+greedy match)",
                 "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                "frac": round(ach / HBM_PEAK_GBS, 5),
+                "traffic": pmc_traffic("match_kernel<true>"),
                 "alg_bytes_per_launch": int(alg), "kernel_ms": round(k_ms, 4)}
 
     # ---- verification + CPU baseline (C oracle = "port"), rank 0, N=1
