@@ -397,7 +397,14 @@ struct MatchArgs {
     int32_t n_rng;
     int32_t n_words;
     int64_t out_stride;  // words between consecutive output rows
+    // optional launch plan (built by the host from the cell table)
+    const int32_t *dt_cell;   // detection -> cell
+    const int32_t *groups;    // [n_groups][2] cell ranges handled per wavefront
+    const int32_t *singles;   // [n_singles] cells handled one per wavefront
+    int32_t n_groups, n_singles;
 };
+
+#define GRP_GCAP 8   // most GTs of one cell inside a multi-cell group
 
 // Fast path: G <= 64.  One wavefront per (cell, word).
 template <bool FUSED>
@@ -406,9 +413,11 @@ __global__ __launch_bounds__(256) void match_kernel(MatchArgs a, IouThr thr)
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t item = (int64_t)blockIdx.x * 4 + wave;
-    if (item >= a.n_cells * a.n_words) return;
-    const int64_t cell = item / a.n_words;
-    const int word = (int)(item - cell * a.n_words);
+    const int64_t n_items = a.singles != nullptr ? a.n_singles : a.n_cells;
+    if (item >= n_items * a.n_words) return;
+    const int64_t ci = item / a.n_words;
+    const int word = (int)(item - ci * a.n_words);
+    const int64_t cell = a.singles != nullptr ? a.singles[ci] : ci;
     const int32_t d0 = __builtin_amdgcn_readfirstlane(a.cell_dt_off[cell]);
     const int32_t D = __builtin_amdgcn_readfirstlane(a.cell_dt_off[cell + 1]) - d0;
     const int32_t g0 = __builtin_amdgcn_readfirstlane(a.cell_gt_off[cell]);
@@ -500,6 +509,180 @@ __global__ __launch_bounds__(256) void match_kernel(MatchArgs a, IouThr thr)
     }
 }
 
+// Multi-cell groups.  Most cells are tiny (a handful of detections, one or two
+// GTs): one wavefront per cell spends its life waiting on three dependent,
+// nearly empty memory round trips.  Here a wavefront takes a run of
+// consecutive cells with at most 64 detections and 64 GTs in total (each cell
+// at most GRP_GCAP GTs): detections and GTs of the run are contiguous, so
+// lane = detection / lane = GT loads are coalesced and issued once per run.
+//   * lane = detection: IoU against the (<= GRP_GCAP) GTs of its own cell,
+//     GT boxes broadcast from LDS -> IoU values to LDS
+//   * lane = combo: the sequential greedy over the run's detections; the
+//     "ignored" / "taken" sets are 64-bit masks over the run's GTs, so moving
+//     from one cell to the next needs no reset at all.
+template <bool FUSED>
+__global__ __launch_bounds__(256) void match_group_kernel(MatchArgs a, IouThr thr)
+{
+    __shared__ double4 s_gt[4][WAVE];
+    __shared__ double s_iou[4][WAVE * GRP_GCAP];
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t item = (int64_t)blockIdx.x * 4 + wave;
+    if (item >= (int64_t)a.n_groups * a.n_words) return;
+    const int64_t grp = item / a.n_words;
+    const int word = (int)(item - grp * a.n_words);
+    const int32_t c0 = __builtin_amdgcn_readfirstlane(a.groups[2 * grp]);
+    const int32_t c1 = __builtin_amdgcn_readfirstlane(a.groups[2 * grp + 1]);
+    const int32_t d0 = __builtin_amdgcn_readfirstlane(a.cell_dt_off[c0]);
+    const int32_t nD = __builtin_amdgcn_readfirstlane(a.cell_dt_off[c1]) - d0;
+    const int32_t g0 = __builtin_amdgcn_readfirstlane(a.cell_gt_off[c0]);
+    const int32_t nG = __builtin_amdgcn_readfirstlane(a.cell_gt_off[c1]) - g0;
+    if (nD == 0) return;
+    const int n_combo = a.n_rng * N_THR;
+    const int combo = word * WAVE + lane;
+    const bool active = combo < n_combo;
+    const int r = active ? combo / N_THR : 0;
+    const int t = active ? combo - r * N_THR : 0;
+    const double thr0 = fmin(thr.v[t], 1 - 1e-10);
+
+    // ---- lane = detection of the run
+    int32_t t_flags = 0, t_rng = 0, gb = 0, ge = 0, dloc = 0, Gc = 0;
+    int64_t t_row = 0, t_ioff = 0;
+    double4 B = make_double4(0, 0, 0, 0);
+    if (lane < nD) {
+        const int32_t d = d0 + lane;
+        const int32_t c = a.dt_cell[d];
+        t_flags = a.dt_flags[d];
+        t_rng = (int32_t)a.dt_rng[d];
+        t_row = a.dst != nullptr ? a.dst[d] : d;
+        const int32_t cg0 = a.cell_gt_off[c];
+        Gc = a.cell_gt_off[c + 1] - cg0;
+        gb = cg0 - g0;
+        ge = gb + Gc;
+        dloc = d - a.cell_dt_off[c];
+        if (a.cell_iou_off != nullptr) t_ioff = a.cell_iou_off[c];
+        if (FUSED) B = reinterpret_cast<const double4 *>(a.dt_box)[d];
+    }
+    // ---- lane = GT of the run
+    uint32_t grng = 0xffffffffu;
+    bool ghid = false;
+    if (lane < nG) {
+        grng = a.gt_rng[g0 + lane];
+        ghid = a.gt_flags[g0 + lane] & TAOAMD_GT_ID_HIDDEN;
+        if (FUSED) s_gt[wave][lane] = reinterpret_cast<const double4 *>(a.gt_box)[g0 + lane];
+    }
+    uint64_t IG = 0;
+    for (int q = 0; q < a.n_rng; q++) {
+        const uint64_t m = __ballot(lane < nG && ((grng >> q) & 1u));
+        IG = (q == r) ? m : IG;
+    }
+    const uint64_t HID = __ballot(ghid);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    // ---- IoU of every detection against the GTs of its own cell
+    for (int k = 0; k < GRP_GCAP; k++) {
+        const bool has = lane < nD && k < Gc;
+        if (__ballot(has) == 0) break;
+        if (has) {
+            double v;
+            if (FUSED) {
+                const double4 A = s_gt[wave][gb + k];
+                v = box_iou(B.x, B.y, B.z, B.w, A.x, A.y, A.z, A.w);
+                if (a.ious_out != nullptr && word == 0)
+                    a.ious_out[t_ioff + (int64_t)dloc * Gc + k] = v;
+            } else {
+                v = a.iou[t_ioff + (int64_t)dloc * Gc + k];
+            }
+            s_iou[wave][lane * GRP_GCAP + k] = v;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    // ---- cells with at most one GT: closed form, lane = detection.
+    // With a single GT the greedy degenerates: a detection takes the GT iff
+    // its IoU reaches the threshold and no earlier *consuming* detection of
+    // the cell did (whether the GT is ignored only changes the `ignored`
+    // bit, never the assignment); with no GT nothing matches.  One ballot
+    // per threshold answers that for all detections of the run at once.
+    uint64_t my_m = 0, my_i = 0;
+    const bool simple = lane < nD && Gc <= 1;
+    {
+        double v0 = 0.0;
+        uint32_t mygrng = 0;
+        bool myghid = false;
+        uint64_t cellmask = 0;
+        if (simple) {
+            if (Gc == 1) {
+                v0 = s_iou[wave][lane * GRP_GCAP];
+                mygrng = a.gt_rng[g0 + gb];
+                myghid = a.gt_flags[g0 + gb] & TAOAMD_GT_ID_HIDDEN;
+            }
+            const int ca = lane - dloc;           // first detection of my cell
+            cellmask = ((1ull << lane) - 1) & ~((1ull << ca) - 1);  // earlier ones
+        }
+        uint32_t m10 = 0;
+        for (int q = 0; q < N_THR; q++) {
+            const double tq = fmin(thr.v[q], 1 - 1e-10);
+            const bool pass = simple && Gc == 1 && !(v0 < tq);
+            const uint64_t cons = __ballot(pass && !(t_flags & TAOAMD_DT_NO_CONSUME));
+            if (pass && (cons & cellmask) == 0) m10 |= 1u << q;
+        }
+        if (simple) {
+            const uint32_t all10 = (1u << N_THR) - 1;
+            const int r_lo = (word * WAVE) / N_THR;
+            const int r_hi = min(a.n_rng - 1, (word * WAVE + WAVE - 1) / N_THR);
+            for (int q = r_lo; q <= r_hi; q++) {
+                const bool igr = (mygrng >> q) & 1u, dig = ((uint32_t)t_rng >> q) & 1u;
+                const uint64_t mb = myghid ? 0u : m10;
+                const uint64_t ib = (igr ? m10 : 0u) |
+                                    (dig ? (myghid ? all10 : (~m10 & all10)) : 0u);
+                const int o = q * N_THR - word * WAVE;
+                my_m |= o >= 0 ? mb << o : mb >> (-o);
+                my_i |= o >= 0 ? ib << o : ib >> (-o);
+            }
+            if (a.match_gt != nullptr)
+                for (int cc = 0; cc < WAVE && word * WAVE + cc < n_combo; cc++)
+                    a.match_gt[(int64_t)(d0 + lane) * n_combo + word * WAVE + cc] =
+                        ((m10 >> ((word * WAVE + cc) % N_THR)) & 1u) ? 0 : -1;
+        }
+    }
+    // ---- lane = combo: sequential greedy over the detections whose cell has
+    // two or more GTs
+    const uint64_t todo = __ballot(lane < nD && Gc >= 2);
+    uint64_t taken = 0;
+    for (uint64_t rest = todo; rest != 0; rest &= rest - 1) {
+        const int i = __builtin_ctzll(rest);
+        const int gbi = __builtin_amdgcn_readlane(gb, i);
+        const int gei = __builtin_amdgcn_readlane(ge, i);
+        const uint32_t df = (uint32_t)__builtin_amdgcn_readlane(t_flags, i);
+        const uint32_t drng = (uint32_t)__builtin_amdgcn_readlane(t_rng, i);
+        double best1 = thr0, best2 = thr0;
+        int m1 = -1, m2 = -1;
+        const uint64_t free1 = ~taken & ~IG, free2 = ~taken & IG;
+        for (int g = gbi; g < gei; g++) {
+            const double v = s_iou[wave][i * GRP_GCAP + (g - gbi)];
+            const bool ok1 = ((free1 >> g) & 1) && !(v < best1);
+            const bool ok2 = ((free2 >> g) & 1) && !(v < best2);
+            best1 = ok1 ? v : best1;  m1 = ok1 ? g : m1;
+            best2 = ok2 ? v : best2;  m2 = ok2 ? g : m2;
+        }
+        const int m = m1 >= 0 ? m1 : m2;
+        if (m >= 0 && !(df & TAOAMD_DT_NO_CONSUME)) taken |= 1ull << m;
+        const bool vis = m >= 0 && !((HID >> m) & 1);
+        bool ig = m >= 0 && ((IG >> m) & 1);
+        if (!vis && ((drng >> r) & 1u)) ig = true;
+        const uint64_t mw = __ballot(active && vis);
+        const uint64_t iw = __ballot(active && ig);
+        if (lane == i) { my_m = mw; my_i = iw; }
+        if (a.match_gt != nullptr && active)
+            a.match_gt[(int64_t)(d0 + i) * n_combo + combo] = m >= 0 ? m - gbi : -1;
+    }
+    if (lane < nD) {
+        a.matched[t_row * a.out_stride + word] = my_m;
+        a.ignored[t_row * a.out_stride + word] = my_i;
+    }
+}
+
 // Slow path: cells with more than 64 ground truths.  One wavefront (one
 // 64-thread block) per (cell, word); dynamic LDS = IoU row [Gmax] doubles +
 // taken bitsets [ceil(Gmax/32)][64] words (lane-minor: conflict free).
@@ -512,8 +695,9 @@ __global__ __launch_bounds__(64) void match_big_kernel(MatchArgs a, IouThr thr,
     uint32_t *takenw = reinterpret_cast<uint32_t *>(smem + (size_t)g_cap * 8);
     const int lane = lane_id();
     const int64_t item = blockIdx.x;
-    const int64_t cell = item / a.n_words;
-    const int word = (int)(item - cell * a.n_words);
+    const int64_t ci = item / a.n_words;
+    const int word = (int)(item - ci * a.n_words);
+    const int64_t cell = a.singles != nullptr ? a.singles[ci] : ci;
     const int32_t d0 = a.cell_dt_off[cell], D = a.cell_dt_off[cell + 1] - d0;
     const int32_t g0 = a.cell_gt_off[cell], G = a.cell_gt_off[cell + 1] - g0;
     if (D == 0 || G <= WAVE) return;
@@ -706,7 +890,10 @@ extern "C" int taoamd_match(int64_t n_cells, const int32_t *cell_dt_off,
                             const uint8_t *dt_flags, const int32_t *dst,
                             int64_t out_stride, uint64_t *matched,
                             uint64_t *ignored, int32_t *match_gt,
-                            double *ious_out, void *stream)
+                            double *ious_out, const int32_t *dt_cell,
+                            const int32_t *groups, int32_t n_groups,
+                            const int32_t *singles, int32_t n_singles,
+                            void *stream)
 {
     if (n_cells == 0) return TAOAMD_OK;
     if (n_rng < 1 || n_rng > 32) return TAOAMD_ERR_ARG;
@@ -714,6 +901,9 @@ extern "C" int taoamd_match(int64_t n_cells, const int32_t *cell_dt_off,
     if (fused ? (gt_box == nullptr) : (iou == nullptr)) return TAOAMD_ERR_ARG;
     if (max_gt_per_cell > TAOAMD_MAX_GT_PER_CELL) return TAOAMD_ERR_TOO_LARGE;
     if ((!fused || ious_out) && cell_iou_off == nullptr) return TAOAMD_ERR_ARG;
+    const bool planned = groups != nullptr;
+    if (planned && (dt_cell == nullptr || (n_singles > 0 && singles == nullptr)))
+        return TAOAMD_ERR_ARG;
     MatchArgs a;
     a.n_cells = n_cells; a.cell_dt_off = cell_dt_off; a.cell_gt_off = cell_gt_off;
     a.cell_iou_off = cell_iou_off; a.dt_box = dt_box; a.gt_box = gt_box;
@@ -723,23 +913,30 @@ extern "C" int taoamd_match(int64_t n_cells, const int32_t *cell_dt_off,
     a.n_words = (n_rng * N_THR + 63) / 64;
     a.out_stride = out_stride > 0 ? out_stride : a.n_words;
     if (a.out_stride < a.n_words) return TAOAMD_ERR_ARG;
+    a.dt_cell = dt_cell; a.groups = groups; a.n_groups = planned ? n_groups : 0;
+    a.singles = planned ? singles : nullptr; a.n_singles = planned ? n_singles : 0;
     hipStream_t s = (hipStream_t)stream;
-    const int64_t items = n_cells * a.n_words;
-    const unsigned blocks = (unsigned)((items + 3) / 4);
-    if (fused)
-        match_kernel<true><<<blocks, 256, 0, s>>>(a, iou_thr());
-    else
-        match_kernel<false><<<blocks, 256, 0, s>>>(a, iou_thr());
-    TAO_LAUNCH_CHECK();
-    if (max_gt_per_cell > WAVE) {
-        const int32_t cap = (max_gt_per_cell + 31) / 32 * 32;
-        const size_t lds = (size_t)cap * 8 + (size_t)(cap / 32) * WAVE * 4;
-        if (fused)
-            match_big_kernel<true><<<(unsigned)items, 64, lds, s>>>(a, iou_thr(), cap);
-        else
-            match_big_kernel<false><<<(unsigned)items, 64, lds, s>>>(a, iou_thr(), cap);
-        TAO_LAUNCH_CHECK();
+    if (planned && n_groups > 0) {
+        const unsigned gb = (unsigned)(((int64_t)n_groups * a.n_words + 3) / 4);
+        if (fused) match_group_kernel<true><<<gb, 256, 0, s>>>(a, iou_thr());
+        else match_group_kernel<false><<<gb, 256, 0, s>>>(a, iou_thr());
     }
+    const int64_t cells = planned ? n_singles : n_cells;
+    const int64_t items = cells * a.n_words;
+    if (items > 0) {
+        const unsigned blocks = (unsigned)((items + 3) / 4);
+        if (fused) match_kernel<true><<<blocks, 256, 0, s>>>(a, iou_thr());
+        else match_kernel<false><<<blocks, 256, 0, s>>>(a, iou_thr());
+        if (max_gt_per_cell > WAVE) {
+            const int32_t cap = (max_gt_per_cell + 31) / 32 * 32;
+            const size_t lds = (size_t)cap * 8 + (size_t)(cap / 32) * WAVE * 4;
+            if (fused)
+                match_big_kernel<true><<<(unsigned)items, 64, lds, s>>>(a, iou_thr(), cap);
+            else
+                match_big_kernel<false><<<(unsigned)items, 64, lds, s>>>(a, iou_thr(), cap);
+        }
+    }
+    TAO_LAUNCH_CHECK();
     return TAOAMD_OK;
 }
 

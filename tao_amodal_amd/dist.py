@@ -75,7 +75,8 @@ class HipBackend:
             None if fused else _ptr(ws.iou), dp.n_rng, _ptr(ws.gt_rng),
             _ptr(ws.dt_rng), _ptr(t["gt_flags"]), _ptr(t["dt_flags"]),
             _ptr(dst), width, base + 16, base + 16 + 8 * dp.n_words, None, None,
-            self._s()), "taoamd_match")
+            _ptr(t["dt_cell"]), _ptr(t["groups"]), dp.n_groups,
+            _ptr(t["singles"]), dp.n_singles, self._s()), "taoamd_match")
 
     def sort(self, n, cat, score, order, ws_buf, ws_bytes):
         _lib.check(self.lib.taoamd_sort_by_cat_score(

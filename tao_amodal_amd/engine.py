@@ -29,6 +29,35 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+def match_plan(d_cnt, g_cnt, cap_d=64, cap_g=64, cap_cell_g=8):
+    """Pack runs of consecutive small cells (<= cap_d detections and <= cap_g
+    GTs in total, <= cap_cell_g GTs per cell) into groups for
+    match_group_kernel; every other cell that has detections is a 'single'."""
+    n = len(d_cnt)
+    small = (d_cnt <= cap_d) & (g_cnt <= cap_cell_g)
+    cum_d = np.zeros(n + 1, dtype=np.int64)
+    cum_g = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(d_cnt, out=cum_d[1:])
+    np.cumsum(g_cnt, out=cum_g[1:])
+    # next non-small cell at or after i
+    idx = np.where(small, n, np.arange(n))
+    nxt = np.minimum.accumulate(idx[::-1])[::-1] if n else idx
+    groups, singles = [], np.flatnonzero(~small & (d_cnt > 0)).astype(np.int32)
+    c = 0
+    while c < n:
+        if not small[c]:
+            c += 1
+            continue
+        e = min(int(np.searchsorted(cum_d, cum_d[c] + cap_d, "right")) - 1,
+                int(np.searchsorted(cum_g, cum_g[c] + cap_g, "right")) - 1,
+                int(nxt[c]))
+        e = max(e, c + 1)
+        if cum_d[e] > cum_d[c]:
+            groups.append((c, e))
+        c = e
+    return np.asarray(groups, dtype=np.int32).reshape(-1, 2), singles
+
+
 class DeviceProblem:
     """A flattened problem (flatten.Flat) resident in HBM."""
 
@@ -55,8 +84,10 @@ class DeviceProblem:
         cat_off = np.zeros(self.n_cat + 1, dtype=np.int32)
         np.cumsum(np.bincount(flat.dt_cat, minlength=self.n_cat),
                   out=cat_off[1:])
+        groups, singles = match_plan(d_cnt, g_cnt)
+        self.n_groups, self.n_singles = len(groups), len(singles)
         names = ["cell_dt_off", "cell_gt_off", "dt_score", "dt_flags",
-                 "dt_cat", "gt_flags", "gt_cat"]
+                 "dt_cat", "gt_flags", "gt_cat", "dt_cell"]
         if self.kind == "lvis":
             names += ["dt_box", "gt_box", "gt_vis"]
         else:
@@ -83,6 +114,11 @@ class DeviceProblem:
         tile_off = np.zeros(self.n_cat + 1, dtype=np.int32)
         np.cumsum(tiles, out=tile_off[1:])
         self.n_tiles = int(tile_off[-1])
+        self.t["groups"] = torch.from_numpy(
+            np.ascontiguousarray(groups) if len(groups) else
+            np.zeros((1, 2), np.int32)).to(self.device)
+        self.t["singles"] = torch.from_numpy(
+            singles if len(singles) else np.zeros(1, np.int32)).to(self.device)
         self.t["cell_iou_off"] = torch.from_numpy(iou_off).to(self.device)
         self.t["cat_off"] = torch.from_numpy(cat_off).to(self.device)
         self.t["gt_cat_off"] = torch.from_numpy(gt_cat_off).to(self.device)
@@ -196,8 +232,9 @@ def stage_match(dp, ws, scatter=True):
         None if fused else _ptr(ws.iou), dp.n_rng, _ptr(ws.gt_rng),
         _ptr(ws.dt_rng), _ptr(t["gt_flags"]), _ptr(t["dt_flags"]),
         _ptr(ws.dst) if scatter else None, 0, _ptr(ws.matched),
-        _ptr(ws.ignored), _ptr(ws.match_gt), _ptr(ws.ious_out), s),
-        "taoamd_match")
+        _ptr(ws.ignored), _ptr(ws.match_gt), _ptr(ws.ious_out),
+        _ptr(t["dt_cell"]), _ptr(t["groups"]), dp.n_groups, _ptr(t["singles"]),
+        dp.n_singles, s), "taoamd_match")
 
 
 def stage_accumulate(dp, ws):
