@@ -131,9 +131,11 @@ int taoamd_tao_ranges(int64_t n_gt, const double *gt_area,
  * pair_frames (optional, int64[1], zeroed by the call) receives the number of
  * same-frame box pairs evaluated (the unit of BASELINE.json's metric).
  * cell_span (optional, int32[n_cells], device) = 1 + the largest timeline
- * position used by the cell.  Cells with (G + 1) * span <= 12288 take the
- * dense-timeline kernel (track rows in LDS, lane = track pair, no data-
- * dependent control flow); the others the two-pointer merge kernel.
+ * position used by the cell.  Cells with at most 16 GT tracks and
+ * (G + 1) * span <= 12288 take the dense-timeline kernel (track rows in LDS;
+ * per chunk of 32 positions the per-frame terms are formed in parallel and
+ * then added in order by one lane per track pair); the others the two-pointer
+ * merge kernel.
  * all_dense: non-zero when the host knows every non-empty cell qualifies, so
  * the merge kernel launch is skipped. */
 int taoamd_track_iou(int64_t n_cells, const int32_t *cell_dt_off,

@@ -25,12 +25,43 @@
 // Precision at a TP row is tp / (fp + tp + eps) in fp64, the very expression
 // of the reference; the envelope is a max of those values, so the order in
 // which chunks are combined cannot change a bit of the result.
+//
+// Two exact shortcuts keep fp64 divisions off the per-row paths:
+//  * the envelope is tracked as the integer pair (tp, n = tp + fp) and
+//    compared by cross-multiplication.  fl(tp / (n + eps)) is monotone in the
+//    rational tp/n, and n + eps == n for n >= 2, so the pair with the largest
+//    rational (ties: larger n, which ranks (1,1) -> 1/(1+eps) below (k,k) -> 1)
+//    yields the largest fp64 value; the division happens once, when a recall
+//    threshold is emitted;
+//  * recall thresholds are crossed at integer TP counts: cj[j] = the smallest
+//    c with fl(c / num_gt) >= rec_thrs[j] is tabulated per (category, range)
+//    by acc_cj_kernel with the reference's fp64 comparison, and the sweep
+//    compares integers.
 #include "common.hpp"
 
 using namespace taoamd;
 
 #define ACC_CH 256
 #define ACC_EPS 2.220446049250313e-16  // np.spacing(1)
+
+// (tp, n) pairs packed as tp << 32 | n.  better(a, b): pair a gives a larger
+// tp / (n + eps) than pair b (see the header comment).
+__device__ __forceinline__ bool pr_better(uint32_t ta, uint32_t na, uint64_t b)
+{
+    const uint32_t tb = (uint32_t)(b >> 32), nb = (uint32_t)b;
+    const uint64_t l = (uint64_t)ta * nb, r = (uint64_t)tb * na;
+    return l > r || (l == r && na > nb);
+}
+__device__ __forceinline__ uint64_t pr_pack(uint32_t t, uint32_t n)
+{
+    return ((uint64_t)t << 32) | n;
+}
+__device__ __forceinline__ double pr_value(uint64_t p)
+{
+    const double t = (double)(uint32_t)(p >> 32), n = (double)(uint32_t)p;
+    return t / (n + ACC_EPS);   // fp + tp == n exactly
+}
+#define PR_ZERO 1ull   // (0, 1): value 0
 
 struct AccArgs {
     int64_t n_dt;
@@ -42,7 +73,8 @@ struct AccArgs {
     int32_t *cat_chunk_off;  // [n_cat + 1]
     uint32_t *cnt_tp, *cnt_fp;   // [chunk][word][64] counts inside the chunk
     uint32_t *pre_tp, *pre_fp;   // exclusive prefix inside the category
-    double *cmax;                // chunk max, then reverse-exclusive max
+    uint64_t *cmax;              // chunk max as (tp << 32 | n), then reverse-exclusive max
+    int32_t *cj;                 // [n_cat][n_rng][N_REC] TP count crossing each recall thr
     double *val;                 // [n_cat][n_rng][N_THR][N_REC]
     double *rec;                 // [n_cat][n_rng][N_THR]
     int32_t k_begin, k_end;      // categories swept by this call
@@ -199,23 +231,20 @@ __global__ __launch_bounds__(256) void acc_chunkmax_kernel(AccArgs a)
     if (!ci.valid) return;
     const int lane = lane_id();
     const int64_t o = ((int64_t)ci.c * a.n_words + ci.word) * WAVE + lane;
-    double tp = (double)a.pre_tp[o], fp = (double)a.pre_fp[o];
-    double best = 0.0;
+    uint32_t tp = a.pre_tp[o], n = tp + a.pre_fp[o];
+    uint64_t best = PR_ZERO;
     const uint64_t *__restrict__ M = a.matched + ci.start * a.n_words + ci.word;
     const uint64_t *__restrict__ I = a.ignored + ci.start * a.n_words + ci.word;
     for (int base = 0; base < ci.len; base += WAVE) {
-        const int n = min(WAVE, ci.len - base);
+        const int nrow = min(WAVE, ci.len - base);
         uint64_t tpw, fpw;
-        load_rows(M, I, a.n_words, base, n, lane, tpw, fpw);
-        for (int q = 0; q < n; q++) {
-            const bool is_tp = (readlane_u64(tpw, q) >> lane) & 1;
-            const bool is_fp = (readlane_u64(fpw, q) >> lane) & 1;
-            if (is_tp) {
-                tp += 1.0;
-                const double pr = tp / (fp + tp + ACC_EPS);
-                best = pr > best ? pr : best;
-            }
-            if (is_fp) fp += 1.0;
+        load_rows(M, I, a.n_words, base, nrow, lane, tpw, fpw);
+        for (int q = 0; q < nrow; q++) {
+            const uint32_t is_tp = (uint32_t)(readlane_u64(tpw, q) >> lane) & 1u;
+            const uint32_t is_fp = (uint32_t)(readlane_u64(fpw, q) >> lane) & 1u;
+            tp += is_tp;
+            n += is_tp + is_fp;
+            if (is_tp && pr_better(tp, n, best)) best = pr_pack(tp, n);
         }
     }
     a.cmax[o] = best;
@@ -230,74 +259,111 @@ __global__ __launch_bounds__(256) void acc_sufmax_kernel(AccArgs a)
     const int word = (int)(item % a.n_words);
     const int lane = lane_id();
     const int32_t c0 = a.cat_chunk_off[k], c1 = a.cat_chunk_off[k + 1];
-    double run = 0.0;
+    uint64_t run = PR_ZERO;
     for (int32_t c = c1 - 1; c >= c0; c--) {
         const int64_t o = ((int64_t)c * a.n_words + word) * WAVE + lane;
-        const double v = a.cmax[o];
+        const uint64_t v = a.cmax[o];
         a.cmax[o] = run;
-        run = v > run ? v : run;
+        if (pr_better((uint32_t)(v >> 32), (uint32_t)v, run)) run = v;
     }
 }
 
-__global__ __launch_bounds__(256) void acc_emit_kernel(AccArgs a, RecThr rec_in)
+// cj[k][r][j]: smallest TP count c with fl(c / num_gt) >= rec_thrs[j]
+// (np.searchsorted(rc, rec_thrs, side="left") on rc = tp / num_gt,
+// reference lvis_amodal/eval.py:386,406-408)
+__global__ void acc_cj_kernel(AccArgs a, RecThr rec)
 {
-    __shared__ double rec[N_REC];
-    if (threadIdx.x < N_REC) rec[threadIdx.x] = rec_in.v[threadIdx.x];
-    __syncthreads();
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)(a.k_end - a.k_begin) * a.n_rng * N_REC;
+    if (i >= total) return;
+    const int j = (int)(i % N_REC);
+    const int64_t kr = (int64_t)a.k_begin * a.n_rng + i / N_REC;
+    const int32_t ng = a.num_gt[kr];
+    if (ng <= 0) return;
+    const double x = rec.v[j], dn = (double)ng;
+    int32_t c = (int32_t)(x * dn);
+    c = c < 0 ? 0 : (c > ng ? ng : c);
+    while (c < ng && (double)c / dn < x) c++;
+    while (c > 0 && (double)(c - 1) / dn >= x) c--;
+    a.cj[kr * N_REC + j] = c;
+}
+
+#define EMIT_RMAX 8   // ranges that can overlap one 64-combo word
+
+__global__ __launch_bounds__(256) void acc_emit_kernel(AccArgs a)
+{
+    __shared__ int32_t s_cj[4][EMIT_RMAX][N_REC];
     const ChunkInfo ci = chunk_info(a);
     if (!ci.valid) return;
     const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int combo = ci.word * WAVE + lane;
     const bool active = combo < a.n_rng * N_THR;
     const int r = active ? combo / N_THR : 0;
     const int t = active ? combo - r * N_THR : 0;
+    const int r_lo = (ci.word * WAVE) / N_THR;
+    const int r_hi = min(a.n_rng - 1, (ci.word * WAVE + WAVE - 1) / N_THR);
+    for (int q = r_lo; q <= r_hi; q++) {
+        const bool has = a.num_gt[(int64_t)ci.k * a.n_rng + q] > 0;
+        for (int j = lane; j < N_REC; j += WAVE)
+            s_cj[wave][q - r_lo][j] =
+                has ? a.cj[((int64_t)ci.k * a.n_rng + q) * N_REC + j] : 0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    const int32_t *__restrict__ cj = s_cj[wave][active ? r - r_lo : 0];
     const int32_t ng = active ? a.num_gt[(int64_t)ci.k * a.n_rng + r] : 0;
     const bool live = active && ng > 0;
     const int64_t o = ((int64_t)ci.c * a.n_words + ci.word) * WAVE + lane;
-    double tp = (double)(a.pre_tp[o] + a.cnt_tp[o]);
-    double fp = (double)(a.pre_fp[o] + a.cnt_fp[o]);
-    double run = a.cmax[o];
-    const double dng = (double)(live ? ng : 1);
+    uint32_t tp = a.pre_tp[o] + a.cnt_tp[o];
+    uint32_t n = tp + a.pre_fp[o] + a.cnt_fp[o];
+    uint64_t run = a.cmax[o];
     double *__restrict__ out =
         a.val + (((int64_t)ci.k * a.n_rng + r) * N_THR + t) * N_REC;
-    // thresholds already reached by the TP count at the end of this chunk
+    // thresholds already reached by the TP count at the end of this chunk:
+    // jcur = #{j : cj[j] <= tp} (cj is non-decreasing in j)
     int jcur = 0;
     if (live) {
-        const double x = tp / dng;
-        jcur = (int)(x * 100.0);
-        jcur = jcur < 0 ? 0 : (jcur > N_REC ? N_REC : jcur);
-        while (jcur < N_REC && rec[jcur] <= x) jcur++;
-        while (jcur > 0 && rec[jcur - 1] > x) jcur--;
+        int lo = 0, hi = N_REC;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (cj[mid] <= (int32_t)tp) lo = mid + 1; else hi = mid;
+        }
+        jcur = lo;
         if (ci.last)
             for (int j = jcur; j < N_REC; j++) out[j] = 0.0;
     }
     const uint64_t *__restrict__ M = a.matched + ci.start * a.n_words + ci.word;
     const uint64_t *__restrict__ I = a.ignored + ci.start * a.n_words + ci.word;
     for (int base = (ci.len - 1) / WAVE * WAVE; base >= 0; base -= WAVE) {
-        const int n = min(WAVE, ci.len - base);
+        const int nrow = min(WAVE, ci.len - base);
         uint64_t tpw, fpw;
-        load_rows(M, I, a.n_words, base, n, lane, tpw, fpw);
-        for (int q = n - 1; q >= 0; q--) {
+        load_rows(M, I, a.n_words, base, nrow, lane, tpw, fpw);
+        for (int q = nrow - 1; q >= 0; q--) {
             const bool is_tp = live && ((readlane_u64(tpw, q) >> lane) & 1);
             const bool is_fp = live && ((readlane_u64(fpw, q) >> lane) & 1);
             if (is_tp) {
-                const double pr = tp / (fp + tp + ACC_EPS);
-                run = pr > run ? pr : run;
-                tp -= 1.0;
-                const double x_prev = tp / dng;
-                while (jcur > 0 && rec[jcur - 1] > x_prev) {
-                    out[jcur - 1] = run;
-                    jcur--;
+                if (pr_better(tp, n, run)) run = pr_pack(tp, n);
+                tp -= 1;
+                n -= 1;
+                if (jcur > 0 && cj[jcur - 1] > (int32_t)tp) {
+                    const double v = pr_value(run);
+                    do {
+                        out[jcur - 1] = v;
+                        jcur--;
+                    } while (jcur > 0 && cj[jcur - 1] > (int32_t)tp);
                 }
             }
-            if (is_fp) fp -= 1.0;
+            if (is_fp) n -= 1;
         }
     }
-    if (live && ci.first)
+    if (live && ci.first && jcur > 0) {
+        const double v = pr_value(run);
         while (jcur > 0) {
-            out[jcur - 1] = run;
+            out[jcur - 1] = v;
             jcur--;
         }
+    }
 }
 
 // val[KR][T*R] -> precision[T*R][KR], rec[KR][T] -> recall[T][KR], -1 fill
@@ -351,7 +417,8 @@ static size_t base_workspace(int64_t n_dt, int32_t n_cat, int32_t n_rng)
     const size_t nw = (size_t)(n_rng * N_THR + 63) / 64;
     const size_t nc = (size_t)max_chunks(n_dt, n_cat);
     return align256(((size_t)n_cat + 1) * 4) + 4 * align256(nc * nw * WAVE * 4) +
-           align256(nc * nw * WAVE * 8) + 4096;
+           align256(nc * nw * WAVE * 8) +
+           align256((size_t)n_cat * n_rng * N_REC * 4) + 4096;
 }
 
 extern "C" size_t taoamd_compact_elems(int32_t n_cat, int32_t n_rng)
@@ -397,15 +464,20 @@ extern "C" int taoamd_accumulate_compact(int64_t n_dt, int32_t n_cat,
     a.cnt_fp = (uint32_t *)w; w += align256(nc * nw * WAVE * 4);
     a.pre_tp = (uint32_t *)w; w += align256(nc * nw * WAVE * 4);
     a.pre_fp = (uint32_t *)w; w += align256(nc * nw * WAVE * 4);
-    a.cmax = (double *)w;
+    a.cmax = (uint64_t *)w; w += align256(nc * nw * WAVE * 8);
+    a.cj = (int32_t *)w;
     const unsigned chunk_blocks = (unsigned)((nc * nw + 3) / 4);
     const unsigned cat_blocks = (unsigned)(((size_t)(k_end - k_begin) * nw + 3) / 4);
     acc_chunks_kernel<<<1, 256, 0, s>>>(a);
+    {
+        const int64_t tot = (int64_t)(k_end - k_begin) * n_rng * N_REC;
+        acc_cj_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, s>>>(a, rec_thr());
+    }
     acc_count_kernel<<<chunk_blocks, 256, 0, s>>>(a);
     acc_prefix_kernel<<<cat_blocks, 256, 0, s>>>(a);
     acc_chunkmax_kernel<<<chunk_blocks, 256, 0, s>>>(a);
     acc_sufmax_kernel<<<cat_blocks, 256, 0, s>>>(a);
-    acc_emit_kernel<<<chunk_blocks, 256, 0, s>>>(a, rec_thr());
+    acc_emit_kernel<<<chunk_blocks, 256, 0, s>>>(a);
     TAO_LAUNCH_CHECK();
     return TAOAMD_OK;
 }

@@ -265,23 +265,32 @@ __global__ __launch_bounds__(256) void track_iou_kernel(
 // Dense-timeline variant (the common case: videos with a few hundred frames).
 // One workgroup per cell.  LDS holds one row per track -- the GT tracks of the
 // cell and a group of its detection tracks -- mapping timeline position ->
-// frame index (-1 = absent).  Then lane = (detection track, GT track) pair and
-// all lanes walk the timeline together: every step fetches the two frames that
-// live at this position (addresses do not depend on earlier steps, so the
-// loads pipeline), forms the term
-//     both: (da + ga - i_, i_)   dt only: (da, 0)   gt only: (ga, 0)
-//     neither: (0, 0)
-// with the reference's per-frame arithmetic (tao_amodal/eval.py:32-48,87-94)
-// and adds it to the lane's running sums.  Adding (0, 0) for an empty position
-// is exact (u, i >= +0), so the sequence of roundings equals the two-pointer
-// merge over the union of frames: same result bit for bit, no data-dependent
-// control flow, no serialized memory round trips.
-#define TD_ENTRIES 12288   // int32 entries of LDS: rows * span <= TD_ENTRIES
-#define TD_UN 8            // positions per software-pipelined block
+// frame (offset inside the track, 0xffff = absent).  The timeline is processed
+// in chunks of TD_CH positions, two phases per chunk:
+//   A  one work item per (detection track, position): fetch the detection
+//      frame at that position (consecutive items = consecutive frames of one
+//      track: coalesced) and, per GT track, the GT frame; form the term
+//          both: (da + ga - i_, i_)   dt only: (da, 0)   gt only: (ga, 0)
+//          neither: (0, 0)
+//      with the reference's per-frame arithmetic (tao_amodal/eval.py:32-48,
+//      87-94) and park it in LDS as terms[position][pair].  Every load is
+//      independent of every other: the memory system sees them all at once.
+//   B  lane = (detection track, GT track) pair: add the chunk's terms in
+//      ascending position -- two fp64 adds per position, operands from LDS,
+//      no global memory on the serial chain.
+// Adding (0, 0) for an empty position is exact (u, i >= +0), so the sequence
+// of roundings equals the two-pointer merge over the union of frames.
+#define TD_MAP_ENTRIES 12288   // uint16 entries: (G + detection tracks) * span
+#define TD_CH 32               // timeline positions per chunk
+#define TD_PAIRS 64            // track pairs per detection-track group
+#define TD_GMAX 16             // GT tracks of a dense cell
+#define TD_NONE 0xffffu
+#define TD_IT 4                // phase-A items per thread and batch
 
 __device__ __forceinline__ bool dense_cell(int32_t span, int32_t D, int32_t G)
 {
-    return D > 0 && G > 0 && G <= 256 && (int64_t)(G + 1) * span <= TD_ENTRIES;
+    return D > 0 && G > 0 && G <= TD_GMAX &&
+           (int64_t)(G + 1) * span <= TD_MAP_ENTRIES;
 }
 
 __global__ __launch_bounds__(256) void track_iou_dense_kernel(
@@ -294,78 +303,113 @@ __global__ __launch_bounds__(256) void track_iou_dense_kernel(
     const int32_t *__restrict__ gfpos, const double *__restrict__ gfbox,
     double *__restrict__ iou, unsigned long long *__restrict__ pair_frames)
 {
-    __shared__ int32_t map[TD_ENTRIES];
+    __shared__ uint16_t map[TD_MAP_ENTRIES];
+    __shared__ double2 terms[TD_CH][TD_PAIRS + 1];
+    __shared__ double4 gbox[TD_GMAX * TD_CH];    // GT frames of the chunk
+    __shared__ int32_t first[2 * TD_PAIRS];   // first frame of every staged track
     const int64_t c = blockIdx.x;
     const int32_t d0 = cell_dt_off[c], D = cell_dt_off[c + 1] - d0;
     const int32_t g0 = cell_gt_off[c], G = cell_gt_off[c + 1] - g0;
     const int32_t span = cell_span[c];
     if (!dense_cell(span, D, G)) return;
     const int64_t ioff = cell_iou_off[c];
-    const int rows = TD_ENTRIES / span;
-    const int DG = min(min(D, rows - G), 256 / G);
-    int32_t *__restrict__ gmap = map;
-    int32_t *__restrict__ dmap = map + G * span;
-    for (int t = threadIdx.x; t < G * span; t += 256) gmap[t] = -1;
-    __syncthreads();
-    for (int g = 0; g < G; g++) {
-        const int32_t js = gfoff[g0 + g], je = gfoff[g0 + g + 1];
-        for (int32_t j = js + (int32_t)threadIdx.x; j < je; j += 256)
-            gmap[g * span + gfpos[j]] = j;
-    }
-    unsigned long long common = 0;
+    const int rows = TD_MAP_ENTRIES / span;
+    const int DG = min(min(D, rows - G), TD_PAIRS / G);
+    uint16_t *__restrict__ gmap = map;
+    uint16_t *__restrict__ dmap = map + G * span;
     const double4 *__restrict__ DB = reinterpret_cast<const double4 *>(dfbox);
     const double4 *__restrict__ GB = reinterpret_cast<const double4 *>(gfbox);
+    for (int t = threadIdx.x; t < G * span; t += 256) gmap[t] = TD_NONE;
+    __syncthreads();
+    for (int g = threadIdx.x >> 6; g < G; g += 4) {
+        const int32_t js = gfoff[g0 + g], je = gfoff[g0 + g + 1];
+        if (lane_id() == 0) first[g] = js;
+        for (int32_t j = js + lane_id(); j < je; j += WAVE)
+            gmap[g * span + gfpos[j]] = (uint16_t)(j - js);
+    }
+    unsigned long long common = 0;
     for (int32_t db = 0; db < D; db += DG) {
         const int nd = min(DG, D - db);
         __syncthreads();
-        for (int t = threadIdx.x; t < nd * span; t += 256) dmap[t] = -1;
+        for (int t = threadIdx.x; t < nd * span; t += 256) dmap[t] = TD_NONE;
         __syncthreads();
-        // one wavefront per detection track of the group, lanes over frames
         for (int dl = threadIdx.x >> 6; dl < nd; dl += 4) {
             const int32_t ks = dfoff[d0 + db + dl], ke = dfoff[d0 + db + dl + 1];
+            if (lane_id() == 0) first[TD_PAIRS + dl] = ks;
             for (int32_t k = ks + lane_id(); k < ke; k += WAVE)
-                dmap[dl * span + dfpos[k]] = k;
+                dmap[dl * span + dfpos[k]] = (uint16_t)(k - ks);
         }
         __syncthreads();
-        if ((int)threadIdx.x < nd * G) {
-            const int dl = threadIdx.x / G, g = threadIdx.x - dl * G;
-            const int32_t *__restrict__ dr = dmap + dl * span;
-            const int32_t *__restrict__ gr = gmap + g * span;
-            double u = 0.0, i = 0.0;
-            // blocks of TD_UN positions: all index reads, then all box loads
-            // (absent frames read a dummy box, so nothing is conditional and
-            // the loads of a block are in flight together), then the adds
-            for (int32_t p0 = 0; p0 < span; p0 += TD_UN) {
-                int32_t dk[TD_UN], gj[TD_UN];
-                double4 B[TD_UN], A[TD_UN];
+        double u = 0.0, i = 0.0;   // running sums of pair = threadIdx.x
+        const int pairs = nd * G;
+        for (int32_t p0 = 0; p0 < span; p0 += TD_CH) {
+            const int np = min(TD_CH, span - p0);
+            // ---- phase A0: the chunk's GT frames -> LDS (each GT box is
+            // needed by every detection track of the group)
+            for (int it = threadIdx.x; it < G * np; it += 256) {
+                const int g = it / np, pp = it - g * np;
+                const uint32_t rg = gmap[g * span + p0 + pp];
+                double4 A = make_double4(0, 0, -1.0, 0);   // w < 0: absent
+                if (rg != TD_NONE) A = GB[first[g] + (int32_t)rg];
+                gbox[g * TD_CH + pp] = A;
+            }
+            __syncthreads();
+            // ---- phase A: item = (detection track, position): consecutive
+            // threads read consecutive frames of one track (coalesced); the
+            // TD_IT box loads of a thread are issued together
+            for (int base = threadIdx.x; base < nd * np; base += 256 * TD_IT) {
+                int32_t kd[TD_IT];
+                bool hd[TD_IT];
+                double4 B[TD_IT];
 #pragma unroll
-                for (int q = 0; q < TD_UN; q++) {
-                    const bool in = p0 + q < span;
-                    dk[q] = in ? dr[p0 + q] : -1;
-                    gj[q] = in ? gr[p0 + q] : -1;
+                for (int q = 0; q < TD_IT; q++) {
+                    const int it = base + q * 256;
+                    const bool ok = it < nd * np;
+                    const int dl = ok ? it / np : 0, pp = ok ? it - dl * np : 0;
+                    const uint32_t rd = dmap[dl * span + p0 + pp];
+                    hd[q] = ok && rd != TD_NONE;
+                    kd[q] = hd[q] ? first[TD_PAIRS + dl] + (int32_t)rd : 0;
                 }
 #pragma unroll
-                for (int q = 0; q < TD_UN; q++) {
-                    B[q] = DB[max(dk[q], 0)];
-                    A[q] = GB[max(gj[q], 0)];
-                }
+                for (int q = 0; q < TD_IT; q++) B[q] = DB[kd[q]];
 #pragma unroll
-                for (int q = 0; q < TD_UN; q++) {
-                    const bool hd = dk[q] >= 0, hg = gj[q] >= 0;
-                    double w = fmin(B[q].x + B[q].z, A[q].x + A[q].z) - fmax(B[q].x, A[q].x);
-                    double h = fmin(B[q].y + B[q].w, A[q].y + A[q].w) - fmax(B[q].y, A[q].y);
-                    w = w > 0 ? w : 0.0;
-                    h = h > 0 ? h : 0.0;
-                    const double i_ = w * h;
-                    const double da = B[q].z * B[q].w, ga = A[q].z * A[q].w;
-                    const double both = da + ga - i_;
-                    const double tu = hd ? (hg ? both : da) : (hg ? ga : 0.0);
-                    const double ti = (hd && hg) ? i_ : 0.0;
-                    common += (hd && hg) ? 1 : 0;
-                    u += tu;
-                    i += ti;
+                for (int q = 0; q < TD_IT; q++) {
+                    const int it = base + q * 256;
+                    if (it < nd * np) {
+                        const int dl = it / np, pp = it - dl * np;
+                        const double da = B[q].z * B[q].w;
+                        for (int g = 0; g < G; g++) {
+                            const double4 A = gbox[g * TD_CH + pp];
+                            const bool hg = !(A.z < 0);
+                            double w = fmin(B[q].x + B[q].z, A.x + A.z) - fmax(B[q].x, A.x);
+                            double h = fmin(B[q].y + B[q].w, A.y + A.w) - fmax(B[q].y, A.y);
+                            w = w > 0 ? w : 0.0;
+                            h = h > 0 ? h : 0.0;
+                            const double i_ = w * h;
+                            const double ga = A.z * A.w;
+                            const bool both = hd[q] && hg;
+                            const double tu = hd[q] ? (hg ? da + ga - i_ : da)
+                                                    : (hg ? ga : 0.0);
+                            terms[pp][dl * G + g] = make_double2(tu, both ? i_ : 0.0);
+                            common += both ? 1 : 0;
+                        }
+                    }
                 }
             }
+            __syncthreads();
+            // ---- phase B
+            if ((int)threadIdx.x < pairs) {
+#pragma unroll 8
+                for (int pp = 0; pp < np; pp++) {
+                    const double2 t = terms[pp][threadIdx.x];
+                    u += t.x;
+                    i += t.y;
+                }
+            }
+            __syncthreads();
+        }
+        if ((int)threadIdx.x < pairs) {
+            const int dl = threadIdx.x / G, g = threadIdx.x - dl * G;
             iou[ioff + (int64_t)(db + dl) * G + g] = u > 0 ? i / u : 0.0;
         }
     }
