@@ -172,8 +172,52 @@ class DTColumns:
         return len(self.image_id)
 
     @classmethod
+    def from_file_native(cls, path):
+        """Parse a prediction file with the native columnar reader
+        (csrc/ingest.cpp); returns None when that library is not built."""
+        import ctypes as C
+        import os
+        so = os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                          "libtao_amodal_ingest.so")
+        if not os.path.exists(so):
+            return None
+        lib = C.CDLL(so)
+        lib.taoamd_pred_parse.restype = C.c_void_p
+        lib.taoamd_pred_parse.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
+        lib.taoamd_pred_count.restype = C.c_int64
+        lib.taoamd_pred_count.argtypes = [C.c_void_p]
+        lib.taoamd_pred_copy.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+        lib.taoamd_pred_free.argtypes = [C.c_void_p]
+        err = C.create_string_buffer(512)
+        h = lib.taoamd_pred_parse(os.fsencode(path), err, 512)
+        if not h:
+            msg = err.value.decode()
+            if "is not a list" in msg:
+                raise AssertionError("results is not a list.")
+            if msg.startswith("cannot open"):
+                raise FileNotFoundError(msg)
+            raise ValueError("malformed prediction file: " + msg)
+        try:
+            n = lib.taoamd_pred_count(h)
+            i64, f64 = np.int64, np.float64
+            out = cls(image_id=np.empty(n, i64), category_id=np.empty(n, i64),
+                      bbox=np.empty((n, 4), f64), score=np.empty(n, f64),
+                      track_id=np.empty(n, i64), video_id=np.empty(n, i64))
+            lib.taoamd_pred_copy(h, out.image_id.ctypes.data,
+                                 out.category_id.ctypes.data,
+                                 out.bbox.ctypes.data, out.score.ctypes.data,
+                                 out.track_id.ctypes.data,
+                                 out.video_id.ctypes.data)
+        finally:
+            lib.taoamd_pred_free(h)
+        return out
+
+    @classmethod
     def from_json(cls, results):
         if isinstance(results, str):
+            native = cls.from_file_native(results)
+            if native is not None:
+                return native
             with open(results, "r") as f:
                 results = json.load(f)
         assert isinstance(results, list), "results is not a list."

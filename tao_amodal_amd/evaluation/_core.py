@@ -21,6 +21,28 @@ def masked_mean(s):
     return np.mean(sel)
 
 
+TIMING = {}   # wall-clock seconds per stage, filled when TAOAMD_TIMING is set
+
+
+def timed(name):
+    """Context manager adding the elapsed wall-clock to TIMING[name]."""
+    import contextlib
+    import os
+    import time
+
+    @contextlib.contextmanager
+    def cm():
+        if not os.environ.get("TAOAMD_TIMING"):
+            yield
+            return
+        t0 = time.perf_counter()
+        try:
+            yield
+        finally:
+            TIMING[name] = TIMING.get(name, 0.0) + time.perf_counter() - t0
+    return cm()
+
+
 class GpuRun:
     """One evaluator pass on the device, split like the reference's API:
     evaluate() = ranges + sort + [track IoU] + match, accumulate() = sweep."""
@@ -36,23 +58,30 @@ class GpuRun:
         self.torch = torch
         self.flat = flat
         self.device = torch.device(device or "cuda")
-        self.dp = engine.DeviceProblem(flat, self.device)
-        self.ws = engine.Workspace(self.dp)
+        with timed("upload+plan"):
+            self.dp = engine.DeviceProblem(flat, self.device)
+            self.ws = engine.Workspace(self.dp)
+            torch.cuda.synchronize(self.device)
         self._detail = None
         self.precision = self.recall = None
 
     def evaluate(self):
         e = self.engine
-        e.stage_ranges(self.dp, self.ws)
-        e.stage_sort(self.dp, self.ws)
-        e.stage_track_iou(self.dp, self.ws)
-        e.stage_match(self.dp, self.ws)
+        with timed("kernels"):
+            e.stage_ranges(self.dp, self.ws)
+            e.stage_sort(self.dp, self.ws)
+            e.stage_track_iou(self.dp, self.ws)
+            e.stage_match(self.dp, self.ws)
+            if TIMING is not None:
+                self.torch.cuda.synchronize(self.device)
 
     def accumulate(self):
-        self.engine.stage_accumulate(self.dp, self.ws)
-        self.torch.cuda.synchronize(self.device)
-        self.precision = self.ws.precision.cpu().numpy()
-        self.recall = self.ws.recall.cpu().numpy()
+        with timed("kernels"):
+            self.engine.stage_accumulate(self.dp, self.ws)
+            self.torch.cuda.synchronize(self.device)
+        with timed("download"):
+            self.precision = self.ws.precision.cpu().numpy()
+            self.recall = self.ws.recall.cpu().numpy()
 
     # ------------------------------------------------------ lazy detail
     def detail(self):

@@ -12,7 +12,7 @@ import numpy as np
 
 from ... import flatten
 from .._core import (N_REC, N_THR, CellView, GpuRun, LazyIous, LazyPointers,
-                     masked_mean, now)
+                     masked_mean, now, timed)
 from .lvis import LVIS
 from .results import LVISResults
 
@@ -101,8 +101,10 @@ class LVISEval:
         if not self.params.use_cats:
             raise NotImplementedError("use_cats=0 is SURVEY.md 8(f) rank 2")
         self.params.img_ids = list(np.unique(self.params.img_ids))
-        flat = flatten.flatten_lvis(self.lvis_gt.columns, self.lvis_dt.columns_dt,
-                                    self.lvis_dt.max_dets)
+        with timed("flatten"):
+            flat = flatten.flatten_lvis(self.lvis_gt.columns,
+                                        self.lvis_dt.columns_dt,
+                                        self.lvis_dt.max_dets)
         self.flat = flat
         self.freq_groups = self._prepare_freq_group()
         self._run = GpuRun(flat, self.device)
@@ -184,7 +186,8 @@ class LVISEval:
     def run(self):
         self.evaluate()
         self.accumulate()
-        self.summarize()
+        with timed("summarize"):
+            self.summarize()
 
     def result_lines(self):
         template = (" {:<18} {} @[ IoU={:<9} | visibility={:>6s} | "

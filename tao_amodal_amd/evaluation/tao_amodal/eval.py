@@ -10,7 +10,7 @@ from collections.abc import Mapping
 import numpy as np
 
 from .._core import (N_REC, N_THR, CellView, GpuRun, LazyIous, LazyPointers,
-                     masked_mean, now)
+                     masked_mean, now, timed)
 from .results import TaoResults
 from .tao import Tao
 
@@ -184,7 +184,8 @@ class TaoEval:
     def run(self, show_progress=False):
         self.evaluate(show_progress=show_progress)
         self.accumulate()
-        self.summarize()
+        with timed("summarize"):
+            self.summarize()
 
     def result_lines(self):
         template = (" {:<18} {} @[ IoU={:<9} | area={:>6s} | dur={:>6s} | "

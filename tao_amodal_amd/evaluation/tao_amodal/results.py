@@ -46,8 +46,10 @@ class TaoResults(Tao):
             logging.error("Did not merge any categories.")
         # cell tables of the track-level problem; this is where the track
         # scores are formed, as in the reference constructor
-        self.flat = flatten.flatten_tao(self.gt.columns, self.columns_dt,
-                                        max_dets)
+        from .._core import timed
+        with timed("flatten"):
+            self.flat = flatten.flatten_tao(self.gt.columns, self.columns_dt,
+                                            max_dets)
         keep = flatten.limit_dets_per_image(self.columns_dt, max_dets)
         b = self.columns_dt.bbox[keep]
         neg = int(np.count_nonzero((b[:, 0] < 0) | (b[:, 1] < 0)

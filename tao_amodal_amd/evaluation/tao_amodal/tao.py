@@ -15,7 +15,9 @@ from ...columns import GTColumns
 
 
 class Tao:
-    def __init__(self, annotation_path, logger=None):
+    def __init__(self, annotation_path, logger=None, columns=None):
+        """``columns``: an already parsed GTColumns of the same file (lets the
+        CLI share one parse between the two evaluators)."""
         if not logger:
             self.logger = logging.getLogger("tao.tao")
         elif isinstance(logger, str):
@@ -33,7 +35,7 @@ class Tao:
             self.dataset = self._load_json(annotation_path)
         assert type(self.dataset) == dict, (
             "Annotation file format {} not supported.".format(type(self.dataset)))
-        self._columns = None
+        self._columns = columns
         self._index = None
         self._announce()
 

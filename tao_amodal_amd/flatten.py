@@ -63,7 +63,8 @@ def _lookup(sorted_keys, values):
 def _last_with_same_id(ids):
     """The reference resolves annotations through a dict keyed by id, so a
     duplicated id silently aliases the *last* annotation carrying it."""
-    if len(np.unique(ids)) == len(ids):
+    if len(ids) < 2 or np.all(ids[1:] > ids[:-1]) or \
+            len(np.unique(ids)) == len(ids):
         return np.arange(len(ids))
     order = np.argsort(ids, kind="stable")
     sid = ids[order]
@@ -74,24 +75,52 @@ def _last_with_same_id(ids):
     return out
 
 
+def first_inverse(ids):
+    """(uniq, first, inv) of ``np.unique(ids, return_index=True,
+    return_inverse=True)``.  Ids in a small non-negative range (the usual
+    case: image / track / video ids) are handled with dense tables instead of
+    a sort."""
+    n = len(ids)
+    if n and ids.min() >= 0 and ids.max() < max(4 * n, 1 << 22):
+        first_of = np.full(int(ids.max()) + 1, -1, dtype=np.int64)
+        first_of[ids[::-1]] = np.arange(n - 1, -1, -1)   # smallest index wins
+        present = np.flatnonzero(first_of >= 0)
+        rank = np.full(len(first_of), -1, dtype=np.int64)
+        rank[present] = np.arange(len(present))
+        return present, first_of[present], rank[ids]
+    uniq, first, inv = np.unique(ids, return_index=True, return_inverse=True)
+    return uniq, first, inv.reshape(-1)
+
+
 def limit_dets_per_image(dt, max_dets=MAX_DETS):
-    """Permutation of kept detections in post-truncation list order."""
+    """Permutation of kept detections in post-truncation list order (images
+    in first-seen order; an image with more than max_dets boxes keeps its
+    best max_dets by score, stable -- reference L/results.py:73-84)."""
     n = len(dt)
     if n == 0:
         return np.zeros(0, dtype=np.int64)
-    uniq, first, inv, cnt = np.unique(dt.image_id, return_index=True,
-                                      return_inverse=True, return_counts=True)
+    cache = getattr(dt, "_limit_cache", None)
+    if cache is not None and cache[0] == max_dets and cache[1] == n:
+        return cache[2]
+    uniq, first, inv = first_inverse(dt.image_id)
+    cnt = np.bincount(inv, minlength=len(uniq))
     rank_of_img = np.empty(len(uniq), dtype=np.int64)
     rank_of_img[np.argsort(first, kind="stable")] = np.arange(len(uniq))
     img_rank = rank_of_img[inv]
-    big = (cnt > max_dets)[inv] if max_dets >= 0 else np.zeros(n, bool)
-    key = np.where(big, -dt.score, 0.0)
-    order = np.lexsort((np.arange(n), key, img_rank))
-    if max_dets >= 0 and big.any():
+    if max_dets >= 0 and (cnt > max_dets).any():
+        big = (cnt > max_dets)[inv]
+        key = np.where(big, -dt.score, 0.0)
+        order = np.lexsort((np.arange(n), key, img_rank))
         r = img_rank[order]
         start = np.flatnonzero(np.r_[True, r[1:] != r[:-1]])
         pos = np.arange(n) - np.repeat(start, np.diff(np.r_[start, n]))
         order = order[pos < max_dets]
+    else:
+        order = np.argsort(img_rank, kind="stable")
+    try:
+        dt._limit_cache = (max_dets, n, order)
+    except AttributeError:
+        pass
     return order
 
 
@@ -102,9 +131,9 @@ def make_track_ids_unique(dt):
     tid, vid = dt.track_id, dt.video_id
     if n == 0:
         return tid.copy(), 0
-    uniq, first, inv = np.unique(tid, return_index=True, return_inverse=True)
-    clash_t = np.zeros(len(uniq), dtype=bool)
-    np.logical_or.at(clash_t, inv, vid != vid[first][inv])
+    uniq, first, inv = first_inverse(tid)
+    clash_t = np.bincount(inv, weights=(vid != vid[first][inv]),
+                          minlength=len(uniq)) > 0
     if not clash_t.any():
         return tid.copy(), 0
     top = max(int(tid.max()), 0)
@@ -133,9 +162,13 @@ def _csr_member(off, val, row, item):
     if len(val) == 0 or len(row) == 0:
         return np.zeros(len(row), dtype=bool)
     rows = np.repeat(np.arange(len(off) - 1), np.diff(off))
+    lo = min(int(val.min()), int(item.min()))
+    width = max(int(val.max()), int(item.max())) - lo + 1
+    if width * (len(off) + 1) < (1 << 62):
+        keys = np.unique(rows * width + (val - lo))
+        return _lookup(keys, row * width + (item - lo)) >= 0
     keys = np.stack([rows, val], 1)
     q = np.stack([row, item], 1)
-    # encode pairs as structured scalars for isin
     kd = np.ascontiguousarray(keys).view([("a", np.int64), ("b", np.int64)])
     qd = np.ascontiguousarray(q).view([("a", np.int64), ("b", np.int64)])
     return np.isin(qd.reshape(-1), kd.reshape(-1))
@@ -274,8 +307,7 @@ def _group_tracks(sel_trk, sel_frame_index):
     Returns (track order = first appearance, per-annotation permutation that
     lists every track's annotations contiguously sorted by frame_index
     (stable), CSR offsets)."""
-    uniq, first, inv = np.unique(sel_trk, return_index=True,
-                                 return_inverse=True)
+    uniq, first, inv = first_inverse(sel_trk)
     t_rank = np.empty(len(uniq), dtype=np.int64)
     t_rank[np.argsort(first, kind="stable")] = np.arange(len(uniq))
     trk_of_ann = t_rank[inv]
@@ -372,7 +404,7 @@ def flatten_tao(gt: GTColumns, dt: DTColumns, max_dets=MAX_DETS):
 
     # ---- predictions: TaoResults
     tid = dt.track_id
-    u, first, inv = np.unique(tid, return_index=True, return_inverse=True)
+    u, first, inv = first_inverse(tid)
     if (dt.video_id != dt.video_id[first][inv]).any():
         bad = tid[np.flatnonzero(dt.video_id != dt.video_id[first][inv])[0]]
         raise AssertionError(
@@ -380,8 +412,7 @@ def flatten_tao(gt: GTColumns, dt: DTColumns, max_dets=MAX_DETS):
     keep = limit_dets_per_image(dt, max_dets)
     d = dt.take(keep)
     d_cat_id = pred_cat[keep]
-    u, first, inv = np.unique(d.track_id, return_index=True,
-                              return_inverse=True)
+    u, first, inv = first_inverse(d.track_id)
     if (d_cat_id != d_cat_id[first][inv]).any():
         bad = d.track_id[np.flatnonzero(d_cat_id != d_cat_id[first][inv])[0]]
         raise AssertionError(
