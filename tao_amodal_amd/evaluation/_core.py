@@ -72,7 +72,8 @@ class GpuRun:
             e.stage_sort(self.dp, self.ws)
             e.stage_track_iou(self.dp, self.ws)
             e.stage_match(self.dp, self.ws)
-            if TIMING is not None:
+            import os
+            if os.environ.get("TAOAMD_TIMING"):
                 self.torch.cuda.synchronize(self.device)
 
     def accumulate(self):
@@ -116,14 +117,15 @@ class CellView:
         self.unit_ids = unit_ids
         self.sentinel = sentinel
         self.unit_key, self.rng_key, self.rng_values = unit_key, rng_key, rng_values
-        f = self.flat
-        K = len(f.cat_ids)
-        self.index = {int(u) * K + int(c): k for k, (u, c) in
-                      enumerate(zip(f.cell_unit, f.cell_cat))}
-        self.K = K
+        self.K = len(self.flat.cat_ids)
+        self._index = None
 
     def cell_of(self, unit_idx, cat_idx):
-        return self.index.get(int(unit_idx) * self.K + int(cat_idx))
+        if self._index is None:     # built on first inspection only
+            f = self.flat
+            self._index = {int(u) * self.K + int(c): k for k, (u, c) in
+                           enumerate(zip(f.cell_unit, f.cell_cat))}
+        return self._index.get(int(unit_idx) * self.K + int(cat_idx))
 
     def iou(self, k):
         f, d = self.flat, self.run.detail()
