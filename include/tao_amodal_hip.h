@@ -137,15 +137,18 @@ int taoamd_tao_ranges(int64_t n_gt, const double *gt_area,
  * then added in order by one lane per track pair); the others the two-pointer
  * merge kernel.
  * all_dense: non-zero when the host knows every non-empty cell qualifies, so
- * the merge kernel launch is skipped. */
+ * the merge kernel launch is skipped.
+ * mode: 0 = 3d_iou (sum inter / sum union, the CLI's), 1 = avg_iou (mean of
+ * the per-frame IoU over the union of frames, T/eval.py:99-117), 2 =
+ * imagenetvid (fraction of frames with inter > 0.5 union, T/eval.py:51-70). */
 int taoamd_track_iou(int64_t n_cells, const int32_t *cell_dt_off,
                      const int32_t *cell_gt_off, const int64_t *cell_iou_off,
                      int64_t n_pairs, const int32_t *dt_frame_off,
                      const int32_t *dt_frame_pos, const double *dt_frame_box,
                      const int32_t *gt_frame_off, const int32_t *gt_frame_pos,
                      const double *gt_frame_box, const int32_t *cell_span,
-                     int32_t all_dense, double *iou, int64_t *pair_frames,
-                     void *stream);
+                     int32_t all_dense, int32_t mode, double *iou,
+                     int64_t *pair_frames, void *stream);
 
 /* ---- greedy assignment --------------------------------------------------------
  * If dt_box/gt_box are non-NULL the IoU matrix of each cell is computed on the

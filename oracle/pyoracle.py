@@ -103,6 +103,48 @@ def track_box_iou(dt_track, gt_track, frame_order, timeline):
     return i / u if u > 0 else 0
 
 
+def track_avg_iou(dt_track, gt_track, frame_order, timeline):
+    """compute_avg_track_iou (T/eval.py:99-117): mean over the union of frames
+    of the per-frame IoU (0 where only one side has a box).  ``set`` order
+    reproduces the reference (np.mean of the list in set order); ``timeline``
+    is the canonical form of the kernels: left-to-right sum in ascending
+    timeline order divided by the number of frames."""
+    keys = set(gt_track.keys()) | set(dt_track.keys())
+    if frame_order != "set":
+        keys = sorted(keys, key=lambda im: timeline[im])
+    ious = []
+    for im in keys:
+        g = gt_track.get(im)
+        d = dt_track.get(im)
+        if d and g:
+            i_, u_ = bb_intersect_union(d, g)
+            ious.append(i_ / u_ if u_ > 0 else 0)
+        else:
+            ious.append(0)
+    if frame_order == "set":
+        return np.mean(ious)
+    total = 0.0
+    for v in ious:
+        total += v
+    return total / len(ious)
+
+
+def track_imagenetvid_iou(dt_track, gt_track, threshold=0.5):
+    """compute_imagenetvid_iou (T/eval.py:51-70): fraction of the union's
+    frames whose boxes overlap with intersection > threshold * union
+    (integer counts: independent of the frame order)."""
+    matched = total = 0
+    for im in set(gt_track.keys()) | set(dt_track.keys()):
+        g = gt_track.get(im)
+        d = dt_track.get(im)
+        if d and g:
+            i_, u_ = bb_intersect_union(d, g)
+            if i_ > threshold * u_:
+                matched += 1
+        total += 1
+    return matched / total
+
+
 # ----------------------------------------------------------- shared pieces
 def make_track_ids_unique(preds):
     """tools/eval_on_tao_amodal.py:44-66 (in place); returns #ids changed."""
@@ -410,10 +452,12 @@ def lvis_lines(results):
 
 
 # ------------------------------------------------------------------- TaoEval
-def tao_eval(gt, preds, frame_order="set"):
+def tao_eval(gt, preds, frame_order="set", iou_3d_type="3d_iou", use_cats=True):
     """Track-level evaluation (T/tao.py:112-254, T/results.py:27-109,
     T/eval.py:178-276,459-584).  ``preds`` must already have unique track ids
-    (the CLI calls make_track_ids_unique first)."""
+    (the CLI calls make_track_ids_unique first).  ``use_cats=False`` restates
+    the class-agnostic mode (T/eval.py:257-260,293-303): one cell per video,
+    no federated filter."""
     gt = copy.deepcopy(gt)
     preds = copy.deepcopy(preds)
     merge = {m["id"]: c["id"] for c in gt["categories"] if "merged" in c
@@ -509,15 +553,21 @@ def tao_eval(gt, preds, frame_order="set"):
         present[g["video_id"]].add(g["category_id"])
     for d in dts:
         v, c = d["video_id"], d["category_id"]
-        if c not in vids[v]["neg_category_ids"] and c not in present[v]:
+        if use_cats and c not in vids[v]["neg_category_ids"] \
+                and c not in present[v]:
             continue
         cell_dt[v, c].append(d)
 
     T = len(IOU_THRS)
     cells = OrderedDict()
+    eval_cats = cat_ids if use_cats else [-1]
     for v in vid_ids:
-        for c in cat_ids:
-            G, D = cell_gt.get((v, c), []), cell_dt.get((v, c), [])
+        for c in eval_cats:
+            if use_cats:
+                G, D = cell_gt.get((v, c), []), cell_dt.get((v, c), [])
+            else:       # all categories of the video, category-major
+                G = [t for k in cat_ids for t in cell_gt.get((v, k), [])]
+                D = [t for k in cat_ids for t in cell_dt.get((v, k), [])]
             if not G and not D:
                 continue
             D = [D[i] for i in stable_desc([d["score"] for d in D])]
@@ -527,9 +577,15 @@ def tao_eval(gt, preds, frame_order="set"):
                      for d in D]
             ious = np.zeros([len(D), len(G)])
             for i, j in np.ndindex(ious.shape):
-                ious[i, j] = track_box_iou(dmaps[i], gmaps[j], frame_order,
-                                           timeline)
-            nel = c in vids[v]["not_exhaustive_category_ids"]
+                if iou_3d_type == "3d_iou":
+                    ious[i, j] = track_box_iou(dmaps[i], gmaps[j], frame_order,
+                                               timeline)
+                elif iou_3d_type == "avg_iou":
+                    ious[i, j] = track_avg_iou(dmaps[i], gmaps[j], frame_order,
+                                               timeline)
+                elif iou_3d_type == "imagenetvid":
+                    ious[i, j] = track_imagenetvid_iou(dmaps[i], gmaps[j])
+            nel_of = vids[v]["not_exhaustive_category_ids"]
             ranges = []
             for a, ar in enumerate(AREA_RNG):
                 for tr in TIME_RNG:
@@ -566,7 +622,8 @@ def tao_eval(gt, preds, frame_order="set"):
                     mask = np.array([
                         d["area"] < ar[0] or d["area"] > ar[1]
                         or len(d["annotations"]) < tr[0]
-                        or len(d["annotations"]) > tr[1] or nel
+                        or len(d["annotations"]) > tr[1]
+                        or d["category_id"] in nel_of
                         for d in D], dtype=bool)
                     dt_ig = np.logical_or(dt_ig, np.logical_and(
                         dt_m == -1, mask[None, :].repeat(T, 0)))
@@ -578,7 +635,7 @@ def tao_eval(gt, preds, frame_order="set"):
                         "dt_ignore": dt_ig, "gt_ignore": gt_ig})
             cells[v, c] = {"ious": ious, "ranges": ranges}
 
-    R, K = len(REC_THRS), len(cat_ids)
+    R, K = len(REC_THRS), len(eval_cats)
     NA, NT = len(AREA_RNG), len(TIME_RNG)
     precision = -np.ones((T, R, K, NA, NT))
     recall = -np.ones((T, K, NA, NT))
@@ -586,7 +643,7 @@ def tao_eval(gt, preds, frame_order="set"):
     by_cat = defaultdict(list)
     for (v, c), cell in cells.items():
         by_cat[c].append(cell)
-    for k, c in enumerate(cat_ids):
+    for k, c in enumerate(eval_cats):
         for a in range(NA):
             for t_ in range(NT):
                 E = [cell["ranges"][a * NT + t_]

@@ -149,13 +149,17 @@ void orc_tao_ranges(int64_t n_gt, const double *gt_area,
 }
 
 /* iou[cell_iou_off[c] + d*G + g]; returns the number of per-frame box pairs
- * evaluated (the P_T of SURVEY.md 8(d)) */
+ * evaluated (the P_T of SURVEY.md 8(d)).
+ * mode 0: 3d_iou       sum_f inter / sum_f union      (eval.py:73-96)
+ * mode 1: avg_iou      mean_f (inter_f / union_f)      (eval.py:99-117), sum
+ *                      taken left to right in timeline order
+ * mode 2: imagenetvid  #{f: inter_f > 0.5 union_f} / #frames (eval.py:51-70) */
 int64_t orc_track_iou(int64_t n_cells, const int32_t *cell_dt_off,
                       const int32_t *cell_gt_off, const int64_t *cell_iou_off,
                       const int32_t *dt_foff, const int32_t *dt_fpos,
                       const double *dt_fbox, const int32_t *gt_foff,
                       const int32_t *gt_fpos, const double *gt_fbox,
-                      double *iou)
+                      int mode, double *iou)
 {
     int64_t pairs = 0;
     for (int64_t c = 0; c < n_cells; c++) {
@@ -165,8 +169,9 @@ int64_t orc_track_iou(int64_t n_cells, const int32_t *cell_dt_off,
             for (int32_t g = 0; g < G; g++) {
                 int32_t pd = dt_foff[d0 + d], ed = dt_foff[d0 + d + 1];
                 int32_t pg = gt_foff[g0 + g], eg = gt_foff[g0 + g + 1];
-                double i = 0, u = 0;
+                double i = 0, u = 0, acc = 0, cnt = 0;
                 while (pd < ed || pg < eg) {
+                    cnt += 1;
                     int32_t fd = pd < ed ? dt_fpos[pd] : INT32_MAX;
                     int32_t fg = pg < eg ? gt_fpos[pg] : INT32_MAX;
                     if (fd == fg) {
@@ -182,6 +187,8 @@ int64_t orc_track_iou(int64_t n_cells, const int32_t *cell_dt_off,
                         double u_ = B[2] * B[3] + A[2] * A[3] - i_;
                         i += i_;
                         u += u_;
+                        if (mode == 1) acc += u_ > 0 ? i_ / u_ : 0;
+                        if (mode == 2 && i_ > 0.5 * u_) acc += 1;
                         pd++, pg++, pairs++;
                     } else if (fg < fd) {
                         u += gt_fbox[4 * (int64_t)pg + 2] *
@@ -193,7 +200,8 @@ int64_t orc_track_iou(int64_t n_cells, const int32_t *cell_dt_off,
                         pd++;
                     }
                 }
-                iou[cell_iou_off[c] + (int64_t)d * G + g] = u > 0 ? i / u : 0;
+                iou[cell_iou_off[c] + (int64_t)d * G + g] =
+                    mode == 0 ? (u > 0 ? i / u : 0) : acc / cnt;
             }
     }
     return pairs;

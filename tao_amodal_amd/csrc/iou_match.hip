@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void track_iou_kernel(
     const double *__restrict__ dfbox, const int32_t *__restrict__ gfoff,
     const int32_t *__restrict__ gfpos, const double *__restrict__ gfbox,
     double *__restrict__ iou, unsigned long long *__restrict__ pair_frames,
-    const int32_t *__restrict__ cell_span)
+    const int32_t *__restrict__ cell_span, int mode)
 {
     int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     unsigned long long common = 0;
@@ -228,11 +228,12 @@ __global__ __launch_bounds__(256) void track_iou_kernel(
         FrameQueue qd, qg;
         qd.init(dfpos, dfbox, dfoff[td], dfoff[td + 1]);
         qg.init(gfpos, gfbox, gfoff[tg], gfoff[tg + 1]);
-        double i = 0.0, u = 0.0;
+        double i = 0.0, u = 0.0, acc = 0.0, cnt = 0.0;
         // ascending timeline order; per frame exactly the arithmetic of
         // reference tao_amodal/eval.py:32-48 and :87-94
         while (qd.f0 != INT32_MAX || qg.f0 != INT32_MAX) {
             const double4 B = qd.b0, A = qg.b0;
+            cnt += 1.0;
             if (qd.f0 == qg.f0) {
                 double w = fmin(B.x + B.z, A.x + A.z) - fmax(B.x, A.x);
                 double h = fmin(B.y + B.w, A.y + A.w) - fmax(B.y, A.y);
@@ -242,6 +243,8 @@ __global__ __launch_bounds__(256) void track_iou_kernel(
                 const double u_ = B.z * B.w + A.z * A.w - i_;
                 i += i_;
                 u += u_;
+                if (mode == 1) acc += u_ > 0 ? i_ / u_ : 0.0;
+                if (mode == 2 && i_ > 0.5 * u_) acc += 1.0;
                 common++;
                 qd.advance();
                 qg.advance();
@@ -253,7 +256,7 @@ __global__ __launch_bounds__(256) void track_iou_kernel(
                 qd.advance();
             }
         }
-        iou[p] = u > 0 ? i / u : 0.0;
+        iou[p] = mode == 0 ? (u > 0 ? i / u : 0.0) : acc / cnt;
     }
     if (pair_frames != nullptr) {
         for (int s = WAVE / 2; s > 0; s >>= 1)
@@ -301,7 +304,8 @@ __global__ __launch_bounds__(256) void track_iou_dense_kernel(
     const int32_t *__restrict__ dfoff, const int32_t *__restrict__ dfpos,
     const double *__restrict__ dfbox, const int32_t *__restrict__ gfoff,
     const int32_t *__restrict__ gfpos, const double *__restrict__ gfbox,
-    double *__restrict__ iou, unsigned long long *__restrict__ pair_frames)
+    double *__restrict__ iou, unsigned long long *__restrict__ pair_frames,
+    int mode)
 {
     __shared__ uint16_t map[TD_MAP_ENTRIES];
     __shared__ double2 terms[TD_CH][TD_PAIRS + 1];
@@ -388,9 +392,17 @@ __global__ __launch_bounds__(256) void track_iou_dense_kernel(
                             const double i_ = w * h;
                             const double ga = A.z * A.w;
                             const bool both = hd[q] && hg;
-                            const double tu = hd[q] ? (hg ? da + ga - i_ : da)
-                                                    : (hg ? ga : 0.0);
-                            terms[pp][dl * G + g] = make_double2(tu, both ? i_ : 0.0);
+                            const double u_ = da + ga - i_;
+                            double tx, ty;
+                            if (mode == 0) {            // (union, intersection)
+                                tx = hd[q] ? (hg ? u_ : da) : (hg ? ga : 0.0);
+                                ty = both ? i_ : 0.0;
+                            } else {                    // (score term, frame count)
+                                ty = (hd[q] || hg) ? 1.0 : 0.0;
+                                if (mode == 1) tx = both ? (u_ > 0 ? i_ / u_ : 0.0) : 0.0;
+                                else tx = (both && i_ > 0.5 * u_) ? 1.0 : 0.0;
+                            }
+                            terms[pp][dl * G + g] = make_double2(tx, ty);
                             common += both ? 1 : 0;
                         }
                     }
@@ -410,7 +422,10 @@ __global__ __launch_bounds__(256) void track_iou_dense_kernel(
         }
         if ((int)threadIdx.x < pairs) {
             const int dl = threadIdx.x / G, g = threadIdx.x - dl * G;
-            iou[ioff + (int64_t)(db + dl) * G + g] = u > 0 ? i / u : 0.0;
+            // mode 0: u = sum of unions, i = sum of intersections;
+            // modes 1/2: u = sum of per-frame scores, i = number of frames
+            iou[ioff + (int64_t)(db + dl) * G + g] =
+                mode == 0 ? (u > 0 ? i / u : 0.0) : u / i;
         }
     }
     if (pair_frames != nullptr) {
@@ -904,22 +919,24 @@ extern "C" int taoamd_track_iou(int64_t n_cells, const int32_t *cell_dt_off,
                                 const int32_t *gt_frame_pos,
                                 const double *gt_frame_box,
                                 const int32_t *cell_span, int32_t all_dense,
-                                double *iou, int64_t *pair_frames, void *stream)
+                                int32_t mode, double *iou, int64_t *pair_frames,
+                                void *stream)
 {
     hipStream_t s = (hipStream_t)stream;
+    if (mode < 0 || mode > 2) return TAOAMD_ERR_ARG;
     if (pair_frames) TAO_HIP(hipMemsetAsync(pair_frames, 0, 8, s));
     if (n_pairs == 0) return TAOAMD_OK;
     if (cell_span != nullptr)
         track_iou_dense_kernel<<<(unsigned)n_cells, 256, 0, s>>>(
             cell_dt_off, cell_gt_off, cell_iou_off, cell_span, dt_frame_off,
             dt_frame_pos, dt_frame_box, gt_frame_off, gt_frame_pos,
-            gt_frame_box, iou, (unsigned long long *)pair_frames);
+            gt_frame_box, iou, (unsigned long long *)pair_frames, mode);
     if (cell_span == nullptr || !all_dense)
         track_iou_kernel<<<(unsigned)((n_pairs + 255) / 256), 256, 0, s>>>(
             n_cells, cell_dt_off, cell_gt_off, cell_iou_off, n_pairs,
             dt_frame_off, dt_frame_pos, dt_frame_box, gt_frame_off,
             gt_frame_pos, gt_frame_box, iou, (unsigned long long *)pair_frames,
-            cell_span);
+            cell_span, mode);
     TAO_LAUNCH_CHECK();
     return TAOAMD_OK;
 }

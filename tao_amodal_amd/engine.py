@@ -61,8 +61,11 @@ def match_plan(d_cnt, g_cnt, cap_d=64, cap_g=64, cap_cell_g=8):
 class DeviceProblem:
     """A flattened problem (flatten.Flat) resident in HBM."""
 
-    def __init__(self, flat, device="cuda"):
+    IOU_MODES = {"3d_iou": 0, "avg_iou": 1, "imagenetvid": 2}
+
+    def __init__(self, flat, device="cuda", iou_3d_type="3d_iou"):
         self.kind = flat.kind
+        self.iou_mode = self.IOU_MODES[iou_3d_type]
         self.device = torch.device(device)
         self.n_rng = _lib.LVIS_RNG if self.kind == "lvis" else _lib.TAO_RNG
         self.n_words = (self.n_rng * N_THR + 63) // 64
@@ -217,7 +220,7 @@ def stage_track_iou(dp, ws):
         _ptr(t["dt_frame_pos"]), _ptr(t["dt_frame_box"]),
         _ptr(t["gt_frame_off"]), _ptr(t["gt_frame_pos"]),
         _ptr(t["gt_frame_box"]), _ptr(t["cell_span"]), dp.all_dense,
-        _ptr(ws.iou), _ptr(ws.pair_frames), s),
+        dp.iou_mode, _ptr(ws.iou), _ptr(ws.pair_frames), s),
         "taoamd_track_iou")
 
 
@@ -279,10 +282,10 @@ def time_stages(dpl, wsl, dpt, wst, reps=10):
     return out
 
 
-def evaluate_flat(flat, device="cuda", detail=False):
+def evaluate_flat(flat, device="cuda", detail=False, iou_3d_type="3d_iou"):
     """Upload, run, download.  Returns a dict of numpy arrays shaped like the
     C oracle's outputs (tests compare the two field by field)."""
-    dp = DeviceProblem(flat, device)
+    dp = DeviceProblem(flat, device, iou_3d_type)
     ws = Workspace(dp, detail=detail)
     run(dp, ws)
     torch.cuda.synchronize(dp.device)

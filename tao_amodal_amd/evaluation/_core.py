@@ -47,7 +47,7 @@ class GpuRun:
     """One evaluator pass on the device, split like the reference's API:
     evaluate() = ranges + sort + [track IoU] + match, accumulate() = sweep."""
 
-    def __init__(self, flat, device=None):
+    def __init__(self, flat, device=None, iou_3d_type="3d_iou"):
         import torch
         from .. import engine
         if not torch.cuda.is_available():
@@ -57,9 +57,10 @@ class GpuRun:
         self.engine = engine
         self.torch = torch
         self.flat = flat
+        self.iou_3d_type = iou_3d_type
         self.device = torch.device(device or "cuda")
         with timed("upload+plan"):
-            self.dp = engine.DeviceProblem(flat, self.device)
+            self.dp = engine.DeviceProblem(flat, self.device, iou_3d_type)
             self.ws = engine.Workspace(self.dp)
             torch.cuda.synchronize(self.device)
         self._detail = None
@@ -89,8 +90,9 @@ class GpuRun:
         """Per-detection match indices / IoUs (a second, detail-mode pass,
         only when the per-cell views are actually inspected)."""
         if self._detail is None:
-            self._detail = self.engine.evaluate_flat(self.flat, self.device,
-                                                     detail=True)
+            self._detail = self.engine.evaluate_flat(
+                self.flat, self.device, detail=True,
+                iou_3d_type=self.iou_3d_type)
         return self._detail
 
     def sorted_rows(self):

@@ -106,21 +106,24 @@ class TaoEval:
         self.logger.info("Evaluate annotation type *{}*".format(self.params.iou_type))
         if self.params.iou_type != "bbox":
             raise NotImplementedError("only iou_type='bbox' runs on the HIP path")
-        if self.params.iou_3d_type != "3d_iou":
-            raise NotImplementedError(
-                "iou_3d_type %r is SURVEY.md 8(f) rank 2 (not on the CLI path)"
-                % self.params.iou_3d_type)
-        if not self.params.use_cats:
-            raise NotImplementedError("use_cats=0 is SURVEY.md 8(f) rank 2")
+        if self.params.iou_3d_type not in ("3d_iou", "avg_iou", "imagenetvid"):
+            raise ValueError("Unknown iou_3d_type %r" % self.params.iou_3d_type)
         self.params.vid_ids = list(np.unique(self.params.vid_ids))
+        if not self.params.use_cats:
+            # class-agnostic cells (reference eval.py:257-260,293-303)
+            from ... import flatten
+            self.flat = flatten.flatten_tao(
+                self.tao_gt.columns, self.tao_dt.columns_dt,
+                self.tao_dt.max_dets, use_cats=False)
         flat = self.flat
-        self._run = GpuRun(flat, self.device)
+        self._run = GpuRun(flat, self.device, self.params.iou_3d_type)
         self._run.evaluate()
         P = self.params
         rngs = [(a, t) for a in P.area_rng for t in P.time_rng]
         view = CellView(self._run, flat.vid_ids, -1, "video_id", "rng", rngs)
-        self.ious = LazyIous(view, P.vid_ids, P.cat_ids)
-        self.eval_vids = _EvalVids(view, len(P.vid_ids), len(P.cat_ids),
+        cats = P.cat_ids if P.use_cats else [-1]
+        self.ious = LazyIous(view, P.vid_ids, cats)
+        self.eval_vids = _EvalVids(view, len(P.vid_ids), len(cats),
                                    len(P.area_rng), len(P.time_rng))
 
     def accumulate(self):
@@ -131,7 +134,7 @@ class TaoEval:
         self._run.accumulate()
         P = self.params
         A, T = len(P.area_rng), len(P.time_rng)
-        K = len(P.cat_ids)
+        K = len(P.cat_ids) if P.use_cats else 1
         self.eval = {
             "params": P,
             "counts": [N_THR, N_REC, K, A, T],

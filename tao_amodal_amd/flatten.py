@@ -335,9 +335,15 @@ def _unique_frames(trk_of, pos_of, n_trk):
     return sel, off
 
 
-def flatten_tao(gt: GTColumns, dt: DTColumns, max_dets=MAX_DETS):
+def flatten_tao(gt: GTColumns, dt: DTColumns, max_dets=MAX_DETS,
+                use_cats=True):
     """``dt.track_id`` must already be unique per video (the CLI runs
-    make_track_ids_unique first; T/results.py:111-119 asserts it)."""
+    make_track_ids_unique first; T/results.py:111-119 asserts it).
+
+    ``use_cats=False`` builds the class-agnostic problem of
+    ``params.use_cats = 0`` (T/eval.py:257-260,293-303): one cell per video
+    holding the tracks of all categories (category-major, as the reference
+    concatenates them), no federated filter, a single pseudo category -1."""
     if len(dt) == 0:
         raise IndexError("list index out of range")  # T/results.py:61
     # ---- category merge (GT annotations + tracks + predictions)
@@ -488,16 +494,26 @@ def flatten_tao(gt: GTColumns, dt: DTColumns, max_dets=MAX_DETS):
 
     # ---- federated filter on the video lists (T/eval.py:214-233)
     U = len(vid_ids)
-    key_present = np.unique(g_cat * U + g_vid)
-    is_present = _lookup(key_present, d_cat * U + d_vid) >= 0
-    is_neg = _csr_member(gt.vid_neg_off, gt.vid_neg, vid_row[d_vid], d_catid)
-    d_keep = np.flatnonzero(is_present | is_neg)
-
-    keys_g = g_cat * U + g_vid
-    keys_d = d_cat[d_keep] * U + d_vid[d_keep]
-    o2 = np.lexsort((np.arange(len(d_keep)), -d_score[d_keep], keys_d))
+    if use_cats:
+        key_present = np.unique(g_cat * U + g_vid)
+        is_present = _lookup(key_present, d_cat * U + d_vid) >= 0
+        is_neg = _csr_member(gt.vid_neg_off, gt.vid_neg, vid_row[d_vid],
+                             d_catid)
+        d_keep = np.flatnonzero(is_present | is_neg)
+        keys_g = g_cat * U + g_vid
+        keys_d = d_cat[d_keep] * U + d_vid[d_keep]
+        o2 = np.lexsort((np.arange(len(d_keep)), -d_score[d_keep], keys_d))
+        og = np.argsort(keys_g, kind="stable")
+    else:
+        d_keep = np.arange(len(d_ids))
+        keys_g = g_vid.copy()
+        keys_d = d_vid.copy()
+        # category-major inside the video, then by score (stable)
+        o2 = np.lexsort((np.arange(len(d_keep)), d_cat, -d_score, keys_d))
+        og = np.lexsort((np.arange(len(g_ids)), g_cat, keys_g))
+        cat_ids = np.array([-1], dtype=np.int64)
+        U = len(vid_ids)
     d_keep, keys_d = d_keep[o2], keys_d[o2]
-    og = np.argsort(keys_g, kind="stable")
     keys_g = keys_g[og]
     cell_keys, g_cell, d_cell, g_off, d_off = _cells(keys_g, keys_d)
 
@@ -534,8 +550,10 @@ def flatten_tao(gt: GTColumns, dt: DTColumns, max_dets=MAX_DETS):
     f.vid_ids, f.cat_ids = vid_ids, cat_ids
     f.required_average = required_average
     f.n_cells = len(cell_keys)
+    f.use_cats = bool(use_cats)
     f.cell_unit = (cell_keys % U).astype(I32)       # video index
-    f.cell_cat = (cell_keys // U).astype(I32)
+    f.cell_cat = (cell_keys // U).astype(I32) if use_cats else \
+        np.zeros(len(cell_keys), dtype=I32)
     f.cell_dt_off = d_off.astype(I32)
     f.cell_gt_off = g_off.astype(I32)
     iou_off = np.zeros(f.n_cells + 1, dtype=np.int64)
@@ -549,7 +567,8 @@ def flatten_tao(gt: GTColumns, dt: DTColumns, max_dets=MAX_DETS):
                   | np.where(d_ids[d_keep] <= 0, DT_NO_CONSUME, 0)
                   ).astype(np.uint8)
     f.dt_id = d_ids[d_keep]
-    f.dt_cat = (keys_d // U).astype(I32)
+    f.dt_cat = (keys_d // U).astype(I32) if use_cats else \
+        np.zeros(len(keys_d), dtype=I32)
     f.dt_cell = d_cell.astype(I32)
     f.dt_frame_off, f.dt_frame_pos, f.dt_frame_box = d_foff, d_fpos, d_fbox
     f.gt_area = np.ascontiguousarray(g_area[og])
@@ -559,7 +578,8 @@ def flatten_tao(gt: GTColumns, dt: DTColumns, max_dets=MAX_DETS):
                   | np.where(g_ids[og] == -1, GT_ID_HIDDEN, 0)
                   ).astype(np.uint8)
     f.gt_id = g_ids[og]
-    f.gt_cat = (keys_g // U).astype(I32)
+    f.gt_cat = (keys_g // U).astype(I32) if use_cats else \
+        np.zeros(len(keys_g), dtype=I32)
     f.gt_cell = g_cell.astype(I32)
     f.gt_frame_off, f.gt_frame_pos, f.gt_frame_box = g_foff, g_fpos, g_fbox
     f.n_pairs = int(iou_off[-1])

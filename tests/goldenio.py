@@ -39,3 +39,26 @@ def load_eval(name):
         r[:, k] = z[side + "_recall"]
         out[side] = (p, r)
     return out
+
+MODE_FIXTURES = ["f1", "f2", "f4"]
+MODES = {"avg_iou": dict(iou_3d_type="avg_iou", use_cats=True),
+         "imagenetvid": dict(iou_3d_type="imagenetvid", use_cats=True),
+         "nocats": dict(iou_3d_type="3d_iou", use_cats=False)}
+
+
+def load_modes(name):
+    """Golden TaoEval outputs for the non-CLI modes: {mode: (cells, precision,
+    recall, results)}."""
+    z = np.load(path(name, "tao_modes.npz"))
+    cells = load_json_gz(name, "tao_modes.json.gz")
+    out = {}
+    for m in MODES:
+        shape = tuple(int(x) for x in z[m + "_shape"])
+        k = z[m + "_k"]
+        p = -np.ones(shape)
+        p[:, :, k] = z[m + "_precision"]
+        r = -np.ones((shape[0],) + shape[2:])
+        r[:, k] = z[m + "_recall"]
+        out[m] = ({tuple(c["key"]): np.asarray(c["ious"], dtype=float)
+                   for c in cells[m]}, p, r, z[m + "_results"])
+    return out

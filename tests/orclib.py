@@ -81,13 +81,16 @@ def iou_offsets(f):
     return off
 
 
-def track_iou(f):
+IOU_MODES = {"3d_iou": 0, "avg_iou": 1, "imagenetvid": 2}
+
+
+def track_iou(f, mode="3d_iou"):
     iou = np.zeros(int(f.cell_iou_off[-1]))
     pairs = lib().orc_track_iou(
         C.c_int64(f.n_cells), _p(f.cell_dt_off), _p(f.cell_gt_off),
         _p(f.cell_iou_off), _p(f.dt_frame_off), _p(f.dt_frame_pos),
         _p(f.dt_frame_box), _p(f.gt_frame_off), _p(f.gt_frame_pos),
-        _p(f.gt_frame_box), _p(iou))
+        _p(f.gt_frame_box), C.c_int(IOU_MODES[mode]), _p(iou))
     return iou, int(pairs)
 
 
@@ -133,12 +136,12 @@ def accumulate(f, gt_rng, matched, ignored):
     return prec, rec, order, num_gt
 
 
-def run_flat(f, detail=True):
+def run_flat(f, detail=True, iou_3d_type="3d_iou"):
     """Whole per-evaluator oracle pipeline on a flattened problem."""
     gt_rng, dt_rng = ranges(f)
     iou = pairs = None
     if f.kind == "tao":
-        iou, pairs = track_iou(f)
+        iou, pairs = track_iou(f, iou_3d_type)
     matched, ignored, mg, ious_out = match(f, gt_rng, dt_rng, iou, detail)
     prec, rec, order, num_gt = accumulate(f, gt_rng, matched, ignored)
     return dict(gt_rng=gt_rng, dt_rng=dt_rng,

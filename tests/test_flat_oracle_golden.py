@@ -128,3 +128,35 @@ def test_bb_iou_against_reference_compiled_from_source():
         gt = np.c_[rng.integers(-50, 500, (90, 2)), rng.integers(0, 300, (90, 2))] * scale
         assert np.array_equal(orclib.bb_iou(dt, gt), orclib.ref_bb_iou(dt, gt))
     assert orclib.bb_iou([[0, 0, 20, 20]], [[0, 0, 10, 10]])[0, 0] == 0.25
+
+
+from goldenio import MODE_FIXTURES, MODES, load_modes
+
+
+@pytest.mark.parametrize("name", MODE_FIXTURES)
+@pytest.mark.parametrize("mode", list(MODES))
+def test_tao_other_modes_flatten_and_c_oracle(name, mode):
+    """avg_iou (canonical frame order: within 1e-12 of the reference's
+    np.mean), imagenetvid (integer counts: exact) and use_cats=0."""
+    gtj, predj = load_inputs(name)
+    dt = DTColumns.from_json(predj)
+    dt.track_id, _ = fl.make_track_ids_unique(dt)
+    cfg = MODES[mode]
+    f = fl.flatten_tao(GTColumns.from_json(gtj), dt, use_cats=cfg["use_cats"])
+    out = orclib.run_flat(f, iou_3d_type=cfg["iou_3d_type"])
+    cells, p, r, _ = load_modes(name)[mode]
+    off = orclib.iou_offsets(f)
+    exact = mode == "imagenetvid" or (mode == "nocats" and name in INTEGER_FIXTURES)
+    for k in range(f.n_cells):
+        key = (int(f.vid_ids[f.cell_unit[k]]), int(f.cat_ids[f.cell_cat[k]]))
+        D = f.cell_dt_off[k + 1] - f.cell_dt_off[k]
+        G = f.cell_gt_off[k + 1] - f.cell_gt_off[k]
+        if D == 0 or G == 0:
+            continue
+        got, want = out["iou"][off[k]:off[k + 1]].reshape(D, G), cells[key]
+        if exact:
+            assert np.array_equal(got, want), key
+        else:
+            assert np.allclose(got, want, rtol=0, atol=1e-12), key
+    assert np.array_equal(out["precision"].reshape(p.shape), p)
+    assert np.array_equal(out["recall"].reshape(r.shape), r)

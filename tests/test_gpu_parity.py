@@ -206,3 +206,43 @@ def test_both_sorts_are_the_stable_mergesort_order(n, n_cat, quant):
     torch.cuda.synchronize()
     assert np.array_equal(order.cpu().numpy(), want)
     assert np.array_equal(dst.cpu().numpy()[want], np.arange(n))
+
+
+from goldenio import MODE_FIXTURES, MODES, load_modes
+
+
+@pytest.mark.parametrize("name", MODE_FIXTURES)
+@pytest.mark.parametrize("mode", list(MODES))
+def test_tao_other_modes_hip_vs_oracle_and_reference(name, mode):
+    """avg_iou / imagenetvid / use_cats=0 through the class API: equal to the
+    C oracle bit for bit, and to the reference's precision/recall."""
+    from tao_amodal_amd.evaluation.tao_amodal import Tao, TaoEval, TaoResults
+    cfg = MODES[mode]
+    dt = DTColumns.from_json(load_inputs(name)[1])
+    dt.track_id, _ = fl.make_track_ids_unique(dt)
+    gt = Tao(load_inputs(name)[0])
+    ev = TaoEval(gt, TaoResults(gt, dt), iou_3d_type=cfg["iou_3d_type"])
+    ev.params.use_cats = 1 if cfg["use_cats"] else 0
+    ev.run()
+    _, p, r, res = load_modes(name)[mode]
+    assert np.array_equal(ev.eval["precision"], p)
+    assert np.array_equal(ev.eval["recall"], r)
+    assert [float(v) for v in ev.results.values()] == res.tolist()
+    f = fl.flatten_tao(gt.columns, dt, use_cats=cfg["use_cats"])
+    want = orclib.run_flat(f, iou_3d_type=cfg["iou_3d_type"])
+    got = _engine().evaluate_flat(f, detail=True, iou_3d_type=cfg["iou_3d_type"])
+    assert np.array_equal(got["iou"], want["iou"])
+    assert np.array_equal(got["matched"], want["matched"])
+    assert np.array_equal(got["precision"], want["precision"])
+
+
+def test_other_modes_on_merge_kernel():
+    gt, dt = synth(seed=41, V=1, F=1100, C=6, dets_per_frame=20,
+                   gt_tracks_per_video=24, n_present=2, n_neg=1)
+    dt.track_id, _ = fl.make_track_ids_unique(dt)
+    f = fl.flatten_tao(gt, dt)
+    for mode in ("avg_iou", "imagenetvid"):
+        want = orclib.run_flat(f, iou_3d_type=mode)
+        got = _engine().evaluate_flat(f, iou_3d_type=mode)
+        assert np.array_equal(got["iou"], want["iou"]), mode
+        assert np.array_equal(got["precision"], want["precision"]), mode

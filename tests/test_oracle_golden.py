@@ -113,3 +113,25 @@ def test_known_answers_from_reference_doctests():
     assert pyoracle.bb_intersect_union([10, 20, 10, 10], [10, 20, 5, 5]) == (25, 100)
     assert pyoracle.bb_intersect_union([0, 0, 20, 20], [0, 0, 30, 30]) == (400, 900)
     assert pyoracle.bb_iou([0, 0, 20, 20], [0, 0, 10, 10]) == 0.25
+
+
+from goldenio import MODE_FIXTURES, MODES, load_modes
+
+
+@pytest.mark.parametrize("name", MODE_FIXTURES)
+@pytest.mark.parametrize("mode", list(MODES))
+def test_tao_oracle_other_modes_match_reference(name, mode):
+    """avg_iou / imagenetvid / use_cats=0 (not on the CLI path)."""
+    gt, pred = load_inputs(name)
+    pyoracle.make_track_ids_unique(pred)
+    got = pyoracle.tao_eval(gt, pred, frame_order="set", **MODES[mode])
+    cells, p, r, res = load_modes(name)[mode]
+    for key, cell in got["cells"].items():
+        w = cells[key]
+        g = np.asarray(cell["ious"], dtype=float)
+        if g.size == 0 and w.size == 0:
+            continue
+        assert np.array_equal(g, w.reshape(g.shape)), (key, mode)
+    assert np.array_equal(got["precision"], p)
+    assert np.array_equal(got["recall"], r)
+    assert [float(v) for v in got["results"].values()] == res.tolist()
