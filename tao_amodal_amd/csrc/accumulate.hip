@@ -26,6 +26,15 @@
 // of the reference; the envelope is a max of those values, so the order in
 // which chunks are combined cannot change a bit of the result.
 //
+// Rows are consumed 64 at a time through a 64 x 64 bit transpose across the
+// wavefront (six butterfly stages of __shfl_xor): lane = row holds the row's
+// TP word (bit = combo); after the transpose lane = combo holds a word whose
+// bit q says whether row q is a TP for that combo.  Counting is then a
+// popcount, and the envelope / emission sweeps visit only the TP rows of each
+// combo (ctz / clz), taking the TP and FP counts at that row from popcounts of
+// the masks below it.  acc_count writes the transposed words once; the two
+// later sweeps read them back (lane-contiguous).
+//
 // Two exact shortcuts keep fp64 divisions off the per-row paths:
 //  * the envelope is tracked as the integer pair (tp, n = tp + fp) and
 //    compared by cross-multiplication.  fl(tp / (n + eps)) is monotone in the
@@ -73,6 +82,7 @@ struct AccArgs {
     int32_t *cat_chunk_off;  // [n_cat + 1]
     uint32_t *cnt_tp, *cnt_fp;   // [chunk][word][64] counts inside the chunk
     uint32_t *pre_tp, *pre_fp;   // exclusive prefix inside the category
+    uint64_t *t_tp, *t_fp;       // [chunk][word][4 blocks][64] transposed TP / FP words
     uint64_t *cmax;              // chunk max as (tp << 32 | n), then reverse-exclusive max
     int32_t *cj;                 // [n_cat][n_rng][N_REC] TP count crossing each recall thr
     double *val;                 // [n_cat][n_rng][N_THR][N_REC]
@@ -140,6 +150,28 @@ __device__ __forceinline__ void load_rows(const uint64_t *__restrict__ M,
     fpw = ~m & ~i;
 }
 
+// 64 x 64 bit-matrix transpose across the wavefront: in: lane i holds row i
+// (bit j = element (i, j)); out: lane j holds column j (bit i = element (i, j)).
+// Stage s swaps the off-diagonal s x s blocks between lanes i and i ^ s.
+__device__ __forceinline__ uint64_t transpose64(uint64_t x, int lane)
+{
+    const uint64_t LO[6] = {0x00000000ffffffffull, 0x0000ffff0000ffffull,
+                            0x00ff00ff00ff00ffull, 0x0f0f0f0f0f0f0f0full,
+                            0x3333333333333333ull, 0x5555555555555555ull};
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const int s = 32 >> k;
+        const uint32_t ylo = (uint32_t)__shfl_xor((int)(uint32_t)x, s, WAVE);
+        const uint32_t yhi = (uint32_t)__shfl_xor((int)(uint32_t)(x >> 32), s, WAVE);
+        const uint64_t y = ((uint64_t)yhi << 32) | ylo;
+        x = (lane & s) ? ((x & ~LO[k]) | ((y & ~LO[k]) >> s))
+                       : ((x & LO[k]) | ((y & LO[k]) << s));
+    }
+    return x;
+}
+
+#define ACC_BLK (ACC_CH / WAVE)   // 64-row blocks per chunk
+
 struct ChunkInfo {
     int32_t k, first, last;  // category, is first / last chunk of it
     int64_t start;
@@ -175,14 +207,20 @@ __global__ __launch_bounds__(256) void acc_count_kernel(AccArgs a)
     uint32_t tp = 0, fp = 0;
     const uint64_t *__restrict__ M = a.matched + ci.start * a.n_words + ci.word;
     const uint64_t *__restrict__ I = a.ignored + ci.start * a.n_words + ci.word;
-    for (int base = 0; base < ci.len; base += WAVE) {
-        const int n = min(WAVE, ci.len - base);
-        uint64_t tpw, fpw;
-        load_rows(M, I, a.n_words, base, n, lane, tpw, fpw);
-        for (int q = 0; q < n; q++) {
-            tp += (uint32_t)((readlane_u64(tpw, q) >> lane) & 1);
-            fp += (uint32_t)((readlane_u64(fpw, q) >> lane) & 1);
+    const int64_t tb = (((int64_t)ci.c * a.n_words + ci.word) * ACC_BLK) * WAVE + lane;
+    for (int blk = 0; blk < ACC_BLK; blk++) {
+        const int base = blk * WAVE;
+        uint64_t T = 0, F = 0;
+        if (base < ci.len) {
+            uint64_t tpw, fpw;
+            load_rows(M, I, a.n_words, base, min(WAVE, ci.len - base), lane, tpw, fpw);
+            T = transpose64(tpw, lane);
+            F = transpose64(fpw, lane);
         }
+        a.t_tp[tb + (int64_t)blk * WAVE] = T;
+        a.t_fp[tb + (int64_t)blk * WAVE] = F;
+        tp += (uint32_t)__popcll(T);
+        fp += (uint32_t)__popcll(F);
     }
     const int64_t o = ((int64_t)ci.c * a.n_words + ci.word) * WAVE + lane;
     a.cnt_tp[o] = tp;
@@ -231,21 +269,21 @@ __global__ __launch_bounds__(256) void acc_chunkmax_kernel(AccArgs a)
     if (!ci.valid) return;
     const int lane = lane_id();
     const int64_t o = ((int64_t)ci.c * a.n_words + ci.word) * WAVE + lane;
-    uint32_t tp = a.pre_tp[o], n = tp + a.pre_fp[o];
+    uint32_t tp0 = a.pre_tp[o], n0 = tp0 + a.pre_fp[o];
     uint64_t best = PR_ZERO;
-    const uint64_t *__restrict__ M = a.matched + ci.start * a.n_words + ci.word;
-    const uint64_t *__restrict__ I = a.ignored + ci.start * a.n_words + ci.word;
-    for (int base = 0; base < ci.len; base += WAVE) {
-        const int nrow = min(WAVE, ci.len - base);
-        uint64_t tpw, fpw;
-        load_rows(M, I, a.n_words, base, nrow, lane, tpw, fpw);
-        for (int q = 0; q < nrow; q++) {
-            const uint32_t is_tp = (uint32_t)(readlane_u64(tpw, q) >> lane) & 1u;
-            const uint32_t is_fp = (uint32_t)(readlane_u64(fpw, q) >> lane) & 1u;
-            tp += is_tp;
-            n += is_tp + is_fp;
-            if (is_tp && pr_better(tp, n, best)) best = pr_pack(tp, n);
+    const int64_t tb = (((int64_t)ci.c * a.n_words + ci.word) * ACC_BLK) * WAVE + lane;
+    for (int blk = 0; blk * WAVE < ci.len; blk++) {
+        const uint64_t T = a.t_tp[tb + (int64_t)blk * WAVE];
+        const uint64_t TF = T | a.t_fp[tb + (int64_t)blk * WAVE];
+        for (uint64_t m = T; m != 0; m &= m - 1) {
+            const int q = __builtin_ctzll(m);
+            const uint64_t le = q == 63 ? ~0ull : ((2ull << q) - 1);   // rows <= q
+            const uint32_t tp = tp0 + (uint32_t)__popcll(T & le);
+            const uint32_t n = n0 + (uint32_t)__popcll(TF & le);
+            if (pr_better(tp, n, best)) best = pr_pack(tp, n);
         }
+        tp0 += (uint32_t)__popcll(T);
+        n0 += (uint32_t)__popcll(TF);
     }
     a.cmax[o] = best;
 }
@@ -333,29 +371,29 @@ __global__ __launch_bounds__(256) void acc_emit_kernel(AccArgs a)
         if (ci.last)
             for (int j = jcur; j < N_REC; j++) out[j] = 0.0;
     }
-    const uint64_t *__restrict__ M = a.matched + ci.start * a.n_words + ci.word;
-    const uint64_t *__restrict__ I = a.ignored + ci.start * a.n_words + ci.word;
-    for (int base = (ci.len - 1) / WAVE * WAVE; base >= 0; base -= WAVE) {
-        const int nrow = min(WAVE, ci.len - base);
-        uint64_t tpw, fpw;
-        load_rows(M, I, a.n_words, base, nrow, lane, tpw, fpw);
-        for (int q = nrow - 1; q >= 0; q--) {
-            const bool is_tp = live && ((readlane_u64(tpw, q) >> lane) & 1);
-            const bool is_fp = live && ((readlane_u64(fpw, q) >> lane) & 1);
-            if (is_tp) {
-                if (pr_better(tp, n, run)) run = pr_pack(tp, n);
-                tp -= 1;
-                n -= 1;
-                if (jcur > 0 && cj[jcur - 1] > (int32_t)tp) {
-                    const double v = pr_value(run);
-                    do {
-                        out[jcur - 1] = v;
-                        jcur--;
-                    } while (jcur > 0 && cj[jcur - 1] > (int32_t)tp);
-                }
+    const int64_t tb = (((int64_t)ci.c * a.n_words + ci.word) * ACC_BLK) * WAVE + lane;
+    for (int blk = (ci.len - 1) / WAVE; blk >= 0; blk--) {
+        const uint64_t T = live ? a.t_tp[tb + (int64_t)blk * WAVE] : 0;
+        const uint64_t TF = T | (live ? a.t_fp[tb + (int64_t)blk * WAVE] : 0);
+        // tp, n: counts at the END of this block; walk its TP rows backwards
+        for (uint64_t m = T; m != 0;) {
+            const int q = 63 - __builtin_clzll(m);
+            const uint64_t gt = q == 63 ? 0ull : ~((2ull << q) - 1);   // rows > q
+            const uint32_t tpq = tp - (uint32_t)__popcll(T & gt);      // incl. row q
+            const uint32_t nq = n - (uint32_t)__popcll(TF & gt);
+            if (pr_better(tpq, nq, run)) run = pr_pack(tpq, nq);
+            const int32_t after = (int32_t)tpq - 1;
+            if (jcur > 0 && cj[jcur - 1] > after) {
+                const double v = pr_value(run);
+                do {
+                    out[jcur - 1] = v;
+                    jcur--;
+                } while (jcur > 0 && cj[jcur - 1] > after);
             }
-            if (is_fp) n -= 1;
+            m &= ~(1ull << q);
         }
+        tp -= (uint32_t)__popcll(T);
+        n -= (uint32_t)__popcll(TF);
     }
     if (live && ci.first && jcur > 0) {
         const double v = pr_value(run);
@@ -418,6 +456,7 @@ static size_t base_workspace(int64_t n_dt, int32_t n_cat, int32_t n_rng)
     const size_t nc = (size_t)max_chunks(n_dt, n_cat);
     return align256(((size_t)n_cat + 1) * 4) + 4 * align256(nc * nw * WAVE * 4) +
            align256(nc * nw * WAVE * 8) +
+           2 * align256(nc * nw * ACC_BLK * WAVE * 8) +
            align256((size_t)n_cat * n_rng * N_REC * 4) + 4096;
 }
 
@@ -465,6 +504,8 @@ extern "C" int taoamd_accumulate_compact(int64_t n_dt, int32_t n_cat,
     a.pre_tp = (uint32_t *)w; w += align256(nc * nw * WAVE * 4);
     a.pre_fp = (uint32_t *)w; w += align256(nc * nw * WAVE * 4);
     a.cmax = (uint64_t *)w; w += align256(nc * nw * WAVE * 8);
+    a.t_tp = (uint64_t *)w; w += align256(nc * nw * ACC_BLK * WAVE * 8);
+    a.t_fp = (uint64_t *)w; w += align256(nc * nw * ACC_BLK * WAVE * 8);
     a.cj = (int32_t *)w;
     const unsigned chunk_blocks = (unsigned)((nc * nw + 3) / 4);
     const unsigned cat_blocks = (unsigned)(((size_t)(k_end - k_begin) * nw + 3) / 4);

@@ -285,9 +285,7 @@ extern "C" int taoamd_sort_by_cat_score(int64_t n, const int32_t *dt_cat,
 // cell tables of flatten.py are), a category is a contiguous run and only the
 // score order inside it is missing.
 //   seg_tile_kernel   one workgroup sorts one tile (<= SEG_TILE elements of one
-//                     category) in LDS with a bitonic network over
-//                     (descending-score key, input position): the position
-//                     makes every key unique, so the result is THE stable order
+//                     category) with a stable LSD radix sort in LDS
 //   seg_merge_kernel  categories longer than one tile: log2(#tiles) passes of
 //                     pairwise run merging; every element finds its output
 //                     slot by one binary search in the partner run (merge by
@@ -309,10 +307,24 @@ struct SegArgs {
     int32_t n_cat, n_tiles;
 };
 
+// LDS radix sort of one tile: 8 LSD passes over the 8 bytes of the descending-
+// score key.  Every pass keeps the tile in registers (<= 16 elements per
+// lane), ranks equal digits with the wave-level match-any of rs_scatter_kernel,
+// combines the four wavefronts' digit counts with one 256-wide scan and
+// scatters back into LDS.  LSD passes are stable, the tile is loaded in input
+// order, so the result is the stable order without carrying the position in
+// the key.  A pass whose digit is the same for the whole tile (sign/exponent
+// bytes of scores in (0,1)) moves nothing and is skipped.
+#define SEG_ROUNDS (SEG_TILE / SEG_THREADS)   // 16 rounds of 64 per wavefront
+
 __global__ __launch_bounds__(SEG_THREADS) void seg_tile_kernel(SegArgs a)
 {
     __shared__ uint64_t key[SEG_TILE];
     __shared__ uint16_t pos[SEG_TILE];
+    __shared__ uint32_t wcnt[4][RS_BINS];
+    __shared__ uint32_t dbase[RS_BINS];
+    __shared__ uint32_t wave_tot[4];
+    __shared__ int32_t skip_flag;
     // category owning this tile: last k with tile_off[k] <= blockIdx.x
     int32_t lo = 0, hi = a.n_cat;
     while (hi - lo > 1) {
@@ -324,39 +336,132 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_tile_kernel(SegArgs a)
     const int32_t b = sb + t * SEG_TILE;
     const int32_t n = min(SEG_TILE, se - b);
     if (n <= 0) return;
-    int N = 64;
-    while (N < n) N <<= 1;
-    for (int i = threadIdx.x; i < N; i += SEG_THREADS) {
-        key[i] = i < n ? desc_key(a.score[b + i]) : ~0ull;
-        pos[i] = (uint16_t)i;
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    if (n <= WAVE) {
+        // tiny category: one wavefront, rank by counting -- element i goes to
+        // the number of elements that precede it in (key, position) order
+        if (wave != 0) return;
+        const uint64_t mine = lane < n ? desc_key(a.score[b + lane]) : ~0ull;
+        int rank = 0;
+        for (int j = 0; j < n; j++) {
+            const uint32_t lo_ = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine, j);
+            const uint32_t hi_ = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mine >> 32), j);
+            const uint64_t other = ((uint64_t)hi_ << 32) | lo_;
+            rank += (other < mine || (other == mine && j < lane)) ? 1 : 0;
+        }
+        if (lane < n) {
+            if (se - sb <= SEG_TILE) {
+                if (a.order) a.order[b + rank] = b + lane;
+                if (a.dst) a.dst[b + lane] = b + rank;
+            } else {    // short last tile of a long category: goes on to merge
+                a.key[0][b + rank] = mine;
+                a.idx[0][b + rank] = b + lane;
+            }
+        }
+        return;
     }
-    __syncthreads();
-    for (int kk = 2; kk <= N; kk <<= 1) {
-        for (int j = kk >> 1; j > 0; j >>= 1) {
-            for (int p = threadIdx.x; p < (N >> 1); p += SEG_THREADS) {
-                const int i = ((p / j) * 2 * j) + (p % j);
-                const int l = i + j;
-                const bool up = (i & kk) == 0;
-                const uint64_t ki = key[i], kl = key[l];
-                const uint16_t pi = pos[i], pl = pos[l];
-                const bool gt = ki > kl || (ki == kl && pi > pl);
-                if (gt == up) {
-                    key[i] = kl; key[l] = ki;
-                    pos[i] = pl; pos[l] = pi;
+    // wavefront w owns the contiguous slice [w*per, (w+1)*per) of the tile
+    const int per = ((n + 4 * WAVE - 1) / (4 * WAVE)) * WAVE;
+    const int rounds = per / WAVE;
+    const int w0 = wave * per;
+    uint64_t kr[SEG_ROUNDS];
+    uint16_t pr[SEG_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < SEG_ROUNDS; r++) {
+        const int i = w0 + r * WAVE + lane;
+        const bool ok = r < rounds && i < n;
+        kr[r] = ok ? desc_key(a.score[b + i]) : 0;
+        pr[r] = (uint16_t)i;
+    }
+    for (int pass = 0; pass < 8; pass++) {
+        for (int i = threadIdx.x; i < 4 * RS_BINS; i += SEG_THREADS)
+            (&wcnt[0][0])[i] = 0;
+        __syncthreads();
+        uint32_t rank[SEG_ROUNDS];
+#pragma unroll
+        for (int r = 0; r < SEG_ROUNDS; r++) {
+            if (r < rounds) {                       // block-uniform
+                const int i = w0 + r * WAVE + lane;
+                const bool ok = i < n;
+                const uint32_t dig = (uint32_t)(kr[r] >> (8 * pass)) & 255u;
+                uint64_t peers = __ballot(ok);
+#pragma unroll
+                for (int bit = 0; bit < 8; bit++) {
+                    const bool one = (dig >> bit) & 1u;
+                    const uint64_t m = __ballot(one);
+                    peers &= one ? m : ~m;
+                }
+                const uint32_t below = (uint32_t)__popcll(peers & ((1ull << lane) - 1));
+                uint32_t old = 0;
+                if (ok) old = wcnt[wave][dig];
+                rank[r] = old + below;
+                if (ok && (peers >> lane) == 1ull) wcnt[wave][dig] = old + below + 1;
+            }
+        }
+        __syncthreads();
+        // thread d: digit d.  totals over the four wavefronts, exclusive scan
+        {
+            const int d = threadIdx.x;
+            const uint32_t c0 = wcnt[0][d], c1 = wcnt[1][d], c2 = wcnt[2][d],
+                           c3 = wcnt[3][d];
+            const uint32_t tot = c0 + c1 + c2 + c3;
+            if (d == 0) skip_flag = 0;
+            uint32_t inc = tot;                    // inclusive scan in the wave
+#pragma unroll
+            for (int off = 1; off < WAVE; off <<= 1) {
+                const uint32_t v = __shfl_up(inc, off, WAVE);
+                if (lane >= off) inc += v;
+            }
+            if (lane == WAVE - 1) wave_tot[wave] = inc;
+            __syncthreads();
+            uint32_t before = 0;
+            for (int w = 0; w < wave; w++) before += wave_tot[w];
+            const uint32_t excl = before + inc - tot;
+            dbase[d] = excl;
+            // exclusive over wavefronts, in place
+            wcnt[0][d] = 0; wcnt[1][d] = c0; wcnt[2][d] = c0 + c1;
+            wcnt[3][d] = c0 + c1 + c2;
+            if (tot == (uint32_t)n) skip_flag = 1;
+        }
+        __syncthreads();
+        if (skip_flag) { __syncthreads(); continue; }
+#pragma unroll
+        for (int r = 0; r < SEG_ROUNDS; r++) {
+            if (r < rounds) {
+                const int i = w0 + r * WAVE + lane;
+                if (i < n) {
+                    const uint32_t dig = (uint32_t)(kr[r] >> (8 * pass)) & 255u;
+                    const uint32_t dst = dbase[dig] + wcnt[wave][dig] + rank[r];
+                    key[dst] = kr[r];
+                    pos[dst] = pr[r];
                 }
             }
-            __syncthreads();
         }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < SEG_ROUNDS; r++) {
+            if (r < rounds) {
+                const int i = w0 + r * WAVE + lane;
+                if (i < n) { kr[r] = key[i]; pr[r] = pos[i]; }
+            }
+        }
+        __syncthreads();
     }
     const bool single = se - sb <= SEG_TILE;
-    for (int i = threadIdx.x; i < n; i += SEG_THREADS) {
-        const int32_t d = b + pos[i];
-        if (single) {
-            if (a.order) a.order[b + i] = d;
-            if (a.dst) a.dst[d] = b + i;
-        } else {
-            a.key[0][b + i] = key[i];
-            a.idx[0][b + i] = d;
+#pragma unroll
+    for (int r = 0; r < SEG_ROUNDS; r++) {
+        if (r < rounds) {
+            const int i = w0 + r * WAVE + lane;
+            if (i < n) {
+                const int32_t d = b + pr[r];
+                if (single) {
+                    if (a.order) a.order[b + i] = d;
+                    if (a.dst) a.dst[d] = b + i;
+                } else {
+                    a.key[0][b + i] = kr[r];
+                    a.idx[0][b + i] = d;
+                }
+            }
         }
     }
 }
