@@ -706,35 +706,42 @@ __global__ __launch_bounds__(256) void match_group_kernel(MatchArgs a, IouThr th
         }
     }
     // ---- lane = combo: sequential greedy over the detections whose cell has
-    // two or more GTs
+    // two or more GTs.  Per detection one readlane brings a packed word
+    // (first GT of the cell | GT count | flags) to the scalar unit; the masks
+    // are narrowed to the cell's <= GRP_GCAP GTs so the inner loop is 32-bit.
     const uint64_t todo = __ballot(lane < nD && Gc >= 2);
+    const int32_t meta = (gb & 0xff) | ((Gc & 0xff) << 8) | ((t_flags & 0xff) << 16);
     uint64_t taken = 0;
     for (uint64_t rest = todo; rest != 0; rest &= rest - 1) {
         const int i = __builtin_ctzll(rest);
-        const int gbi = __builtin_amdgcn_readlane(gb, i);
-        const int gei = __builtin_amdgcn_readlane(ge, i);
-        const uint32_t df = (uint32_t)__builtin_amdgcn_readlane(t_flags, i);
+        const uint32_t mt = (uint32_t)__builtin_amdgcn_readlane(meta, i);
+        const int gbi = mt & 0xff, gci = (mt >> 8) & 0xff;
+        const uint32_t df = (mt >> 16) & 0xff;
         const uint32_t drng = (uint32_t)__builtin_amdgcn_readlane(t_rng, i);
+        const uint32_t cellbits = (1u << gci) - 1;
+        const uint32_t igl = (uint32_t)(IG >> gbi) & cellbits;
+        const uint32_t freel = ~(uint32_t)(taken >> gbi) & cellbits;
+        const uint32_t free1 = freel & ~igl, free2 = freel & igl;
         double best1 = thr0, best2 = thr0;
         int m1 = -1, m2 = -1;
-        const uint64_t free1 = ~taken & ~IG, free2 = ~taken & IG;
-        for (int g = gbi; g < gei; g++) {
-            const double v = s_iou[wave][i * GRP_GCAP + (g - gbi)];
-            const bool ok1 = ((free1 >> g) & 1) && !(v < best1);
-            const bool ok2 = ((free2 >> g) & 1) && !(v < best2);
+        const double *__restrict__ row = &s_iou[wave][i * GRP_GCAP];
+        for (int g = 0; g < gci; g++) {
+            const double v = row[g];
+            const bool ok1 = ((free1 >> g) & 1u) && !(v < best1);
+            const bool ok2 = ((free2 >> g) & 1u) && !(v < best2);
             best1 = ok1 ? v : best1;  m1 = ok1 ? g : m1;
             best2 = ok2 ? v : best2;  m2 = ok2 ? g : m2;
         }
-        const int m = m1 >= 0 ? m1 : m2;
-        if (m >= 0 && !(df & TAOAMD_DT_NO_CONSUME)) taken |= 1ull << m;
-        const bool vis = m >= 0 && !((HID >> m) & 1);
-        bool ig = m >= 0 && ((IG >> m) & 1);
+        const int m = m1 >= 0 ? m1 : m2;            // cell-local index
+        if (m >= 0 && !(df & TAOAMD_DT_NO_CONSUME)) taken |= 1ull << (gbi + m);
+        const bool vis = m >= 0 && !((HID >> (gbi + (m >= 0 ? m : 0))) & 1);
+        bool ig = m >= 0 && ((igl >> (m >= 0 ? m : 0)) & 1u);
         if (!vis && ((drng >> r) & 1u)) ig = true;
         const uint64_t mw = __ballot(active && vis);
         const uint64_t iw = __ballot(active && ig);
         if (lane == i) { my_m = mw; my_i = iw; }
         if (a.match_gt != nullptr && active)
-            a.match_gt[(int64_t)(d0 + i) * n_combo + combo] = m >= 0 ? m - gbi : -1;
+            a.match_gt[(int64_t)(d0 + i) * n_combo + combo] = m;
     }
     if (lane < nD) {
         a.matched[t_row * a.out_stride + word] = my_m;
