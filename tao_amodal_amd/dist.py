@@ -64,6 +64,8 @@ class HipBackend:
         self.engine.stage_track_iou(dp, ws)
 
     def match_into(self, dp, ws, dst, records, width):
+        if dp.n_dt == 0:
+            return
         t, lib = dp.t, self.lib
         fused = dp.kind == "lvis"
         base = records.data_ptr()

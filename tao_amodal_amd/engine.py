@@ -211,7 +211,7 @@ def stage_sort(dp, ws):
 
 
 def stage_track_iou(dp, ws):
-    if dp.kind != "tao":
+    if dp.kind != "tao" or dp.n_iou == 0:
         return
     lib, t, s = _lib.load(), dp.t, _stream()
     _lib.check(lib.taoamd_track_iou(
@@ -225,6 +225,8 @@ def stage_track_iou(dp, ws):
 
 
 def stage_match(dp, ws, scatter=True):
+    if dp.n_dt == 0:        # nothing was detected: every cell is GT-only
+        return
     lib, t, s = _lib.load(), dp.t, _stream()
     fused = dp.kind == "lvis"
     _lib.check(lib.taoamd_match(
