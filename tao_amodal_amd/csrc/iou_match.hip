@@ -350,8 +350,11 @@ __global__ __launch_bounds__(256) void track_iou_dense_kernel(
             const int np = min(TD_CH, span - p0);
             // ---- phase A0: the chunk's GT frames -> LDS (each GT box is
             // needed by every detection track of the group)
-            for (int it = threadIdx.x; it < G * np; it += 256) {
-                const int g = it / np, pp = it - g * np;
+            // (items are laid out with a fixed stride of TD_CH positions, so the
+            // decode is a shift and a mask; positions >= np are skipped)
+            for (int it = threadIdx.x; it < G * TD_CH; it += 256) {
+                const int g = it / TD_CH, pp = it % TD_CH;
+                if (pp >= np) continue;
                 const uint32_t rg = gmap[g * span + p0 + pp];
                 double4 A = make_double4(0, 0, -1.0, 0);   // w < 0: absent
                 if (rg != TD_NONE) A = GB[first[g] + (int32_t)rg];
@@ -361,15 +364,16 @@ __global__ __launch_bounds__(256) void track_iou_dense_kernel(
             // ---- phase A: item = (detection track, position): consecutive
             // threads read consecutive frames of one track (coalesced); the
             // TD_IT box loads of a thread are issued together
-            for (int base = threadIdx.x; base < nd * np; base += 256 * TD_IT) {
+            for (int base = threadIdx.x; base < nd * TD_CH; base += 256 * TD_IT) {
                 int32_t kd[TD_IT];
                 bool hd[TD_IT];
                 double4 B[TD_IT];
 #pragma unroll
                 for (int q = 0; q < TD_IT; q++) {
                     const int it = base + q * 256;
-                    const bool ok = it < nd * np;
-                    const int dl = ok ? it / np : 0, pp = ok ? it - dl * np : 0;
+                    const int dl0 = it / TD_CH, pp0 = it % TD_CH;
+                    const bool ok = dl0 < nd && pp0 < np;
+                    const int dl = ok ? dl0 : 0, pp = ok ? pp0 : 0;
                     const uint32_t rd = dmap[dl * span + p0 + pp];
                     hd[q] = ok && rd != TD_NONE;
                     kd[q] = hd[q] ? first[TD_PAIRS + dl] + (int32_t)rd : 0;
@@ -379,8 +383,8 @@ __global__ __launch_bounds__(256) void track_iou_dense_kernel(
 #pragma unroll
                 for (int q = 0; q < TD_IT; q++) {
                     const int it = base + q * 256;
-                    if (it < nd * np) {
-                        const int dl = it / np, pp = it - dl * np;
+                    const int dl = it / TD_CH, pp = it % TD_CH;
+                    if (dl < nd && pp < np) {
                         const double da = B[q].z * B[q].w;
                         for (int g = 0; g < G; g++) {
                             const double4 A = gbox[g * TD_CH + pp];
