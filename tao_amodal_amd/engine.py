@@ -262,6 +262,49 @@ def run(dp, ws):
         fn(dp, ws)
 
 
+class Overlap:
+    """Runs evaluator passes concurrently on separate HIP streams.
+
+    Every kernel of this path is latency / dependency bound (rocprofv3 SQ
+    counters: 20-45 % active cycles), so independent work fills the idle
+    issue slots: the image-level and the track-level pass share nothing, and
+    inside a pass range masks, sort and 3D IoU only meet at the match kernel.
+    Streams are forked from / joined to the caller's current stream with
+    events, so the caller's barrier + synchronize bracketing stays valid."""
+
+    def __init__(self, device, n=4):
+        self.device = torch.device(device)
+        self.streams = [torch.cuda.Stream(self.device) for _ in range(n)]
+
+    def _fork(self, k):
+        s = self.streams[k]
+        s.wait_stream(torch.cuda.current_stream(self.device))
+        return s
+
+    def run_pair(self, dpl, wsl, dpt, wst):
+        cur = torch.cuda.current_stream(self.device)
+        sl, st, s_aux_l, s_aux_t = (self._fork(k) for k in range(4))
+        # image-level pass: ranges || sort -> match -> accumulate
+        with torch.cuda.stream(s_aux_l):
+            stage_ranges(dpl, wsl)
+        with torch.cuda.stream(sl):
+            stage_sort(dpl, wsl)
+            sl.wait_stream(s_aux_l)
+            stage_match(dpl, wsl)
+            stage_accumulate(dpl, wsl)
+        # track-level pass: (ranges, sort) || 3D IoU -> match -> accumulate
+        with torch.cuda.stream(s_aux_t):
+            stage_ranges(dpt, wst)
+            stage_sort(dpt, wst)
+        with torch.cuda.stream(st):
+            stage_track_iou(dpt, wst)
+            st.wait_stream(s_aux_t)
+            stage_match(dpt, wst)
+            stage_accumulate(dpt, wst)
+        cur.wait_stream(sl)
+        cur.wait_stream(st)
+
+
 def time_stages(dpl, wsl, dpt, wst, reps=10):
     """Average duration (ms) of every stage of both evaluators, measured with
     HIP events recorded on the stream the kernels are launched on."""

@@ -246,3 +246,23 @@ def test_other_modes_on_merge_kernel():
         got = _engine().evaluate_flat(f, iou_3d_type=mode)
         assert np.array_equal(got["iou"], want["iou"]), mode
         assert np.array_equal(got["precision"], want["precision"]), mode
+
+
+def test_overlapped_streams_give_the_same_tensors():
+    import torch
+    from tao_amodal_amd import engine
+    gt, dt = synth(seed=51, V=6, F=40, C=60, dets_per_frame=40)
+    fl_ = fl.flatten_lvis(gt, dt)
+    dt.track_id, _ = fl.make_track_ids_unique(dt)
+    ft_ = fl.flatten_tao(gt, dt)
+    dpl, dpt = engine.DeviceProblem(fl_), engine.DeviceProblem(ft_)
+    wsl, wst = engine.Workspace(dpl), engine.Workspace(dpt)
+    ov = engine.Overlap("cuda")
+    for _ in range(3):
+        ov.run_pair(dpl, wsl, dpt, wst)
+    torch.cuda.synchronize()
+    wl, wt = orclib.run_flat(fl_, detail=False), orclib.run_flat(ft_, detail=False)
+    assert np.array_equal(wsl.precision.cpu().numpy(), wl["precision"])
+    assert np.array_equal(wsl.recall.cpu().numpy(), wl["recall"])
+    assert np.array_equal(wst.precision.cpu().numpy(), wt["precision"])
+    assert np.array_equal(wst.recall.cpu().numpy(), wt["recall"])
