@@ -47,8 +47,20 @@ def parse():
                         "oracle for cpu_baseline (rank 0, N=1 only)")
     p.add_argument("--no-cpu", action="store_true")
     p.add_argument("--no-verify", action="store_true")
+    p.add_argument("--graph", action="store_true",
+                   help="replay the step from captured hipGraphs instead of "
+                        "launching the kernels (experimental: slower than the "
+                        "stream launches on one GPU, see DESIGN.md)")
     p.add_argument("--serial", action="store_true",
                    help="run the two evaluator passes back to back on one stream")
+    p.add_argument("--shard", choices=["category", "unit"], default="category",
+                   help="multi-GPU partition: contiguous category blocks (no "
+                        "record exchange) or the ranks' own videos (records "
+                        "meet at the category owners)")
+    p.add_argument("--emulate", default=None, metavar="W:R",
+                   help="with --force-dist on one GPU: run the per-rank work of "
+                        "rank R of a W-rank category-sharded job (diagnostic; "
+                        "the printed value counts this rank's pairs only)")
     p.add_argument("--force-dist", action="store_true",
                    help="take the multi-GPU code path even with one rank")
     return p.parse_args()
@@ -90,6 +102,11 @@ def pmc_traffic(kernel_substr):
 
 def main():
     args = parse()
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 or args.force_dist:
+        # the category-partitioned step keeps 4 compute streams + the RCCL
+        # stream busy; with the default of 4 hardware queues per process they
+        # alias and serialise (measured 1.25 -> 0.94 ms/step with 8)
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -107,15 +124,38 @@ def main():
     from tao_amodal_amd import engine, flatten
     from tao_amodal_amd.synth import synth
 
+    by_category = use_dist and args.shard == "category"
+    data_world, data_rank = world, rank
+    if args.emulate:
+        assert by_category and world == 1, "--emulate needs --force-dist on one GPU"
+        data_world, data_rank = (int(x) for x in args.emulate.split(":"))
     t0 = time.time()
-    gt, dt = synth(seed=args.seed + rank, V=args.videos, F=args.frames,
-                   C=args.cats, dets_per_frame=args.dets,
-                   video_id_base=rank * args.videos)
+    if by_category:
+        # weak scaling: the data set grows with the number of ranks (one
+        # 200-video shard per rank) and every rank evaluates its category
+        # block of the WHOLE set, so the work per GPU stays fixed
+        from tao_amodal_amd.columns import DTColumns, GTColumns
+        parts = [synth(seed=args.seed + r, V=args.videos, F=args.frames,
+                       C=args.cats, dets_per_frame=args.dets,
+                       video_id_base=r * args.videos)
+                 for r in range(data_world)]
+        gt = GTColumns.concat([p[0] for p in parts])
+        dt = DTColumns.concat([p[1] for p in parts])
+        del parts
+    else:
+        gt, dt = synth(seed=args.seed + rank, V=args.videos, F=args.frames,
+                       C=args.cats, dets_per_frame=args.dets,
+                       video_id_base=rank * args.videos)
     t_gen = time.time() - t0
     t0 = time.time()
     fl = flatten.flatten_lvis(gt, dt)
     dt.track_id, _ = flatten.make_track_ids_unique(dt)
     ft = flatten.flatten_tao(gt, dt)
+    if by_category:
+        from tao_amodal_amd import dist as tdist
+        k0, k1, _ = tdist.category_block(len(fl.cat_ids), data_rank, data_world)
+        fl = tdist.shard_by_category(fl, k0, k1)
+        ft = tdist.shard_by_category(ft, k0, k1)
     t_flat = time.time() - t0
     t0 = time.time()
     dpl, dpt = engine.DeviceProblem(fl, dev), engine.DeviceProblem(ft, dev)
@@ -125,10 +165,13 @@ def main():
 
     if use_dist:
         from tao_amodal_amd import dist as tdist
-        plan = tdist.ExchangePlan(dpl, dpt, rank, world, dev)
+        if by_category:
+            plan = tdist.CategoryPlan(dpl, dpt, rank, world, dev)
+        else:
+            plan = tdist.ExchangePlan(dpl, dpt, rank, world, dev)
 
         def step():
-            tdist.step(plan)
+            plan.step()
     elif args.serial:
         def step():
             engine.run(dpl, wsl)
@@ -139,6 +182,11 @@ def main():
 
         def step():
             overlap.run_pair(dpl, wsl, dpt, wst)
+        if args.graph:
+            # the launch sequence of a step is fixed: capture it once (stream
+            # forks become parallel branches), a step is two hipGraph launches
+            graphed = engine.GraphedPair(overlap, dpl, wsl, dpt, wst)
+            step = graphed.run
 
     for _ in range(args.warmup):
         step()
@@ -149,6 +197,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    host_ms = (time.perf_counter() - t0) / args.steps * 1e3   # launch side only
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -161,7 +210,11 @@ def main():
 
     # ---- pairs: exact counts from the cell tables / the kernel's counter
     p_l = dpl.n_pairs
-    p_t = int(plan.pair_frames()) if use_dist else int(wst.pair_frames.item())
+    if args.graph and not use_dist:   # the counter's memset node is unreliable under replay
+        engine.stage_track_iou(dpt, wst)
+        p_t = int(wst.pair_frames.item())
+    else:
+        p_t = int(plan.pair_frames()) if use_dist else int(wst.pair_frames.item())
     pairs = torch.tensor([p_l + p_t], dtype=torch.int64, device=dev)
     if use_dist:
         dist.all_reduce(pairs)
@@ -172,7 +225,7 @@ def main():
     # ---- stage breakdown + dominant-kernel roofline (HIP events on the
     # stream the kernels run on), measured outside the timed region
     stages, roof, roof_other = None, None, None
-    if not use_dist:
+    if rank == 0:
         stages = engine.time_stages(dpl, wsl, dpt, wst, reps=max(args.steps, 10))
         # the two single-kernel stages; `roofline` reports the one that takes
         # longer (the dominant kernel of the step), `roofline_other` the other
@@ -249,11 +302,17 @@ def main():
                        "lvis_pairs_rank0": p_l, "tao_pairs_rank0": p_t,
                        "detections_rank0": dpl.n_dt, "tracks_rank0": dpt.n_dt,
                        "cells_rank0": [dpl.n_cells, dpt.n_cells],
-                       "parallelism": "video-sharded x%d" % world},
+                       "parallelism": ("single GPU" if not use_dist else
+                                       "%s-sharded x%d" % (args.shard, world))},
             "roofline": roof, "roofline_other": roof_other, "cpu_baseline": cpu,
-            "stages_ms": stages, "streams": "serial" if (args.serial or use_dist)
+            "stages_ms": stages, "streams": "serial" if (args.serial or (use_dist and not by_category))
+            else "4 (image-level || track-level, ranges/sort || IoU) + RCCL all_gather" if use_dist
             else "4 (image-level || track-level, ranges/sort || IoU)",
+            "host_launch_ms_per_step": round(host_ms, 4),
+            "hip_graph": bool(args.graph and not args.serial and not use_dist),
             "bit_exact_vs_oracle": verified,
+            "exchange_chunk_bytes": ([plan.lvis.chunk_bytes, plan.tao.chunk_bytes]
+                                     if by_category else None),
             "host_s": {"generate": round(t_gen, 2), "flatten": round(t_flat, 2),
                        "upload": round(t_h2d, 2)},
         }

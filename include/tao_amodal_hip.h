@@ -251,6 +251,46 @@ int taoamd_accumulate(int64_t n_dt, int32_t n_cat, int32_t n_rng,
                       const int32_t *num_gt, double *precision, double *recall,
                       void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- multi-GPU result exchange (category-partitioned evaluation) -------------------
+ * No reference counterpart (the reference is single-process); these carry the
+ * tables of taoamd_accumulate_compact between ranks and end in the layout of
+ * taoamd_finalize, i.e. of `eval["precision"]` / `eval["recall"]`
+ * (lvis_amodal/eval.py:366-371,420-426, tao_amodal/eval.py:521-526,576-584).
+ * Rank b owns the categories [b * block_cats, (b+1) * block_cats); a row is a
+ * (category, range) pair, global row = category * n_rng + range.
+ *
+ * A chunk holds one rank's share: the num_gt and rec of its rows and, per row
+ * with num_gt > 0 and per IoU threshold, the distinct runs ("levels") of the
+ * 101 recall columns -- a row with n ground truths has at most min(n,100)+1
+ * of them, and which columns coincide follows from n alone, so receivers
+ * rebuild the map from the chunk header.  Chunks of all ranks have
+ * taoamd_exchange_chunk_bytes(block_cats, n_rng, capacity) bytes and sit
+ * back to back in `chunks` (one in-place all-gather moves them).
+ *  _sizes   levels needed by every block (device int64[world]) from the
+ *           gathered num_gt[world * block_cats][n_rng]; capacity = their max
+ *  _pack    own rows of val / rec / num_gt (tables addressed by GLOBAL row,
+ *           as written by taoamd_accumulate_compact) -> `chunk` (this rank's)
+ *  _unpack  all chunks -> precision[T][R][n_cat][n_rng], recall[T][n_cat][n_rng]
+ *           (-1 fill) and optionally the assembled num_gt[n_cat][n_rng]
+ * *overflow (device int32, may be NULL) is OR-ed with 1 if a block needs more
+ * than `capacity` levels (the excess is dropped, results are then invalid).
+ * Workspace: taoamd_exchange_workspace(block_cats, n_rng, world). */
+size_t taoamd_exchange_chunk_bytes(int32_t block_cats, int32_t n_rng, int64_t capacity);
+size_t taoamd_exchange_workspace(int32_t block_cats, int32_t n_rng, int32_t world);
+int taoamd_exchange_sizes(int32_t block_cats, int32_t n_rng, int32_t world,
+                          const int32_t *num_gt, int64_t *totals, void *workspace,
+                          size_t workspace_bytes, void *stream);
+int taoamd_exchange_pack(int32_t n_cat, int32_t n_rng, int32_t block_cats,
+                         int32_t world, int32_t rank, const int32_t *num_gt,
+                         const double *val, const double *rec, void *chunk,
+                         int64_t capacity, int32_t *overflow, void *workspace,
+                         size_t workspace_bytes, void *stream);
+int taoamd_exchange_unpack(int32_t n_cat, int32_t n_rng, int32_t block_cats,
+                           int32_t world, const void *chunks, int64_t capacity,
+                           int32_t *num_gt_out, double *precision, double *recall,
+                           int32_t *overflow, void *workspace,
+                           size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

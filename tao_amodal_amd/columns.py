@@ -105,6 +105,34 @@ class GTColumns:
                                    for a in anns], dtype=np.uint8),
         )
 
+    @classmethod
+    def concat(cls, parts):
+        """Union of several annotation sets with disjoint ids over the same
+        category table (used to assemble a multi-shard synthetic dataset)."""
+        def cat(name):
+            return np.concatenate([getattr(p, name) for p in parts])
+
+        def csr(off, val):
+            offs, base = [np.zeros(1, dtype=np.int64)], 0
+            for p in parts:
+                o = getattr(p, off)
+                offs.append(o[1:] + base)
+                base += int(o[-1])
+            return np.concatenate(offs), cat(val)
+        first = parts[0]
+        vneg, vnel = csr("vid_neg_off", "vid_neg"), csr("vid_nel_off", "vid_nel")
+        ineg, inel = csr("img_neg_off", "img_neg"), csr("img_nel_off", "img_nel")
+        kw = dict(cat_id=first.cat_id, cat_freq=first.cat_freq,
+                  cat_merged=first.cat_merged,
+                  vid_neg_off=vneg[0], vid_neg=vneg[1],
+                  vid_nel_off=vnel[0], vid_nel=vnel[1],
+                  img_neg_off=ineg[0], img_neg=ineg[1],
+                  img_nel_off=inel[0], img_nel=inel[1])
+        for f in cls.FIELDS:
+            if f not in kw:
+                kw[f] = cat(f)
+        return cls(**kw)
+
     def to_json(self):
         """Inverse of from_json (used by the synthetic generator and tests)."""
         def num(x):
@@ -250,3 +278,8 @@ class DTColumns:
 
     def take(self, idx):
         return DTColumns(**{f: getattr(self, f)[idx] for f in self.FIELDS})
+
+    @classmethod
+    def concat(cls, parts):
+        return cls(**{f: np.concatenate([getattr(p, f) for p in parts])
+                      for f in cls.FIELDS})

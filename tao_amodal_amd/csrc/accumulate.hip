@@ -318,12 +318,7 @@ __global__ void acc_cj_kernel(AccArgs a, RecThr rec)
     const int64_t kr = (int64_t)a.k_begin * a.n_rng + i / N_REC;
     const int32_t ng = a.num_gt[kr];
     if (ng <= 0) return;
-    const double x = rec.v[j], dn = (double)ng;
-    int32_t c = (int32_t)(x * dn);
-    c = c < 0 ? 0 : (c > ng ? ng : c);
-    while (c < ng && (double)c / dn < x) c++;
-    while (c > 0 && (double)(c - 1) / dn >= x) c--;
-    a.cj[kr * N_REC + j] = c;
+    a.cj[kr * N_REC + j] = recall_crossing(rec.v[j], ng);
 }
 
 #define EMIT_RMAX 8   // ranges that can overlap one 64-combo word

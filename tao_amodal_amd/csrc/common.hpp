@@ -59,6 +59,19 @@ __device__ __forceinline__ double box_iou(double dx, double dy, double dw,
     return i / u;
 }
 
+// Smallest TP count c with fl(c / num_gt) >= x, the integer form of
+// np.searchsorted(tp / num_gt, x, side="left") (reference
+// lvis_amodal/eval.py:386,406-408); ng > 0.
+__device__ __forceinline__ int32_t recall_crossing(double x, int32_t ng)
+{
+    const double dn = (double)ng;
+    int32_t c = (int32_t)(x * dn);
+    c = c < 0 ? 0 : (c > ng ? ng : c);
+    while (c < ng && (double)c / dn < x) c++;
+    while (c > 0 && (double)(c - 1) / dn >= x) c--;
+    return c;
+}
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
 
 __device__ __forceinline__ double readlane_f64(double v, int lane)

@@ -1,0 +1,359 @@
+// Result exchange of the category-partitioned multi-GPU evaluation (gfx950).
+//
+// A rank that swept the categories of its block holds, per (category, range)
+// row, the table val[t][j] = precision at recall threshold j (reference
+// lvis_amodal/eval.py:398-417 == tao_amodal/eval.py:555-573).  Shipping the
+// 101 columns of every row to every rank would move 58 MB (image level) +
+// 194 MB (track level) per pass, most of it redundant: column j depends on j
+// only through cj[j] = the TP count at which recall first reaches
+// rec_thrs[j] (acc_cj_kernel), a function of num_gt alone.  A row with n
+// ground truths has at most min(n, 100) + 1 distinct crossings, so its 101
+// columns hold at most that many distinct values ("levels"), in runs.  Track
+// level rows typically have a handful of ground-truth tracks.
+//
+// The exchange therefore ships, per rank, ONE chunk
+//
+//     [ num_gt of the block rows | rec of the block rows | levels ]
+//
+// where `levels` stores for every row with num_gt > 0 and every IoU threshold
+// only the first column of each run.  Receivers rebuild the run map from the
+// num_gt in the chunk header with the very fp64 comparison the sweep used
+// (recall_crossing), expand, and write the reference layout
+// precision[T][R][K][A] / recall[T][K][A] directly (the transpose that
+// acc_finalize_kernel does on a single GPU), so expansion costs no extra pass.
+// Copying runs is exact by construction: no arithmetic touches the values.
+//
+// One chunk per rank and equal chunk sizes make the whole exchange a single
+// in-place all_gather_into_tensor per evaluator.  The chunk capacity is fixed
+// when the plan is built (taoamd_exchange_sizes on the gathered num_gt; the
+// ground truth of a plan does not change between passes); an overflow flag
+// guards against misuse.
+#include "common.hpp"
+
+using namespace taoamd;
+
+namespace {
+
+__host__ __device__ inline size_t ex_align(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct NumSrc {             // where the num_gt of a global row lives
+    const unsigned char *base;
+    int64_t block_stride;   // bytes between the tables of consecutive blocks
+    int64_t valid_rows;     // rows at or beyond are padding (num_gt = 0)
+    int32_t block_rows;
+};
+
+__device__ __forceinline__ int32_t num_of(const NumSrc &s, int64_t row)
+{
+    if (row >= s.valid_rows) return 0;
+    const int64_t b = row / s.block_rows, i = row - b * s.block_rows;
+    return *(const int32_t *)(s.base + b * s.block_stride + i * 4);
+}
+
+struct ExWs {
+    uint8_t *dmap;    // [rows][N_REC] run index of column j
+    int32_t *nd;      // [rows] runs of the row (0: no ground truth)
+    int32_t *off;     // [rows] first level of the row inside its block's levels
+    int64_t *totals;  // [world] levels per block
+};
+
+// one wave per row: run index of each recall column
+__global__ __launch_bounds__(256) void ex_levels_kernel(NumSrc src, int64_t row0,
+                                                         int64_t row1, ExWs w,
+                                                         RecThr rec)
+{
+    const int lane = lane_id();
+    const int64_t row = row0 + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= row1) return;
+    const int32_t ng = num_of(src, row);
+    if (ng <= 0) {
+        if (lane == 0) w.nd[row] = 0;
+        return;
+    }
+    const int j0 = lane, j1 = lane + WAVE;
+    const bool has1 = j1 < N_REC;
+    const int32_t c0 = recall_crossing(rec.v[j0], ng);
+    const int32_t p0 = j0 > 0 ? recall_crossing(rec.v[j0 - 1], ng) : c0;
+    const int32_t c1 = has1 ? recall_crossing(rec.v[j1], ng) : 0;
+    const int32_t p1 = has1 ? recall_crossing(rec.v[j1 - 1], ng) : 0;
+    const uint64_t f0 = __ballot(j0 > 0 && c0 != p0);
+    const uint64_t f1 = __ballot(has1 && c1 != p1);
+    const uint64_t incl = lane == 63 ? ~0ull : ((2ull << lane) - 1);
+    const int d0 = __popcll(f0 & incl);
+    const int d1 = __popcll(f0) + __popcll(f1 & incl);
+    w.dmap[row * N_REC + j0] = (uint8_t)d0;
+    if (has1) w.dmap[row * N_REC + j1] = (uint8_t)d1;
+    if (lane == 0) w.nd[row] = __popcll(f0) + __popcll(f1) + 1;
+}
+
+// one workgroup per block of rows: exclusive scan of nd * T.  Each thread
+// owns a contiguous run of rows, so the block-wide scan is a single round.
+__global__ __launch_bounds__(1024) void ex_offsets_kernel(int32_t block_first,
+                                                           int32_t block_rows,
+                                                           int64_t capacity, ExWs w,
+                                                           int32_t *overflow)
+{
+    __shared__ int64_t s_wave[16];
+    const int b = block_first + blockIdx.x;
+    const int64_t r0 = (int64_t)b * block_rows;
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int32_t per = (block_rows + 1023) / 1024;
+    const int32_t i0 = min(block_rows, (int32_t)threadIdx.x * per);
+    const int32_t i1 = min(block_rows, i0 + per);
+    int64_t mine = 0;
+    for (int32_t i = i0; i < i1; i++) mine += (int64_t)w.nd[r0 + i] * N_THR;
+    int64_t x = mine;
+    for (int d = 1; d < WAVE; d <<= 1) {
+        const int64_t y = __shfl_up(x, d);
+        if (lane >= d) x += y;
+    }
+    if (lane == WAVE - 1) s_wave[wave] = x;
+    __syncthreads();
+    int64_t before = x - mine;
+    for (int q = 0; q < wave; q++) before += s_wave[q];
+    for (int32_t i = i0; i < i1; i++) {
+        w.off[r0 + i] = (int32_t)before;
+        before += (int64_t)w.nd[r0 + i] * N_THR;
+    }
+    if (threadIdx.x == 1023) {
+        w.totals[b] = before;
+        if (before > capacity && overflow) atomicOr(overflow, 1);
+    }
+}
+
+struct Chunk {
+    size_t hdr_bytes, rec_bytes, bytes;
+};
+
+inline Chunk chunk_layout(int32_t block_cats, int32_t n_rng, int64_t capacity)
+{
+    const size_t rows = (size_t)block_cats * n_rng;
+    Chunk c;
+    c.hdr_bytes = ex_align(rows * 4);
+    c.rec_bytes = ex_align(rows * N_THR * 8);
+    c.bytes = c.hdr_bytes + c.rec_bytes + ex_align((size_t)capacity * 8);
+    return c;
+}
+
+struct PackArgs {
+    int64_t row0;          // first global row of the block
+    int32_t block_rows;
+    int64_t valid_rows;    // n_cat * n_rng
+    const int32_t *num_gt; // local table [n_cat][n_rng]
+    const double *val, *rec;
+    int32_t *hdr;
+    double *rec_out, *levels;
+    int64_t capacity;
+    ExWs w;
+};
+
+// thread = (row of the block, column (t, j)): the first column of each run is
+// copied to its level slot
+__global__ __launch_bounds__(256) void ex_pack_kernel(PackArgs a)
+{
+    const int64_t COLS = (int64_t)N_THR * N_REC;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t i = idx / COLS;
+    if (i >= a.block_rows) return;
+    const int col = (int)(idx - i * COLS);
+    const int64_t row = a.row0 + i;
+    const int32_t ng = row < a.valid_rows ? a.num_gt[row] : 0;
+    if (col == 0) a.hdr[i] = ng;
+    if (col < N_THR) a.rec_out[i * N_THR + col] = ng > 0 ? a.rec[row * N_THR + col] : -1.0;
+    if (ng <= 0) return;
+    const int t = col / N_REC, j = col - t * N_REC;
+    const uint8_t *dm = a.w.dmap + row * N_REC;
+    const int d = dm[j];
+    if (j > 0 && dm[j - 1] == d) return;
+    const int64_t slot = (int64_t)a.w.off[row] + (int64_t)t * a.w.nd[row] + d;
+    if (slot < a.capacity) a.levels[slot] = a.val[row * COLS + col];
+}
+
+struct UnpackArgs {
+    int32_t n_cat, n_rng, block_rows;
+    const unsigned char *chunks;
+    size_t chunk_bytes, hdr_bytes, rec_bytes;
+    int64_t capacity;
+    int32_t *num_gt_out;
+    double *precision, *recall;
+    ExWs w;
+};
+
+// levels -> precision[T][R][K][A], rec -> recall[T][K][A]; same 32 x 32 LDS
+// transpose as acc_finalize_kernel, the load side expands the runs
+__global__ __launch_bounds__(256) void ex_unpack_kernel(UnpackArgs a)
+{
+    __shared__ double tile[32][33];
+    const int64_t KR = (int64_t)a.n_cat * a.n_rng;
+    const int64_t COLS = (int64_t)N_THR * N_REC;
+    const int64_t row0 = (int64_t)blockIdx.x * 32;
+    const int64_t col0 = (int64_t)blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int64_t row = row0 + i, col = col0 + tx;
+        double v = -1.0;
+        if (row < KR && col < COLS) {
+            const int32_t nd = a.w.nd[row];
+            if (nd > 0) {
+                const int64_t b = row / a.block_rows;
+                const double *lv = (const double *)(a.chunks + b * a.chunk_bytes +
+                                                    a.hdr_bytes + a.rec_bytes);
+                const int t = (int)(col / N_REC), j = (int)(col - (int64_t)t * N_REC);
+                const int64_t slot = (int64_t)a.w.off[row] + (int64_t)t * nd +
+                                     a.w.dmap[row * N_REC + j];
+                v = slot < a.capacity ? lv[slot] : 0.0;
+            }
+        }
+        tile[i][tx] = v;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int64_t col = col0 + i, row = row0 + tx;
+        if (row < KR && col < COLS) a.precision[col * KR + row] = tile[tx][i];
+    }
+    if (blockIdx.y == 0) {
+        for (int i = threadIdx.x; i < 32 * N_THR; i += 256) {
+            const int64_t row = row0 + i / N_THR;
+            const int t = i % N_THR;
+            if (row >= KR) continue;
+            const int64_t b = row / a.block_rows, li = row - b * a.block_rows;
+            const unsigned char *ch = a.chunks + b * a.chunk_bytes;
+            a.recall[(int64_t)t * KR + row] =
+                ((const double *)(ch + a.hdr_bytes))[li * N_THR + t];
+            if (t == 0 && a.num_gt_out)
+                a.num_gt_out[row] = ((const int32_t *)ch)[li];
+        }
+    }
+}
+
+size_t ws_bytes(int64_t rows, int32_t world)
+{
+    return ex_align((size_t)rows * N_REC) + 2 * ex_align((size_t)rows * 4) +
+           ex_align((size_t)world * 8) + 256;
+}
+
+ExWs carve(void *workspace, int64_t rows, int32_t world)
+{
+    unsigned char *p = (unsigned char *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    ExWs w;
+    w.dmap = p; p += ex_align((size_t)rows * N_REC);
+    w.nd = (int32_t *)p; p += ex_align((size_t)rows * 4);
+    w.off = (int32_t *)p; p += ex_align((size_t)rows * 4);
+    w.totals = (int64_t *)p;
+    return w;
+}
+
+bool bad_shape(int32_t block_cats, int32_t n_rng, int32_t world)
+{
+    return block_cats <= 0 || n_rng < 1 || n_rng > 32 || world < 1 ||
+           (int64_t)block_cats * n_rng * N_THR * N_REC > 0x7fffffffll;
+}
+
+}  // namespace
+
+extern "C" size_t taoamd_exchange_chunk_bytes(int32_t block_cats, int32_t n_rng,
+                                              int64_t capacity)
+{
+    return chunk_layout(block_cats, n_rng, capacity).bytes;
+}
+
+extern "C" size_t taoamd_exchange_workspace(int32_t block_cats, int32_t n_rng,
+                                            int32_t world)
+{
+    return ws_bytes((int64_t)block_cats * n_rng * world, world);
+}
+
+extern "C" int taoamd_exchange_sizes(int32_t block_cats, int32_t n_rng,
+                                     int32_t world, const int32_t *num_gt,
+                                     int64_t *totals, void *workspace,
+                                     size_t workspace_bytes, void *stream)
+{
+    if (bad_shape(block_cats, n_rng, world) || !num_gt || !totals || !workspace)
+        return TAOAMD_ERR_ARG;
+    const int32_t BR = block_cats * n_rng;
+    const int64_t rows = (int64_t)BR * world;
+    if (workspace_bytes < ws_bytes(rows, world)) return TAOAMD_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    ExWs w = carve(workspace, rows, world);
+    NumSrc src{(const unsigned char *)num_gt, (int64_t)BR * 4, rows, BR};
+    ex_levels_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, s>>>(src, 0, rows, w,
+                                                                rec_thr());
+    ex_offsets_kernel<<<world, 1024, 0, s>>>(0, BR, INT64_MAX, w, nullptr);
+    TAO_LAUNCH_CHECK();
+    TAO_HIP(hipMemcpyAsync(totals, w.totals, (size_t)world * 8,
+                           hipMemcpyDeviceToDevice, s));
+    return TAOAMD_OK;
+}
+
+extern "C" int taoamd_exchange_pack(int32_t n_cat, int32_t n_rng,
+                                    int32_t block_cats, int32_t world,
+                                    int32_t rank, const int32_t *num_gt,
+                                    const double *val, const double *rec,
+                                    void *chunk, int64_t capacity,
+                                    int32_t *overflow, void *workspace,
+                                    size_t workspace_bytes, void *stream)
+{
+    if (bad_shape(block_cats, n_rng, world) || n_cat <= 0 || rank < 0 ||
+        rank >= world || (int64_t)block_cats * world < n_cat || capacity < 0)
+        return TAOAMD_ERR_ARG;
+    if (!num_gt || !val || !rec || !chunk || !workspace) return TAOAMD_ERR_ARG;
+    const int32_t BR = block_cats * n_rng;
+    const int64_t rows = (int64_t)BR * world;
+    if (workspace_bytes < ws_bytes(rows, world)) return TAOAMD_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    ExWs w = carve(workspace, rows, world);
+    const int64_t valid = (int64_t)n_cat * n_rng;
+    const int64_t r0 = (int64_t)rank * BR;
+    // the local table is addressed by global row: one "block" spanning it all
+    NumSrc src{(const unsigned char *)num_gt, 0, valid, (int32_t)0x7fffffff};
+    ex_levels_kernel<<<(unsigned)((BR + 3) / 4), 256, 0, s>>>(src, r0, r0 + BR, w,
+                                                              rec_thr());
+    ex_offsets_kernel<<<1, 1024, 0, s>>>(rank, BR, capacity, w, overflow);
+    const Chunk c = chunk_layout(block_cats, n_rng, capacity);
+    PackArgs a;
+    a.row0 = r0; a.block_rows = BR; a.valid_rows = valid;
+    a.num_gt = num_gt; a.val = val; a.rec = rec;
+    a.hdr = (int32_t *)chunk;
+    a.rec_out = (double *)((unsigned char *)chunk + c.hdr_bytes);
+    a.levels = (double *)((unsigned char *)chunk + c.hdr_bytes + c.rec_bytes);
+    a.capacity = capacity; a.w = w;
+    const int64_t threads = (int64_t)BR * N_THR * N_REC;
+    ex_pack_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>(a);
+    TAO_LAUNCH_CHECK();
+    return TAOAMD_OK;
+}
+
+extern "C" int taoamd_exchange_unpack(int32_t n_cat, int32_t n_rng,
+                                      int32_t block_cats, int32_t world,
+                                      const void *chunks, int64_t capacity,
+                                      int32_t *num_gt_out, double *precision,
+                                      double *recall, int32_t *overflow,
+                                      void *workspace, size_t workspace_bytes,
+                                      void *stream)
+{
+    if (bad_shape(block_cats, n_rng, world) || n_cat <= 0 ||
+        (int64_t)block_cats * world < n_cat || capacity < 0)
+        return TAOAMD_ERR_ARG;
+    if (!chunks || !precision || !recall || !workspace) return TAOAMD_ERR_ARG;
+    const int32_t BR = block_cats * n_rng;
+    const int64_t rows = (int64_t)BR * world;
+    if (workspace_bytes < ws_bytes(rows, world)) return TAOAMD_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    ExWs w = carve(workspace, rows, world);
+    const Chunk c = chunk_layout(block_cats, n_rng, capacity);
+    NumSrc src{(const unsigned char *)chunks, (int64_t)c.bytes, rows, BR};
+    ex_levels_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, s>>>(src, 0, rows, w,
+                                                                rec_thr());
+    ex_offsets_kernel<<<world, 1024, 0, s>>>(0, BR, capacity, w, overflow);
+    UnpackArgs a;
+    a.n_cat = n_cat; a.n_rng = n_rng; a.block_rows = BR;
+    a.chunks = (const unsigned char *)chunks;
+    a.chunk_bytes = c.bytes; a.hdr_bytes = c.hdr_bytes; a.rec_bytes = c.rec_bytes;
+    a.capacity = capacity; a.num_gt_out = num_gt_out;
+    a.precision = precision; a.recall = recall; a.w = w;
+    const int64_t KR = (int64_t)n_cat * n_rng;
+    dim3 grid((unsigned)((KR + 31) / 32), (unsigned)((N_THR * N_REC + 31) / 32));
+    ex_unpack_kernel<<<grid, 256, 0, s>>>(a);
+    TAO_LAUNCH_CHECK();
+    return TAOAMD_OK;
+}

@@ -1,5 +1,17 @@
-"""Multi-GPU evaluation: one process per GPU, units (images / videos) sharded
-across ranks, RCCL (``torch.distributed`` backend "nccl") over xGMI.
+"""Multi-GPU evaluation: one process per GPU, RCCL (``torch.distributed``
+backend "nccl") over xGMI.  Two partitions of the path are implemented:
+
+* BY CATEGORY (``CategoryPlan``, default of bench.py): the match and the AP
+  sweep are independent per category and the cell tables are category-major,
+  so a rank evaluates a contiguous category block with no record exchange at
+  all; the only collectives are the in-place all-gathers that assemble the
+  category-major result tables.  This is the natural mode when one
+  prediction file is evaluated on several GPUs.
+* BY UNIT (``ExchangePlan``): every rank holds the detections of its own
+  images / videos (e.g. produced by data-parallel inference) and the records
+  meet at the category owners -- described next.
+
+Units (images / videos) sharded across ranks:
 
 Why an exchange is needed at all: IoU + greedy match is
 independent per cell, but AP needs every category's detections in ONE global
@@ -80,6 +92,16 @@ class HipBackend:
             _ptr(t["dt_cell"]), _ptr(t["groups"]), dp.n_groups,
             _ptr(t["singles"]), dp.n_singles, self._s()), "taoamd_match")
 
+    def sort_local(self, dp, ws):
+        self.engine.stage_sort(dp, ws)
+
+    def local_head(self, dp, ws, aux):
+        """ranges, sort, [3D IoU], match with the independent stages on `aux`."""
+        self.engine.run_forked(dp, ws, aux, head_only=True)
+
+    def match_local(self, dp, ws):
+        self.engine.stage_match(dp, ws)
+
     def sort(self, n, cat, score, order, ws_buf, ws_bytes):
         _lib.check(self.lib.taoamd_sort_by_cat_score(
             n, _ptr(cat), _ptr(score), _ptr(order), None, _ptr(ws_buf),
@@ -102,6 +124,32 @@ class HipBackend:
         _lib.check(self.lib.taoamd_finalize(
             n_cat, n_rng, _ptr(num_gt), _ptr(val), _ptr(rec), _ptr(precision),
             _ptr(recall), self._s()), "taoamd_finalize")
+
+    # ---- result exchange of the category-partitioned mode
+    def exchange_chunk_bytes(self, block_cats, n_rng, capacity):
+        return int(self.lib.taoamd_exchange_chunk_bytes(block_cats, n_rng, capacity))
+
+    def exchange_workspace(self, block_cats, n_rng, world):
+        return int(self.lib.taoamd_exchange_workspace(block_cats, n_rng, world))
+
+    def exchange_sizes(self, block_cats, n_rng, world, num_gt, totals, xws):
+        _lib.check(self.lib.taoamd_exchange_sizes(
+            block_cats, n_rng, world, _ptr(num_gt), _ptr(totals), _ptr(xws),
+            xws.numel(), self._s()), "taoamd_exchange_sizes")
+
+    def exchange_pack(self, n_cat, n_rng, block_cats, world, rank, num_gt, val,
+                      rec, chunk, capacity, overflow, xws):
+        _lib.check(self.lib.taoamd_exchange_pack(
+            n_cat, n_rng, block_cats, world, rank, _ptr(num_gt), _ptr(val),
+            _ptr(rec), _ptr(chunk), capacity, _ptr(overflow), _ptr(xws),
+            xws.numel(), self._s()), "taoamd_exchange_pack")
+
+    def exchange_unpack(self, n_cat, n_rng, block_cats, world, chunks, capacity,
+                        num_gt, precision, recall, overflow, xws):
+        _lib.check(self.lib.taoamd_exchange_unpack(
+            n_cat, n_rng, block_cats, world, _ptr(chunks), capacity,
+            _ptr(num_gt), _ptr(precision), _ptr(recall), _ptr(overflow),
+            _ptr(xws), xws.numel(), self._s()), "taoamd_exchange_unpack")
 
 
 class ShardedEval:
@@ -199,6 +247,166 @@ class ShardedEval:
                     self.precision, self.recall)
 
 
+def category_block(n_cat, rank, world):
+    """Contiguous, equally sized category blocks: rank r owns [k0, k1)."""
+    kb = (n_cat + world - 1) // world
+    return min(rank * kb, n_cat), min((rank + 1) * kb, n_cat), kb
+
+
+def shard_by_category(flat, k0, k1):
+    """Cells of the categories [k0, k1) -- one contiguous slice of the
+    category-major cell table."""
+    c0 = int(np.searchsorted(flat.cell_cat, k0, "left"))
+    c1 = int(np.searchsorted(flat.cell_cat, k1, "left"))
+    return shard_flat(flat, c0, c1)
+
+
+class CategoryShardedEval:
+    """One evaluator of one rank when the problem is partitioned BY CATEGORY.
+
+    A category's cells, detections and ground truth are one contiguous slice
+    of the category-major cell tables (shard_by_category), and both the greedy
+    match and the AP sweep are independent per category.  So a rank that holds
+    the slice of its category block needs NO record exchange: it runs the
+    ordinary single-GPU stages on the slice and sweeps its categories into the
+    category-major tables.  The result then travels in ONE in-place
+    ``all_gather_into_tensor`` of run-length packed chunks (csrc/exchange.hip:
+    a row's 101 recall columns hold at most min(num_gt, 100) + 1 distinct
+    values, and which columns coincide follows from num_gt alone), and every
+    rank expands the chunks straight into the reference layout.
+
+    Building the evaluator is collective: the chunk capacity is the largest
+    block's level count, derived once from the all-gathered num_gt (the ground
+    truth of a plan does not change between passes).
+    """
+
+    def __init__(self, dp, ws, rank, world, backend, group=None):
+        self.dp, self.ws, self.rank, self.world = dp, ws, rank, world
+        self.be, self.group = backend, group
+        dev = dp.device
+        K, R = dp.n_cat, dp.n_rng
+        self.k0, self.k1, self.Kb = category_block(K, rank, world)
+        Kb = self.Kb
+        # own block of the category-major tables, addressed by global row
+        self.val = torch.zeros((K, R, N_THR, N_REC), dtype=torch.float64, device=dev)
+        self.rec = torch.zeros((K, R, N_THR), dtype=torch.float64, device=dev)
+        self.num_gt = torch.zeros((K, R), dtype=torch.int32, device=dev)
+        self.precision = torch.empty((N_THR, N_REC, K, R), dtype=torch.float64,
+                                     device=dev)
+        self.recall = torch.empty((N_THR, K, R), dtype=torch.float64, device=dev)
+        self.overflow = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.xws = torch.empty(backend.exchange_workspace(Kb, R, world),
+                               dtype=torch.uint8, device=dev)
+        # ---- capacity: levels of the largest block (collective, once)
+        backend.ranges(dp, ws)
+        table = torch.zeros((Kb * world, R), dtype=torch.int32, device=dev)
+        lo, hi = rank * Kb, min((rank + 1) * Kb, K)
+        table[lo:hi].copy_(ws.num_gt[lo:hi])
+        dist.all_gather_into_tensor(table, table[rank * Kb:(rank + 1) * Kb].clone(),
+                                    group=group)
+        totals = torch.zeros(world, dtype=torch.int64, device=dev)
+        backend.exchange_sizes(Kb, R, world, table, totals, self.xws)
+        self.capacity = int(totals.max().item())
+        self.chunk_bytes = backend.exchange_chunk_bytes(Kb, R, self.capacity)
+        self.chunks = torch.zeros(world * self.chunk_bytes, dtype=torch.uint8,
+                                  device=dev)
+
+    def compute(self, aux=None):
+        """Local stages (no collective): ranges, sort, [3D IoU], match, sweep,
+        pack of the own block into its chunk.  `aux`: a second stream for the
+        stages that do not depend on each other."""
+        dp, ws, be = self.dp, self.ws, self.be
+        if aux is not None:
+            be.local_head(dp, ws, aux)
+        else:
+            be.ranges(dp, ws)
+            be.sort_local(dp, ws)
+            be.track_iou(dp, ws)
+            be.match_local(dp, ws)
+        self.sweep()
+
+    def sweep(self):
+        """AP sweep of the own categories + pack into the own chunk."""
+        dp, ws, be = self.dp, self.ws, self.be
+        be.accumulate_compact(dp.n_dt, dp.n_cat, dp.n_rng, dp.t["cat_off"],
+                              ws.matched, ws.ignored, ws.num_gt, self.k0,
+                              self.k1, self.val, self.rec, ws.acc_ws,
+                              ws.acc_bytes)
+        lo, hi = self.rank * self.chunk_bytes, (self.rank + 1) * self.chunk_bytes
+        be.exchange_pack(dp.n_cat, dp.n_rng, self.Kb, self.world, self.rank,
+                         ws.num_gt, self.val, self.rec, self.chunks[lo:hi],
+                         self.capacity, self.overflow, self.xws)
+
+    def gather(self):
+        """The only collective of the pass."""
+        lo, hi = self.rank * self.chunk_bytes, (self.rank + 1) * self.chunk_bytes
+        dist.all_gather_into_tensor(self.chunks, self.chunks[lo:hi],
+                                    group=self.group)
+
+    def expand(self):
+        """Chunks of all ranks -> reference layout."""
+        dp = self.dp
+        self.be.exchange_unpack(dp.n_cat, dp.n_rng, self.Kb, self.world,
+                                self.chunks, self.capacity, self.num_gt,
+                                self.precision, self.recall, self.overflow,
+                                self.xws)
+
+    def assemble(self):
+        self.gather()
+        self.expand()
+
+    def step(self):
+        self.compute()
+        self.assemble()
+
+    def check(self):
+        """Host-side guard (synchronises): the capacity held."""
+        if int(self.overflow.item()):
+            raise _lib.TaoAmdError("exchange chunk overflow: the ground truth "
+                                   "changed after the plan was built")
+
+
+class CategoryPlan:
+    """Both evaluators of one rank, category-partitioned.
+
+    The two evaluators run on their own HIP streams (plus one auxiliary stream
+    each for the stages that are independent inside a pass), so the image-level
+    all-gather travels while the track-level kernels still run.  Five streams
+    are busy at once (4 + RCCL's): run with GPU_MAX_HW_QUEUES >= 8, the
+    default of 4 hardware queues per process makes them alias (bench.py sets
+    it)."""
+
+    def __init__(self, dpl, dpt, rank, world, device, backend=None, group=None):
+        from . import engine
+        self.device = torch.device(device)
+        backend = backend or HipBackend()
+        self.lvis = CategoryShardedEval(dpl, engine.Workspace(dpl), rank, world,
+                                        backend, group)
+        self.tao = CategoryShardedEval(dpt, engine.Workspace(dpt), rank, world,
+                                       backend, group)
+        self.streams = None
+        if self.device.type == "cuda":
+            self.streams = [torch.cuda.Stream(self.device) for _ in range(4)]
+
+    def pair_frames(self):
+        return int(self.tao.ws.pair_frames.item())
+
+    def step(self):
+        if self.streams is None:
+            self.lvis.step()
+            self.tao.step()
+            return
+        cur = torch.cuda.current_stream(self.device)
+        for k, ev in enumerate((self.lvis, self.tao)):
+            s = self.streams[k]
+            s.wait_stream(cur)
+            with torch.cuda.stream(s):
+                ev.compute(self.streams[2 + k])
+                ev.assemble()
+        for s in self.streams[:2]:
+            cur.wait_stream(s)
+
+
 class ExchangePlan:
     """Both evaluators of one rank (what bench.py steps)."""
 
@@ -213,10 +421,13 @@ class ExchangePlan:
     def pair_frames(self):
         return int(self.tao.ws.pair_frames.item())
 
+    def step(self):
+        self.lvis.step()
+        self.tao.step()
+
 
 def step(plan):
-    plan.lvis.step()
-    plan.tao.step()
+    plan.step()
 
 
 # --------------------------------------------------------------------------

@@ -15,6 +15,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+import exchange_ref
 import orclib
 
 N_THR, N_REC = 10, 101
@@ -97,7 +98,7 @@ class OracleBackend:
                     rr[k, r] = rc[:, k, r]
 
     def finalize(self, n_cat, n_rng, num_gt, val, rec, precision, recall):
-        ng = num_gt.numpy() > 0
+        ng = num_gt.numpy()[:n_cat] > 0
         v = val.numpy()[:n_cat]
         p = np.where(ng[None, None], v.transpose(2, 3, 0, 1), -1.0)
         r = np.where(ng[None], rec.numpy()[:n_cat].transpose(2, 0, 1), -1.0)
@@ -194,3 +195,139 @@ def test_shard_flat_partitions_the_problem():
                 assert np.array_equal(o["matched"], whole["matched"][d_off:d_off + n])
                 assert np.array_equal(o["ignored"], whole["ignored"][d_off:d_off + n])
                 d_off += n
+
+
+class OracleCategoryBackend(OracleBackend):
+    """Adds the two local stages the category-partitioned mode uses."""
+
+    def sort_local(self, dp, ws):
+        f = self._f(dp)
+        n = dp.n_dt
+        order = np.lexsort((np.arange(n), -(f.dt_score + 0.0), f.dt_cat))
+        dst = np.empty(n, np.int64)
+        dst[order] = np.arange(n)
+        ws.order[:n] = torch.from_numpy(order.astype(np.int32))
+        ws.dst[:n] = torch.from_numpy(dst.astype(np.int32))
+
+    def match_local(self, dp, ws):
+        f = self._f(dp)
+        g = ws.gt_rng[:dp.n_gt].numpy().view(np.uint32)
+        d = ws.dt_rng[:dp.n_dt].numpy().view(np.uint32)
+        iou = ws.iou[:dp.n_iou].numpy() if dp.kind == "tao" else None
+        m, i, _, _ = orclib.match(f, g, d, iou, detail=False)
+        dst = ws.dst[:dp.n_dt].numpy().astype(np.int64)
+        ws.matched[:dp.n_dt][dst] = torch.from_numpy(m.view(np.int64))
+        ws.ignored[:dp.n_dt][dst] = torch.from_numpy(i.view(np.int64))
+
+    # ---- result exchange: the numpy restatement of the chunk format
+    def exchange_chunk_bytes(self, block_cats, n_rng, capacity):
+        return exchange_ref.layout(block_cats, n_rng, capacity)[2]
+
+    def exchange_workspace(self, block_cats, n_rng, world):
+        return 8
+
+    def exchange_sizes(self, block_cats, n_rng, world, num_gt, totals, xws):
+        totals.copy_(torch.from_numpy(
+            exchange_ref.sizes(block_cats, n_rng, world, num_gt.numpy())))
+
+    def exchange_pack(self, n_cat, n_rng, block_cats, world, rank, num_gt, val,
+                      rec, chunk, capacity, overflow, xws):
+        chunk.copy_(torch.from_numpy(exchange_ref.pack(
+            n_cat, n_rng, block_cats, rank, num_gt.numpy(), val.numpy(),
+            rec.numpy(), capacity)))
+
+    def exchange_unpack(self, n_cat, n_rng, block_cats, world, chunks, capacity,
+                        num_gt, precision, recall, overflow, xws):
+        ng, p, r = exchange_ref.unpack(n_cat, n_rng, block_cats, world,
+                                       chunks.numpy(), capacity)
+        num_gt.copy_(torch.from_numpy(ng))
+        precision.copy_(torch.from_numpy(p))
+        recall.copy_(torch.from_numpy(r))
+
+
+def _worker_cat(rank, world, port, out):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "tests")]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tao_amodal_amd import dist as tdist, engine, flatten
+    from tao_amodal_amd.columns import DTColumns, GTColumns
+    from tao_amodal_amd.synth import synth
+    parts = [synth(seed=23 + r, V=3, F=10, C=23, dets_per_frame=25, n_present=4,
+                   video_id_base=r * 3) for r in range(world)]
+    gt = GTColumns.concat([p[0] for p in parts])
+    dt = DTColumns.concat([p[1] for p in parts])
+    fl = flatten.flatten_lvis(gt, dt)
+    dt.track_id, _ = flatten.make_track_ids_unique(dt)
+    ft = flatten.flatten_tao(gt, dt)
+    res = {}
+    for name, flat in (("lvis", fl), ("tao", ft)):
+        k0, k1, _ = tdist.category_block(len(flat.cat_ids), rank, world)
+        shard = tdist.shard_by_category(flat, k0, k1)
+        dp = engine.DeviceProblem(shard, "cpu")
+        ws = engine.Workspace(dp)
+        ev = tdist.CategoryShardedEval(dp, ws, rank, world,
+                                       OracleCategoryBackend({id(dp): shard}))
+        ev.step()
+        ev.step()
+        res[name] = (ev.precision.numpy().copy(), ev.recall.numpy().copy(),
+                     shard.n_pairs)
+    torch.save(res, os.path.join(out, "cat_rank%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_category_partition_two_ranks_reproduce_the_whole_problem(tmp_path):
+    world = 2
+    mp.spawn(_worker_cat, args=(world, _free_port(), str(tmp_path)), nprocs=world,
+             join=True)
+    from tao_amodal_amd import flatten
+    from tao_amodal_amd.columns import DTColumns, GTColumns
+    from tao_amodal_amd.synth import synth
+    parts = [synth(seed=23 + r, V=3, F=10, C=23, dets_per_frame=25, n_present=4,
+                   video_id_base=r * 3) for r in range(world)]
+    gt = GTColumns.concat([p[0] for p in parts])
+    dt = DTColumns.concat([p[1] for p in parts])
+    fl = flatten.flatten_lvis(gt, dt)
+    dt.track_id, _ = flatten.make_track_ids_unique(dt)
+    ft = flatten.flatten_tao(gt, dt)
+    want = {"lvis": orclib.run_flat(fl, detail=False),
+            "tao": orclib.run_flat(ft, detail=False)}
+    total = {"lvis": 0, "tao": 0}
+    for rank in range(world):
+        got = torch.load(os.path.join(str(tmp_path), "cat_rank%d.pt" % rank),
+                         weights_only=False)
+        for name in ("lvis", "tao"):
+            p, r, n_pairs = got[name]
+            assert n_pairs > 0
+            total[name] += n_pairs
+            assert np.array_equal(p, want[name]["precision"]), (rank, name)
+            assert np.array_equal(r, want[name]["recall"]), (rank, name)
+    assert total["lvis"] == fl.n_pairs and total["tao"] == ft.n_pairs
+
+
+def test_chunk_format_round_trip_numpy():
+    """The run-length chunk format loses nothing: pack -> unpack returns the
+    tables, for rows with 0, few, exactly 100/101 and many ground truths."""
+    E = exchange_ref
+    rng = np.random.default_rng(0)
+    K, R, W, Kb = 7, 3, 2, 4
+    ng = rng.integers(0, 5, (K, R)).astype(np.int32)
+    ng[2, 1], ng[3, 0], ng[0, 0] = 250, 100, 101
+    val, rec = np.zeros((K, R, N_THR, N_REC)), rng.random((K, R, N_THR))
+    for k in range(K):
+        for r in range(R):
+            if ng[k, r] > 0:
+                d = E.run_map(int(ng[k, r]))
+                val[k, r] = rng.random((N_THR, d[-1] + 1))[:, d]
+    tab = np.zeros((Kb * W, R), np.int32)
+    tab[:K] = ng
+    cap = int(E.sizes(Kb, R, W, tab).max())
+    chunks = np.concatenate([E.pack(K, R, Kb, b, ng, val, rec, cap) for b in range(W)])
+    n2, p, r = E.unpack(K, R, Kb, W, chunks, cap)
+    m = ng > 0
+    assert np.array_equal(n2, ng)
+    assert np.array_equal(p.transpose(2, 3, 0, 1)[m], val[m])
+    assert np.array_equal(r.transpose(1, 2, 0)[m], rec[m])
+    assert (p.transpose(2, 3, 0, 1)[~m] == -1).all() and (r.transpose(1, 2, 0)[~m] == -1).all()

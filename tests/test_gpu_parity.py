@@ -161,6 +161,41 @@ def test_sharded_path_on_one_gpu_equals_plain_path():
             assert np.array_equal(ev.num_gt.cpu().numpy(), want["num_gt"])
             assert np.array_equal(ev.precision.cpu().numpy(), want["precision"])
             assert np.array_equal(ev.recall.cpu().numpy(), want["recall"])
+            # category-partitioned mode: local stages + in-place all_gather
+            cv = tdist.CategoryShardedEval(dp, engine.Workspace(dp), 0, 1,
+                                           tdist.HipBackend())
+            cv.step()
+            cv.step()
+            torch.cuda.synchronize()
+            assert np.array_equal(cv.precision.cpu().numpy(), want["precision"])
+            assert np.array_equal(cv.recall.cpu().numpy(), want["recall"])
+            # a rank of a two-rank job: its block of the tables must equal
+            # the same block of the whole problem (rows of the other block
+            # stay zero until the all_gather fills them)
+            K = len(flat.cat_ids)
+            for rank in range(2):
+                k0, k1, Kb = tdist.category_block(K, rank, 2)
+                shard = tdist.shard_by_category(flat, k0, k1)
+                sdp = engine.DeviceProblem(shard, "cuda:0")
+                half = tdist.CategoryShardedEval(sdp, engine.Workspace(sdp), 0, 1,
+                                                 tdist.HipBackend())
+                half.k0, half.k1 = k0, k1      # block of `rank`, group of one
+                half.compute()
+                torch.cuda.synchronize()
+                val = half.val.cpu().numpy()[k0:k1]
+                ng = want["num_gt"][k0:k1] > 0
+                ref = want["precision"][:, :, k0:k1].transpose(2, 3, 0, 1)
+                assert np.array_equal(val[ng], ref[ng])
+        plan = tdist.CategoryPlan(engine.DeviceProblem(fl_, "cuda:0"),
+                                  engine.DeviceProblem(ft_, "cuda:0"), 0, 1,
+                                  torch.device("cuda", 0))
+        plan.step()
+        plan.step()
+        torch.cuda.synchronize()
+        for ev, flat in ((plan.lvis, fl_), (plan.tao, ft_)):
+            want = orclib.run_flat(flat, detail=False)
+            assert np.array_equal(ev.precision.cpu().numpy(), want["precision"])
+            assert np.array_equal(ev.recall.cpu().numpy(), want["recall"])
     finally:
         dist.destroy_process_group()
 
@@ -266,3 +301,80 @@ def test_overlapped_streams_give_the_same_tensors():
     assert np.array_equal(wsl.recall.cpu().numpy(), wl["recall"])
     assert np.array_equal(wst.precision.cpu().numpy(), wt["precision"])
     assert np.array_equal(wst.recall.cpu().numpy(), wt["recall"])
+    # the same launch sequence captured into a hipGraph and replayed
+    g = engine.GraphedPair(ov, dpl, wsl, dpt, wst)
+    for t in (wsl.precision, wsl.recall, wst.precision, wst.recall, wsl.matched,
+              wst.matched, wst.iou):
+        t.zero_()
+    g.run()
+    g.run()
+    torch.cuda.synchronize()
+    assert np.array_equal(wsl.precision.cpu().numpy(), wl["precision"])
+    assert np.array_equal(wsl.recall.cpu().numpy(), wl["recall"])
+    assert np.array_equal(wst.precision.cpu().numpy(), wt["precision"])
+    assert np.array_equal(wst.recall.cpu().numpy(), wt["recall"])
+    assert int(wst.pair_frames.item()) == wt["pairs"]
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_exchange_chunks_hip_vs_numpy_restatement(world):
+    """taoamd_exchange_{sizes,pack,unpack} against tests/exchange_ref.py: the
+    packed chunks byte for byte, the expanded tables against the plain
+    single-GPU finalize (no collective needed: every block is packed here)."""
+    import torch
+    import exchange_ref
+    from tao_amodal_amd import dist as tdist, engine
+    be = tdist.HipBackend()
+    gt, dt = synth(seed=31, V=6, F=20, C=53, dets_per_frame=40, n_present=9)
+    fl_ = fl.flatten_lvis(gt, dt)
+    dt.track_id, _ = fl.make_track_ids_unique(dt)
+    ft_ = fl.flatten_tao(gt, dt)
+    for flat in (fl_, ft_):
+        dp = engine.DeviceProblem(flat, "cuda:0")
+        ws = engine.Workspace(dp)
+        engine.run(dp, ws)
+        K, R = dp.n_cat, dp.n_rng
+        val = torch.zeros((K, R, 10, 101), dtype=torch.float64, device="cuda")
+        rec = torch.zeros((K, R, 10), dtype=torch.float64, device="cuda")
+        be.accumulate_compact(dp.n_dt, K, R, dp.t["cat_off"], ws.matched, ws.ignored,
+                              ws.num_gt, 0, K, val, rec, ws.acc_ws, ws.acc_bytes)
+        _, _, Kb = tdist.category_block(K, 0, world)
+        table = torch.zeros((Kb * world, R), dtype=torch.int32, device="cuda")
+        table[:K] = ws.num_gt
+        xws = torch.empty(be.exchange_workspace(Kb, R, world), dtype=torch.uint8,
+                          device="cuda")
+        totals = torch.zeros(world, dtype=torch.int64, device="cuda")
+        be.exchange_sizes(Kb, R, world, table, totals, xws)
+        want_sizes = exchange_ref.sizes(Kb, R, world, table.cpu().numpy())
+        assert np.array_equal(totals.cpu().numpy(), want_sizes)
+        cap = int(want_sizes.max())
+        assert cap < Kb * R * 1010          # the run-length form is smaller
+        cb = be.exchange_chunk_bytes(Kb, R, cap)
+        assert cb == exchange_ref.layout(Kb, R, cap)[2]
+        chunks = torch.zeros(world * cb, dtype=torch.uint8, device="cuda")
+        over = torch.zeros(1, dtype=torch.int32, device="cuda")
+        hv, hr, hn = val.cpu().numpy(), rec.cpu().numpy(), ws.num_gt.cpu().numpy()
+        for b in range(world):
+            be.exchange_pack(K, R, Kb, world, b, ws.num_gt, val, rec,
+                             chunks[b * cb:(b + 1) * cb], cap, over, xws)
+            want = exchange_ref.pack(K, R, Kb, b, hn, hv, hr, cap)
+            got = chunks[b * cb:(b + 1) * cb].cpu().numpy()
+            assert np.array_equal(got, want), (flat.kind, world, b)
+        prec = torch.empty((10, 101, K, R), dtype=torch.float64, device="cuda")
+        rcl = torch.empty((10, K, R), dtype=torch.float64, device="cuda")
+        ng = torch.zeros((K, R), dtype=torch.int32, device="cuda")
+        be.exchange_unpack(K, R, Kb, world, chunks, cap, ng, prec, rcl, over, xws)
+        torch.cuda.synchronize()
+        assert int(over.item()) == 0
+        assert np.array_equal(ng.cpu().numpy(), hn)
+        assert np.array_equal(prec.cpu().numpy(), ws.precision.cpu().numpy())
+        assert np.array_equal(rcl.cpu().numpy(), ws.recall.cpu().numpy())
+        n2, p2, r2 = exchange_ref.unpack(K, R, Kb, world, chunks.cpu().numpy(), cap)
+        assert np.array_equal(p2, ws.precision.cpu().numpy())
+        assert np.array_equal(r2, ws.recall.cpu().numpy())
+        # too small a capacity is reported, not silently wrong
+        if cap > 10:
+            be.exchange_unpack(K, R, Kb, world, chunks, cap - 10, ng, prec, rcl,
+                               over, xws)
+            torch.cuda.synchronize()
+            assert int(over.item()) == 1
