@@ -102,6 +102,12 @@ def pmc_traffic(kernel_substr):
 
 def main():
     args = parse()
+    # stdout carries exactly one JSON line: RCCL and the HIP runtime print
+    # banners to the C-level stdout, so fd 1 is pointed at stderr for the run
+    # and the line goes to the saved descriptor
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     if int(os.environ.get("WORLD_SIZE", "1")) > 1 or args.force_dist:
         # the category-partitioned step keeps 4 compute streams + the RCCL
         # stream busy; with the default of 4 hardware queues per process they
@@ -316,7 +322,8 @@ def main():
             "host_s": {"generate": round(t_gen, 2), "flatten": round(t_flat, 2),
                        "upload": round(t_h2d, 2)},
         }
-        print(json.dumps(out))
+        real_stdout.write(json.dumps(out) + "\n")
+        real_stdout.flush()
     if use_dist:
         dist.destroy_process_group()
 

@@ -259,7 +259,7 @@ int taoamd_accumulate(int64_t n_dt, int32_t n_cat, int32_t n_rng,
  * Rank b owns the categories [b * block_cats, (b+1) * block_cats); a row is a
  * (category, range) pair, global row = category * n_rng + range.
  *
- * A chunk holds one rank's share: the num_gt and rec of its rows and, per row
+ * A chunk holds one rank's share: the num_gt, level offset and rec of its rows and, per row
  * with num_gt > 0 and per IoU threshold, the distinct runs ("levels") of the
  * 101 recall columns -- a row with n ground truths has at most min(n,100)+1
  * of them, and which columns coincide follows from n alone, so receivers

@@ -15,8 +15,9 @@
 //
 //     [ num_gt of the block rows | rec of the block rows | levels ]
 //
-// where `levels` stores for every row with num_gt > 0 and every IoU threshold
-// only the first column of each run.  Receivers rebuild the run map from the
+// (the header also carries each row's offset into `levels`) where `levels`
+// stores for every row with num_gt > 0 and every IoU threshold only the first
+// column of each run.  Receivers rebuild the run map from the
 // num_gt in the chunk header with the very fp64 comparison the sweep used
 // (recall_crossing), expand, and write the reference layout
 // precision[T][R][K][A] / recall[T][K][A] directly (the transpose that
@@ -86,8 +87,9 @@ __global__ __launch_bounds__(256) void ex_levels_kernel(NumSrc src, int64_t row0
     if (lane == 0) w.nd[row] = __popcll(f0) + __popcll(f1) + 1;
 }
 
-// one workgroup per block of rows: exclusive scan of nd * T.  Each thread
-// owns a contiguous run of rows, so the block-wide scan is a single round.
+// one workgroup per block of rows: exclusive scan of nd * T.  Each of the 16
+// waves scans a contiguous share of the rows 64 at a time (coalesced, carry in
+// a register), the wave totals meet once in LDS, a second sweep adds the base.
 __global__ __launch_bounds__(1024) void ex_offsets_kernel(int32_t block_first,
                                                            int32_t block_rows,
                                                            int64_t capacity, ExWs w,
@@ -97,27 +99,29 @@ __global__ __launch_bounds__(1024) void ex_offsets_kernel(int32_t block_first,
     const int b = block_first + blockIdx.x;
     const int64_t r0 = (int64_t)b * block_rows;
     const int lane = lane_id(), wave = threadIdx.x >> 6;
-    const int32_t per = (block_rows + 1023) / 1024;
-    const int32_t i0 = min(block_rows, (int32_t)threadIdx.x * per);
-    const int32_t i1 = min(block_rows, i0 + per);
-    int64_t mine = 0;
-    for (int32_t i = i0; i < i1; i++) mine += (int64_t)w.nd[r0 + i] * N_THR;
-    int64_t x = mine;
-    for (int d = 1; d < WAVE; d <<= 1) {
-        const int64_t y = __shfl_up(x, d);
-        if (lane >= d) x += y;
+    const int32_t per = ((block_rows + 15) / 16 + WAVE - 1) / WAVE * WAVE;
+    const int32_t i0 = min(block_rows, wave * per), i1 = min(block_rows, i0 + per);
+    int64_t carry = 0;
+    for (int32_t i = i0 + lane; i - lane < i1; i += WAVE) {
+        const int64_t v = i < i1 ? (int64_t)w.nd[r0 + i] * N_THR : 0;
+        int64_t x = v;
+        for (int d = 1; d < WAVE; d <<= 1) {
+            const int64_t y = __shfl_up(x, d);
+            if (lane >= d) x += y;
+        }
+        if (i < i1) w.off[r0 + i] = (int32_t)(carry + x - v);
+        carry += __shfl(x, WAVE - 1);
     }
-    if (lane == WAVE - 1) s_wave[wave] = x;
+    if (lane == 0) s_wave[wave] = carry;
     __syncthreads();
-    int64_t before = x - mine;
-    for (int q = 0; q < wave; q++) before += s_wave[q];
-    for (int32_t i = i0; i < i1; i++) {
-        w.off[r0 + i] = (int32_t)before;
-        before += (int64_t)w.nd[r0 + i] * N_THR;
-    }
+    int64_t base = 0;
+    for (int q = 0; q < wave; q++) base += s_wave[q];
+    if (base != 0)
+        for (int32_t i = i0 + lane; i < i1; i += WAVE) w.off[r0 + i] += (int32_t)base;
     if (threadIdx.x == 1023) {
-        w.totals[b] = before;
-        if (before > capacity && overflow) atomicOr(overflow, 1);
+        const int64_t total = base + carry;
+        w.totals[b] = total;
+        if (total > capacity && overflow) atomicOr(overflow, 1);
     }
 }
 
@@ -129,7 +133,7 @@ inline Chunk chunk_layout(int32_t block_cats, int32_t n_rng, int64_t capacity)
 {
     const size_t rows = (size_t)block_cats * n_rng;
     Chunk c;
-    c.hdr_bytes = ex_align(rows * 4);
+    c.hdr_bytes = ex_align(rows * 8);     // num_gt[rows], off[rows]
     c.rec_bytes = ex_align(rows * N_THR * 8);
     c.bytes = c.hdr_bytes + c.rec_bytes + ex_align((size_t)capacity * 8);
     return c;
@@ -158,7 +162,10 @@ __global__ __launch_bounds__(256) void ex_pack_kernel(PackArgs a)
     const int col = (int)(idx - i * COLS);
     const int64_t row = a.row0 + i;
     const int32_t ng = row < a.valid_rows ? a.num_gt[row] : 0;
-    if (col == 0) a.hdr[i] = ng;
+    if (col == 0) {
+        a.hdr[i] = ng;
+        a.hdr[a.block_rows + i] = ng > 0 ? a.w.off[row] : 0;
+    }
     if (col < N_THR) a.rec_out[i * N_THR + col] = ng > 0 ? a.rec[row * N_THR + col] : -1.0;
     if (ng <= 0) return;
     const int t = col / N_REC, j = col - t * N_REC;
@@ -176,11 +183,14 @@ struct UnpackArgs {
     int64_t capacity;
     int32_t *num_gt_out;
     double *precision, *recall;
+    int32_t *overflow;
     ExWs w;
 };
 
 // levels -> precision[T][R][K][A], rec -> recall[T][K][A]; same 32 x 32 LDS
-// transpose as acc_finalize_kernel, the load side expands the runs
+// transpose as acc_finalize_kernel, the load side expands the runs.  The run
+// maps come from ex_levels_kernel on the received headers, the row offsets
+// from the headers themselves (no scan on the receiving side).
 __global__ __launch_bounds__(256) void ex_unpack_kernel(UnpackArgs a)
 {
     __shared__ double tile[32][33];
@@ -195,13 +205,16 @@ __global__ __launch_bounds__(256) void ex_unpack_kernel(UnpackArgs a)
         if (row < KR && col < COLS) {
             const int32_t nd = a.w.nd[row];
             if (nd > 0) {
-                const int64_t b = row / a.block_rows;
-                const double *lv = (const double *)(a.chunks + b * a.chunk_bytes +
-                                                    a.hdr_bytes + a.rec_bytes);
+                const int64_t b = row / a.block_rows, li = row - b * a.block_rows;
+                const unsigned char *ch = a.chunks + b * a.chunk_bytes;
+                const double *lv = (const double *)(ch + a.hdr_bytes + a.rec_bytes);
+                const int32_t off = ((const int32_t *)ch)[a.block_rows + li];
                 const int t = (int)(col / N_REC), j = (int)(col - (int64_t)t * N_REC);
-                const int64_t slot = (int64_t)a.w.off[row] + (int64_t)t * nd +
+                const int64_t slot = (int64_t)off + (int64_t)t * nd +
                                      a.w.dmap[row * N_REC + j];
-                v = slot < a.capacity ? lv[slot] : 0.0;
+                v = 0.0;
+                if (slot < a.capacity) v = lv[slot];
+                else if (a.overflow) atomicOr(a.overflow, 1);
             }
         }
         tile[i][tx] = v;
@@ -339,18 +352,17 @@ extern "C" int taoamd_exchange_unpack(int32_t n_cat, int32_t n_rng,
     const int64_t rows = (int64_t)BR * world;
     if (workspace_bytes < ws_bytes(rows, world)) return TAOAMD_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
-    ExWs w = carve(workspace, rows, world);
     const Chunk c = chunk_layout(block_cats, n_rng, capacity);
-    NumSrc src{(const unsigned char *)chunks, (int64_t)c.bytes, rows, BR};
-    ex_levels_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, s>>>(src, 0, rows, w,
-                                                                rec_thr());
-    ex_offsets_kernel<<<world, 1024, 0, s>>>(0, BR, capacity, w, overflow);
     UnpackArgs a;
+    a.w = carve(workspace, rows, world);
+    NumSrc src{(const unsigned char *)chunks, (int64_t)c.bytes, rows, BR};
+    ex_levels_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, s>>>(src, 0, rows, a.w,
+                                                                rec_thr());
     a.n_cat = n_cat; a.n_rng = n_rng; a.block_rows = BR;
     a.chunks = (const unsigned char *)chunks;
     a.chunk_bytes = c.bytes; a.hdr_bytes = c.hdr_bytes; a.rec_bytes = c.rec_bytes;
     a.capacity = capacity; a.num_gt_out = num_gt_out;
-    a.precision = precision; a.recall = recall; a.w = w;
+    a.precision = precision; a.recall = recall; a.overflow = overflow;
     const int64_t KR = (int64_t)n_cat * n_rng;
     dim3 grid((unsigned)((KR + 31) / 32), (unsigned)((N_THR * N_REC + 31) / 32));
     ex_unpack_kernel<<<grid, 256, 0, s>>>(a);

@@ -14,7 +14,7 @@ def align(x):
 
 def layout(block_cats, n_rng, capacity):
     rows = block_cats * n_rng
-    hdr = align(rows * 4)
+    hdr = align(rows * 8)          # num_gt[rows], off[rows]
     rec = align(rows * N_THR * 8)
     return hdr, rec, hdr + rec + align(capacity * 8)
 
@@ -44,6 +44,7 @@ def pack(n_cat, n_rng, block_cats, rank, num_gt, val, rec, capacity):
     rows = block_cats * n_rng
     chunk = np.zeros(total, np.uint8)
     h = chunk[:rows * 4].view(np.int32)
+    ho = chunk[rows * 4:rows * 8].view(np.int32)
     r = chunk[hdr:hdr + rows * N_THR * 8].view(np.float64).reshape(rows, N_THR)
     lv = chunk[hdr + recb:hdr + recb + capacity * 8].view(np.float64)
     ng = np.asarray(num_gt).reshape(-1)
@@ -58,6 +59,7 @@ def pack(n_cat, n_rng, block_cats, rank, num_gt, val, rec, capacity):
         if n <= 0:
             continue
         r[i] = rr[row]
+        ho[i] = off
         d = run_map(n)
         first = np.r_[0, np.flatnonzero(d[1:] != d[:-1]) + 1]
         nd = len(first)
@@ -77,9 +79,9 @@ def unpack(n_cat, n_rng, block_cats, world, chunks, capacity):
     for b in range(world):
         c = chunks[b * total:(b + 1) * total]
         h = c[:rows * 4].view(np.int32)
+        ho = c[rows * 4:rows * 8].view(np.int32)
         r = c[hdr:hdr + rows * N_THR * 8].view(np.float64).reshape(rows, N_THR)
         lv = c[hdr + recb:hdr + recb + capacity * 8].view(np.float64)
-        off = 0
         for i in range(rows):
             row = b * rows + i
             if row >= KR:
@@ -91,9 +93,9 @@ def unpack(n_cat, n_rng, block_cats, world, chunks, capacity):
                 continue
             d = run_map(n)
             nd = d[-1] + 1
+            off = int(ho[i])
             block = lv[off:off + nd * N_THR].reshape(N_THR, nd)
             precision[:, :, row] = block[:, d]
-            off += nd * N_THR
     return (num_gt.reshape(n_cat, n_rng),
             precision.reshape(N_THR, N_REC, n_cat, n_rng),
             recall.reshape(N_THR, n_cat, n_rng))
