@@ -52,9 +52,65 @@ class GTColumns:
 
     # ------------------------------------------------------------------ json
     @classmethod
+    def from_file_native(cls, path):
+        """Parse an annotation file with the native columnar reader
+        (csrc/ingest.cpp: one walk of the document, the five tables read in
+        parallel); returns None when that library is not built.  Errors are
+        those ``json.load`` + ``from_json`` would raise."""
+        import ctypes as C
+        import os
+        so = os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                          "libtao_amodal_ingest.so")
+        if not os.path.exists(so):
+            return None
+        lib = C.CDLL(so)
+        if not hasattr(lib, "taoamd_gt_parse"):
+            return None
+        lib.taoamd_gt_parse.restype = C.c_void_p
+        lib.taoamd_gt_parse.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
+        lib.taoamd_gt_array.argtypes = [C.c_void_p, C.c_char_p,
+                                        C.POINTER(C.c_void_p),
+                                        C.POINTER(C.c_int64), C.POINTER(C.c_int)]
+        lib.taoamd_gt_free.argtypes = [C.c_void_p]
+        err = C.create_string_buffer(512)
+        h = lib.taoamd_gt_parse(os.fsencode(path), err, 512)
+        if not h:
+            msg = err.value.decode()
+            if msg.startswith("not a dict"):
+                kind = list if msg.endswith("list") else object
+                raise AssertionError(
+                    "Annotation file format {} not supported.".format(kind))
+            if msg.startswith("cannot open"):
+                raise FileNotFoundError(msg)
+            if msg.startswith("KeyError: "):
+                raise KeyError(msg[len("KeyError: "):].strip("'"))
+            raise ValueError("malformed annotation file: " + msg)
+        try:
+            kw = {}
+            for f in cls.FIELDS:
+                ptr, n, el = C.c_void_p(), C.c_int64(), C.c_int()
+                if lib.taoamd_gt_array(h, f.encode(), C.byref(ptr), C.byref(n),
+                                       C.byref(el)):
+                    raise RuntimeError("native reader has no array " + f)
+                dtype = {8: np.int64, -8: np.float64, 1: np.uint8}[el.value]
+                if n.value:
+                    buf = (C.c_char * (n.value * abs(el.value))).from_address(ptr.value)
+                    kw[f] = np.frombuffer(buf, dtype=dtype).copy()
+                else:
+                    kw[f] = np.zeros(0, dtype=dtype)
+            kw["cat_merged"] = kw["cat_merged"].reshape(-1, 2)
+            kw["ann_bbox"] = kw["ann_bbox"].reshape(-1, 4)
+        finally:
+            lib.taoamd_gt_free(h)
+        return cls(**kw)
+
+    @classmethod
     def from_json(cls, dataset):
         """dataset: parsed annotation dict (or a path)."""
         if isinstance(dataset, str):
+            native = cls.from_file_native(dataset)
+            if native is not None:
+                return native
             with open(dataset, "r") as f:
                 dataset = json.load(f)
         assert type(dataset) == dict, (

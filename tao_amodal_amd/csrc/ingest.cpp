@@ -1,4 +1,5 @@
-// Native columnar ingest of the prediction list (host only, no GPU code).
+// Native columnar ingest of the two input files (host only, no GPU code):
+// the prediction list (taoamd_pred_*) and the annotation file (taoamd_gt_*).
 //
 // The reference loads `prediction.json` with json.load into ~N Python dicts
 // (twice: reference lvis_amodal/results.py:29-30 and tools/eval_on_tao_amodal.py:
@@ -10,6 +11,12 @@
 //           (string/escape aware depth counter)
 //   pass 2  OpenMP over objects: a small recursive-descent reader pulls the
 //           known keys, skips everything else (any JSON value)
+//
+// The annotation file ({info, images, videos, tracks, annotations,
+// categories}; reference tao_amodal/evaluation/tao_amodal/tao.py:4-60,108-160)
+// goes the same way into the arrays of `GTColumns`: the top-level object is
+// walked once, each of the five tables is cut into objects and read in
+// parallel, ragged id lists become CSR.
 //
 // Numbers are converted with std::from_chars (correctly rounded, the same
 // value Python's float() gives), so the columns are bit-identical to what
@@ -163,6 +170,282 @@ bool parse_object(const char *b, const char *e, int64_t i, Columns &c, std::stri
     return true;
 }
 
+
+// ---------------------------------------------------------------------------
+// annotation file
+// ---------------------------------------------------------------------------
+struct GT {
+    std::vector<int64_t> cat_id, cat_merged;
+    std::vector<uint8_t> cat_freq;
+    std::vector<int64_t> vid_id, vid_neg_off, vid_neg, vid_nel_off, vid_nel;
+    std::vector<int64_t> img_id, img_vid, img_neg_off, img_neg, img_nel_off, img_nel;
+    std::vector<double> img_frame;
+    std::vector<int64_t> trk_id, trk_cat, trk_vid;
+    std::vector<uint8_t> trk_ignore;
+    std::vector<int64_t> ann_id, ann_img, ann_trk, ann_cat;
+    std::vector<double> ann_bbox, ann_area, ann_vis;
+    std::vector<uint8_t> ann_oof, ann_ignore;
+};
+
+typedef std::vector<std::pair<const char *, const char *>> Ranges;
+
+// Python truthiness of a JSON value (`1 if a.get("ignore", 0) else 0`)
+bool truthy(Cursor &c)
+{
+    c.ws();
+    if (c.p >= c.e) { c.bad("unexpected end"); return false; }
+    const char ch = *c.p;
+    if (ch == 't') { c.skip(); return true; }
+    if (ch == 'f' || ch == 'n') { c.skip(); return false; }
+    if (ch == '"') { const char *b = nullptr, *e = nullptr; c.str(b, e); return e > b; }
+    if (ch == '[' || ch == '{') {
+        const char *q = c.p + 1;
+        while (q < c.e && (*q == ' ' || *q == '\n' || *q == '\t' || *q == '\r')) q++;
+        const bool empty = q < c.e && (*q == ']' || *q == '}');
+        c.skip();
+        return !empty;
+    }
+    double v;
+    if (!c.number(v)) return false;
+    return v != 0.0;   // NaN is truthy, as in Python
+}
+
+// [ obj, obj, ... ] -> byte range of every element; the cursor ends after ']'
+bool scan_array(Cursor &c, Ranges &out)
+{
+    out.clear();
+    if (!c.eat('[')) { c.bad("table is not a list"); return false; }
+    if (c.eat(']')) return true;
+    for (;;) {
+        c.ws();
+        const char *b = c.p;
+        c.skip();
+        if (c.fail) return false;
+        out.emplace_back(b, c.p);
+        if (c.eat(',')) continue;
+        if (c.eat(']')) return true;
+        c.bad("expected , or ]");
+        return false;
+    }
+}
+
+bool id_list(Cursor &c, std::vector<int64_t> &out)
+{
+    out.clear();
+    if (!c.eat('[')) { c.bad("expected a list of ids"); return false; }
+    if (c.eat(']')) return true;
+    for (;;) {
+        int64_t v;
+        if (!c.integer(v)) return false;
+        out.push_back(v);
+        if (c.eat(',')) continue;
+        if (c.eat(']')) return true;
+        c.bad("expected , or ]");
+        return false;
+    }
+}
+
+// generic object walk: f(key_begin, key_end, cursor) consumes the value
+template <class F>
+bool walk_object(const char *b, const char *e, std::string &err, F f)
+{
+    Cursor cur{b, e};
+    if (!cur.eat('{')) { err = "table element is not an object"; return false; }
+    if (!cur.eat('}')) {
+        for (;;) {
+            const char *kb, *ke;
+            if (!cur.str(kb, ke) || !cur.eat(':')) { cur.bad("expected key"); break; }
+            f(kb, ke, cur);
+            if (cur.fail) break;
+            if (cur.eat(',')) continue;
+            if (cur.eat('}')) break;
+            cur.bad("expected , or }");
+            break;
+        }
+    }
+    if (cur.fail) { err = cur.why; return false; }
+    return true;
+}
+
+void csr(const std::vector<std::vector<int64_t>> &lists, std::vector<int64_t> &off,
+         std::vector<int64_t> &val)
+{
+    off.assign(lists.size() + 1, 0);
+    for (size_t i = 0; i < lists.size(); i++) off[i + 1] = off[i] + (int64_t)lists[i].size();
+    val.resize((size_t)off.back());
+    for (size_t i = 0; i < lists.size(); i++)
+        std::copy(lists[i].begin(), lists[i].end(), val.begin() + off[i]);
+}
+
+struct Fail {
+    bool ok = true;
+    std::string msg;
+    void set(const std::string &table, int64_t i, const std::string &m)
+    {
+#pragma omp critical(taoamd_gt_fail)
+        { if (ok) { ok = false; msg = m.rfind("KeyError", 0) == 0 ? m : table + " " + std::to_string(i) + ": " + m; } }
+    }
+};
+
+#define NEED(flag, name) if (!(flag)) { fl.set(table, i, "KeyError: '" name "'"); continue; }
+
+void parse_categories(const Ranges &r, GT &g, Fail &fl)
+{
+    const char *table = "category";
+    const int64_t n = (int64_t)r.size();
+    g.cat_id.resize(n); g.cat_freq.assign(n, (uint8_t)'?');
+    std::vector<std::vector<int64_t>> merged(n);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; i++) {
+        bool has_id = false;
+        std::string er;
+        const bool ok = walk_object(r[i].first, r[i].second, er, [&](const char *kb, const char *ke, Cursor &c) {
+            int64_t v;
+            if (key_is(kb, ke, "id")) { if (c.integer(v)) { g.cat_id[i] = v; has_id = true; } }
+            else if (key_is(kb, ke, "frequency")) {
+                const char *b, *e;
+                if (c.str(b, e)) {
+                    if (e == b || *b == '\\' || (unsigned char)*b >= 0x80) c.bad("unsupported frequency string");
+                    else g.cat_freq[i] = (uint8_t)*b;
+                }
+            } else if (key_is(kb, ke, "merged")) {
+                Ranges ms;
+                merged[i].clear();
+                if (scan_array(c, ms))
+                    for (auto &m : ms) {
+                        bool got = false;
+                        std::string e2;
+                        if (!walk_object(m.first, m.second, e2, [&](const char *b2, const char *e3, Cursor &c2) {
+                                int64_t w;
+                                if (key_is(b2, e3, "id")) { if (c2.integer(w)) { merged[i].push_back(w); got = true; } }
+                                else c2.skip();
+                            })) { c.bad("malformed merged entry"); break; }
+                        if (!got) { c.bad("KeyError: 'id'"); break; }
+                    }
+            } else c.skip();
+        });
+        if (!ok) { fl.set(table, i, er); continue; }
+        NEED(has_id, "id");
+    }
+    for (int64_t i = 0; i < n; i++)
+        for (int64_t m : merged[i]) { g.cat_merged.push_back(m); g.cat_merged.push_back(g.cat_id[i]); }
+}
+
+void parse_videos(const Ranges &r, GT &g, Fail &fl)
+{
+    const char *table = "video";
+    const int64_t n = (int64_t)r.size();
+    g.vid_id.resize(n);
+    std::vector<std::vector<int64_t>> neg(n), nel(n);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; i++) {
+        bool has_id = false, has_neg = false, has_nel = false;
+        std::string er;
+        const bool ok = walk_object(r[i].first, r[i].second, er, [&](const char *kb, const char *ke, Cursor &c) {
+            int64_t v;
+            if (key_is(kb, ke, "id")) { if (c.integer(v)) { g.vid_id[i] = v; has_id = true; } }
+            else if (key_is(kb, ke, "neg_category_ids")) has_neg = id_list(c, neg[i]);
+            else if (key_is(kb, ke, "not_exhaustive_category_ids")) has_nel = id_list(c, nel[i]);
+            else c.skip();
+        });
+        if (!ok) { fl.set(table, i, er); continue; }
+        NEED(has_id, "id"); NEED(has_neg, "neg_category_ids");
+        NEED(has_nel, "not_exhaustive_category_ids");
+    }
+    csr(neg, g.vid_neg_off, g.vid_neg);
+    csr(nel, g.vid_nel_off, g.vid_nel);
+}
+
+void parse_images(const Ranges &r, GT &g, Fail &fl)
+{
+    const char *table = "image";
+    const int64_t n = (int64_t)r.size();
+    g.img_id.resize(n); g.img_vid.resize(n); g.img_frame.resize(n);
+    std::vector<std::vector<int64_t>> neg(n), nel(n);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; i++) {
+        bool has_id = false, has_vid = false, has_fr = false, has_neg = false, has_nel = false;
+        std::string er;
+        const bool ok = walk_object(r[i].first, r[i].second, er, [&](const char *kb, const char *ke, Cursor &c) {
+            int64_t v;
+            double d;
+            if (key_is(kb, ke, "id")) { if (c.integer(v)) { g.img_id[i] = v; has_id = true; } }
+            else if (key_is(kb, ke, "video_id")) { if (c.integer(v)) { g.img_vid[i] = v; has_vid = true; } }
+            else if (key_is(kb, ke, "frame_index")) { if (c.number(d)) { g.img_frame[i] = d; has_fr = true; } }
+            else if (key_is(kb, ke, "neg_category_ids")) has_neg = id_list(c, neg[i]);
+            else if (key_is(kb, ke, "not_exhaustive_category_ids")) has_nel = id_list(c, nel[i]);
+            else c.skip();
+        });
+        if (!ok) { fl.set(table, i, er); continue; }
+        NEED(has_id, "id"); NEED(has_vid, "video_id"); NEED(has_fr, "frame_index");
+        NEED(has_neg, "neg_category_ids"); NEED(has_nel, "not_exhaustive_category_ids");
+    }
+    csr(neg, g.img_neg_off, g.img_neg);
+    csr(nel, g.img_nel_off, g.img_nel);
+}
+
+void parse_tracks(const Ranges &r, GT &g, Fail &fl)
+{
+    const char *table = "track";
+    const int64_t n = (int64_t)r.size();
+    g.trk_id.resize(n); g.trk_cat.resize(n); g.trk_vid.resize(n); g.trk_ignore.assign(n, 0);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; i++) {
+        bool has_id = false, has_cat = false, has_vid = false;
+        std::string er;
+        const bool ok = walk_object(r[i].first, r[i].second, er, [&](const char *kb, const char *ke, Cursor &c) {
+            int64_t v;
+            if (key_is(kb, ke, "id")) { if (c.integer(v)) { g.trk_id[i] = v; has_id = true; } }
+            else if (key_is(kb, ke, "category_id")) { if (c.integer(v)) { g.trk_cat[i] = v; has_cat = true; } }
+            else if (key_is(kb, ke, "video_id")) { if (c.integer(v)) { g.trk_vid[i] = v; has_vid = true; } }
+            else if (key_is(kb, ke, "ignore")) g.trk_ignore[i] = truthy(c) ? 1 : 0;
+            else c.skip();
+        });
+        if (!ok) { fl.set(table, i, er); continue; }
+        NEED(has_id, "id"); NEED(has_cat, "category_id"); NEED(has_vid, "video_id");
+    }
+}
+
+void parse_annotations(const Ranges &r, GT &g, Fail &fl)
+{
+    const char *table = "annotation";
+    const int64_t n = (int64_t)r.size();
+    g.ann_id.resize(n); g.ann_img.resize(n); g.ann_trk.resize(n); g.ann_cat.resize(n);
+    g.ann_bbox.resize(4 * n); g.ann_area.resize(n); g.ann_vis.resize(n);
+    g.ann_oof.assign(n, 0); g.ann_ignore.assign(n, 0);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; i++) {
+        bool has_id = false, has_img = false, has_trk = false, has_cat = false,
+             has_box = false, has_area = false, has_vis = false, has_oof = false;
+        std::string er;
+        const bool ok = walk_object(r[i].first, r[i].second, er, [&](const char *kb, const char *ke, Cursor &c) {
+            int64_t v;
+            double d;
+            if (key_is(kb, ke, "id")) { if (c.integer(v)) { g.ann_id[i] = v; has_id = true; } }
+            else if (key_is(kb, ke, "image_id")) { if (c.integer(v)) { g.ann_img[i] = v; has_img = true; } }
+            else if (key_is(kb, ke, "track_id")) { if (c.integer(v)) { g.ann_trk[i] = v; has_trk = true; } }
+            else if (key_is(kb, ke, "category_id")) { if (c.integer(v)) { g.ann_cat[i] = v; has_cat = true; } }
+            else if (key_is(kb, ke, "area")) { if (c.number(d)) { g.ann_area[i] = d; has_area = true; } }
+            else if (key_is(kb, ke, "visibility")) { if (c.number(d)) { g.ann_vis[i] = d; has_vis = true; } }
+            else if (key_is(kb, ke, "out_of_frame")) { g.ann_oof[i] = truthy(c) ? 1 : 0; has_oof = true; }
+            else if (key_is(kb, ke, "ignore")) g.ann_ignore[i] = truthy(c) ? 1 : 0;
+            else if (key_is(kb, ke, "bbox")) {
+                if (!c.eat('[')) c.bad("bbox is not a list");
+                for (int k = 0; k < 4 && !c.fail; k++) {
+                    if (k && !c.eat(',')) c.bad("bbox needs 4 numbers");
+                    if (c.number(d)) g.ann_bbox[4 * i + k] = d;
+                }
+                if (!c.fail && !c.eat(']')) c.bad("bbox needs 4 numbers");
+                has_box = !c.fail;
+            } else c.skip();
+        });
+        if (!ok) { fl.set(table, i, er); continue; }
+        NEED(has_id, "id"); NEED(has_img, "image_id"); NEED(has_trk, "track_id");
+        NEED(has_cat, "category_id"); NEED(has_box, "bbox"); NEED(has_area, "area");
+        NEED(has_vis, "visibility"); NEED(has_oof, "out_of_frame");
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -247,5 +530,87 @@ int taoamd_pred_copy(void *h, int64_t *image_id, int64_t *category_id, double *b
 }
 
 void taoamd_pred_free(void *h) { delete (Columns *)h; }
+
+// Annotation file -> handle of GTColumns arrays (NULL + message on error;
+// "KeyError: 'x'" when a required key is absent, as the reference's dict
+// accesses would raise).
+void *taoamd_gt_parse(const char *path, char *err, size_t errlen)
+{
+    auto fail = [&](const std::string &m) -> void * {
+        if (err && errlen) snprintf(err, errlen, "%s", m.c_str());
+        return nullptr;
+    };
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) return fail(std::string("cannot open ") + path);
+    struct stat st;
+    fstat(fd, &st);
+    size_t len = (size_t)st.st_size;
+    const char *buf = len ? (const char *)mmap(nullptr, len, PROT_READ, MAP_PRIVATE, fd, 0) : "";
+    close(fd);
+    if (len && buf == MAP_FAILED) return fail("mmap failed");
+    auto done = [&]() { if (len) munmap((void *)buf, len); };
+    Cursor cur{buf, buf + len};
+    cur.ws();
+    if (cur.p >= cur.e || *cur.p != '{') {
+        const bool is_list = cur.p < cur.e && *cur.p == '[';
+        done();
+        return fail(is_list ? "not a dict: list" : "not a dict");
+    }
+    cur.p++;
+    Ranges cats, vids, imgs, trks, anns;
+    bool h_cats = false, h_vids = false, h_imgs = false, h_trks = false, h_anns = false;
+    if (!cur.eat('}')) {
+        for (;;) {
+            const char *kb, *ke;
+            if (!cur.str(kb, ke) || !cur.eat(':')) { cur.bad("expected key"); break; }
+            if (key_is(kb, ke, "categories")) h_cats = scan_array(cur, cats);
+            else if (key_is(kb, ke, "videos")) h_vids = scan_array(cur, vids);
+            else if (key_is(kb, ke, "images")) h_imgs = scan_array(cur, imgs);
+            else if (key_is(kb, ke, "tracks")) h_trks = scan_array(cur, trks);
+            else if (key_is(kb, ke, "annotations")) h_anns = scan_array(cur, anns);
+            else cur.skip();
+            if (cur.fail) break;
+            if (cur.eat(',')) continue;
+            if (cur.eat('}')) break;
+            cur.bad("expected , or }");
+            break;
+        }
+    }
+    if (cur.fail) { std::string w = cur.why; done(); return fail("malformed annotation file: " + w); }
+    const char *missing = !h_cats ? "categories" : !h_vids ? "videos" : !h_imgs ? "images"
+                          : !h_trks ? "tracks" : !h_anns ? "annotations" : nullptr;
+    if (missing) { done(); return fail(std::string("KeyError: '") + missing + "'"); }
+    GT *g = new GT;
+    Fail fl;
+    parse_categories(cats, *g, fl);
+    parse_videos(vids, *g, fl);
+    parse_images(imgs, *g, fl);
+    parse_tracks(trks, *g, fl);
+    parse_annotations(anns, *g, fl);
+    done();
+    if (!fl.ok) { delete g; return fail(fl.msg); }
+    return g;
+}
+
+// one named array of the handle: pointer, element count, element size
+int taoamd_gt_array(void *h, const char *name, const void **ptr, int64_t *count, int *elem)
+{
+    GT *g = (GT *)h;
+#define I64(f) if (!strcmp(name, #f)) { *ptr = g->f.data(); *count = (int64_t)g->f.size(); *elem = 8; return 0; }
+#define F64(f) if (!strcmp(name, #f)) { *ptr = g->f.data(); *count = (int64_t)g->f.size(); *elem = -8; return 0; }
+#define U8(f) if (!strcmp(name, #f)) { *ptr = g->f.data(); *count = (int64_t)g->f.size(); *elem = 1; return 0; }
+    I64(cat_id) I64(cat_merged) U8(cat_freq)
+    I64(vid_id) I64(vid_neg_off) I64(vid_neg) I64(vid_nel_off) I64(vid_nel)
+    I64(img_id) I64(img_vid) F64(img_frame) I64(img_neg_off) I64(img_neg) I64(img_nel_off) I64(img_nel)
+    I64(trk_id) I64(trk_cat) I64(trk_vid) U8(trk_ignore)
+    I64(ann_id) I64(ann_img) I64(ann_trk) I64(ann_cat) F64(ann_bbox) F64(ann_area) F64(ann_vis)
+    U8(ann_oof) U8(ann_ignore)
+#undef I64
+#undef F64
+#undef U8
+    return -1;
+}
+
+void taoamd_gt_free(void *h) { delete (GT *)h; }
 
 }  // extern "C"

@@ -43,16 +43,18 @@ def match_plan(d_cnt, g_cnt, cap_d=64, cap_g=64, cap_cell_g=8):
     idx = np.where(small, n, np.arange(n))
     nxt = np.minimum.accumulate(idx[::-1])[::-1] if n else idx
     groups, singles = [], np.flatnonzero(~small & (d_cnt > 0)).astype(np.int32)
+    # where a group starting at cell c would end, for every c at once; the
+    # greedy segmentation then only follows that jump table
+    end = np.minimum(np.searchsorted(cum_d, cum_d[:-1] + cap_d, "right") - 1,
+                     np.searchsorted(cum_g, cum_g[:-1] + cap_g, "right") - 1)
+    end = np.maximum(np.minimum(end, nxt), np.arange(n) + 1)
+    jump = np.where(small, end, np.arange(n) + 1).tolist()
+    has_dt = (cum_d[end] > cum_d[:-1]).tolist() if n else []
+    is_small = small.tolist()
     c = 0
     while c < n:
-        if not small[c]:
-            c += 1
-            continue
-        e = min(int(np.searchsorted(cum_d, cum_d[c] + cap_d, "right")) - 1,
-                int(np.searchsorted(cum_g, cum_g[c] + cap_g, "right")) - 1,
-                int(nxt[c]))
-        e = max(e, c + 1)
-        if cum_d[e] > cum_d[c]:
+        e = jump[c]
+        if is_small[c] and has_dt[c]:
             groups.append((c, e))
         c = e
     return np.asarray(groups, dtype=np.int32).reshape(-1, 2), singles

@@ -19,18 +19,33 @@ class LVIS:
         accepts a path only; an already parsed dict is accepted as well)."""
         self.logger = logging.getLogger(__name__)
         self.logger.info("Loading annotations.")
-        if isinstance(annotation_path, dict):
-            self.dataset = annotation_path
-        else:
-            self.dataset = self._load_json(annotation_path)
-        assert type(self.dataset) == dict, (
-            "Annotation file format {} not supported.".format(type(self.dataset)))
         self._columns = None
         self._index = None
+        self._dataset = None
+        self._path = None
+        if isinstance(annotation_path, dict):
+            self._dataset = annotation_path
+        else:
+            # the native reader goes straight to columns; the dict form of the
+            # file is only parsed if somebody asks for ``dataset``
+            self._columns = GTColumns.from_file_native(annotation_path) \
+                if isinstance(annotation_path, str) else None
+            if self._columns is None:
+                self._dataset = self._load_json(annotation_path)
+            else:
+                self._path = annotation_path
+        assert self._columns is not None or type(self._dataset) == dict, (
+            "Annotation file format {} not supported.".format(type(self._dataset)))
 
     def _load_json(self, path):
         with open(path, "r") as f:
             return json.load(f)
+
+    @property
+    def dataset(self):
+        if self._dataset is None:
+            self._dataset = self._load_json(self._path)
+        return self._dataset
 
     @property
     def columns(self):
@@ -79,10 +94,10 @@ class LVIS:
                 if a["category_id"] in cat_ids and lo < a["area"] < hi]
 
     def get_cat_ids(self):
-        return [c["id"] for c in self.dataset["categories"]]
+        return self.columns.cat_id.tolist()
 
     def get_img_ids(self):
-        return [i["id"] for i in self.dataset["images"]]
+        return self.columns.img_id.tolist()
 
     def _load_helper(self, _dict, ids):
         return list(_dict.values()) if ids is None else [_dict[i] for i in ids]

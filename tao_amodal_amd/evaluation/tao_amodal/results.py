@@ -17,7 +17,7 @@ from .tao import Tao
 
 
 class TaoResults(Tao):
-    def __init__(self, tao_gt, results, max_dets=300):
+    def __init__(self, tao_gt, results, max_dets=300, _flat=None):
         if isinstance(tao_gt, Tao):
             self.gt = tao_gt
         elif isinstance(tao_gt, str):
@@ -47,13 +47,15 @@ class TaoResults(Tao):
         # cell tables of the track-level problem; this is where the track
         # scores are formed, as in the reference constructor
         from .._core import timed
+        # (_flat: the same tables prepared ahead of time by the CLI, which
+        # builds them on a worker thread while the image-level pass runs)
         with timed("flatten"):
-            self.flat = flatten.flatten_tao(self.gt.columns, self.columns_dt,
-                                            max_dets)
+            self.flat = _flat if _flat is not None else flatten.flatten_tao(
+                self.gt.columns, self.columns_dt, max_dets)
         keep = flatten.limit_dets_per_image(self.columns_dt, max_dets)
-        b = self.columns_dt.bbox[keep]
-        neg = int(np.count_nonzero((b[:, 0] < 0) | (b[:, 1] < 0)
-                                   | (b[:, 2] <= 0) | (b[:, 3] <= 0)))
+        b = self.columns_dt.bbox
+        bad = (b[:, 0] < 0) | (b[:, 1] < 0) | (b[:, 2] <= 0) | (b[:, 3] <= 0)
+        neg = int(np.count_nonzero(bad[keep])) if bad.any() else 0
         if neg:
             self.logger.warning(
                 f"{neg} annotations had negative values in coordinates!")
@@ -67,8 +69,7 @@ class TaoResults(Tao):
     def ensure_unique_track_ids(dt):
         if len(dt) == 0:
             return
-        u, first, inv = np.unique(dt.track_id, return_index=True,
-                                  return_inverse=True)
+        u, first, inv = flatten.first_inverse(dt.track_id)
         bad = np.flatnonzero(dt.video_id != dt.video_id[first][inv])
         if len(bad):
             t = int(dt.track_id[bad[0]])

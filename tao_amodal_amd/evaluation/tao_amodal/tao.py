@@ -25,23 +25,37 @@ class Tao:
         else:
             self.logger = logger
         self.logger.info("Loading annotations.")
+        self._columns = columns
+        self._index = None
+        self._dataset = None
+        self._path = None
         if isinstance(annotation_path, dict):
             for key in ("info", "images", "annotations", "categories",
                         "videos", "tracks"):
                 assert key in annotation_path, (
                     f"Provided dictionary does not contain key {key}")
-            self.dataset = annotation_path
+            self._dataset = annotation_path
         else:
-            self.dataset = self._load_json(annotation_path)
-        assert type(self.dataset) == dict, (
-            "Annotation file format {} not supported.".format(type(self.dataset)))
-        self._columns = columns
-        self._index = None
+            # native reader -> columns; the dict form is parsed on demand
+            if self._columns is None and isinstance(annotation_path, str):
+                self._columns = GTColumns.from_file_native(annotation_path)
+            if self._columns is None:
+                self._dataset = self._load_json(annotation_path)
+            else:
+                self._path = annotation_path
+        assert self._columns is not None or type(self._dataset) == dict, (
+            "Annotation file format {} not supported.".format(type(self._dataset)))
         self._announce()
 
     def _load_json(self, path):
         with open(path, "r") as f:
             return json.load(f)
+
+    @property
+    def dataset(self):
+        if self._dataset is None:
+            self._dataset = self._load_json(self._path)
+        return self._dataset
 
     @property
     def columns(self):
@@ -106,13 +120,13 @@ class Tao:
     track_ann_map = property(lambda self: self._create_index()["track_ann_map"])
 
     def get_cat_ids(self):
-        return [c["id"] for c in self.dataset["categories"]]
+        return self.columns.cat_id.tolist()
 
     def get_vid_ids(self):
-        return [v["id"] for v in self.dataset["videos"]]
+        return self.columns.vid_id.tolist()
 
     def get_img_ids(self):
-        return [i["id"] for i in self.dataset["images"]]
+        return self.columns.img_id.tolist()
 
     def _load_helper(self, _dict, ids):
         return list(_dict.values()) if ids is None else [_dict[i] for i in ids]

@@ -52,9 +52,18 @@ DT_NO_CONSUME = 2         # id <= 0: a match does not mark the GT as taken
 
 
 def _lookup(sorted_keys, values):
-    """index of each value in sorted_keys, -1 when absent"""
+    """index of each value in sorted_keys (ascending, unique), -1 when absent"""
     if len(sorted_keys) == 0:
         return np.full(len(values), -1, dtype=np.int64)
+    lo, hi = int(sorted_keys[0]), int(sorted_keys[-1])
+    if len(values) > 4096 and hi - lo < max(8 * len(values), 1 << 22):
+        # ids in a modest range (image / category / track ids): one gather
+        # through a dense table instead of a binary search per value
+        table = np.full(hi - lo + 2, -1, dtype=np.int64)
+        table[sorted_keys - lo] = np.arange(len(sorted_keys))
+        v = np.asarray(values, dtype=np.int64) - lo
+        ok = (v >= 0) & (v <= hi - lo)
+        return table[np.where(ok, v, hi - lo + 1)]
     pos = np.searchsorted(sorted_keys, values)
     pos = np.minimum(pos, len(sorted_keys) - 1)
     return np.where(sorted_keys[pos] == values, pos, -1)
@@ -200,12 +209,14 @@ def flatten_lvis(gt: GTColumns, dt: DTColumns, max_dets=MAX_DETS):
     img_row[_lookup(img_ids, gt.img_id)] = np.arange(len(gt.img_id))
 
     keep = limit_dets_per_image(dt, max_dets)
-    d = dt.take(keep)
+    # columns of the kept detections (the boxes are gathered once, at the end)
+    d_image, d_catid = dt.image_id[keep], dt.category_id[keep]
+    d_score = dt.score[keep]
     d_id = np.arange(1, len(keep) + 1, dtype=np.int64)
-    d_img = _lookup(img_ids, d.image_id)
+    d_img = _lookup(img_ids, d_image)
     if (d_img < 0).any():
         raise AssertionError("Results do not correspond to current LVIS set.")
-    d_area = d.bbox[:, 2] * d.bbox[:, 3]
+    d_area = (dt.bbox[:, 2] * dt.bbox[:, 3])[keep]
 
     # ---- ground truth selection (sorted image order, dataset order inside)
     a_img = _lookup(img_ids, gt.ann_img)
@@ -219,7 +230,7 @@ def flatten_lvis(gt: GTColumns, dt: DTColumns, max_dets=MAX_DETS):
     g_img, g_cat = a_img[g_sel], a_cat[g_sel]
 
     # ---- detection selection + federated filter
-    d_cat = _lookup(cat_ids, d.category_id)
+    d_cat = _lookup(cat_ids, d_catid)
     order = np.argsort(d_img, kind="stable")
     order = order[(d_cat[order] >= 0) & (d_area[order] > 0)
                   & (d_area[order] < np.inf)]
@@ -229,14 +240,14 @@ def flatten_lvis(gt: GTColumns, dt: DTColumns, max_dets=MAX_DETS):
     is_present = _lookup(key_present, k_of) >= 0
     rows = img_row[d_img[order]]
     is_neg = _csr_member(gt.img_neg_off, gt.img_neg, rows,
-                         d.category_id[order])
+                         d_catid[order])
     order = order[is_present | is_neg]
 
     # ---- cells
     keys_g = g_cat * U + g_img
     keys_d = d_cat[order] * U + d_img[order]
     # detections: by cell, then descending score, stable in visiting order
-    o2 = np.lexsort((np.arange(len(order)), -d.score[order], keys_d))
+    o2 = np.lexsort((np.arange(len(order)), -d_score[order], keys_d))
     order = order[o2]
     keys_d = keys_d[o2]
     og = np.argsort(keys_g, kind="stable")
@@ -244,7 +255,7 @@ def flatten_lvis(gt: GTColumns, dt: DTColumns, max_dets=MAX_DETS):
     cell_keys, g_cell, d_cell, g_off, d_off = _cells(keys_g, keys_d)
 
     rows = img_row[d_img[order]]
-    nel = _csr_member(gt.img_nel_off, gt.img_nel, rows, d.category_id[order])
+    nel = _csr_member(gt.img_nel_off, gt.img_nel, rows, d_catid[order])
     area = d_area[order]
     d_flags = np.where((area < 0) | (area > 1e5 ** 2) | nel,
                        DT_IGNORE_UNMATCHED, 0).astype(np.uint8)
@@ -262,8 +273,8 @@ def flatten_lvis(gt: GTColumns, dt: DTColumns, max_dets=MAX_DETS):
     f.cell_cat = (cell_keys // U).astype(I32)
     f.cell_dt_off = d_off.astype(I32)
     f.cell_gt_off = g_off.astype(I32)
-    f.dt_box = np.ascontiguousarray(d.bbox[order])
-    f.dt_score = np.ascontiguousarray(d.score[order])
+    f.dt_box = np.ascontiguousarray(dt.bbox[keep[order]])
+    f.dt_score = np.ascontiguousarray(d_score[order])
     f.dt_flags = d_flags
     f.dt_id = d_id[order]
     f.dt_cat = (keys_d // U).astype(I32)

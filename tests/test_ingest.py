@@ -67,3 +67,101 @@ def test_errors(tmp_path):
         DTColumns.from_file_native(str(p))
     with pytest.raises(FileNotFoundError):
         DTColumns.from_file_native(str(tmp_path / "missing.json"))
+
+
+# ---------------------------------------------------------------- annotation file
+from goldenio import load_inputs            # noqa: E402
+from tao_amodal_amd.columns import GTColumns  # noqa: E402
+from tao_amodal_amd.synth import synth      # noqa: E402
+
+
+def _same_gt(a, b):
+    for f in GTColumns.FIELDS:
+        x, y = getattr(a, f), getattr(b, f)
+        assert x.dtype == y.dtype and x.shape == y.shape, f
+        assert np.array_equal(x, y, equal_nan=x.dtype.kind == "f"), f
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_annotation_fixtures_parse_identically(name, tmp_path):
+    gt, _ = load_inputs(name)
+    p = tmp_path / "gt.json"
+    p.write_text(json.dumps(gt))
+    _same_gt(GTColumns.from_file_native(str(p)), GTColumns.from_json(gt))
+    p.write_text(json.dumps(gt, indent=1))
+    _same_gt(GTColumns.from_file_native(str(p)), GTColumns.from_json(gt))
+
+
+def test_annotation_awkward_but_valid(tmp_path):
+    gt, _ = synth(seed=9, V=4, F=6, C=30, dets_per_frame=4, n_merged=3)
+    d = gt.to_json()
+    d["info"] = {"note": 'braces } ] { [ "quoted\\" text', "nested": [[{"a": "]"}]]}
+    d["licenses"] = [{"id": 1, "url": "http://x/{y}"}]
+    for k, a in enumerate(d["annotations"]):
+        a["segmentation"] = [[1.5, 2, 3]]
+        a["name"] = "ann } %d" % k
+        # every truthiness flavour Python accepts for `if a.get("ignore", 0)`
+        a["ignore"] = [0, 1, True, False, None, 0.0, 2.5, "", "x", [], [0], {}, {"a": 0}][k % 13]
+        a["out_of_frame"] = [False, True, 0, 1, None, "yes", ""][k % 7]
+        if k % 5 == 0:
+            a["area"] = float(a["area"]) + 0.125
+    for k, t in enumerate(d["tracks"]):
+        t["ignore"] = [0, 1, True, None, "x"][k % 5]
+        if k % 3 == 0:
+            del t["ignore"]
+    d["categories"][0].pop("frequency", None)
+    d["images"][0]["frame_index"] = 3.5
+    d["images"][1]["id"] = d["images"][1]["id"]           # untouched
+    d["annotations"][2]["id"] = 2 ** 60 + 7                # beyond double precision
+    p = tmp_path / "gt.json"
+    p.write_text(json.dumps(d, indent=2))
+    a = GTColumns.from_file_native(str(p))
+    _same_gt(a, GTColumns.from_json(d))
+    assert a.ann_id[2] == 2 ** 60 + 7 and a.cat_freq[0] == ord("?")
+    assert a.cat_merged.shape[0] > 0
+
+
+def test_annotation_errors(tmp_path):
+    gt, _ = synth(seed=9, V=2, F=3, C=20, dets_per_frame=2)
+    base = gt.to_json()
+    p = tmp_path / "gt.json"
+    p.write_text("[1, 2]")
+    with pytest.raises(AssertionError, match="not supported"):
+        GTColumns.from_file_native(str(p))
+    with pytest.raises(FileNotFoundError):
+        GTColumns.from_file_native(str(tmp_path / "missing.json"))
+    d = dict(base)
+    del d["tracks"]
+    p.write_text(json.dumps(d))
+    with pytest.raises(KeyError, match="tracks"):
+        GTColumns.from_file_native(str(p))
+    d = json.loads(json.dumps(base))
+    del d["images"][1]["neg_category_ids"]
+    p.write_text(json.dumps(d))
+    with pytest.raises(KeyError, match="neg_category_ids"):
+        GTColumns.from_file_native(str(p))
+    d = json.loads(json.dumps(base))
+    del d["annotations"][0]["visibility"]
+    p.write_text(json.dumps(d))
+    with pytest.raises(KeyError, match="visibility"):
+        GTColumns.from_file_native(str(p))
+    p.write_text(json.dumps(base)[:-20])
+    with pytest.raises(ValueError):
+        GTColumns.from_file_native(str(p))
+
+
+def test_annotation_classes_share_the_native_columns(tmp_path):
+    """LVIS(path) / Tao(path) take the native reader and only parse the dict
+    form of the file when ``dataset`` is asked for."""
+    from tao_amodal_amd.evaluation.lvis_amodal import LVIS
+    from tao_amodal_amd.evaluation.tao_amodal import Tao
+    gt, _ = synth(seed=3, V=2, F=4, C=20, dets_per_frame=3)
+    p = tmp_path / "gt.json"
+    p.write_text(json.dumps(gt.to_json()))
+    for cls in (LVIS, Tao):
+        obj = cls(str(p))
+        assert obj._dataset is None
+        _same_gt(obj.columns, gt)
+        assert obj.get_cat_ids() == gt.cat_id.tolist()
+        assert obj._dataset is None
+        assert len(obj.dataset["annotations"]) == len(gt.ann_id)

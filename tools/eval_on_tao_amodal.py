@@ -69,6 +69,24 @@ def make_track_ids_unique(dt):
     return n
 
 
+def prepare_track_level(gt_columns, dt_columns):
+    """Worker-thread body: the unique track ids and the track-level cell
+    tables, computed while the main thread runs the image-level evaluator
+    (numpy releases the GIL in its sorts / gathers).  Works on a shallow copy:
+    ``dt_columns.track_id`` is only replaced where the reference does it."""
+    ids, _ = flatten.make_track_ids_unique(dt_columns)
+    view = DTColumns(**{f: getattr(dt_columns, f) for f in DTColumns.FIELDS})
+    view.track_id = ids
+    cache = getattr(dt_columns, "_limit_cache", None)
+    if cache is not None:
+        view._limit_cache = cache
+    try:
+        flat = flatten.flatten_tao(gt_columns, view)
+    except Exception:       # raised again, at the reference's place, by TaoResults
+        flat = None
+    return ids, flat
+
+
 def evaluate_predictions_on_lvis(lvis_gt, track_result, dt_columns, iou_type,
                                  logger):
     logger.info("Evaluating {} on LVIS...".format(track_result))
@@ -85,17 +103,25 @@ def evaluate_predictions_on_lvis(lvis_gt, track_result, dt_columns, iou_type,
     return results
 
 
-def eval_tao_track(ann_path, gt_dataset, gt_columns, dt_columns, logger):
+def eval_tao_track(ann_path, gt_dataset, gt_columns, dt_columns, logger,
+                   prepared=None):
     logger.setLevel(logging.INFO)
     results = {}
     logger.info("Loading gt {}...".format(ann_path))
     tao_gt = Tao(gt_dataset, columns=gt_columns)
     logger.info("Done")
     logger.info("Loading results...")
-    make_track_ids_unique(dt_columns)
+    flat = None
+    if prepared is not None:
+        from tao_amodal_amd.evaluation._core import timed
+        with timed("flatten (wait for worker)"):
+            dt_columns.track_id, flat = prepared.result()
+    else:
+        make_track_ids_unique(dt_columns)
     logger.info("Done")
     logger.info("Building")
-    tao_eval = TaoEval(tao_gt, TaoResults(tao_gt, dt_columns), logger=logger)
+    tao_eval = TaoEval(tao_gt, TaoResults(tao_gt, dt_columns, _flat=flat),
+                       logger=logger)
     logger.info("Done")
     tao_eval.run()
     tao_eval.print_results()
@@ -123,15 +149,31 @@ def main(argv=None):
     logger.addHandler(handler)
     from tao_amodal_amd.evaluation._core import TIMING, timed
     try:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=1)
         with timed("parse"):
-            with open(annotation, "r") as f:
-                gt_dataset = json.load(f)
-            lvis_gt = LVIS(gt_dataset)
+            # the native readers run outside the GIL: the two files are
+            # parsed side by side
+            dt_future = pool.submit(DTColumns.from_json, args.track_result)
+            lvis_gt = LVIS(annotation)      # native reader when built
             lvis_gt.columns
-            dt_columns = DTColumns.from_json(args.track_result)
-        evaluate_predictions_on_lvis(lvis_gt, args.track_result, dt_columns,
-                                     "bbox", logger)
-        eval_tao_track(annotation, gt_dataset, lvis_gt.columns, dt_columns, logger)
+            gt_dataset = annotation          # the track level shares the columns
+            dt_columns = dt_future.result()
+        prepared = None
+        if len(dt_columns):
+            flatten.limit_dets_per_image(dt_columns)    # shared by both passes
+            prepared = pool.submit(prepare_track_level, lvis_gt.columns,
+                                   dt_columns)
+        try:
+            evaluate_predictions_on_lvis(lvis_gt, args.track_result, dt_columns,
+                                         "bbox", logger)
+        except BaseException:
+            if prepared is not None:
+                prepared.cancel()
+            raise
+        eval_tao_track(annotation, gt_dataset, lvis_gt.columns, dt_columns,
+                       logger, prepared)
+        pool.shutdown(wait=False)
     finally:
         logger.removeHandler(handler)
         handler.close()
