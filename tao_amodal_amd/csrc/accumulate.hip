@@ -275,7 +275,9 @@ __global__ __launch_bounds__(256) void acc_chunkmax_kernel(AccArgs a)
     for (int blk = 0; blk * WAVE < ci.len; blk++) {
         const uint64_t T = a.t_tp[tb + (int64_t)blk * WAVE];
         const uint64_t TF = T | a.t_fp[tb + (int64_t)blk * WAVE];
-        for (uint64_t m = T; m != 0; m &= m - 1) {
+        // a TP row directly followed by a TP row cannot hold the maximum:
+        // (tp+1)/(n+1) >= tp/n, and on a tie the larger n wins (pr_better)
+        for (uint64_t m = T & ~(T >> 1); m != 0; m &= m - 1) {
             const int q = __builtin_ctzll(m);
             const uint64_t le = q == 63 ? ~0ull : ((2ull << q) - 1);   // rows <= q
             const uint32_t tp = tp0 + (uint32_t)__popcll(T & le);
@@ -367,28 +369,50 @@ __global__ __launch_bounds__(256) void acc_emit_kernel(AccArgs a)
             for (int j = jcur; j < N_REC; j++) out[j] = 0.0;
     }
     const int64_t tb = (((int64_t)ci.c * a.n_words + ci.word) * ACC_BLK) * WAVE + lane;
+    // next threshold to write, cached in a register: cj[jcur - 1], or -1
+    int32_t cnext = jcur > 0 ? cj[jcur - 1] : -1;
     for (int blk = (ci.len - 1) / WAVE; blk >= 0; blk--) {
         const uint64_t T = live ? a.t_tp[tb + (int64_t)blk * WAVE] : 0;
         const uint64_t TF = T | (live ? a.t_fp[tb + (int64_t)blk * WAVE] : 0);
-        // tp, n: counts at the END of this block; walk its TP rows backwards
-        for (uint64_t m = T; m != 0;) {
+        // tp, n: counts at the END of this block.  Walk backwards over the TP
+        // rows that can raise the envelope: a TP row directly followed by a
+        // TP row never does ((tp+1)/(n+1) >= tp/n, ties go to the larger n),
+        // so only the last row of each run of consecutive TP rows is visited.
+        // Thresholds reached at a skipped row take the envelope of the rows
+        // above it, i.e. the running value BEFORE the next visited row.
+        for (uint64_t m = T & ~(T >> 1); m != 0;) {
             const int q = 63 - __builtin_clzll(m);
             const uint64_t gt = q == 63 ? 0ull : ~((2ull << q) - 1);   // rows > q
             const uint32_t tpq = tp - (uint32_t)__popcll(T & gt);      // incl. row q
             const uint32_t nq = n - (uint32_t)__popcll(TF & gt);
-            if (pr_better(tpq, nq, run)) run = pr_pack(tpq, nq);
-            const int32_t after = (int32_t)tpq - 1;
-            if (jcur > 0 && cj[jcur - 1] > after) {
+            if (cnext > (int32_t)tpq) {        // reached above row q
                 const double v = pr_value(run);
                 do {
-                    out[jcur - 1] = v;
-                    jcur--;
-                } while (jcur > 0 && cj[jcur - 1] > after);
+                    out[--jcur] = v;
+                    cnext = jcur > 0 ? cj[jcur - 1] : -1;
+                } while (cnext > (int32_t)tpq);
+            }
+            if (pr_better(tpq, nq, run)) run = pr_pack(tpq, nq);
+            if (cnext == (int32_t)tpq) {       // reached exactly at row q
+                const double v = pr_value(run);
+                do {
+                    out[--jcur] = v;
+                    cnext = jcur > 0 ? cj[jcur - 1] : -1;
+                } while (cnext == (int32_t)tpq);
             }
             m &= ~(1ull << q);
         }
         tp -= (uint32_t)__popcll(T);
         n -= (uint32_t)__popcll(TF);
+        // rows of this block below its lowest visited row: thresholds between
+        // the block's first TP count and that row see the current envelope
+        if (cnext > (int32_t)tp) {
+            const double v = pr_value(run);
+            do {
+                out[--jcur] = v;
+                cnext = jcur > 0 ? cj[jcur - 1] : -1;
+            } while (cnext > (int32_t)tp);
+        }
     }
     if (live && ci.first && jcur > 0) {
         const double v = pr_value(run);
