@@ -307,24 +307,136 @@ struct SegArgs {
     int32_t n_cat, n_tiles;
 };
 
-// LDS radix sort of one tile: 8 LSD passes over the 8 bytes of the descending-
-// score key.  Every pass keeps the tile in registers (<= 16 elements per
-// lane), ranks equal digits with the wave-level match-any of rs_scatter_kernel,
-// combines the four wavefronts' digit counts with one 256-wide scan and
-// scatters back into LDS.  LSD passes are stable, the tile is loaded in input
-// order, so the result is the stable order without carrying the position in
-// the key.  A pass whose digit is the same for the whole tile (sign/exponent
-// bytes of scores in (0,1)) moves nothing and is skipped.
+// LDS radix sort of one tile, LSD, one byte of the descending-score key per
+// pass.  Every pass keeps the elements in registers (<= 16 per lane), ranks
+// equal digits with the wave-level match-any of rs_scatter_kernel, combines
+// the four wavefronts' digit counts with one 256-wide scan and scatters back
+// into LDS.  LSD passes are stable and the tile is loaded in input order, so
+// the result is the stable order without carrying the position in the key.  A
+// pass whose digit is the same for all elements (sign / exponent bytes of
+// scores in (0,1)) moves nothing and is skipped.
+//
+// The tile is sorted by the four bytes of the HIGH key word only; the low
+// word matters just inside runs of equal high words that hold an inversion:
+//   * such a run of <= SEG_RUN_MAX members is repaired when the tile is
+//     written out: every member goes to its rank in the run;
+//   * a longer one (e.g. many scores within 1e-6 of each other) gets the
+//     four low-byte passes, on its own index range only;
+//   * more than SEG_LONG_MAX long runs: the tile starts over with 8 passes.
+#define SEG_RUN_MAX 64
+#define SEG_LONG_MAX 8
 #define SEG_ROUNDS (SEG_TILE / SEG_THREADS)   // 16 rounds of 64 per wavefront
+
+struct SegLds {
+    uint64_t key[SEG_TILE];
+    uint16_t pos[SEG_TILE];     // bits 0-11 input position, 14/15 run marks
+    uint32_t wcnt[4][RS_BINS];
+    uint32_t dbase[RS_BINS];
+    uint32_t wave_tot[4];
+    int32_t flag;
+    int32_t n_long;
+    int32_t long_s[SEG_LONG_MAX], long_e[SEG_LONG_MAX];
+};
+
+// passes [p0, p1) over the elements [base, base + n) of the tile, in place
+// in LDS (all threads of the workgroup; ends with a barrier)
+__device__ __forceinline__ void seg_passes(SegLds &L, int base, int n, int p0, int p1)
+{
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    // wavefront w owns the contiguous slice [w*per, (w+1)*per) of the range
+    const int per = ((n + 4 * WAVE - 1) / (4 * WAVE)) * WAVE;
+    const int rounds = per / WAVE;
+    const int w0 = wave * per;
+    uint64_t kr[SEG_ROUNDS];
+    uint16_t pr[SEG_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < SEG_ROUNDS; r++) {
+        const int i = w0 + r * WAVE + lane;
+        const bool ok = r < rounds && i < n;
+        kr[r] = ok ? L.key[base + i] : 0;
+        pr[r] = ok ? L.pos[base + i] : (uint16_t)0;
+    }
+    __syncthreads();
+#pragma nounroll
+    for (int pass = p0; pass < p1; pass++) {
+        for (int i = threadIdx.x; i < 4 * RS_BINS; i += SEG_THREADS)
+            (&L.wcnt[0][0])[i] = 0;
+        __syncthreads();
+        uint32_t rank[SEG_ROUNDS];
+#pragma unroll
+        for (int r = 0; r < SEG_ROUNDS; r++) {
+            if (r < rounds) {                       // block-uniform
+                const int i = w0 + r * WAVE + lane;
+                const bool ok = i < n;
+                const uint32_t dig = (uint32_t)(kr[r] >> (8 * pass)) & 255u;
+                uint64_t peers = __ballot(ok);
+#pragma unroll
+                for (int bit = 0; bit < 8; bit++) {
+                    const bool one = (dig >> bit) & 1u;
+                    const uint64_t m = __ballot(one);
+                    peers &= one ? m : ~m;
+                }
+                const uint32_t below = (uint32_t)__popcll(peers & ((1ull << lane) - 1));
+                uint32_t old = 0;
+                if (ok) old = L.wcnt[wave][dig];
+                rank[r] = old + below;
+                if (ok && (peers >> lane) == 1ull) L.wcnt[wave][dig] = old + below + 1;
+            }
+        }
+        __syncthreads();
+        // thread d: digit d.  totals over the four wavefronts, exclusive scan
+        {
+            const int d = threadIdx.x;
+            const uint32_t c0 = L.wcnt[0][d], c1 = L.wcnt[1][d], c2 = L.wcnt[2][d],
+                           c3 = L.wcnt[3][d];
+            const uint32_t tot = c0 + c1 + c2 + c3;
+            if (d == 0) L.flag = 0;
+            uint32_t inc = tot;                    // inclusive scan in the wave
+#pragma unroll
+            for (int off = 1; off < WAVE; off <<= 1) {
+                const uint32_t v = __shfl_up(inc, off, WAVE);
+                if (lane >= off) inc += v;
+            }
+            if (lane == WAVE - 1) L.wave_tot[wave] = inc;
+            __syncthreads();
+            uint32_t before = 0;
+            for (int w = 0; w < wave; w++) before += L.wave_tot[w];
+            const uint32_t excl = before + inc - tot;
+            L.dbase[d] = excl;
+            // exclusive over wavefronts, in place
+            L.wcnt[0][d] = 0; L.wcnt[1][d] = c0; L.wcnt[2][d] = c0 + c1;
+            L.wcnt[3][d] = c0 + c1 + c2;
+            if (tot == (uint32_t)n) L.flag = 1;
+        }
+        __syncthreads();
+        if (L.flag) { __syncthreads(); continue; }
+#pragma unroll
+        for (int r = 0; r < SEG_ROUNDS; r++) {
+            if (r < rounds) {
+                const int i = w0 + r * WAVE + lane;
+                if (i < n) {
+                    const uint32_t dig = (uint32_t)(kr[r] >> (8 * pass)) & 255u;
+                    const uint32_t dst = L.dbase[dig] + L.wcnt[wave][dig] + rank[r];
+                    L.key[base + dst] = kr[r];
+                    L.pos[base + dst] = pr[r];
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < SEG_ROUNDS; r++) {
+            if (r < rounds) {
+                const int i = w0 + r * WAVE + lane;
+                if (i < n) { kr[r] = L.key[base + i]; pr[r] = L.pos[base + i]; }
+            }
+        }
+        __syncthreads();
+    }
+}
 
 __global__ __launch_bounds__(SEG_THREADS) void seg_tile_kernel(SegArgs a)
 {
-    __shared__ uint64_t key[SEG_TILE];
-    __shared__ uint16_t pos[SEG_TILE];
-    __shared__ uint32_t wcnt[4][RS_BINS];
-    __shared__ uint32_t dbase[RS_BINS];
-    __shared__ uint32_t wave_tot[4];
-    __shared__ int32_t skip_flag;
+    __shared__ SegLds L;
     // category owning this tile: last k with tile_off[k] <= blockIdx.x
     int32_t lo = 0, hi = a.n_cat;
     while (hi - lo > 1) {
@@ -360,108 +472,105 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_tile_kernel(SegArgs a)
         }
         return;
     }
-    // wavefront w owns the contiguous slice [w*per, (w+1)*per) of the tile
-    const int per = ((n + 4 * WAVE - 1) / (4 * WAVE)) * WAVE;
-    const int rounds = per / WAVE;
-    const int w0 = wave * per;
-    uint64_t kr[SEG_ROUNDS];
-    uint16_t pr[SEG_ROUNDS];
-#pragma unroll
-    for (int r = 0; r < SEG_ROUNDS; r++) {
-        const int i = w0 + r * WAVE + lane;
-        const bool ok = r < rounds && i < n;
-        kr[r] = ok ? desc_key(a.score[b + i]) : 0;
-        pr[r] = (uint16_t)i;
-    }
-    for (int pass = 0; pass < 8; pass++) {
-        for (int i = threadIdx.x; i < 4 * RS_BINS; i += SEG_THREADS)
-            (&wcnt[0][0])[i] = 0;
-        __syncthreads();
-        uint32_t rank[SEG_ROUNDS];
-#pragma unroll
-        for (int r = 0; r < SEG_ROUNDS; r++) {
-            if (r < rounds) {                       // block-uniform
-                const int i = w0 + r * WAVE + lane;
-                const bool ok = i < n;
-                const uint32_t dig = (uint32_t)(kr[r] >> (8 * pass)) & 255u;
-                uint64_t peers = __ballot(ok);
-#pragma unroll
-                for (int bit = 0; bit < 8; bit++) {
-                    const bool one = (dig >> bit) & 1u;
-                    const uint64_t m = __ballot(one);
-                    peers &= one ? m : ~m;
-                }
-                const uint32_t below = (uint32_t)__popcll(peers & ((1ull << lane) - 1));
-                uint32_t old = 0;
-                if (ok) old = wcnt[wave][dig];
-                rank[r] = old + below;
-                if (ok && (peers >> lane) == 1ull) wcnt[wave][dig] = old + below + 1;
-            }
+    bool repaired = false;
+#pragma nounroll
+    for (int attempt = 0; attempt < 2; attempt++) {
+#pragma nounroll
+        for (int i = threadIdx.x; i < n; i += SEG_THREADS) {
+            L.key[i] = desc_key(a.score[b + i]);
+            L.pos[i] = (uint16_t)i;
         }
+        if (threadIdx.x == 0) L.n_long = 0;
         __syncthreads();
-        // thread d: digit d.  totals over the four wavefronts, exclusive scan
+        seg_passes(L, 0, n, attempt == 0 ? 4 : 0, 8);
+        if (attempt == 1) break;            // all 8 bytes done: sorted
+        // ---- runs of equal high words holding an inversion of low words
+        // (the tile is stably sorted by the high word: a run is contiguous
+        // and in input order).  The element that sees an inversion marks its
+        // run: bit 15 on every member of a short run, bit 14 on the first
+        // member of a long one.
+        if (threadIdx.x == 0) L.flag = 0;
+        __syncthreads();
         {
-            const int d = threadIdx.x;
-            const uint32_t c0 = wcnt[0][d], c1 = wcnt[1][d], c2 = wcnt[2][d],
-                           c3 = wcnt[3][d];
-            const uint32_t tot = c0 + c1 + c2 + c3;
-            if (d == 0) skip_flag = 0;
-            uint32_t inc = tot;                    // inclusive scan in the wave
-#pragma unroll
-            for (int off = 1; off < WAVE; off <<= 1) {
-                const uint32_t v = __shfl_up(inc, off, WAVE);
-                if (lane >= off) inc += v;
-            }
-            if (lane == WAVE - 1) wave_tot[wave] = inc;
-            __syncthreads();
-            uint32_t before = 0;
-            for (int w = 0; w < wave; w++) before += wave_tot[w];
-            const uint32_t excl = before + inc - tot;
-            dbase[d] = excl;
-            // exclusive over wavefronts, in place
-            wcnt[0][d] = 0; wcnt[1][d] = c0; wcnt[2][d] = c0 + c1;
-            wcnt[3][d] = c0 + c1 + c2;
-            if (tot == (uint32_t)n) skip_flag = 1;
-        }
-        __syncthreads();
-        if (skip_flag) { __syncthreads(); continue; }
-#pragma unroll
-        for (int r = 0; r < SEG_ROUNDS; r++) {
-            if (r < rounds) {
-                const int i = w0 + r * WAVE + lane;
-                if (i < n) {
-                    const uint32_t dig = (uint32_t)(kr[r] >> (8 * pass)) & 255u;
-                    const uint32_t dst = dbase[dig] + wcnt[wave][dig] + rank[r];
-                    key[dst] = kr[r];
-                    pos[dst] = pr[r];
+            int state = 0;
+#pragma nounroll
+            for (int i = threadIdx.x + 1; i < n; i += SEG_THREADS) {
+                const uint64_t prev = L.key[i - 1], cur = L.key[i];
+                if ((prev >> 32) == (cur >> 32) && prev > cur) {
+                    const uint32_t h = (uint32_t)(cur >> 32);
+                    int s0 = i - 1, e0 = i + 1;
+                    while (s0 > 0 && e0 - s0 <= SEG_RUN_MAX &&
+                           (uint32_t)(L.key[s0 - 1] >> 32) == h) s0--;
+                    while (e0 < n && e0 - s0 <= SEG_RUN_MAX &&
+                           (uint32_t)(L.key[e0] >> 32) == h) e0++;
+                    if (e0 - s0 > SEG_RUN_MAX) {
+                        while (s0 > 0 && (uint32_t)(L.key[s0 - 1] >> 32) == h) s0--;
+                        L.pos[s0] |= 0x4000u;
+                        state = 2;
+                    } else {
+                        for (int j = s0; j < e0; j++) L.pos[j] |= 0x8000u;
+                        state = max(state, 1);
+                    }
                 }
             }
+            if (state) atomicMax(&L.flag, state);
         }
         __syncthreads();
-#pragma unroll
-        for (int r = 0; r < SEG_ROUNDS; r++) {
-            if (r < rounds) {
-                const int i = w0 + r * WAVE + lane;
-                if (i < n) { kr[r] = key[i]; pr[r] = pos[i]; }
+        repaired = L.flag != 0;
+        if (L.flag != 2) break;
+        // ---- long runs: list them, then four low-byte passes on each
+#pragma nounroll
+        for (int i = threadIdx.x; i < n; i += SEG_THREADS) {
+            if (L.pos[i] & 0x4000u) {
+                L.pos[i] &= 0xbfffu;
+                const int slot = atomicAdd(&L.n_long, 1);
+                if (slot < SEG_LONG_MAX) { L.long_s[slot] = i; L.long_e[slot] = n; }
             }
         }
         __syncthreads();
+        const int n_long = L.n_long;
+        if (n_long > SEG_LONG_MAX) { repaired = false; continue; }    // start over
+        {   // end of every long run: first index past it with another high word
+            for (int q = 0; q < n_long; q++) {
+                const int s0 = L.long_s[q];
+                const uint32_t h = (uint32_t)(L.key[s0] >> 32);
+#pragma nounroll
+                for (int i = s0 + 1 + threadIdx.x; i < n; i += SEG_THREADS)
+                    if ((uint32_t)(L.key[i] >> 32) != h) { atomicMin(&L.long_e[q], i); break; }
+            }
+        }
+        __syncthreads();
+        for (int q = 0; q < n_long; q++)
+            seg_passes(L, L.long_s[q], L.long_e[q] - L.long_s[q], 0, 4);
+        break;
     }
+    // ---- output from LDS; a marked element goes to its rank in its run by
+    // (key, position in the run)
     const bool single = se - sb <= SEG_TILE;
-#pragma unroll
-    for (int r = 0; r < SEG_ROUNDS; r++) {
-        if (r < rounds) {
-            const int i = w0 + r * WAVE + lane;
-            if (i < n) {
-                const int32_t d = b + pr[r];
-                if (single) {
-                    if (a.order) a.order[b + i] = d;
-                    if (a.dst) a.dst[d] = b + i;
-                } else {
-                    a.key[0][b + i] = kr[r];
-                    a.idx[0][b + i] = d;
-                }
+#pragma nounroll
+    for (int i = threadIdx.x; i < n; i += SEG_THREADS) {
+        const uint64_t mine = L.key[i];
+        const uint32_t pw = L.pos[i];
+        int to = i;
+        if (repaired && (pw & 0x8000u)) {
+            const uint32_t h = (uint32_t)(mine >> 32);
+            int s0 = i, e0 = i + 1;
+            while (s0 > 0 && (uint32_t)(L.key[s0 - 1] >> 32) == h) s0--;
+            while (e0 < n && (uint32_t)(L.key[e0] >> 32) == h) e0++;
+            int rk = 0;
+            for (int j = s0; j < e0; j++) {
+                const uint64_t o = L.key[j];
+                rk += (o < mine || (o == mine && j < i)) ? 1 : 0;
             }
+            to = s0 + rk;
+        }
+        const int32_t d = b + (int32_t)(pw & 0x0fffu);
+        if (single) {
+            if (a.order) a.order[b + to] = d;
+            if (a.dst) a.dst[d] = b + to;
+        } else {
+            a.key[0][b + to] = mine;
+            a.idx[0][b + to] = d;
         }
     }
 }

@@ -201,7 +201,9 @@ def test_sharded_path_on_one_gpu_equals_plain_path():
 
 
 @pytest.mark.parametrize("n,n_cat,quant", [(50000, 7, 50), (200000, 3, 0), (3000, 500, 5),
-                                            (70000, 1, 3)])
+                                            (70000, 1, 3), (60000, 40, -1), (60000, 40, -2),
+                                            (20000, 300, -1), (9000, 2, -2), (30000, 20, -3),
+                                            (5000, 1, -3), (100000, 60, -4)])
 def test_both_sorts_are_the_stable_mergesort_order(n, n_cat, quant):
     """Radix sort and tile+merge sort against numpy's stable argsort, with
     heavy score ties and categories far longer than one LDS tile."""
@@ -211,8 +213,25 @@ def test_both_sorts_are_the_stable_mergesort_order(n, n_cat, quant):
     rng = np.random.default_rng(n + n_cat)
     cat = np.sort(rng.integers(0, n_cat, n)).astype(np.int32)
     score = rng.random(n)
-    if quant:
+    if quant > 0:
         score = np.round(score * quant) / quant
+    elif quant == -1:
+        # few elements per high key word, different low words: the run repair
+        base = np.round(rng.random(n) * (n // 3)) / (n // 3) * 0.5 + 0.25
+        score = base + rng.integers(0, 1 << 20, n) * 2.0 ** -50
+    elif quant in (-3, -4):
+        # a few long runs of equal high words per tile (low-byte passes on the
+        # run only); -4: mixed with ordinary scores and exact ties
+        base = np.round(rng.random(n) * 3) / 3 * 0.5 + 0.25
+        score = base + rng.integers(0, 1 << 20, n) * 2.0 ** -50
+        if quant == -4:
+            other = rng.random(n)
+            score = np.where(rng.random(n) < 0.5, other, score)
+            score[rng.random(n) < 0.1] = 0.75
+    elif quant == -2:
+        # long runs of equal high words with different low words: full sort
+        base = np.round(rng.random(n) * 20) / 20 * 0.5 + 0.25
+        score = base + rng.integers(0, 1 << 20, n) * 2.0 ** -50
     score[rng.integers(0, n, 5)] = -0.0
     score[rng.integers(0, n, 5)] = 0.0
     want = np.lexsort((np.arange(n), -score, cat))
