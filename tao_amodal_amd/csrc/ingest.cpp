@@ -21,6 +21,8 @@
 // Numbers are converted with std::from_chars (correctly rounded, the same
 // value Python's float() gives), so the columns are bit-identical to what
 // `json.load` + numpy conversion produce (tests/test_ingest.py).
+#include "../../include/tao_amodal_ingest.h"
+
 #include <charconv>
 #include <cmath>
 #include <cstdint>

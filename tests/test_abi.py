@@ -21,6 +21,17 @@ def test_header_symbols_are_exported_and_bound():
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
 
 
+def test_ingest_header_symbols_are_exported():
+    import ctypes
+    text = open(os.path.join(ROOT, "include", "tao_amodal_ingest.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    declared = set(re.findall(r"\b(taoamd_[a-z_0-9]+)\s*\(", text))
+    assert len(declared) == 7, declared
+    lib = ctypes.CDLL(os.path.join(ROOT, "tao_amodal_amd", "libtao_amodal_ingest.so"))
+    for name in sorted(declared):
+        assert hasattr(lib, name), name
+
+
 def test_thresholds_are_numpy_linspace_bit_for_bit():
     lib = _lib.load()
     a, b = np.zeros(10), np.zeros(101)

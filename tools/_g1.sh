@@ -1,4 +1,5 @@
-cd /root/repo
-mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/t.log 2>&1; grep -E "passed|failed|^E  " gpurun_out/t.log | head -20
-timeout 600 python bench.py --steps 50 --warmup 5 > gpurun_out/b_single.json 2> gpurun_out/b_single.err; tail -2 gpurun_out/b_single.err
+cd /tmp; export TMPDIR=/tmp
+R=/root/repo
+mkdir -p $R/gpurun_out/prof4
+cd $R
+timeout 900 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/prof4 -o s -- python bench.py --steps 20 --warmup 5 --no-cpu > gpurun_out/b_prof.json 2> gpurun_out/b_prof.err
