@@ -253,6 +253,36 @@ def main():
         cands.sort(key=lambda c: -c["kernel_ms"])
         roof, roof_other = cands[0], cands[1]
 
+    # ---- multi-GPU: every rank checks the assembled tables against what the
+    # owners computed.  Own block: the plain single-GPU pass over this rank's
+    # shard must give the same precision / recall block, bit for bit.  Other
+    # blocks: a checksum of checksums -- each owner publishes the wrapping
+    # int64 sum of its block's bit patterns, every rank compares it with the
+    # sum over that block of ITS assembled table.
+    exchange_ok = None
+    if by_category and not args.emulate:
+        ok = True
+        for ev, dp, ws in ((plan.lvis, dpl, wsl), (plan.tao, dpt, wst)):
+            engine.run(dp, ws)
+            k0, k1, Kb = ev.k0, ev.k1, ev.Kb
+            own = torch.zeros(2, dtype=torch.int64, device=dev)
+            if k1 > k0:
+                ok &= bool(torch.equal(ws.precision[:, :, k0:k1], ev.precision[:, :, k0:k1]))
+                ok &= bool(torch.equal(ws.recall[:, k0:k1], ev.recall[:, k0:k1]))
+                own[0] = ws.precision[:, :, k0:k1].contiguous().view(torch.int64).sum()
+                own[1] = ws.recall[:, k0:k1].contiguous().view(torch.int64).sum()
+            sums = torch.zeros((world, 2), dtype=torch.int64, device=dev)
+            dist.all_gather_into_tensor(sums, own)
+            for r in range(world):
+                a, b = min(r * Kb, dp.n_cat), min((r + 1) * Kb, dp.n_cat)
+                if b > a:
+                    ok &= int(ev.precision[:, :, a:b].contiguous().view(torch.int64).sum()) == int(sums[r, 0])
+                    ok &= int(ev.recall[:, a:b].contiguous().view(torch.int64).sum()) == int(sums[r, 1])
+            ev.check()
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        exchange_ok = bool(flag.item())
+
     # ---- verification + CPU baseline (C oracle = "port"), rank 0, N=1
     cpu, verified = None, None
     if not use_dist and rank == 0 and not args.no_cpu:
@@ -317,6 +347,7 @@ def main():
             "host_launch_ms_per_step": round(host_ms, 4),
             "hip_graph": bool(args.graph and not args.serial and not use_dist),
             "bit_exact_vs_oracle": verified,
+            "exchange_verified": exchange_ok,
             "exchange_chunk_bytes": ([plan.lvis.chunk_bytes, plan.tao.chunk_bytes]
                                      if by_category else None),
             "host_s": {"generate": round(t_gen, 2), "flatten": round(t_flat, 2),
