@@ -284,11 +284,17 @@ __global__ __launch_bounds__(256) void track_iou_kernel(
 // Adding (0, 0) for an empty position is exact (u, i >= +0), so the sequence
 // of roundings equals the two-pointer merge over the union of frames.
 #define TD_MAP_ENTRIES 12288   // uint16 entries: (G + detection tracks) * span
-#define TD_CH 32               // timeline positions per chunk
+#ifndef TD_CH
+#define TD_CH 32
+#endif
+//              // timeline positions per chunk
 #define TD_PAIRS 64            // track pairs per detection-track group
 #define TD_GMAX 16             // GT tracks of a dense cell
 #define TD_NONE 0xffffu
-#define TD_IT 4                // phase-A items per thread and batch
+#ifndef TD_IT
+#define TD_IT 4
+#endif
+//               // phase-A items per thread and batch
 
 __device__ __forceinline__ bool dense_cell(int32_t span, int32_t D, int32_t G)
 {

@@ -165,17 +165,31 @@ class Flat(dict):
     __setattr__ = dict.__setitem__
 
 
+DENSE_TABLE_MAX = 1 << 28     # entries of a boolean membership table (256 MB)
+
+
+def _member(keys, universe, queries):
+    """queries[k] in keys, for non-negative integer keys < universe."""
+    if universe <= DENSE_TABLE_MAX:
+        table = np.zeros(universe + 1, dtype=bool)      # last slot: "absent"
+        table[keys[(keys >= 0) & (keys < universe)]] = True
+        ok = (queries >= 0) & (queries < universe)
+        return table[np.where(ok, queries, universe)]
+    return _lookup(np.unique(keys), queries) >= 0
+
+
 def _csr_member(off, val, row, item):
-    """item[k] in val[off[row[k]]:off[row[k]+1]] for every k (vectorised via a
-    sorted key table)."""
+    """item[k] in val[off[row[k]]:off[row[k]+1]] for every k (one gather
+    through a boolean table over (row, value); a sorted key table when that
+    would be too large)."""
     if len(val) == 0 or len(row) == 0:
         return np.zeros(len(row), dtype=bool)
     rows = np.repeat(np.arange(len(off) - 1), np.diff(off))
     lo = min(int(val.min()), int(item.min()))
     width = max(int(val.max()), int(item.max())) - lo + 1
     if width * (len(off) + 1) < (1 << 62):
-        keys = np.unique(rows * width + (val - lo))
-        return _lookup(keys, row * width + (item - lo)) >= 0
+        return _member(rows * width + (val - lo), width * (len(off) - 1),
+                       row * width + (item - lo))
     keys = np.stack([rows, val], 1)
     q = np.stack([row, item], 1)
     kd = np.ascontiguousarray(keys).view([("a", np.int64), ("b", np.int64)])
@@ -235,9 +249,8 @@ def flatten_lvis(gt: GTColumns, dt: DTColumns, max_dets=MAX_DETS):
     order = order[(d_cat[order] >= 0) & (d_area[order] > 0)
                   & (d_area[order] < np.inf)]
     U = len(img_ids)
-    key_present = np.unique(g_cat * U + g_img)
     k_of = d_cat[order] * U + d_img[order]
-    is_present = _lookup(key_present, k_of) >= 0
+    is_present = _member(g_cat * U + g_img, K * U, k_of)
     rows = img_row[d_img[order]]
     is_neg = _csr_member(gt.img_neg_off, gt.img_neg, rows,
                          d_catid[order])
@@ -506,8 +519,7 @@ def flatten_tao(gt: GTColumns, dt: DTColumns, max_dets=MAX_DETS,
     # ---- federated filter on the video lists (T/eval.py:214-233)
     U = len(vid_ids)
     if use_cats:
-        key_present = np.unique(g_cat * U + g_vid)
-        is_present = _lookup(key_present, d_cat * U + d_vid) >= 0
+        is_present = _member(g_cat * U + g_vid, K * U, d_cat * U + d_vid)
         is_neg = _csr_member(gt.vid_neg_off, gt.vid_neg, vid_row[d_vid],
                              d_catid)
         d_keep = np.flatnonzero(is_present | is_neg)
