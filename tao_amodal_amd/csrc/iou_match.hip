@@ -283,18 +283,12 @@ __global__ __launch_bounds__(256) void track_iou_kernel(
 //      no global memory on the serial chain.
 // Adding (0, 0) for an empty position is exact (u, i >= +0), so the sequence
 // of roundings equals the two-pointer merge over the union of frames.
-#define TD_MAP_ENTRIES 12288   // uint16 entries: (G + detection tracks) * span
-#ifndef TD_CH
-#define TD_CH 32
-#endif
-//              // timeline positions per chunk
+#define TD_MAP_ENTRIES 10240   // uint16 entries: (G + detection tracks) * span
+#define TD_CH 16               // timeline positions per chunk
 #define TD_PAIRS 64            // track pairs per detection-track group
-#define TD_GMAX 16             // GT tracks of a dense cell
+#define TD_GMAX 8              // GT tracks of a dense cell
 #define TD_NONE 0xffffu
-#ifndef TD_IT
-#define TD_IT 4
-#endif
-//               // phase-A items per thread and batch
+#define TD_IT 2                // phase-A items per thread and batch
 
 __device__ __forceinline__ bool dense_cell(int32_t span, int32_t D, int32_t G)
 {
@@ -315,8 +309,9 @@ __global__ __launch_bounds__(256) void track_iou_dense_kernel(
 {
     __shared__ uint16_t map[TD_MAP_ENTRIES];
     __shared__ double2 terms[TD_CH][TD_PAIRS + 1];
-    __shared__ double4 gbox[TD_GMAX * TD_CH];    // GT frames of the chunk
-    __shared__ int32_t first[2 * TD_PAIRS];   // first frame of every staged track
+    __shared__ double4 gbox[2][TD_GMAX * TD_CH];   // GT frames of this / the next chunk
+    // frame offsets of the staged tracks: [0, G] GT, [TD_PAIRS, TD_PAIRS + nd] detections
+    __shared__ int32_t first[2 * TD_PAIRS + 2];
     const int64_t c = blockIdx.x;
     const int32_t d0 = cell_dt_off[c], D = cell_dt_off[c + 1] - d0;
     const int32_t g0 = cell_gt_off[c], G = cell_gt_off[c + 1] - g0;
@@ -329,44 +324,65 @@ __global__ __launch_bounds__(256) void track_iou_dense_kernel(
     uint16_t *__restrict__ dmap = map + G * span;
     const double4 *__restrict__ DB = reinterpret_cast<const double4 *>(dfbox);
     const double4 *__restrict__ GB = reinterpret_cast<const double4 *>(gfbox);
+    // position -> frame rows.  The frames of the cell's tracks are one
+    // contiguous run of the CSR arrays: the rows are filled by a flat loop
+    // over that run (one round trip for the offsets, one for the positions)
+    // instead of track by track.
     for (int t = threadIdx.x; t < G * span; t += 256) gmap[t] = TD_NONE;
+    for (int g = threadIdx.x; g <= G; g += 256) first[g] = gfoff[g0 + g];
     __syncthreads();
-    for (int g = threadIdx.x >> 6; g < G; g += 4) {
-        const int32_t js = gfoff[g0 + g], je = gfoff[g0 + g + 1];
-        if (lane_id() == 0) first[g] = js;
-        for (int32_t j = js + lane_id(); j < je; j += WAVE)
-            gmap[g * span + gfpos[j]] = (uint16_t)(j - js);
+    for (int32_t j = first[0] + (int32_t)threadIdx.x; j < first[G]; j += 256) {
+        int g = 0;
+        while (g + 1 < G && first[g + 1] <= j) g++;
+        gmap[g * span + gfpos[j]] = (uint16_t)(j - first[g]);
     }
     unsigned long long common = 0;
     for (int32_t db = 0; db < D; db += DG) {
         const int nd = min(DG, D - db);
         __syncthreads();
         for (int t = threadIdx.x; t < nd * span; t += 256) dmap[t] = TD_NONE;
+        for (int dl = threadIdx.x; dl <= nd; dl += 256)
+            first[TD_PAIRS + dl] = dfoff[d0 + db + dl];
         __syncthreads();
-        for (int dl = threadIdx.x >> 6; dl < nd; dl += 4) {
-            const int32_t ks = dfoff[d0 + db + dl], ke = dfoff[d0 + db + dl + 1];
-            if (lane_id() == 0) first[TD_PAIRS + dl] = ks;
-            for (int32_t k = ks + lane_id(); k < ke; k += WAVE)
-                dmap[dl * span + dfpos[k]] = (uint16_t)(k - ks);
+        for (int32_t k = first[TD_PAIRS] + (int32_t)threadIdx.x; k < first[TD_PAIRS + nd];
+             k += 256) {
+            int lo = 0, hi = nd;            // last dl with first[dl] <= k
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (first[TD_PAIRS + mid] <= k) lo = mid; else hi = mid;
+            }
+            dmap[lo * span + dfpos[k]] = (uint16_t)(k - first[TD_PAIRS + lo]);
+        }
+        // GT frames of chunk 0 (later chunks are staged one chunk ahead,
+        // inside phase A)
+        if ((int)threadIdx.x < G * TD_CH) {
+            const int g = threadIdx.x / TD_CH, pp = threadIdx.x % TD_CH;
+            double4 A = make_double4(0, 0, -1.0, 0);   // w < 0: absent
+            if (pp < span) {
+                const uint32_t rg = gmap[g * span + pp];
+                if (rg != TD_NONE) A = GB[first[g] + (int32_t)rg];
+            }
+            gbox[0][g * TD_CH + pp] = A;
         }
         __syncthreads();
         double u = 0.0, i = 0.0;   // running sums of pair = threadIdx.x
         const int pairs = nd * G;
         for (int32_t p0 = 0; p0 < span; p0 += TD_CH) {
             const int np = min(TD_CH, span - p0);
-            // ---- phase A0: the chunk's GT frames -> LDS (each GT box is
-            // needed by every detection track of the group)
-            // (items are laid out with a fixed stride of TD_CH positions, so the
-            // decode is a shift and a mask; positions >= np are skipped)
-            for (int it = threadIdx.x; it < G * TD_CH; it += 256) {
-                const int g = it / TD_CH, pp = it % TD_CH;
-                if (pp >= np) continue;
-                const uint32_t rg = gmap[g * span + p0 + pp];
-                double4 A = make_double4(0, 0, -1.0, 0);   // w < 0: absent
-                if (rg != TD_NONE) A = GB[first[g] + (int32_t)rg];
-                gbox[g * TD_CH + pp] = A;
+            const int cur = (p0 / TD_CH) & 1;
+            // GT frames of the NEXT chunk: the load is issued here, together
+            // with the detection-box loads of phase A, and parked in the
+            // other half of gbox at the end of the phase (one global round
+            // trip and one barrier per chunk instead of two)
+            double4 An = make_double4(0, 0, -1.0, 0);   // w < 0: absent
+            const bool stage = (int)threadIdx.x < G * TD_CH && p0 + TD_CH < span;
+            if (stage) {
+                const int g = threadIdx.x / TD_CH, pp = threadIdx.x % TD_CH;
+                if (p0 + TD_CH + pp < span) {
+                    const uint32_t rg = gmap[g * span + p0 + TD_CH + pp];
+                    if (rg != TD_NONE) An = GB[first[g] + (int32_t)rg];
+                }
             }
-            __syncthreads();
             // ---- phase A: item = (detection track, position): consecutive
             // threads read consecutive frames of one track (coalesced); the
             // TD_IT box loads of a thread are issued together
@@ -393,7 +409,7 @@ __global__ __launch_bounds__(256) void track_iou_dense_kernel(
                     if (dl < nd && pp < np) {
                         const double da = B[q].z * B[q].w;
                         for (int g = 0; g < G; g++) {
-                            const double4 A = gbox[g * TD_CH + pp];
+                            const double4 A = gbox[cur][g * TD_CH + pp];
                             const bool hg = !(A.z < 0);
                             double w = fmin(B[q].x + B[q].z, A.x + A.z) - fmax(B[q].x, A.x);
                             double h = fmin(B[q].y + B[q].w, A.y + A.w) - fmax(B[q].y, A.y);
@@ -418,6 +434,7 @@ __global__ __launch_bounds__(256) void track_iou_dense_kernel(
                     }
                 }
             }
+            if (stage) gbox[cur ^ 1][threadIdx.x] = An;   // index = g * TD_CH + pp
             __syncthreads();
             // ---- phase B
             if ((int)threadIdx.x < pairs) {

@@ -79,12 +79,13 @@ def test_synthetic_hip_vs_c_oracle(seed, V, F, C, dpf):
 
 
 def test_long_timelines_take_the_merge_kernel_and_gt_groups():
-    """(G + 1) * span > 12288 (or more than 16 GT tracks) -> two-pointer merge kernel; otherwise the
+    """(G + 1) * span > 10240 (or more than 8 GT tracks) -> two-pointer merge kernel; otherwise the
     dense-timeline kernel, with detection tracks staged in several groups
     when the cell has many of them."""
     from tao_amodal_amd import engine
     for seed, V, F, G, dense in ((31, 1, 1100, 24, False), (32, 2, 200, 40, False),
-                                 (34, 2, 200, 24, True), (33, 1, 300, 8, True)):
+                                 (34, 2, 200, 14, True), (33, 1, 300, 8, True),
+                                 (35, 2, 150, 18, False)):
         gt, dt = synth(seed=seed, V=V, F=F, C=6, dets_per_frame=40,
                        gt_tracks_per_video=G, n_present=2, n_neg=1)
         dt.track_id, _ = fl.make_track_ids_unique(dt)
