@@ -278,8 +278,8 @@ def _worker_cat(rank, world, port, out):
 
 
 @pytest.mark.timeout(600)
-def test_category_partition_two_ranks_reproduce_the_whole_problem(tmp_path):
-    world = 2
+@pytest.mark.parametrize("world", [2, 3])
+def test_category_partition_ranks_reproduce_the_whole_problem(tmp_path, world):
     mp.spawn(_worker_cat, args=(world, _free_port(), str(tmp_path)), nprocs=world,
              join=True)
     from tao_amodal_amd import flatten
