@@ -56,6 +56,14 @@ int taoamd_gt_array(void *handle, const char *name, const void **ptr,
                     int64_t *count, int *elem);
 void taoamd_gt_free(void *handle);
 
+/* ---- host-side sort used while the cell tables are built
+ * order[] = np.lexsort((arange(n), -score, key)) -- the (cell, descending
+ * score, stable) order of lvis_amodal/eval.py:168-174 and the top-300
+ * selection of lvis_amodal/results.py:73-84 -- as a parallel stable merge
+ * sort; score may be NULL (stable argsort of key).  Returns 0. */
+int taoamd_host_sort_key_score(int64_t n, const int64_t *key, const double *score,
+                               int64_t *order);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,6 +23,8 @@
 // `json.load` + numpy conversion produce (tests/test_ingest.py).
 #include "../../include/tao_amodal_ingest.h"
 
+#include <parallel/algorithm>
+
 #include <charconv>
 #include <cmath>
 #include <cstdint>
@@ -614,5 +616,31 @@ int taoamd_gt_array(void *h, const char *name, const void **ptr, int64_t *count,
 }
 
 void taoamd_gt_free(void *h) { delete (GT *)h; }
+
+// order[] = np.lexsort((arange(n), -score, key)): ascending key, descending
+// score inside a key (NaN scores last, -0.0 == 0.0), input order on ties.
+// score may be NULL (plain stable argsort of key).  Records are sorted by
+// value (no indirect comparisons) with the parallel stable merge sort of
+// libstdc++.
+int taoamd_host_sort_key_score(int64_t n, const int64_t *key, const double *score,
+                               int64_t *order)
+{
+    if (n < 0 || (n > 0 && (!key || !order))) return 1;
+    struct Rec { int64_t key; double neg; int64_t idx; };
+    std::vector<Rec> r((size_t)n);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; i++) r[i] = Rec{key[i], score ? -score[i] : 0.0, i};
+    if (score)
+        __gnu_parallel::stable_sort(r.begin(), r.end(), [](const Rec &a, const Rec &b) {
+            if (a.key != b.key) return a.key < b.key;
+            return a.neg < b.neg || (b.neg != b.neg && a.neg == a.neg);
+        });
+    else
+        __gnu_parallel::stable_sort(r.begin(), r.end(),
+                                    [](const Rec &a, const Rec &b) { return a.key < b.key; });
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; i++) order[i] = r[i].idx;
+    return 0;
+}
 
 }  // extern "C"

@@ -51,6 +51,47 @@ DT_IGNORE_UNMATCHED = 1   # unmatched detection is ignored (not exhaustive...)
 DT_NO_CONSUME = 2         # id <= 0: a match does not mark the GT as taken
 
 
+_HOST_LIB = None
+
+
+def _host_lib():
+    """libtao_amodal_ingest.so (native host helpers) or False when not built."""
+    global _HOST_LIB
+    if _HOST_LIB is None:
+        import ctypes as C
+        import os
+        so = os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                          "libtao_amodal_ingest.so")
+        _HOST_LIB = False
+        if os.path.exists(so):
+            lib = C.CDLL(so)
+            if hasattr(lib, "taoamd_host_sort_key_score"):
+                lib.taoamd_host_sort_key_score.argtypes = [
+                    C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+                _HOST_LIB = lib
+    return _HOST_LIB
+
+
+def sort_key_score(key, score=None):
+    """``np.lexsort((arange(n), -score, key))`` (``score=None``: stable argsort
+    of key) through the parallel native sort when the host library is built
+    and the input is large enough to pay for the call."""
+    n = len(key)
+    lib = _host_lib() if n >= 50000 else False
+    if not lib:
+        if score is None:
+            return np.argsort(key, kind="stable")
+        return np.lexsort((np.arange(n), -np.asarray(score, dtype=np.float64), key))
+    key = np.ascontiguousarray(key, dtype=np.int64)
+    sc = None if score is None else np.ascontiguousarray(score, dtype=np.float64)
+    order = np.empty(n, dtype=np.int64)
+    rc = lib.taoamd_host_sort_key_score(n, key.ctypes.data,
+                                        None if sc is None else sc.ctypes.data,
+                                        order.ctypes.data)
+    assert rc == 0
+    return order
+
+
 def _lookup(sorted_keys, values):
     """index of each value in sorted_keys (ascending, unique), -1 when absent"""
     if len(sorted_keys) == 0:
@@ -118,14 +159,13 @@ def limit_dets_per_image(dt, max_dets=MAX_DETS):
     img_rank = rank_of_img[inv]
     if max_dets >= 0 and (cnt > max_dets).any():
         big = (cnt > max_dets)[inv]
-        key = np.where(big, -dt.score, 0.0)
-        order = np.lexsort((np.arange(n), key, img_rank))
+        order = sort_key_score(img_rank, np.where(big, dt.score, 0.0))
         r = img_rank[order]
         start = np.flatnonzero(np.r_[True, r[1:] != r[:-1]])
         pos = np.arange(n) - np.repeat(start, np.diff(np.r_[start, n]))
         order = order[pos < max_dets]
     else:
-        order = np.argsort(img_rank, kind="stable")
+        order = sort_key_score(img_rank)
     try:
         dt._limit_cache = (max_dets, n, order)
     except AttributeError:
@@ -260,10 +300,10 @@ def flatten_lvis(gt: GTColumns, dt: DTColumns, max_dets=MAX_DETS):
     keys_g = g_cat * U + g_img
     keys_d = d_cat[order] * U + d_img[order]
     # detections: by cell, then descending score, stable in visiting order
-    o2 = np.lexsort((np.arange(len(order)), -d_score[order], keys_d))
+    o2 = sort_key_score(keys_d, d_score[order])
     order = order[o2]
     keys_d = keys_d[o2]
-    og = np.argsort(keys_g, kind="stable")
+    og = sort_key_score(keys_g)
     g_sel, keys_g = g_sel[og], keys_g[og]
     cell_keys, g_cell, d_cell, g_off, d_off = _cells(keys_g, keys_d)
 
@@ -335,7 +375,7 @@ def _group_tracks(sel_trk, sel_frame_index):
     t_rank = np.empty(len(uniq), dtype=np.int64)
     t_rank[np.argsort(first, kind="stable")] = np.arange(len(uniq))
     trk_of_ann = t_rank[inv]
-    perm = np.lexsort((np.arange(len(sel_trk)), sel_frame_index, trk_of_ann))
+    perm = sort_key_score(trk_of_ann, -np.asarray(sel_frame_index, dtype=np.float64))
     off = np.zeros(len(uniq) + 1, dtype=np.int64)
     np.cumsum(np.bincount(trk_of_ann, minlength=len(uniq)), out=off[1:])
     ids = np.empty(len(uniq), dtype=np.int64)
@@ -349,7 +389,7 @@ def _unique_frames(trk_of, pos_of, n_trk):
     Inputs are per-annotation arrays already grouped by track.  Returns
     (selection into the annotations, CSR offsets)."""
     n = len(trk_of)
-    order = np.lexsort((np.arange(n), pos_of, trk_of))
+    order = sort_key_score(trk_of, -pos_of.astype(np.float64))
     t, p = trk_of[order], pos_of[order]
     last = np.r_[(t[1:] != t[:-1]) | (p[1:] != p[:-1]), True] if n else \
         np.zeros(0, bool)
@@ -525,8 +565,8 @@ def flatten_tao(gt: GTColumns, dt: DTColumns, max_dets=MAX_DETS,
         d_keep = np.flatnonzero(is_present | is_neg)
         keys_g = g_cat * U + g_vid
         keys_d = d_cat[d_keep] * U + d_vid[d_keep]
-        o2 = np.lexsort((np.arange(len(d_keep)), -d_score[d_keep], keys_d))
-        og = np.argsort(keys_g, kind="stable")
+        o2 = sort_key_score(keys_d, d_score[d_keep])
+        og = sort_key_score(keys_g)
     else:
         d_keep = np.arange(len(d_ids))
         keys_g = g_vid.copy()

@@ -165,3 +165,44 @@ def test_annotation_classes_share_the_native_columns(tmp_path):
         assert obj.get_cat_ids() == gt.cat_id.tolist()
         assert obj._dataset is None
         assert len(obj.dataset["annotations"]) == len(gt.ann_id)
+
+
+# ---------------------------------------------------------------- host sort
+def test_native_sort_equals_numpy_lexsort():
+    from tao_amodal_amd import flatten
+    assert flatten._host_lib(), "host library not built"
+    rng = np.random.default_rng(5)
+    for n, nkeys, quant in ((60000, 7, 0), (200000, 50000, 20), (70000, 1, 3)):
+        key = rng.integers(0, nkeys, n).astype(np.int64) * 1000003 - 17
+        score = rng.random(n)
+        if quant:
+            score = np.round(score * quant) / quant
+        score[rng.integers(0, n, 50)] = np.nan
+        score[rng.integers(0, n, 50)] = -0.0
+        score[rng.integers(0, n, 50)] = 0.0
+        score[rng.integers(0, n, 20)] = np.inf
+        want = np.lexsort((np.arange(n), -score, key))
+        assert np.array_equal(flatten.sort_key_score(key, score), want)
+        assert np.array_equal(flatten.sort_key_score(key),
+                              np.argsort(key, kind="stable"))
+
+
+def test_flatten_is_the_same_with_and_without_the_native_sort(monkeypatch):
+    from tao_amodal_amd import flatten
+    gt, dt = synth(seed=12, V=8, F=120, C=40, dets_per_frame=70, n_present=6)
+    assert len(dt) > 50000
+    a_l = flatten.flatten_lvis(gt, dt)
+    ids, _ = flatten.make_track_ids_unique(dt)
+    dt.track_id = ids
+    a_t = flatten.flatten_tao(gt, dt)
+    monkeypatch.setattr(flatten, "_HOST_LIB", False)
+    dt._limit_cache = None
+    b_l = flatten.flatten_lvis(gt, dt)
+    b_t = flatten.flatten_tao(gt, dt)
+    for a, b in ((a_l, b_l), (a_t, b_t)):
+        assert a.keys() == b.keys()
+        for k in a:
+            if isinstance(a[k], np.ndarray):
+                assert np.array_equal(a[k], b[k]), k
+            else:
+                assert a[k] == b[k], k
