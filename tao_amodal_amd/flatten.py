@@ -480,24 +480,26 @@ def flatten_tao(gt: GTColumns, dt: DTColumns, max_dets=MAX_DETS,
         raise AssertionError(
             "Track id {} appears in more than one video".format(int(bad)))
     keep = limit_dets_per_image(dt, max_dets)
-    d = dt.take(keep)
+    # columns of the kept boxes (the boxes themselves are gathered once, when
+    # the frame lists are built)
+    d_track, d_image = dt.track_id[keep], dt.image_id[keep]
     d_cat_id = pred_cat[keep]
-    u, first, inv = first_inverse(d.track_id)
+    u, first, inv = first_inverse(d_track)
     if (d_cat_id != d_cat_id[first][inv]).any():
-        bad = d.track_id[np.flatnonzero(d_cat_id != d_cat_id[first][inv])[0]]
+        bad = d_track[np.flatnonzero(d_cat_id != d_cat_id[first][inv])[0]]
         raise AssertionError(
             "Annotations for track {} have multiple categories".format(
                 int(bad)))
-    d_img = _lookup(img_ids, d.image_id)
+    d_img = _lookup(img_ids, d_image)
     if (d_img < 0).any():
         raise AssertionError("Results do not correspond to current Tao set.")
-    d_area = d.bbox[:, 2] * d.bbox[:, 3]
+    d_area = (dt.bbox[:, 2] * dt.bbox[:, 3])[keep]
     # track score over *all* kept boxes of the track (T/results.py:88-98)
     trk_score = np.empty(len(u))
     by_trk = np.argsort(inv, kind="stable")
     t_off = np.zeros(len(u) + 1, dtype=np.int64)
     np.cumsum(np.bincount(inv, minlength=len(u)), out=t_off[1:])
-    sc = d.score[by_trk]
+    sc = dt.score[keep[by_trk]]
     seg_min = np.minimum.reduceat(sc, t_off[:-1])
     seg_max = np.maximum.reduceat(sc, t_off[:-1])
     trk_score[:] = sc[t_off[:-1]]
@@ -505,14 +507,14 @@ def flatten_tao(gt: GTColumns, dt: DTColumns, max_dets=MAX_DETS,
     for k in np.flatnonzero(seg_min != seg_max):
         required_average = True
         trk_score[k] = np.mean(sc[t_off[k]:t_off[k + 1]])
-    dt_trk_vid = d.video_id[first]
+    dt_trk_vid = dt.video_id[keep[first]]
     dt_trk_cat = d_cat_id[first]
 
     def select(a_img_idx, a_cat_idx, a_area, a_ids):
         """get_ann_ids(vid_ids, cat_ids) + load_anns (T/tao.py:203-254)"""
         sel = np.flatnonzero(a_img_idx >= 0)
         sel = sel[visit_rank[a_img_idx[sel]] >= 0]
-        sel = sel[np.argsort(visit_rank[a_img_idx[sel]], kind="stable")]
+        sel = sel[sort_key_score(visit_rank[a_img_idx[sel]])]
         sel = sel[(a_cat_idx[sel] >= 0) & (a_area[sel] > 0)
                   & (a_area[sel] < np.inf)]
         return _last_with_same_id(a_ids)[sel]
@@ -532,7 +534,7 @@ def flatten_tao(gt: GTColumns, dt: DTColumns, max_dets=MAX_DETS,
     g_ann = g_sel[g_perm]                          # annotations, track-major
     g_trk_of_ann = np.repeat(np.arange(len(g_ids)), np.diff(g_aoff))
     d_ids, d_perm, d_aoff = _group_tracks(
-        d.track_id[d_sel], gt.img_frame[img_row[d_img[d_sel]]])
+        d_track[d_sel], gt.img_frame[img_row[d_img[d_sel]]])
     d_ann = d_sel[d_perm]
     d_trk_of_ann = np.repeat(np.arange(len(d_ids)), np.diff(d_aoff))
 
@@ -581,31 +583,55 @@ def flatten_tao(gt: GTColumns, dt: DTColumns, max_dets=MAX_DETS,
     cell_keys, g_cell, d_cell, g_off, d_off = _cells(keys_g, keys_d)
 
     # ---- frames per track (unique images, timeline order)
-    def frames(trk_order, trk_of_ann, ann_rows, img_idx_of_ann, boxes):
-        # renumber tracks to their final (cell) position
-        new_of_old = np.full(int(trk_of_ann.max()) + 1 if len(trk_of_ann)
-                             else 0, -1, dtype=np.int64)
-        new_of_old[trk_order] = np.arange(len(trk_order))
-        nt = new_of_old[trk_of_ann]
-        live = np.flatnonzero(nt >= 0)
-        sel, off = _unique_frames(nt[live], tl_pos[img_idx_of_ann[live]],
-                                  len(trk_order))
-        rows = live[sel]
-        return (tl_pos[img_idx_of_ann[rows]].astype(I32),
+    def frames(trk_order, trk_of_ann, aoff, ann_rows, img_idx_of_ann, boxes):
+        """Frame lists of the tracks `trk_order` (final, cell order).  The
+        annotations are grouped by track (CSR `aoff`) in frame_index order."""
+        pos = tl_pos[img_idx_of_ann]
+        if len(pos) > 1:
+            rising = pos[1:] > pos[:-1]
+            rising[aoff[1:-1][aoff[1:-1] < len(pos)] - 1] = True   # track boundaries
+        if len(pos) <= 1 or rising.all():
+            # every track already lists distinct images in timeline order (the
+            # usual case): the result is just the tracks' segments, permuted
+            lens = np.diff(aoff)[trk_order]
+            off = np.zeros(len(trk_order) + 1, dtype=np.int64)
+            np.cumsum(lens, out=off[1:])
+            rows = np.repeat(aoff[:-1][trk_order] - off[:-1], lens) + \
+                np.arange(int(off[-1]))
+        else:
+            # renumber tracks to their final (cell) position, sort, keep the
+            # last annotation of every (track, image)
+            new_of_old = np.full(int(trk_of_ann.max()) + 1 if len(trk_of_ann)
+                                 else 0, -1, dtype=np.int64)
+            new_of_old[trk_order] = np.arange(len(trk_order))
+            nt = new_of_old[trk_of_ann]
+            live = np.flatnonzero(nt >= 0)
+            sel, off = _unique_frames(nt[live], pos[live], len(trk_order))
+            rows = live[sel]
+        return (pos[rows].astype(I32),
                 np.ascontiguousarray(boxes[ann_rows[rows]]), off.astype(I32))
 
-    g_fpos, g_fbox, g_foff = frames(og, g_trk_of_ann, g_ann, a_img[g_ann],
+    g_fpos, g_fbox, g_foff = frames(og, g_trk_of_ann, g_aoff, g_ann, a_img[g_ann],
                                     gt.ann_bbox)
-    d_fpos, d_fbox, d_foff = frames(d_keep, d_trk_of_ann, d_ann, d_img[d_ann],
-                                    d.bbox)
+    d_fpos, d_fbox, d_foff = frames(d_keep, d_trk_of_ann, d_aoff, keep[d_ann],
+                                    d_img[d_ann], dt.bbox)
 
     # 1 + largest timeline position used by a cell (sizes the LDS tables of
     # the dense-timeline 3D-IoU kernel)
-    span = np.zeros(len(cell_keys), dtype=np.int64)
-    if len(g_fpos):
-        np.maximum.at(span, np.repeat(g_cell, np.diff(g_foff)), g_fpos + 1)
-    if len(d_fpos):
-        np.maximum.at(span, np.repeat(d_cell, np.diff(d_foff)), d_fpos + 1)
+    def cell_span(fpos, foff, coff):
+        # positions ascend inside a track and the tracks of a cell are
+        # contiguous: last position of every track, then a segmented max
+        ts = np.zeros(len(foff) - 1, dtype=np.int64)
+        has = np.diff(foff) > 0
+        ts[has] = fpos[foff[1:][has] - 1].astype(np.int64) + 1
+        cs = np.zeros(len(coff) - 1, dtype=np.int64)
+        ne = np.diff(coff) > 0
+        if ne.any():
+            cs[ne] = np.maximum.reduceat(ts, coff[:-1][ne])
+        return cs
+
+    span = np.maximum(cell_span(g_fpos, g_foff, g_off),
+                      cell_span(d_fpos, d_foff, d_off))
     nel = _csr_member(gt.vid_nel_off, gt.vid_nel, vid_row[d_vid[d_keep]],
                       d_catid[d_keep])
     f = Flat()
