@@ -23,6 +23,7 @@
 // `json.load` + numpy conversion produce (tests/test_ingest.py).
 #include "../../include/tao_amodal_ingest.h"
 
+#include <omp.h>
 #include <parallel/algorithm>
 
 #include <charconv>
@@ -125,6 +126,103 @@ struct Cursor {
     }
 };
 
+// Byte ranges of the container elements of a JSON list, `p0` = first byte
+// after the list's '['.  Returns the position of the list's closing bracket
+// (nullptr: unterminated); *closed_by is that character (']' for a well
+// formed list).  Elements that are not containers (numbers, strings) are not
+// reported, like the one-pass scan this replaces.
+//
+// Large inputs are scanned in parallel, simdjson-style, in three sweeps over
+// per-thread chunks: (A) unescaped quotes per chunk -> is a chunk's first
+// byte inside a string; (B) bracket depth change and minimum per chunk ->
+// absolute depth at every chunk start and the chunk holding the closing
+// bracket; (C) element starts / ends.  Chunk starts are moved past backslash
+// runs, so an escape never straddles two chunks.
+const char *find_elements(const char *p0, const char *e,
+                          std::vector<std::pair<const char *, const char *>> &out,
+                          char *closed_by)
+{
+    out.clear();
+    *closed_by = 0;
+    const size_t len = (size_t)(e - p0);
+    int T = omp_get_max_threads();
+    if (len < (1u << 20) || T < 2) T = 1;
+    if ((size_t)T > len / 65536 + 1) T = (int)(len / 65536 + 1);
+    std::vector<const char *> cb((size_t)T + 1);
+    for (int t = 0; t <= T; t++) {
+        const char *q = t == T ? e : p0 + len / T * t;
+        while (t > 0 && t < T && q < e && q[-1] == '\\') q++;
+        cb[t] = q;
+    }
+    for (int t = 1; t <= T; t++) if (cb[t] < cb[t - 1]) cb[t] = cb[t - 1];
+    std::vector<uint8_t> in_str((size_t)T + 1, 0);
+    if (T > 1) {
+        std::vector<size_t> quotes((size_t)T, 0);
+#pragma omp parallel for schedule(static, 1)
+        for (int t = 0; t < T; t++) {
+            size_t q = 0;
+            for (const char *p = cb[t]; p < cb[t + 1]; p++) {
+                if (*p == '\\') p++;
+                else if (*p == '"') q++;
+            }
+            quotes[t] = q;
+        }
+        size_t acc = 0;
+        for (int t = 0; t < T; t++) { in_str[t] = acc & 1; acc += quotes[t]; }
+    }
+    // (B) depth change / minimum of every chunk
+    std::vector<int64_t> delta((size_t)T, 0), lowest((size_t)T, 0), base((size_t)T + 1, 0);
+#pragma omp parallel for schedule(static, 1) if (T > 1)
+    for (int t = 0; t < T; t++) {
+        bool s = in_str[t];
+        int64_t d = 0, lo = 0;
+        for (const char *p = cb[t]; p < cb[t + 1]; p++) {
+            const char c = *p;
+            if (s) { if (c == '\\') p++; else if (c == '"') s = false; continue; }
+            if (c == '"') s = true;
+            else if (c == '{' || c == '[') d++;
+            else if (c == '}' || c == ']') { d--; if (d < lo) lo = d; }
+        }
+        delta[t] = d; lowest[t] = lo;
+    }
+    int last = -1;                  // chunk in which the depth reaches -1
+    for (int t = 0; t < T; t++) {
+        if (base[t] + lowest[t] < 0) { last = t; break; }
+        base[t + 1] = base[t] + delta[t];
+    }
+    if (last < 0) return nullptr;
+    // (C) element boundaries
+    std::vector<std::vector<const char *>> starts((size_t)last + 1), ends((size_t)last + 1);
+    const char *close_pos = nullptr;
+#pragma omp parallel for schedule(static, 1) if (T > 1)
+    for (int t = 0; t <= last; t++) {
+        bool s = in_str[t];
+        int64_t d = base[t];
+        for (const char *p = cb[t]; p < cb[t + 1]; p++) {
+            const char c = *p;
+            if (s) { if (c == '\\') p++; else if (c == '"') s = false; continue; }
+            if (c == '"') s = true;
+            else if (c == '{' || c == '[') { if (d == 0) starts[t].push_back(p); d++; }
+            else if (c == '}' || c == ']') {
+                if (d == 0) { close_pos = p; break; }      // only in chunk `last`
+                d--;
+                if (d == 0) ends[t].push_back(p + 1);
+            }
+        }
+    }
+    if (!close_pos) return nullptr;
+    size_t ns = 0, ne = 0;
+    for (int t = 0; t <= last; t++) { ns += starts[t].size(); ne += ends[t].size(); }
+    if (ns != ne) return nullptr;
+    out.resize(ns);
+    size_t k = 0;
+    for (int t = 0; t <= last; t++) for (const char *q : starts[t]) out[k++].first = q;
+    k = 0;
+    for (int t = 0; t <= last; t++) for (const char *q : ends[t]) out[k++].second = q;
+    *closed_by = *close_pos;
+    return close_pos;
+}
+
 bool key_is(const char *b, const char *e, const char *name)
 {
     size_t n = strlen(name);
@@ -219,18 +317,11 @@ bool scan_array(Cursor &c, Ranges &out)
 {
     out.clear();
     if (!c.eat('[')) { c.bad("table is not a list"); return false; }
-    if (c.eat(']')) return true;
-    for (;;) {
-        c.ws();
-        const char *b = c.p;
-        c.skip();
-        if (c.fail) return false;
-        out.emplace_back(b, c.p);
-        if (c.eat(',')) continue;
-        if (c.eat(']')) return true;
-        c.bad("expected , or ]");
-        return false;
-    }
+    char closer = 0;
+    const char *close_pos = find_elements(c.p, c.e, out, &closer);
+    if (!close_pos || closer != ']') { c.bad("unterminated list"); return false; }
+    c.p = close_pos + 1;
+    return true;
 }
 
 bool id_list(Cursor &c, std::vector<int64_t> &out)
@@ -473,29 +564,16 @@ void *taoamd_pred_parse(const char *path, char *err, size_t errlen)
     while (p < e && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) p++;
     if (p >= e || *p != '[') { done(); return fail("results is not a list."); }
     p++;
-    // pass 1: object boundaries at depth 1
+    // pass 1: byte range of every element of the list
     std::vector<std::pair<size_t, size_t>> objs;
     {
-        int depth = 0;
-        size_t start = 0;
-        bool closed = false;
-        while (p < e) {
-            char c = *p;
-            if (c == '"') {
-                p++;
-                while (p < e && *p != '"') { if (*p == '\\') p++; p++; }
-                p++;
-                continue;
-            }
-            if (c == '{' || c == '[') { if (depth == 0) start = (size_t)(p - buf); depth++; }
-            else if (c == '}' || c == ']') {
-                if (depth == 0) { closed = c == ']'; break; }
-                depth--;
-                if (depth == 0) objs.emplace_back(start, (size_t)(p - buf) + 1);
-            }
-            p++;
-        }
-        if (!closed) { done(); return fail("unterminated list"); }
+        std::vector<std::pair<const char *, const char *>> el;
+        char closer = 0;
+        const char *close_pos = find_elements(p, e, el, &closer);
+        if (!close_pos || closer != ']') { done(); return fail("unterminated list"); }
+        objs.resize(el.size());
+        for (size_t i = 0; i < el.size(); i++)
+            objs[i] = {(size_t)(el[i].first - buf), (size_t)(el[i].second - buf)};
     }
     Columns *c = new Columns;
     const int64_t n = (int64_t)objs.size();

@@ -206,3 +206,26 @@ def test_flatten_is_the_same_with_and_without_the_native_sort(monkeypatch):
                 assert np.array_equal(a[k], b[k]), k
             else:
                 assert a[k] == b[k], k
+
+
+def test_parallel_boundary_scan_with_hostile_strings(tmp_path):
+    """Files above 1 MB are cut into per-thread chunks; strings full of
+    quotes, backslash runs and brackets must not confuse the chunk logic."""
+    gt, dt = synth(seed=2, V=6, F=100, C=40, dets_per_frame=60, n_present=6)
+    preds = dt.to_json()
+    for k in range(0, len(preds), 7):
+        preds[k]["note"] = 'q"\\" } ] \\\\' + "\\" * ((k % 5) * 2) + ' [ {' + "x" * (k % 211)
+    p = tmp_path / "p.json"
+    p.write_text(json.dumps(preds))
+    assert p.stat().st_size > (2 << 20)
+    _same(DTColumns.from_file_native(str(p)), DTColumns.from_json(preds))
+    d = gt.to_json()
+    for k, a in enumerate(d["annotations"]):
+        a["note"] = '\\\\"' * (k % 4) + "]}" + "y" * (k % 173)
+    p = tmp_path / "g.json"
+    p.write_text(json.dumps(d) + "   \n")
+    _same_gt(GTColumns.from_file_native(str(p)), GTColumns.from_json(d))
+    # trailing garbage after the list / truncated list
+    p.write_text(json.dumps(preds)[:-1])
+    with pytest.raises(ValueError):
+        DTColumns.from_file_native(str(p))
