@@ -37,7 +37,9 @@ class LVISResults(LVIS):
         self.max_dets = max_dets
         if len(self.columns_dt) == 0:
             raise IndexError("list index out of range")  # results.py:42
-        assert np.isin(self.columns_dt.image_id, self.gt.columns.img_id).all(), \
+        from ...flatten import _lookup
+        assert (_lookup(np.unique(self.gt.columns.img_id),
+                        self.columns_dt.image_id) >= 0).all(), \
             "Results do not correspond to current LVIS set."
         self._index = None
         self._columns = None
