@@ -167,11 +167,14 @@ int taoamd_track_iou(int64_t n_cells, const int32_t *cell_dt_off,
  * from the CSR table); cells with more than 64 GTs take a slower kernel and
  * more than TAOAMD_MAX_GT_PER_CELL is an error.
  * Launch plan (optional, all NULL/0 = one wavefront per cell): `groups`
- * (int32[n_groups][2], device) lists runs [c0, c1) of consecutive cells with
- * at most 64 detections and 64 GTs in total and at most 8 GTs per cell -- one
- * wavefront evaluates a whole run with coalesced loads; `singles`
- * (int32[n_singles]) lists the remaining cells that hold detections;
- * `dt_cell` (int32 per detection) maps a detection to its cell. */
+ * (int32[n_groups][4], device) lists runs of consecutive cells with at most
+ * 64 detections and 64 GTs in total and at most 8 GTs per cell, as {first
+ * detection, detections, first GT, GTs} of the run -- one wavefront evaluates
+ * a whole run with coalesced loads; `singles` (int32[n_singles]) lists the
+ * remaining cells that hold detections; `dt_group` (int32[n_dt][4]) gives per
+ * detection {first GT of its cell, GT count of its cell, its position inside
+ * the cell, cell index}, so the kernel reaches everything with two dependent
+ * loads instead of walking detection -> cell -> cell tables. */
 #define TAOAMD_MAX_GT_PER_CELL 3072
 int taoamd_match(int64_t n_cells, const int32_t *cell_dt_off,
                  const int32_t *cell_gt_off, const int64_t *cell_iou_off,
@@ -181,7 +184,7 @@ int taoamd_match(int64_t n_cells, const int32_t *cell_dt_off,
                  const uint8_t *gt_flags, const uint8_t *dt_flags,
                  const int32_t *dst, int64_t out_stride, uint64_t *matched,
                  uint64_t *ignored, int32_t *match_gt, double *ious_out,
-                 const int32_t *dt_cell, const int32_t *groups,
+                 const int32_t *dt_group, const int32_t *groups,
                  int32_t n_groups, const int32_t *singles, int32_t n_singles,
                  void *stream);
 

@@ -484,8 +484,8 @@ struct MatchArgs {
     int32_t n_words;
     int64_t out_stride;  // words between consecutive output rows
     // optional launch plan (built by the host from the cell table)
-    const int32_t *dt_cell;   // detection -> cell
-    const int32_t *groups;    // [n_groups][2] cell ranges handled per wavefront
+    const int32_t *dt_group;  // [n_dt][4] first GT / GT count of the cell, position in it, cell
+    const int32_t *groups;    // [n_groups][4] first detection, count, first GT, count of a run
     const int32_t *singles;   // [n_singles] cells handled one per wavefront
     int32_t n_groups, n_singles;
 };
@@ -617,12 +617,14 @@ __global__ __launch_bounds__(256) void match_group_kernel(MatchArgs a, IouThr th
     if (item >= (int64_t)a.n_groups * a.n_words) return;
     const int64_t grp = item / a.n_words;
     const int word = (int)(item - grp * a.n_words);
-    const int32_t c0 = __builtin_amdgcn_readfirstlane(a.groups[2 * grp]);
-    const int32_t c1 = __builtin_amdgcn_readfirstlane(a.groups[2 * grp + 1]);
-    const int32_t d0 = __builtin_amdgcn_readfirstlane(a.cell_dt_off[c0]);
-    const int32_t nD = __builtin_amdgcn_readfirstlane(a.cell_dt_off[c1]) - d0;
-    const int32_t g0 = __builtin_amdgcn_readfirstlane(a.cell_gt_off[c0]);
-    const int32_t nG = __builtin_amdgcn_readfirstlane(a.cell_gt_off[c1]) - g0;
+    // Everything a wavefront needs is at most two dependent loads away: the
+    // run descriptor, then the per-detection / per-GT rows (the host resolved
+    // cell -> GT range per detection, so no chain through the cell table).
+    const int4 run = reinterpret_cast<const int4 *>(a.groups)[grp];
+    const int32_t d0 = __builtin_amdgcn_readfirstlane(run.x);
+    const int32_t nD = __builtin_amdgcn_readfirstlane(run.y);
+    const int32_t g0 = __builtin_amdgcn_readfirstlane(run.z);
+    const int32_t nG = __builtin_amdgcn_readfirstlane(run.w);
     if (nD == 0) return;
     const int n_combo = a.n_rng * N_THR;
     const int combo = word * WAVE + lane;
@@ -637,16 +639,15 @@ __global__ __launch_bounds__(256) void match_group_kernel(MatchArgs a, IouThr th
     double4 B = make_double4(0, 0, 0, 0);
     if (lane < nD) {
         const int32_t d = d0 + lane;
-        const int32_t c = a.dt_cell[d];
+        const int4 dg = reinterpret_cast<const int4 *>(a.dt_group)[d];
         t_flags = a.dt_flags[d];
         t_rng = (int32_t)a.dt_rng[d];
         t_row = a.dst != nullptr ? a.dst[d] : d;
-        const int32_t cg0 = a.cell_gt_off[c];
-        Gc = a.cell_gt_off[c + 1] - cg0;
-        gb = cg0 - g0;
+        Gc = dg.y;
+        gb = dg.x - g0;
         ge = gb + Gc;
-        dloc = d - a.cell_dt_off[c];
-        if (a.cell_iou_off != nullptr) t_ioff = a.cell_iou_off[c];
+        dloc = dg.z;
+        if (a.cell_iou_off != nullptr) t_ioff = a.cell_iou_off[dg.w];
         if (FUSED) B = reinterpret_cast<const double4 *>(a.dt_box)[d];
     }
     // ---- lane = GT of the run
@@ -985,7 +986,7 @@ extern "C" int taoamd_match(int64_t n_cells, const int32_t *cell_dt_off,
                             const uint8_t *dt_flags, const int32_t *dst,
                             int64_t out_stride, uint64_t *matched,
                             uint64_t *ignored, int32_t *match_gt,
-                            double *ious_out, const int32_t *dt_cell,
+                            double *ious_out, const int32_t *dt_group,
                             const int32_t *groups, int32_t n_groups,
                             const int32_t *singles, int32_t n_singles,
                             void *stream)
@@ -997,7 +998,7 @@ extern "C" int taoamd_match(int64_t n_cells, const int32_t *cell_dt_off,
     if (max_gt_per_cell > TAOAMD_MAX_GT_PER_CELL) return TAOAMD_ERR_TOO_LARGE;
     if ((!fused || ious_out) && cell_iou_off == nullptr) return TAOAMD_ERR_ARG;
     const bool planned = groups != nullptr;
-    if (planned && (dt_cell == nullptr || (n_singles > 0 && singles == nullptr)))
+    if (planned && (dt_group == nullptr || (n_singles > 0 && singles == nullptr)))
         return TAOAMD_ERR_ARG;
     MatchArgs a;
     a.n_cells = n_cells; a.cell_dt_off = cell_dt_off; a.cell_gt_off = cell_gt_off;
@@ -1008,7 +1009,7 @@ extern "C" int taoamd_match(int64_t n_cells, const int32_t *cell_dt_off,
     a.n_words = (n_rng * N_THR + 63) / 64;
     a.out_stride = out_stride > 0 ? out_stride : a.n_words;
     if (a.out_stride < a.n_words) return TAOAMD_ERR_ARG;
-    a.dt_cell = dt_cell; a.groups = groups; a.n_groups = planned ? n_groups : 0;
+    a.dt_group = dt_group; a.groups = groups; a.n_groups = planned ? n_groups : 0;
     a.singles = planned ? singles : nullptr; a.n_singles = planned ? n_singles : 0;
     hipStream_t s = (hipStream_t)stream;
     if (planned && n_groups > 0) {

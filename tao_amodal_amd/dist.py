@@ -89,7 +89,7 @@ class HipBackend:
             None if fused else _ptr(ws.iou), dp.n_rng, _ptr(ws.gt_rng),
             _ptr(ws.dt_rng), _ptr(t["gt_flags"]), _ptr(t["dt_flags"]),
             _ptr(dst), width, base + 16, base + 16 + 8 * dp.n_words, None, None,
-            _ptr(t["dt_cell"]), _ptr(t["groups"]), dp.n_groups,
+            _ptr(t["dt_group"]), _ptr(t["groups"]), dp.n_groups,
             _ptr(t["singles"]), dp.n_singles, self._s()), "taoamd_match")
 
     def sort_local(self, dp, ws):

@@ -119,9 +119,25 @@ class DeviceProblem:
         tile_off = np.zeros(self.n_cat + 1, dtype=np.int32)
         np.cumsum(tiles, out=tile_off[1:])
         self.n_tiles = int(tile_off[-1])
-        self.t["groups"] = torch.from_numpy(
-            np.ascontiguousarray(groups) if len(groups) else
-            np.zeros((1, 2), np.int32)).to(self.device)
+        # run descriptors {first detection, detections, first GT, GTs}
+        runs = np.zeros((max(len(groups), 1), 4), dtype=np.int32)
+        if len(groups):
+            c0, c1 = groups[:, 0], groups[:, 1]
+            runs[:, 0] = flat.cell_dt_off[c0]
+            runs[:, 1] = flat.cell_dt_off[c1] - flat.cell_dt_off[c0]
+            runs[:, 2] = flat.cell_gt_off[c0]
+            runs[:, 3] = flat.cell_gt_off[c1] - flat.cell_gt_off[c0]
+        self.t["groups"] = torch.from_numpy(runs).to(self.device)
+        # per detection {first GT of its cell, GT count, position in the cell,
+        # cell}: resolved here, on the device, from the uploaded cell tables
+        cell = self.t["dt_cell"].long()
+        g_off, d_off = self.t["cell_gt_off"], self.t["cell_dt_off"]
+        self.t["dt_group"] = torch.stack(
+            [g_off[cell], g_off[cell + 1] - g_off[cell],
+             torch.arange(self.n_dt, dtype=torch.int32, device=self.device)
+             - d_off[cell], self.t["dt_cell"]], dim=1).to(torch.int32).contiguous() \
+            if self.n_dt else torch.zeros((1, 4), dtype=torch.int32,
+                                          device=self.device)
         self.t["singles"] = torch.from_numpy(
             singles if len(singles) else np.zeros(1, np.int32)).to(self.device)
         self.t["cell_iou_off"] = torch.from_numpy(iou_off).to(self.device)
@@ -240,7 +256,7 @@ def stage_match(dp, ws, scatter=True):
         _ptr(ws.dt_rng), _ptr(t["gt_flags"]), _ptr(t["dt_flags"]),
         _ptr(ws.dst) if scatter else None, 0, _ptr(ws.matched),
         _ptr(ws.ignored), _ptr(ws.match_gt), _ptr(ws.ious_out),
-        _ptr(t["dt_cell"]), _ptr(t["groups"]), dp.n_groups, _ptr(t["singles"]),
+        _ptr(t["dt_group"]), _ptr(t["groups"]), dp.n_groups, _ptr(t["singles"]),
         dp.n_singles, s), "taoamd_match")
 
 
