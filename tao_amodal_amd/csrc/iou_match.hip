@@ -685,34 +685,58 @@ __global__ __launch_bounds__(256) void match_group_kernel(MatchArgs a, IouThr th
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
-    // ---- cells with at most one GT: closed form, lane = detection.
-    // With a single GT the greedy degenerates: a detection takes the GT iff
-    // its IoU reaches the threshold and no earlier *consuming* detection of
-    // the cell did (whether the GT is ignored only changes the `ignored`
-    // bit, never the assignment); with no GT nothing matches.  One ballot
-    // per threshold answers that for all detections of the run at once.
+    // ---- closed form, lane = detection, for every cell in which no detection
+    // has more than one CANDIDATE -- a GT whose IoU reaches the lowest
+    // threshold (a GT below it can never be chosen).  With at most one
+    // candidate per detection the greedy has no choice to make: a detection
+    // takes its candidate iff the IoU reaches the threshold and no earlier
+    // *consuming* detection of the cell with the same candidate did (whether
+    // the GT is ignored only changes the `ignored` bit, never the
+    // assignment); without a candidate nothing matches.  Cells with zero or
+    // one GT are the special case "candidate = GT 0".  One ballot per
+    // (threshold, candidate index) answers that for all detections of the
+    // run at once; only cells where some detection overlaps two GTs by the
+    // lowest threshold or more go through the sequential loop below.
     uint64_t my_m = 0, my_i = 0;
-    const bool simple = lane < nD && Gc <= 1;
+    const double tmin = fmin(thr.v[0], 1 - 1e-10);
+    int cand = -1, ncand = 0;
+    double vc = 0.0;
+    if (lane < nD)
+        for (int k = 0; k < Gc && k < GRP_GCAP; k++) {
+            const double v = s_iou[wave][lane * GRP_GCAP + k];
+            if (!(v < tmin)) { ncand++; cand = k; vc = v; }
+        }
+    // lanes [ca, ce) hold the detections of my cell
+    const uint64_t starts = __ballot(lane < nD && dloc == 0);
+    const int ca = lane - dloc;
+    const uint64_t above = lane >= 63 ? 0ull : starts & ~((2ull << lane) - 1);
+    const int ce = above ? __builtin_ctzll(above) : nD;
+    const uint64_t below_me = (1ull << lane) - 1, below_ca = (1ull << ca) - 1;
+    const uint64_t cell_all = (ce >= 64 ? ~0ull : ((1ull << ce) - 1)) & ~below_ca;
+    const uint64_t multi = __ballot(lane < nD && ncand >= 2);
+    const bool simple = lane < nD && (multi & cell_all) == 0;
     {
-        double v0 = 0.0;
         uint32_t mygrng = 0;
         bool myghid = false;
-        uint64_t cellmask = 0;
-        if (simple) {
-            if (Gc == 1) {
-                v0 = s_iou[wave][lane * GRP_GCAP];
-                mygrng = a.gt_rng[g0 + gb];
-                myghid = a.gt_flags[g0 + gb] & TAOAMD_GT_ID_HIDDEN;
-            }
-            const int ca = lane - dloc;           // first detection of my cell
-            cellmask = ((1ull << lane) - 1) & ~((1ull << ca) - 1);  // earlier ones
+        const uint64_t cellmask = below_me & ~below_ca;     // earlier ones of my cell
+        // the candidate's range mask / hidden flag sit in the GT lane gb + cand
+        const uint32_t grng_c = (uint32_t)__shfl((int)grng, (gb + max(cand, 0)) & 63);
+        if (simple && cand >= 0) {
+            mygrng = grng_c;
+            myghid = (HID >> (gb + cand)) & 1ull;
         }
+        const bool consumes = !(t_flags & TAOAMD_DT_NO_CONSUME);
         uint32_t m10 = 0;
         for (int q = 0; q < N_THR; q++) {
             const double tq = fmin(thr.v[q], 1 - 1e-10);
-            const bool pass = simple && Gc == 1 && !(v0 < tq);
-            const uint64_t cons = __ballot(pass && !(t_flags & TAOAMD_DT_NO_CONSUME));
-            if (pass && (cons & cellmask) == 0) m10 |= 1u << q;
+            const bool pass = simple && cand >= 0 && !(vc < tq);
+            bool taken_before = false;
+            for (int c = 0; c < GRP_GCAP; c++) {
+                const uint64_t cons = __ballot(pass && consumes && cand == c);
+                if (__ballot(simple && cand > c) == 0 && cons == 0) break;   // wave-uniform
+                if (cand == c) taken_before = (cons & cellmask) != 0;
+            }
+            if (pass && !taken_before) m10 |= 1u << q;
         }
         if (simple) {
             const uint32_t all10 = (1u << N_THR) - 1;
@@ -730,14 +754,14 @@ __global__ __launch_bounds__(256) void match_group_kernel(MatchArgs a, IouThr th
             if (a.match_gt != nullptr)
                 for (int cc = 0; cc < WAVE && word * WAVE + cc < n_combo; cc++)
                     a.match_gt[(int64_t)(d0 + lane) * n_combo + word * WAVE + cc] =
-                        ((m10 >> ((word * WAVE + cc) % N_THR)) & 1u) ? 0 : -1;
+                        ((m10 >> ((word * WAVE + cc) % N_THR)) & 1u) ? cand : -1;
         }
     }
-    // ---- lane = combo: sequential greedy over the detections whose cell has
-    // two or more GTs.  Per detection one readlane brings a packed word
+    // ---- lane = combo: sequential greedy over the detections of the remaining
+    // cells.  Per detection one readlane brings a packed word
     // (first GT of the cell | GT count | flags) to the scalar unit; the masks
     // are narrowed to the cell's <= GRP_GCAP GTs so the inner loop is 32-bit.
-    const uint64_t todo = __ballot(lane < nD && Gc >= 2);
+    const uint64_t todo = __ballot(lane < nD && !simple);
     const int32_t meta = (gb & 0xff) | ((Gc & 0xff) << 8) | ((t_flags & 0xff) << 16);
     uint64_t taken = 0;
     for (uint64_t rest = todo; rest != 0; rest &= rest - 1) {
