@@ -283,17 +283,16 @@ __global__ __launch_bounds__(256) void track_iou_kernel(
 //      no global memory on the serial chain.
 // Adding (0, 0) for an empty position is exact (u, i >= +0), so the sequence
 // of roundings equals the two-pointer merge over the union of frames.
-#define TD_MAP_ENTRIES 10240   // uint16 entries: (G + detection tracks) * span
+#define TD_BM_WORDS 1024       // 64-bit words of presence bitmaps: (G + detection tracks) * ceil(span / 64)
 #define TD_CH 16               // timeline positions per chunk
 #define TD_PAIRS 64            // track pairs per detection-track group
 #define TD_GMAX 8              // GT tracks of a dense cell
-#define TD_NONE 0xffffu
 #define TD_IT 2                // phase-A items per thread and batch
 
 __device__ __forceinline__ bool dense_cell(int32_t span, int32_t D, int32_t G)
 {
     return D > 0 && G > 0 && G <= TD_GMAX &&
-           (int64_t)(G + 1) * span <= TD_MAP_ENTRIES;
+           (int64_t)(G + 1) * ((span + 63) / 64) <= TD_BM_WORDS;
 }
 
 __global__ __launch_bounds__(256) void track_iou_dense_kernel(
@@ -307,7 +306,11 @@ __global__ __launch_bounds__(256) void track_iou_dense_kernel(
     double *__restrict__ iou, unsigned long long *__restrict__ pair_frames,
     int mode)
 {
-    __shared__ uint16_t map[TD_MAP_ENTRIES];
+    // presence bitmap of every staged track over the timeline + frames before
+    // each 64-position word: frame at position p = first + pre[w] + popcount(
+    // bits of word w below p) -- 1/16 of the LDS a position -> frame table takes
+    __shared__ uint64_t bm[TD_BM_WORDS];
+    __shared__ uint16_t pre[TD_BM_WORDS];
     __shared__ double2 terms[TD_CH][TD_PAIRS + 1];
     __shared__ double4 gbox[2][TD_GMAX * TD_CH];   // GT frames of this / the next chunk
     // frame offsets of the staged tracks: [0, G] GT, [TD_PAIRS, TD_PAIRS + nd] detections
@@ -318,29 +321,45 @@ __global__ __launch_bounds__(256) void track_iou_dense_kernel(
     const int32_t span = cell_span[c];
     if (!dense_cell(span, D, G)) return;
     const int64_t ioff = cell_iou_off[c];
-    const int rows = TD_MAP_ENTRIES / span;
+    const int nw = (span + 63) >> 6;                 // bitmap words per track
+    const int rows = TD_BM_WORDS / nw;
     const int DG = min(min(D, rows - G), TD_PAIRS / G);
-    uint16_t *__restrict__ gmap = map;
-    uint16_t *__restrict__ dmap = map + G * span;
+    uint64_t *__restrict__ gbm = bm, *__restrict__ dbm = bm + G * nw;
+    uint16_t *__restrict__ gpre = pre, *__restrict__ dpre = pre + G * nw;
+    // frame index inside the track of timeline position p, or -1
+    auto frame_at = [nw](const uint64_t *b, const uint16_t *pr, int track, int p) -> int {
+        const int w = track * nw + (p >> 6);
+        const uint64_t word = b[w], bit = 1ull << (p & 63);
+        return (word & bit) ? (int)pr[w] + __popcll(word & (bit - 1)) : -1;
+    };
     const double4 *__restrict__ DB = reinterpret_cast<const double4 *>(dfbox);
     const double4 *__restrict__ GB = reinterpret_cast<const double4 *>(gfbox);
     // position -> frame rows.  The frames of the cell's tracks are one
     // contiguous run of the CSR arrays: the rows are filled by a flat loop
     // over that run (one round trip for the offsets, one for the positions)
     // instead of track by track.
-    for (int t = threadIdx.x; t < G * span; t += 256) gmap[t] = TD_NONE;
+    for (int t = threadIdx.x; t < G * nw; t += 256) gbm[t] = 0;
     for (int g = threadIdx.x; g <= G; g += 256) first[g] = gfoff[g0 + g];
     __syncthreads();
     for (int32_t j = first[0] + (int32_t)threadIdx.x; j < first[G]; j += 256) {
         int g = 0;
         while (g + 1 < G && first[g + 1] <= j) g++;
-        gmap[g * span + gfpos[j]] = (uint16_t)(j - first[g]);
+        const int32_t p = gfpos[j];
+        atomicOr((unsigned long long *)&gbm[g * nw + (p >> 6)], 1ull << (p & 63));
+    }
+    __syncthreads();
+    for (int g = threadIdx.x; g < G; g += 256) {
+        int acc = 0;
+        for (int w = 0; w < nw; w++) {
+            gpre[g * nw + w] = (uint16_t)acc;
+            acc += __popcll(gbm[g * nw + w]);
+        }
     }
     unsigned long long common = 0;
     for (int32_t db = 0; db < D; db += DG) {
         const int nd = min(DG, D - db);
         __syncthreads();
-        for (int t = threadIdx.x; t < nd * span; t += 256) dmap[t] = TD_NONE;
+        for (int t = threadIdx.x; t < nd * nw; t += 256) dbm[t] = 0;
         for (int dl = threadIdx.x; dl <= nd; dl += 256)
             first[TD_PAIRS + dl] = dfoff[d0 + db + dl];
         __syncthreads();
@@ -351,7 +370,16 @@ __global__ __launch_bounds__(256) void track_iou_dense_kernel(
                 const int mid = (lo + hi) >> 1;
                 if (first[TD_PAIRS + mid] <= k) lo = mid; else hi = mid;
             }
-            dmap[lo * span + dfpos[k]] = (uint16_t)(k - first[TD_PAIRS + lo]);
+            const int32_t p = dfpos[k];
+            atomicOr((unsigned long long *)&dbm[lo * nw + (p >> 6)], 1ull << (p & 63));
+        }
+        __syncthreads();
+        for (int dl = threadIdx.x; dl < nd; dl += 256) {
+            int acc = 0;
+            for (int w = 0; w < nw; w++) {
+                dpre[dl * nw + w] = (uint16_t)acc;
+                acc += __popcll(dbm[dl * nw + w]);
+            }
         }
         // GT frames of chunk 0 (later chunks are staged one chunk ahead,
         // inside phase A)
@@ -359,8 +387,8 @@ __global__ __launch_bounds__(256) void track_iou_dense_kernel(
             const int g = threadIdx.x / TD_CH, pp = threadIdx.x % TD_CH;
             double4 A = make_double4(0, 0, -1.0, 0);   // w < 0: absent
             if (pp < span) {
-                const uint32_t rg = gmap[g * span + pp];
-                if (rg != TD_NONE) A = GB[first[g] + (int32_t)rg];
+                const int rg = frame_at(gbm, gpre, g, pp);
+                if (rg >= 0) A = GB[first[g] + rg];
             }
             gbox[0][g * TD_CH + pp] = A;
         }
@@ -379,8 +407,8 @@ __global__ __launch_bounds__(256) void track_iou_dense_kernel(
             if (stage) {
                 const int g = threadIdx.x / TD_CH, pp = threadIdx.x % TD_CH;
                 if (p0 + TD_CH + pp < span) {
-                    const uint32_t rg = gmap[g * span + p0 + TD_CH + pp];
-                    if (rg != TD_NONE) An = GB[first[g] + (int32_t)rg];
+                    const int rg = frame_at(gbm, gpre, g, p0 + TD_CH + pp);
+                    if (rg >= 0) An = GB[first[g] + rg];
                 }
             }
             // ---- phase A: item = (detection track, position): consecutive
@@ -396,9 +424,9 @@ __global__ __launch_bounds__(256) void track_iou_dense_kernel(
                     const int dl0 = it / TD_CH, pp0 = it % TD_CH;
                     const bool ok = dl0 < nd && pp0 < np;
                     const int dl = ok ? dl0 : 0, pp = ok ? pp0 : 0;
-                    const uint32_t rd = dmap[dl * span + p0 + pp];
-                    hd[q] = ok && rd != TD_NONE;
-                    kd[q] = hd[q] ? first[TD_PAIRS + dl] + (int32_t)rd : 0;
+                    const int rd = frame_at(dbm, dpre, dl, p0 + pp);
+                    hd[q] = ok && rd >= 0;
+                    kd[q] = hd[q] ? first[TD_PAIRS + dl] + rd : 0;
                 }
 #pragma unroll
                 for (int q = 0; q < TD_IT; q++) B[q] = DB[kd[q]];

@@ -101,8 +101,8 @@ class DeviceProblem:
                       "gt_frame_off", "gt_frame_pos", "gt_frame_box",
                       "cell_span"]
             live = (d_cnt > 0) & (g_cnt > 0)
-            fits = (g_cnt <= 8) & ((g_cnt + 1) * flat.cell_span.astype(np.int64)
-                                    <= 10240)
+            fits = (g_cnt <= 8) & ((g_cnt + 1) * ((flat.cell_span.astype(np.int64)
+                                                    + 63) // 64) <= 1024)
             self.all_dense = int(bool(np.all(fits[live])))
         self.t = {}
         for n in names:

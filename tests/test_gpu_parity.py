@@ -79,7 +79,7 @@ def test_synthetic_hip_vs_c_oracle(seed, V, F, C, dpf):
 
 
 def test_long_timelines_take_the_merge_kernel_and_gt_groups():
-    """(G + 1) * span > 10240 (or more than 8 GT tracks) -> two-pointer merge kernel; otherwise the
+    """More than 8 GT tracks (or presence bitmaps beyond 1024 words) -> two-pointer merge kernel; otherwise the
     dense-timeline kernel, with detection tracks staged in several groups
     when the cell has many of them."""
     from tao_amodal_amd import engine
