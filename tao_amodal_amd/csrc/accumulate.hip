@@ -365,8 +365,22 @@ __global__ __launch_bounds__(256) void acc_emit_kernel(AccArgs a)
             if (cj[mid] <= (int32_t)tp) lo = mid + 1; else hi = mid;
         }
         jcur = lo;
-        if (ci.last)
-            for (int j = jcur; j < N_REC; j++) out[j] = 0.0;
+    }
+    if (ci.last) {
+        // thresholds the category never reaches get precision 0.  The tail of
+        // a lane's row is contiguous: the wavefront writes the tails row by
+        // row with coalesced stores instead of every lane walking its own row
+        // (64 scattered 8-byte stores per step).
+        const int jz = live ? jcur : N_REC;
+        for (int l = 0; l < WAVE; l++) {
+            const int jl = __builtin_amdgcn_readlane(jz, l);
+            if (jl >= N_REC) continue;
+            const int cl = ci.word * WAVE + l;
+            const int rl = cl / N_THR, tl = cl - rl * N_THR;
+            double *__restrict__ row =
+                a.val + (((int64_t)ci.k * a.n_rng + rl) * N_THR + tl) * N_REC;
+            for (int j = jl + lane; j < N_REC; j += WAVE) row[j] = 0.0;
+        }
     }
     const int64_t tb = (((int64_t)ci.c * a.n_words + ci.word) * ACC_BLK) * WAVE + lane;
     // next threshold to write, cached in a register: cj[jcur - 1], or -1
