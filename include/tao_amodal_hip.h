@@ -205,7 +205,7 @@ int taoamd_sort_by_cat_score(int64_t n, const int32_t *dt_cat,
  * n_tiles its total; max_segment = host value of the longest run.  Tiles are
  * sorted in LDS, longer runs finished by rank-merge passes.
  * Workspace: taoamd_sort_segments_workspace(n). */
-#define TAOAMD_SEGMENT_TILE 4096
+#define TAOAMD_SEGMENT_TILE 3072
 size_t taoamd_sort_segments_workspace(int64_t n);
 int taoamd_sort_segments(int64_t n, int32_t n_cat, const int32_t *cat_off,
                          const int32_t *tile_off, int32_t n_tiles,

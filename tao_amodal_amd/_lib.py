@@ -15,7 +15,7 @@ OK = 0
 N_THR, N_REC = 10, 101
 LVIS_RNG, TAO_RNG = 6, 20
 MAX_GT_PER_CELL = 3072
-SEGMENT_TILE = 4096
+SEGMENT_TILE = 3072
 
 _vp, _i64, _i32, _sz = C.c_void_p, C.c_int64, C.c_int32, C.c_size_t
 

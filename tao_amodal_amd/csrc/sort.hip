@@ -292,7 +292,7 @@ extern "C" int taoamd_sort_by_cat_score(int64_t n, const int32_t *dt_cat,
 //                     rank -- no serial merge loop)
 //   seg_finish_kernel order / dst of the multi-tile categories
 // ---------------------------------------------------------------------------
-#define SEG_TILE 4096
+#define SEG_TILE 3072
 #define SEG_THREADS 256
 
 struct SegArgs {
