@@ -237,13 +237,18 @@ size_t taoamd_accumulate_workspace(int64_t n_dt, int32_t n_cat, int32_t n_rng);
  *  _finalize turns complete tables into the reference layout (-1 fill).
  * Category-major tables make a rank's share one contiguous block, so ranks
  * exchange them with a single all-gather.
+ * max_segment: rows of the longest category among those swept (the host
+ * knows it from cat_off), or 0 if unknown.  When every category fits one
+ * workgroup (<= 4096 rows with one combo word, <= 1024 with four) the sweep
+ * is a single fused launch with all intermediates in LDS / registers;
+ * otherwise (or with 0) categories are cut into chunks spread over the chip.
  * Workspace of _compact: taoamd_accumulate_workspace (val/rec excluded). */
 size_t taoamd_compact_elems(int32_t n_cat, int32_t n_rng); /* doubles in val */
 int taoamd_accumulate_compact(int64_t n_dt, int32_t n_cat, int32_t n_rng,
                               const int32_t *cat_off, const uint64_t *matched,
                               const uint64_t *ignored, const int32_t *num_gt,
-                              int32_t k_begin, int32_t k_end, double *val,
-                              double *rec, void *workspace,
+                              int32_t k_begin, int32_t k_end, int32_t max_segment,
+                              double *val, double *rec, void *workspace,
                               size_t workspace_bytes, void *stream);
 int taoamd_finalize(int32_t n_cat, int32_t n_rng, const int32_t *num_gt,
                     const double *val, const double *rec, double *precision,
@@ -251,8 +256,9 @@ int taoamd_finalize(int32_t n_cat, int32_t n_rng, const int32_t *num_gt,
 int taoamd_accumulate(int64_t n_dt, int32_t n_cat, int32_t n_rng,
                       const int32_t *cat_off, const uint64_t *matched,
                       const uint64_t *ignored,
-                      const int32_t *num_gt, double *precision, double *recall,
-                      void *workspace, size_t workspace_bytes, void *stream);
+                      const int32_t *num_gt, int32_t max_segment, double *precision,
+                      double *recall, void *workspace, size_t workspace_bytes,
+                      void *stream);
 
 /* ---- multi-GPU result exchange (category-partitioned evaluation) -------------------
  * No reference counterpart (the reference is single-process); these carry the

@@ -43,8 +43,8 @@ SIGNATURES = {
                                      _vp, _vp]),
     "taoamd_compact_elems": (_sz, [_i32, _i32]),
     "taoamd_accumulate_compact": (C.c_int, [_i64, _i32, _i32, _vp, _vp, _vp,
-                                            _vp, _i32, _i32, _vp, _vp, _vp,
-                                            _sz, _vp]),
+                                            _vp, _i32, _i32, _i32, _vp, _vp,
+                                            _vp, _sz, _vp]),
     "taoamd_finalize": (C.c_int, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "taoamd_exchange_chunk_bytes": (_sz, [_i32, _i32, _i64]),
     "taoamd_exchange_workspace": (_sz, [_i32, _i32, _i32]),
@@ -57,8 +57,8 @@ SIGNATURES = {
     "taoamd_sort_by_cat_score": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _sz,
                                            _vp]),
     "taoamd_accumulate_workspace": (_sz, [_i64, _i32, _i32]),
-    "taoamd_accumulate": (C.c_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp,
-                                    _vp, _vp, _sz, _vp]),
+    "taoamd_accumulate": (C.c_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _i32,
+                                    _vp, _vp, _vp, _sz, _vp]),
 }
 
 _lib = None

@@ -88,6 +88,7 @@ struct AccArgs {
     double *val;                 // [n_cat][n_rng][N_THR][N_REC]
     double *rec;                 // [n_cat][n_rng][N_THR]
     int32_t k_begin, k_end;      // categories swept by this call
+    int32_t fused_rows;          // categories up to this many rows take acc_fused_kernel
 };
 
 __global__ __launch_bounds__(256) void acc_chunks_kernel(AccArgs a)
@@ -96,8 +97,12 @@ __global__ __launch_bounds__(256) void acc_chunks_kernel(AccArgs a)
     const int per = (a.n_cat + 255) / 256;
     const int lo = threadIdx.x * per, hi = min(lo + per, a.n_cat);
     int32_t s = 0;
-    for (int k = lo; k < hi; k++)
-        s += (a.cat_off[k + 1] - a.cat_off[k] + ACC_CH - 1) / ACC_CH;
+    // (categories short enough for acc_fused_kernel get no chunks here)
+    auto chunks_of = [&](int k) {
+        const int32_t rows = a.cat_off[k + 1] - a.cat_off[k];
+        return (a.fused_rows > 0 && rows <= a.fused_rows) ? 0 : (rows + ACC_CH - 1) / ACC_CH;
+    };
+    for (int k = lo; k < hi; k++) s += chunks_of(k);
     part[threadIdx.x] = s;
     __syncthreads();
     for (int off = 1; off < 256; off <<= 1) {
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(256) void acc_chunks_kernel(AccArgs a)
     int32_t run = part[threadIdx.x] - s;
     for (int k = lo; k < hi; k++) {
         a.cat_chunk_off[k] = run;
-        run += (a.cat_off[k + 1] - a.cat_off[k] + ACC_CH - 1) / ACC_CH;
+        run += chunks_of(k);
     }
     if (threadIdx.x == 255) a.cat_chunk_off[a.n_cat] = part[255];
 }
@@ -236,6 +241,8 @@ __global__ __launch_bounds__(256) void acc_prefix_kernel(AccArgs a)
     const int32_t k = a.k_begin + (int32_t)(item / a.n_words);
     const int word = (int)(item % a.n_words);
     const int lane = lane_id();
+    if (a.fused_rows > 0 && a.cat_off[k + 1] - a.cat_off[k] <= a.fused_rows)
+        return;                                    // acc_fused_kernel's
     const int32_t c0 = a.cat_chunk_off[k], c1 = a.cat_chunk_off[k + 1];
     uint32_t tp = 0, fp = 0;
     for (int32_t c = c0; c < c1; c++) {
@@ -437,6 +444,185 @@ __global__ __launch_bounds__(256) void acc_emit_kernel(AccArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------
+// Fused sweep for problems whose categories all fit one workgroup
+// (chunks x words <= ACC_FUSED_WAVES wavefronts, i.e. <= 4096 rows at one
+// combo word, <= 1024 rows at four): ONE kernel, one workgroup per category,
+// wavefront = (chunk, word).  Counts, prefixes, chunk maxima and the recall
+// crossings live in LDS, the transposed TP / FP words of a wavefront's 256
+// rows stay in its registers from the counting pass to the emission pass --
+// none of the intermediates of the general path (cnt, pre, cmax, t_tp, t_fp,
+// cj: ~100 MB of traffic and six more launches at Config 2) exists.
+// The arithmetic is the general path's, statement by statement.
+#define ACC_FUSED_WAVES 16
+
+__global__ __launch_bounds__(ACC_FUSED_WAVES * WAVE) void acc_fused_kernel(AccArgs a,
+                                                                           RecThr rec)
+{
+    __shared__ uint32_t s_tp[ACC_FUSED_WAVES][WAVE], s_fp[ACC_FUSED_WAVES][WAVE];
+    __shared__ uint64_t s_max[ACC_FUSED_WAVES][WAVE];
+    __shared__ int32_t s_cj[32 * N_REC];            // [n_rng][N_REC]
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int32_t k = a.k_begin + (int32_t)blockIdx.x;
+    const int32_t sb = a.cat_off[k], se = a.cat_off[k + 1];
+    if (se - sb > a.fused_rows) return;     // long category: the chunked kernels' job
+    const int nw = a.n_words;
+    const int nch = (se - sb + ACC_CH - 1) / ACC_CH;
+    const int j = wave / nw, word = wave - j * nw;   // my chunk, my combo word
+    const bool mine = j < nch;                        // wave-uniform
+    const int32_t start = sb + j * ACC_CH;
+    const int len = mine ? min(ACC_CH, se - start) : 0;
+    // ---- recall crossings of the category's ranges
+    for (int i = threadIdx.x; i < a.n_rng * N_REC; i += ACC_FUSED_WAVES * WAVE) {
+        const int q = i / N_REC;
+        const int32_t ngq = a.num_gt[(int64_t)k * a.n_rng + q];
+        s_cj[i] = ngq > 0 ? recall_crossing(rec.v[i - q * N_REC], ngq) : 0;
+    }
+    // ---- counting pass: transposed words of my rows -> registers
+    uint64_t T[ACC_BLK], TF[ACC_BLK];
+    uint32_t tp_own = 0, fp_own = 0;
+    {
+        const uint64_t *__restrict__ M = a.matched + (int64_t)start * nw + word;
+        const uint64_t *__restrict__ I = a.ignored + (int64_t)start * nw + word;
+#pragma unroll
+        for (int blk = 0; blk < ACC_BLK; blk++) {
+            const int base = blk * WAVE;
+            uint64_t t_ = 0, f_ = 0;
+            if (base < len) {
+                uint64_t tpw, fpw;
+                load_rows(M, I, nw, base, min(WAVE, len - base), lane, tpw, fpw);
+                t_ = transpose64(tpw, lane);
+                f_ = transpose64(fpw, lane);
+            }
+            T[blk] = t_;
+            TF[blk] = t_ | f_;
+            tp_own += (uint32_t)__popcll(t_);
+            fp_own += (uint32_t)__popcll(f_);
+        }
+    }
+    s_tp[wave][lane] = tp_own;
+    s_fp[wave][lane] = fp_own;
+    __syncthreads();
+    // ---- prefix over the earlier chunks of my word; recall; empty category
+    uint32_t tp0 = 0, fp0 = 0;
+    for (int jj = 0; jj < j && jj < nch; jj++) {
+        tp0 += s_tp[jj * nw + word][lane];
+        fp0 += s_fp[jj * nw + word][lane];
+    }
+    const int combo = word * WAVE + lane;
+    const bool active = combo < a.n_rng * N_THR;
+    const int r = active ? combo / N_THR : 0;
+    const int t = active ? combo - r * N_THR : 0;
+    const int32_t ng = active ? a.num_gt[(int64_t)k * a.n_rng + r] : 0;
+    const bool live = active && ng > 0;
+    const int64_t kr = (int64_t)k * a.n_rng + r;
+    double *__restrict__ out = a.val + (kr * N_THR + t) * N_REC;
+    const bool last = mine && j == nch - 1, first = mine && j == 0;
+    if (live && (last || (nch == 0 && j == 0 && wave < nw))) {
+        a.rec[kr * N_THR + t] = (double)(tp0 + tp_own) / (double)ng;
+        // a category without detections still has precision 0 / recall 0
+        // where it has evaluated GT (reference lvis_amodal/eval.py:412-417)
+        if (nch == 0)
+            for (int jj = 0; jj < N_REC; jj++) out[jj] = 0.0;
+    }
+    // ---- largest precision at a TP row of my chunk (see acc_chunkmax_kernel)
+    uint64_t best = PR_ZERO;
+    {
+        uint32_t tpb = tp0, nb = tp0 + fp0;
+#pragma unroll
+        for (int blk = 0; blk < ACC_BLK; blk++) {
+            for (uint64_t m = T[blk] & ~(T[blk] >> 1); m != 0; m &= m - 1) {
+                const int q = __builtin_ctzll(m);
+                const uint64_t le = q == 63 ? ~0ull : ((2ull << q) - 1);   // rows <= q
+                const uint32_t tpq = tpb + (uint32_t)__popcll(T[blk] & le);
+                const uint32_t nq = nb + (uint32_t)__popcll(TF[blk] & le);
+                if (pr_better(tpq, nq, best)) best = pr_pack(tpq, nq);
+            }
+            tpb += (uint32_t)__popcll(T[blk]);
+            nb += (uint32_t)__popcll(TF[blk]);
+        }
+    }
+    s_max[wave][lane] = best;
+    __syncthreads();
+    if (!mine) return;
+    // ---- envelope of the later chunks, then the emission sweep of mine
+    // (acc_emit_kernel)
+    uint64_t run = PR_ZERO;
+    for (int jj = nch - 1; jj > j; jj--) {
+        const uint64_t v = s_max[jj * nw + word][lane];
+        if (pr_better((uint32_t)(v >> 32), (uint32_t)v, run)) run = v;
+    }
+    const int32_t *__restrict__ cj = s_cj + r * N_REC;
+    uint32_t tp = tp0 + tp_own;
+    uint32_t n = tp + fp0 + fp_own;
+    int jcur = 0;
+    if (live) {
+        int lo = 0, hi = N_REC;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (cj[mid] <= (int32_t)tp) lo = mid + 1; else hi = mid;
+        }
+        jcur = lo;
+    }
+    if (last) {
+        const int jz = live ? jcur : N_REC;
+        for (int l = 0; l < WAVE; l++) {
+            const int jl = __builtin_amdgcn_readlane(jz, l);
+            if (jl >= N_REC) continue;
+            const int cl = word * WAVE + l;
+            const int rl = cl / N_THR, tl = cl - rl * N_THR;
+            double *__restrict__ row =
+                a.val + (((int64_t)k * a.n_rng + rl) * N_THR + tl) * N_REC;
+            for (int jj = jl + lane; jj < N_REC; jj += WAVE) row[jj] = 0.0;
+        }
+    }
+    int32_t cnext = jcur > 0 ? cj[jcur - 1] : -1;
+#pragma unroll
+    for (int blk = ACC_BLK - 1; blk >= 0; blk--) {
+        if (blk * WAVE >= len) continue;
+        const uint64_t Tb = live ? T[blk] : 0, TFb = live ? TF[blk] : 0;
+        for (uint64_t m = Tb & ~(Tb >> 1); m != 0;) {
+            const int q = 63 - __builtin_clzll(m);
+            const uint64_t gt = q == 63 ? 0ull : ~((2ull << q) - 1);   // rows > q
+            const uint32_t tpq = tp - (uint32_t)__popcll(Tb & gt);     // incl. row q
+            const uint32_t nq = n - (uint32_t)__popcll(TFb & gt);
+            if (cnext > (int32_t)tpq) {        // reached above row q
+                const double v = pr_value(run);
+                do {
+                    out[--jcur] = v;
+                    cnext = jcur > 0 ? cj[jcur - 1] : -1;
+                } while (cnext > (int32_t)tpq);
+            }
+            if (pr_better(tpq, nq, run)) run = pr_pack(tpq, nq);
+            if (cnext == (int32_t)tpq) {       // reached exactly at row q
+                const double v = pr_value(run);
+                do {
+                    out[--jcur] = v;
+                    cnext = jcur > 0 ? cj[jcur - 1] : -1;
+                } while (cnext == (int32_t)tpq);
+            }
+            m &= ~(1ull << q);
+        }
+        tp -= (uint32_t)__popcll(Tb);
+        n -= (uint32_t)__popcll(TFb);
+        if (cnext > (int32_t)tp) {
+            const double v = pr_value(run);
+            do {
+                out[--jcur] = v;
+                cnext = jcur > 0 ? cj[jcur - 1] : -1;
+            } while (cnext > (int32_t)tp);
+        }
+    }
+    if (live && first && jcur > 0) {
+        const double v = pr_value(run);
+        while (jcur > 0) {
+            out[jcur - 1] = v;
+            jcur--;
+        }
+    }
+}
+
 // val[KR][T*R] -> precision[T*R][KR], rec[KR][T] -> recall[T][KR], -1 fill
 struct FinArgs {
     int32_t n_cat, n_rng;
@@ -511,7 +697,8 @@ extern "C" int taoamd_accumulate_compact(int64_t n_dt, int32_t n_cat,
                                          const uint64_t *matched,
                                          const uint64_t *ignored,
                                          const int32_t *num_gt, int32_t k_begin,
-                                         int32_t k_end, double *val, double *rec,
+                                         int32_t k_end, int32_t max_segment,
+                                         double *val, double *rec,
                                          void *workspace, size_t workspace_bytes,
                                          void *stream)
 {
@@ -523,12 +710,26 @@ extern "C" int taoamd_accumulate_compact(int64_t n_dt, int32_t n_cat,
     if (k_begin == k_end) return TAOAMD_OK;
     hipStream_t s = (hipStream_t)stream;
     AccArgs a;
+    a.cat_chunk_off = nullptr; a.cnt_tp = a.cnt_fp = a.pre_tp = a.pre_fp = nullptr;
+    a.cmax = a.t_tp = a.t_fp = nullptr; a.cj = nullptr;
     a.n_dt = n_dt; a.n_cat = n_cat; a.n_rng = n_rng;
     a.n_words = (n_rng * N_THR + 63) / 64;
     a.n_chunks_max = max_chunks(n_dt, n_cat);
     a.cat_off = cat_off; a.matched = matched; a.ignored = ignored;
     a.num_gt = num_gt; a.val = val; a.rec = rec;
     a.k_begin = k_begin; a.k_end = k_end;
+    // every category fits one workgroup (the host says so): the fused
+    // single-launch sweep.  Mixing the two paths per category was measured
+    // slower than the chunked path alone when long categories exist (image
+    // level, Config 2: 0.23 vs 0.18 ms), so it is all or nothing.
+    a.fused_rows = ACC_FUSED_WAVES / a.n_words * ACC_CH;
+    if (max_segment > 0 && max_segment <= a.fused_rows) {
+        acc_fused_kernel<<<(unsigned)(k_end - k_begin), ACC_FUSED_WAVES * WAVE, 0, s>>>(
+            a, rec_thr());
+        TAO_LAUNCH_CHECK();
+        return TAOAMD_OK;
+    }
+    a.fused_rows = 0;
     unsigned char *w = (unsigned char *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     const size_t nc = (size_t)a.n_chunks_max, nw = (size_t)a.n_words;
     a.cat_chunk_off = (int32_t *)w; w += align256(((size_t)n_cat + 1) * 4);
@@ -577,9 +778,9 @@ extern "C" int taoamd_accumulate(int64_t n_dt, int32_t n_cat, int32_t n_rng,
                                  const int32_t *cat_off,
                                  const uint64_t *matched,
                                  const uint64_t *ignored, const int32_t *num_gt,
-                                 double *precision, double *recall,
-                                 void *workspace, size_t workspace_bytes,
-                                 void *stream)
+                                 int32_t max_segment, double *precision,
+                                 double *recall, void *workspace,
+                                 size_t workspace_bytes, void *stream)
 {
     if (n_cat <= 0 || n_rng < 1 || n_rng > 32) return TAOAMD_ERR_ARG;
     if (!workspace) return TAOAMD_ERR_ARG;
@@ -590,8 +791,8 @@ extern "C" int taoamd_accumulate(int64_t n_dt, int32_t n_cat, int32_t n_rng,
     double *val = (double *)(w + base);
     double *rec = val + (align256(taoamd_compact_elems(n_cat, n_rng) * 8) / 8);
     int st = taoamd_accumulate_compact(n_dt, n_cat, n_rng, cat_off, matched,
-                                       ignored, num_gt, 0, n_cat, val, rec, w,
-                                       base, stream);
+                                       ignored, num_gt, 0, n_cat, max_segment,
+                                       val, rec, w, base, stream);
     if (st != TAOAMD_OK) return st;
     return taoamd_finalize(n_cat, n_rng, num_gt, val, rec, precision, recall, stream);
 }

@@ -114,11 +114,12 @@ class HipBackend:
             _ptr(matched), _ptr(ignored), self._s()), "taoamd_gather_rows")
 
     def accumulate_compact(self, n, n_cat, n_rng, cat_off, matched, ignored,
-                           num_gt, k0, k1, val, rec, ws_buf, ws_bytes):
+                           num_gt, k0, k1, val, rec, ws_buf, ws_bytes,
+                           max_segment=0):
         _lib.check(self.lib.taoamd_accumulate_compact(
             n, n_cat, n_rng, _ptr(cat_off), _ptr(matched), _ptr(ignored),
-            _ptr(num_gt), k0, k1, _ptr(val), _ptr(rec), _ptr(ws_buf), ws_bytes,
-            self._s()), "taoamd_accumulate_compact")
+            _ptr(num_gt), k0, k1, max_segment, _ptr(val), _ptr(rec),
+            _ptr(ws_buf), ws_bytes, self._s()), "taoamd_accumulate_compact")
 
     def finalize(self, n_cat, n_rng, num_gt, val, rec, precision, recall):
         _lib.check(self.lib.taoamd_finalize(
@@ -331,7 +332,7 @@ class CategoryShardedEval:
         be.accumulate_compact(dp.n_dt, dp.n_cat, dp.n_rng, dp.t["cat_off"],
                               ws.matched, ws.ignored, ws.num_gt, self.k0,
                               self.k1, self.val, self.rec, ws.acc_ws,
-                              ws.acc_bytes)
+                              ws.acc_bytes, dp.acc_hint)
         lo, hi = self.rank * self.chunk_bytes, (self.rank + 1) * self.chunk_bytes
         be.exchange_pack(dp.n_cat, dp.n_rng, self.Kb, self.world, self.rank,
                          ws.num_gt, self.val, self.rec, self.chunks[lo:hi],

@@ -115,6 +115,8 @@ class DeviceProblem:
         self.grouped = bool(np.all(np.diff(flat.dt_cat) >= 0)
                             and np.all(np.diff(flat.gt_cat) >= 0))
         self.max_segment = int(np.diff(cat_off).max()) if self.n_cat else 0
+        # hint for the sweep: longest category (0 = unknown -> chunked kernels)
+        self.acc_hint = self.max_segment
         tiles = (np.diff(cat_off) + _lib.SEGMENT_TILE - 1) // _lib.SEGMENT_TILE
         tile_off = np.zeros(self.n_cat + 1, dtype=np.int32)
         np.cumsum(tiles, out=tile_off[1:])
@@ -264,7 +266,7 @@ def stage_accumulate(dp, ws):
     lib, t, s = _lib.load(), dp.t, _stream()
     _lib.check(lib.taoamd_accumulate(
         dp.n_dt, dp.n_cat, dp.n_rng, _ptr(t["cat_off"]), _ptr(ws.matched),
-        _ptr(ws.ignored), _ptr(ws.num_gt), _ptr(ws.precision),
+        _ptr(ws.ignored), _ptr(ws.num_gt), dp.acc_hint, _ptr(ws.precision),
         _ptr(ws.recall), _ptr(ws.acc_ws), ws.acc_bytes, s),
         "taoamd_accumulate")
 

@@ -68,7 +68,8 @@ class OracleBackend:
         ignored[:n] = torch.from_numpy(rec[o, 2 + n_words:2 + 2 * n_words].copy())
 
     def accumulate_compact(self, n, n_cat, n_rng, cat_off, matched, ignored,
-                           num_gt, k0, k1, val, rec, ws_buf, ws_bytes):
+                           num_gt, k0, k1, val, rec, ws_buf, ws_bytes,
+                           max_segment=0):
         import ctypes as C
         co = cat_off.numpy().astype(np.int64)
         cat = np.repeat(np.arange(n_cat, dtype=np.int32), np.diff(co))
