@@ -631,6 +631,34 @@ __global__ __launch_bounds__(256) void seg_finish_kernel(SegArgs a, int sel)
     if (a.dst) a.dst[d] = (int32_t)p;
 }
 
+// Categories of up to SEG_KWAY tiles are finished in ONE pass: every element
+// adds up its rank in each of the other sorted tiles of its category (one
+// binary search per tile, unique (key, input position) order) -- that sum is
+// its final place.  log2(tiles) pairwise passes with their round trips
+// through memory are only used for longer categories.
+#define SEG_KWAY 16
+
+__global__ __launch_bounds__(256) void seg_kmerge_kernel(SegArgs a)
+{
+    const int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (p >= a.n) return;
+    const int32_t k = a.cat[p];
+    const int32_t sb = a.cat_off[k], se = a.cat_off[k + 1];
+    if (se - sb <= SEG_TILE) return;
+    const uint64_t *__restrict__ kin = a.key[0];
+    const int32_t *__restrict__ iin = a.idx[0];
+    const uint64_t kx = kin[p];
+    const int32_t ix = iin[p];
+    const int32_t mine = (int32_t)((p - sb) / SEG_TILE);
+    int64_t pos = sb;
+    for (int32_t tb = sb, t = 0; tb < se; tb += SEG_TILE, t++) {
+        const int32_t te = min(tb + SEG_TILE, se);
+        pos += t == mine ? p - tb : rank_in(kin, iin, tb, te, kx, ix);
+    }
+    if (a.order) a.order[pos] = ix;
+    if (a.dst) a.dst[ix] = (int32_t)pos;
+}
+
 extern "C" size_t taoamd_sort_segments_workspace(int64_t n)
 {
     if (n < 1) n = 1;
@@ -659,7 +687,9 @@ extern "C" int taoamd_sort_segments(int64_t n, int32_t n_cat,
     a.idx[0] = (int32_t *)w;  w += align256((size_t)n * 4);
     a.idx[1] = (int32_t *)w;
     seg_tile_kernel<<<(unsigned)n_tiles, SEG_THREADS, 0, s>>>(a);
-    if (max_segment > SEG_TILE) {
+    if (max_segment > SEG_TILE && max_segment <= (int64_t)SEG_KWAY * SEG_TILE) {
+        seg_kmerge_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(a);
+    } else if (max_segment > SEG_TILE) {
         int passes = 0;
         for (int64_t L = SEG_TILE; L < max_segment; L <<= 1) passes++;
         const unsigned blocks = (unsigned)((n + 255) / 256);
