@@ -232,20 +232,25 @@ __global__ __launch_bounds__(256) void acc_count_kernel(AccArgs a)
     a.cnt_fp[o] = fp;
 }
 
-// one wavefront per (category, word)
+// one workgroup per (category, word): the four wavefronts scan a quarter of
+// the category's chunks each, the quarters are stitched through LDS (long
+// categories -- a rank's share of a multi-GPU job -- would otherwise be one
+// serial chain of dependent loads)
 __global__ __launch_bounds__(256) void acc_prefix_kernel(AccArgs a)
 {
+    __shared__ uint32_t s_tp[4][WAVE], s_fp[4][WAVE];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t item = (int64_t)blockIdx.x * 4 + wave;
-    if (item >= (int64_t)(a.k_end - a.k_begin) * a.n_words) return;
+    const int64_t item = blockIdx.x;
     const int32_t k = a.k_begin + (int32_t)(item / a.n_words);
     const int word = (int)(item % a.n_words);
     const int lane = lane_id();
     if (a.fused_rows > 0 && a.cat_off[k + 1] - a.cat_off[k] <= a.fused_rows)
         return;                                    // acc_fused_kernel's
     const int32_t c0 = a.cat_chunk_off[k], c1 = a.cat_chunk_off[k + 1];
+    const int32_t q = (c1 - c0 + 3) / 4;
+    const int32_t lo = min(c1, c0 + wave * q), hi = min(c1, lo + q);
     uint32_t tp = 0, fp = 0;
-    for (int32_t c = c0; c < c1; c++) {
+    for (int32_t c = lo; c < hi; c++) {
         const int64_t o = ((int64_t)c * a.n_words + word) * WAVE + lane;
         const uint32_t t_ = a.cnt_tp[o], f_ = a.cnt_fp[o];
         a.pre_tp[o] = tp;
@@ -253,6 +258,19 @@ __global__ __launch_bounds__(256) void acc_prefix_kernel(AccArgs a)
         tp += t_;
         fp += f_;
     }
+    s_tp[wave][lane] = tp;
+    s_fp[wave][lane] = fp;
+    __syncthreads();
+    uint32_t btp = 0, bfp = 0;
+    for (int w = 0; w < wave; w++) { btp += s_tp[w][lane]; bfp += s_fp[w][lane]; }
+    if (wave > 0 && (__ballot(btp | bfp) != 0))
+        for (int32_t c = lo; c < hi; c++) {
+            const int64_t o = ((int64_t)c * a.n_words + word) * WAVE + lane;
+            a.pre_tp[o] += btp;
+            a.pre_fp[o] += bfp;
+        }
+    if (wave != 3) return;
+    tp += btp;                                     // whole category
     const int combo = word * WAVE + lane;
     if (combo < a.n_rng * N_THR) {
         const int r = combo / N_THR, t = combo - r * N_THR;
@@ -297,22 +315,39 @@ __global__ __launch_bounds__(256) void acc_chunkmax_kernel(AccArgs a)
     a.cmax[o] = best;
 }
 
+// reverse exclusive maximum over the chunks of a category; one workgroup per
+// (category, word), quarters stitched like acc_prefix_kernel
 __global__ __launch_bounds__(256) void acc_sufmax_kernel(AccArgs a)
 {
+    __shared__ uint64_t s_max[4][WAVE];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t item = (int64_t)blockIdx.x * 4 + wave;
-    if (item >= (int64_t)(a.k_end - a.k_begin) * a.n_words) return;
+    const int64_t item = blockIdx.x;
     const int32_t k = a.k_begin + (int32_t)(item / a.n_words);
     const int word = (int)(item % a.n_words);
     const int lane = lane_id();
     const int32_t c0 = a.cat_chunk_off[k], c1 = a.cat_chunk_off[k + 1];
+    const int32_t q = (c1 - c0 + 3) / 4;
+    const int32_t lo = min(c1, c0 + wave * q), hi = min(c1, lo + q);
     uint64_t run = PR_ZERO;
-    for (int32_t c = c1 - 1; c >= c0; c--) {
+    for (int32_t c = hi - 1; c >= lo; c--) {
         const int64_t o = ((int64_t)c * a.n_words + word) * WAVE + lane;
         const uint64_t v = a.cmax[o];
         a.cmax[o] = run;
         if (pr_better((uint32_t)(v >> 32), (uint32_t)v, run)) run = v;
     }
+    s_max[wave][lane] = run;
+    __syncthreads();
+    uint64_t later = PR_ZERO;                      // maximum of the later quarters
+    for (int w = 3; w > wave; w--) {
+        const uint64_t v = s_max[w][lane];
+        if (pr_better((uint32_t)(v >> 32), (uint32_t)v, later)) later = v;
+    }
+    if (wave < 3 && __ballot(later != PR_ZERO) != 0)
+        for (int32_t c = lo; c < hi; c++) {
+            const int64_t o = ((int64_t)c * a.n_words + word) * WAVE + lane;
+            const uint64_t v = a.cmax[o];
+            if (pr_better((uint32_t)(later >> 32), (uint32_t)later, v)) a.cmax[o] = later;
+        }
 }
 
 // cj[k][r][j]: smallest TP count c with fl(c / num_gt) >= rec_thrs[j]
@@ -742,7 +777,7 @@ extern "C" int taoamd_accumulate_compact(int64_t n_dt, int32_t n_cat,
     a.t_fp = (uint64_t *)w; w += align256(nc * nw * ACC_BLK * WAVE * 8);
     a.cj = (int32_t *)w;
     const unsigned chunk_blocks = (unsigned)((nc * nw + 3) / 4);
-    const unsigned cat_blocks = (unsigned)(((size_t)(k_end - k_begin) * nw + 3) / 4);
+    const unsigned cat_blocks = (unsigned)((size_t)(k_end - k_begin) * nw);
     acc_chunks_kernel<<<1, 256, 0, s>>>(a);
     {
         const int64_t tot = (int64_t)(k_end - k_begin) * n_rng * N_REC;

@@ -128,26 +128,39 @@ __global__ void tao_ranges_kernel(
     }
 }
 
-// num_gt without atomics: GTs grouped by category, one wavefront per category,
-// lane r < n_rng ends up owning the count of range r
+// num_gt without global atomics: GTs grouped by category, one workgroup per
+// category; the four wavefronts stride over its GTs 64 at a time (four loads
+// in flight each), lane r < n_rng ends up owning the count of range r
 __global__ __launch_bounds__(256) void count_gt_kernel(
     int32_t n_cat, int32_t n_rng, const int32_t *__restrict__ gt_cat_off,
     const uint32_t *__restrict__ gt_rng, int32_t *__restrict__ num_gt)
 {
+    __shared__ int32_t part[4][32];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int32_t k = blockIdx.x * 4 + wave;
-    if (k >= n_cat) return;
+    const int32_t k = blockIdx.x;
     const int lane = lane_id();
     const int32_t b = gt_cat_off[k], e = gt_cat_off[k + 1];
     int32_t mine = 0;
-    for (int32_t base = b; base < e; base += WAVE) {
-        const uint32_t m = base + lane < e ? gt_rng[base + lane] : 0xffffffffu;
-        for (int r = 0; r < n_rng; r++) {
-            const int c = __popcll(__ballot(!((m >> r) & 1u)));
-            if (lane == r) mine += c;
+    for (int32_t base = b + wave * WAVE; base < e; base += 4 * 4 * WAVE) {
+        uint32_t m[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int32_t i = base + u * 4 * WAVE + lane;
+            m[u] = i < e ? gt_rng[i] : 0xffffffffu;
         }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            for (int r = 0; r < n_rng; r++) {
+                const int c = __popcll(__ballot(!((m[u] >> r) & 1u)));
+                if (lane == r) mine += c;
+            }
     }
-    if (lane < n_rng) num_gt[(int64_t)k * n_rng + lane] = mine;
+    if (lane < 32) part[wave][lane] = mine;
+    __syncthreads();
+    if (threadIdx.x < (unsigned)n_rng)
+        num_gt[(int64_t)k * n_rng + threadIdx.x] =
+            part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] +
+            part[3][threadIdx.x];
 }
 
 // ------------------------------------------------------------------ 3D IoU
@@ -964,7 +977,7 @@ extern "C" int taoamd_lvis_ranges(int64_t n_gt, const double *gt_vis,
             grouped ? nullptr : num_gt);
     }
     if (grouped)
-        count_gt_kernel<<<(unsigned)((n_cat + 3) / 4), 256, 0, s>>>(
+        count_gt_kernel<<<(unsigned)n_cat, 256, 0, s>>>(
             n_cat, TAOAMD_LVIS_RNG, gt_cat_off, gt_rng, num_gt);
     TAO_LAUNCH_CHECK();
     return TAOAMD_OK;
@@ -990,7 +1003,7 @@ extern "C" int taoamd_tao_ranges(int64_t n_gt, const double *gt_area,
             dt_len, dt_flags, gt_rng, dt_rng, grouped ? nullptr : num_gt);
     }
     if (grouped)
-        count_gt_kernel<<<(unsigned)((n_cat + 3) / 4), 256, 0, s>>>(
+        count_gt_kernel<<<(unsigned)n_cat, 256, 0, s>>>(
             n_cat, TAOAMD_TAO_RNG, gt_cat_off, gt_rng, num_gt);
     TAO_LAUNCH_CHECK();
     return TAOAMD_OK;
