@@ -706,17 +706,23 @@ int taoamd_host_sort_key_score(int64_t n, const int64_t *key, const double *scor
     if (n < 0 || (n > 0 && (!key || !order))) return 1;
     struct Rec { int64_t key; double neg; int64_t idx; };
     std::vector<Rec> r((size_t)n);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(std::min(32, omp_get_max_threads()))
     for (int64_t i = 0; i < n; i++) r[i] = Rec{key[i], score ? -score[i] : 0.0, i};
+    // a team sized to the input: on a 256-core host the full team costs more
+    // in start-up and merge steps than it saves below a few million records
+    int team = (int)std::min<int64_t>(32, std::max<int64_t>(1, n / 65536));
+    team = std::min(team, omp_get_max_threads());
+    const __gnu_parallel::multiway_mergesort_tag tag(team);
     if (score)
         __gnu_parallel::stable_sort(r.begin(), r.end(), [](const Rec &a, const Rec &b) {
             if (a.key != b.key) return a.key < b.key;
             return a.neg < b.neg || (b.neg != b.neg && a.neg == a.neg);
-        });
+        }, tag);
     else
         __gnu_parallel::stable_sort(r.begin(), r.end(),
-                                    [](const Rec &a, const Rec &b) { return a.key < b.key; });
-#pragma omp parallel for schedule(static)
+                                    [](const Rec &a, const Rec &b) { return a.key < b.key; },
+                                    tag);
+#pragma omp parallel for schedule(static) num_threads(std::min(32, omp_get_max_threads()))
     for (int64_t i = 0; i < n; i++) order[i] = r[i].idx;
     return 0;
 }
