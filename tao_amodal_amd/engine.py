@@ -29,6 +29,31 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+_RAW_TABLES = {}     # id(host table) -> (weakref, {device: tensor})
+
+
+def _to_device(v, device):
+    """Upload a table of a flattened problem.  flatten.LazyRows (rows of a raw
+    input table) are gathered on the device from ONE upload of the raw table,
+    shared by every problem built from the same input."""
+    from .flatten import LazyRows
+    if not isinstance(v, LazyRows):
+        return torch.from_numpy(np.ascontiguousarray(v)).to(device)
+    import weakref
+    key = id(v.source)
+    ent = _RAW_TABLES.get(key)
+    if ent is None or ent[0]() is not v.source:
+        ent = (weakref.ref(v.source, lambda _r, k=key: _RAW_TABLES.pop(k, None)), {})
+        _RAW_TABLES[key] = ent
+    dev = torch.device(device)
+    if dev not in ent[1]:
+        ent[1][dev] = torch.from_numpy(np.ascontiguousarray(v.source)).to(dev)
+    if len(v.index) == 0:
+        return torch.zeros((0,) + tuple(v.source.shape[1:]), dtype=ent[1][dev].dtype,
+                           device=dev)
+    return ent[1][dev].index_select(0, torch.from_numpy(v.index).to(dev))
+
+
 def match_plan(d_cnt, g_cnt, cap_d=64, cap_g=64, cap_cell_g=8):
     """Pack runs of consecutive small cells (<= cap_d detections and <= cap_g
     GTs in total, <= cap_cell_g GTs per cell) into groups for
@@ -106,8 +131,7 @@ class DeviceProblem:
             self.all_dense = int(bool(np.all(fits[live])))
         self.t = {}
         for n in names:
-            self.t[n] = torch.from_numpy(np.ascontiguousarray(flat[n])).to(
-                self.device)
+            self.t[n] = _to_device(flat[n], self.device)
         gt_cat_off = np.zeros(self.n_cat + 1, dtype=np.int32)
         np.cumsum(np.bincount(flat.gt_cat, minlength=self.n_cat),
                   out=gt_cat_off[1:])

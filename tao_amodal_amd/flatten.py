@@ -199,6 +199,40 @@ def make_track_ids_unique(dt):
     return out, int(clash_t.sum())
 
 
+class LazyRows:
+    """``source[index]`` (rows of an (N, 4) float64 table), not gathered yet.
+
+    The gathers of the kept detections' boxes are the largest single step of
+    the cell-table build on the host; the device has to receive those rows
+    anyway, so ``engine.DeviceProblem`` uploads the raw table once (shared by
+    the image-level and the track-level problem) and gathers there.  On the
+    host the object turns into the gathered array on demand (``np.asarray``)."""
+
+    def __init__(self, source, index):
+        self.source = source
+        self.index = np.asarray(index, dtype=np.int64)
+
+    @property
+    def shape(self):
+        return (len(self.index),) + tuple(self.source.shape[1:])
+
+    @property
+    def dtype(self):
+        return self.source.dtype
+
+    def __len__(self):
+        return len(self.index)
+
+    def __array__(self, dtype=None, copy=None):
+        a = np.ascontiguousarray(self.source[self.index])
+        return a if dtype is None else a.astype(dtype, copy=False)
+
+    def __getitem__(self, key):
+        if isinstance(key, slice):
+            return LazyRows(self.source, self.index[key])
+        return np.asarray(self)[key]
+
+
 class Flat(dict):
     """A bag of arrays with attribute access."""
     __getattr__ = dict.__getitem__
@@ -326,7 +360,7 @@ def flatten_lvis(gt: GTColumns, dt: DTColumns, max_dets=MAX_DETS):
     f.cell_cat = (cell_keys // U).astype(I32)
     f.cell_dt_off = d_off.astype(I32)
     f.cell_gt_off = g_off.astype(I32)
-    f.dt_box = np.ascontiguousarray(dt.bbox[keep[order]])
+    f.dt_box = LazyRows(dt.bbox, keep[order])
     f.dt_score = np.ascontiguousarray(d_score[order])
     f.dt_flags = d_flags
     f.dt_id = d_id[order]
@@ -608,8 +642,8 @@ def flatten_tao(gt: GTColumns, dt: DTColumns, max_dets=MAX_DETS,
             live = np.flatnonzero(nt >= 0)
             sel, off = _unique_frames(nt[live], pos[live], len(trk_order))
             rows = live[sel]
-        return (pos[rows].astype(I32),
-                np.ascontiguousarray(boxes[ann_rows[rows]]), off.astype(I32))
+        return (pos[rows].astype(I32), LazyRows(boxes, ann_rows[rows]),
+                off.astype(I32))
 
     g_fpos, g_fbox, g_foff = frames(og, g_trk_of_ann, g_aoff, g_ann, a_img[g_ann],
                                     gt.ann_bbox)

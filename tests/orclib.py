@@ -86,11 +86,12 @@ IOU_MODES = {"3d_iou": 0, "avg_iou": 1, "imagenetvid": 2}
 
 def track_iou(f, mode="3d_iou"):
     iou = np.zeros(int(f.cell_iou_off[-1]))
+    dfb, gfb = np.ascontiguousarray(f.dt_frame_box), np.ascontiguousarray(f.gt_frame_box)
     pairs = lib().orc_track_iou(
         C.c_int64(f.n_cells), _p(f.cell_dt_off), _p(f.cell_gt_off),
         _p(f.cell_iou_off), _p(f.dt_frame_off), _p(f.dt_frame_pos),
-        _p(f.dt_frame_box), _p(f.gt_frame_off), _p(f.gt_frame_pos),
-        _p(f.gt_frame_box), C.c_int(IOU_MODES[mode]), _p(iou))
+        _p(dfb), _p(f.gt_frame_off), _p(f.gt_frame_pos),
+        _p(gfb), C.c_int(IOU_MODES[mode]), _p(iou))
     return iou, int(pairs)
 
 
@@ -106,8 +107,9 @@ def match(f, gt_rng, dt_rng, iou=None, detail=True):
     ious_out = None
     if f.kind == "lvis":
         ious_out = np.zeros(int(off[-1])) if detail else None
+        dbox, gbox = np.ascontiguousarray(f.dt_box), np.ascontiguousarray(f.gt_box)
         lib().orc_match(C.c_int64(f.n_cells), _p(f.cell_dt_off),
-                        _p(f.cell_gt_off), _p(off), _p(f.dt_box), _p(f.gt_box),
+                        _p(f.cell_gt_off), _p(off), _p(dbox), _p(gbox),
                         None, C.c_int(n_rng), _p(gt_rng), _p(dt_rng),
                         _p(f.gt_flags), _p(f.dt_flags), _p(matched),
                         _p(ignored), _p(mg), _p(ious_out))
