@@ -396,6 +396,38 @@ class GraphedPair:
             cur.wait_stream(s)
 
 
+class StageProbe:
+    """HIP events around single-kernel stages, recorded on the stream the
+    kernel is launched on while the (overlapped) steps run: the dominant
+    kernels' launch durations inside the timed region of bench.py."""
+
+    def __init__(self):
+        self.events = {}
+
+    def wrap(self, name, fn, dp, ws):
+        a = torch.cuda.Event(enable_timing=True)
+        b = torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn(dp, ws)
+        b.record()
+        self.events.setdefault(name, []).append((a, b))
+
+    def mean_ms(self):
+        """(call after a synchronize)"""
+        return {k: sum(a.elapsed_time(b) for a, b in v) / len(v)
+                for k, v in self.events.items()}
+
+
+PROBE = None     # set to a StageProbe to time stage_track_iou / stage_match
+
+
+def _probed(name, fn, dp, ws):
+    if PROBE is None:
+        fn(dp, ws)
+    else:
+        PROBE.wrap(dp.kind + ":" + name, fn, dp, ws)
+
+
 def run_forked(dp, ws, aux, head_only=False):
     """One evaluator pass on the current stream, its independent head stages
     on the stream `aux` (forked from and joined to the current stream):
@@ -411,9 +443,9 @@ def run_forked(dp, ws, aux, head_only=False):
         with torch.cuda.stream(aux):
             stage_ranges(dp, ws)
             stage_sort(dp, ws)
-        stage_track_iou(dp, ws)
+        _probed("track_iou", stage_track_iou, dp, ws)
     cur.wait_stream(aux)
-    stage_match(dp, ws)
+    _probed("match", stage_match, dp, ws)
     if not head_only:
         stage_accumulate(dp, ws)
 
