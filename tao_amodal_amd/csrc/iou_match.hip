@@ -279,10 +279,11 @@ __global__ __launch_bounds__(256) void track_iou_kernel(
 }
 
 // Dense-timeline variant (the common case: videos with a few hundred frames).
-// One workgroup per cell.  LDS holds one row per track -- the GT tracks of the
-// cell and a group of its detection tracks -- mapping timeline position ->
-// frame (offset inside the track, 0xffff = absent).  The timeline is processed
-// in chunks of TD_CH positions, two phases per chunk:
+// One workgroup per cell.  LDS holds, per track -- the GT tracks of the cell
+// and a group of its detection tracks -- a presence bitmap over the timeline
+// plus the frame count before each 64-position word (frame at position p =
+// first + count before its word + popcount of the bits below p).  The
+// timeline is processed in chunks of TD_CH positions, two phases per chunk:
 //   A  one work item per (detection track, position): fetch the detection
 //      frame at that position (consecutive items = consecutive frames of one
 //      track: coalesced) and, per GT track, the GT frame; form the term
