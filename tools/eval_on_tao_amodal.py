@@ -173,8 +173,9 @@ def main(argv=None):
             raise
         eval_tao_track(annotation, gt_dataset, lvis_gt.columns, dt_columns,
                        logger, prepared)
-        pool.shutdown(wait=False)
     finally:
+        if "pool" in locals():
+            pool.shutdown(wait=False)
         logger.removeHandler(handler)
         handler.close()
     if os.environ.get("TAOAMD_TIMING"):
