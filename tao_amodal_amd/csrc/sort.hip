@@ -286,11 +286,10 @@ extern "C" int taoamd_sort_by_cat_score(int64_t n, const int32_t *dt_cat,
 // score order inside it is missing.
 //   seg_tile_kernel   one workgroup sorts one tile (<= SEG_TILE elements of one
 //                     category) with a stable LSD radix sort in LDS
-//   seg_merge_kernel  categories longer than one tile: log2(#tiles) passes of
-//                     pairwise run merging; every element finds its output
-//                     slot by one binary search in the partner run (merge by
-//                     rank -- no serial merge loop)
-//   seg_finish_kernel order / dst of the multi-tile categories
+//   seg_kmerge_kernel categories of 2..SEG_KMERGE_TILES tiles: one pass, every
+//                     element sums its ranks in the other tiles
+//   seg_mpass_kernel  longer categories: log2(#tiles) pairwise merge-path
+//                     passes, the last one writes order / dst
 // ---------------------------------------------------------------------------
 #define SEG_TILE 3072
 #define SEG_THREADS 256
@@ -591,52 +590,14 @@ __device__ __forceinline__ int32_t rank_in(const uint64_t *__restrict__ key,
     return lo - b;
 }
 
-__global__ __launch_bounds__(256) void seg_merge_kernel(SegArgs a, int pass)
-{
-    const int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (p >= a.n) return;
-    const int32_t k = a.cat[p];
-    const int32_t sb = a.cat_off[k], se = a.cat_off[k + 1];
-    if (se - sb <= SEG_TILE) return;
-    const int s = pass & 1;
-    const uint64_t *__restrict__ kin = a.key[s];
-    const int32_t *__restrict__ iin = a.idx[s];
-    const int64_t L = (int64_t)SEG_TILE << pass;
-    const uint64_t kx = kin[p];
-    const int32_t ix = iin[p];
-    const int64_t local = p - sb;
-    const int64_t base = sb + (local / (2 * L)) * (2 * L);
-    const int64_t a_end = min(base + L, (int64_t)se);
-    const int64_t b_end = min(a_end + L, (int64_t)se);
-    int64_t out = p;
-    if (a_end < b_end) {
-        if (p < a_end)
-            out = p + rank_in(kin, iin, (int32_t)a_end, (int32_t)b_end, kx, ix);
-        else
-            out = base + (p - a_end) +
-                  rank_in(kin, iin, (int32_t)base, (int32_t)a_end, kx, ix);
-    }
-    a.key[s ^ 1][out] = kx;
-    a.idx[s ^ 1][out] = ix;
-}
-
-__global__ __launch_bounds__(256) void seg_finish_kernel(SegArgs a, int sel)
-{
-    const int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (p >= a.n) return;
-    const int32_t k = a.cat[p];
-    if (a.cat_off[k + 1] - a.cat_off[k] <= SEG_TILE) return;
-    const int32_t d = a.idx[sel][p];
-    if (a.order) a.order[p] = d;
-    if (a.dst) a.dst[d] = (int32_t)p;
-}
-
-// Categories of up to SEG_KWAY tiles are finished in ONE pass: every element
+// Categories of up to SEG_KMERGE_TILES tiles are finished in ONE pass: every element
 // adds up its rank in each of the other sorted tiles of its category (one
 // binary search per tile, unique (key, input position) order) -- that sum is
-// its final place.  log2(tiles) pairwise passes with their round trips
-// through memory are only used for longer categories.
-#define SEG_KWAY 16
+// its final place.  Longer categories take log2(tiles) pairwise merge-path
+// passes (seg_mpass_kernel; measured: equal at 5 tiles, 20 % faster at 6).
+#ifndef SEG_KMERGE_TILES
+#define SEG_KMERGE_TILES 5      // longest category (in tiles) finished by seg_kmerge_kernel
+#endif
 
 __global__ __launch_bounds__(256) void seg_kmerge_kernel(SegArgs a)
 {
@@ -657,6 +618,97 @@ __global__ __launch_bounds__(256) void seg_kmerge_kernel(SegArgs a)
     }
     if (a.order) a.order[pos] = ix;
     if (a.dst) a.dst[ix] = (int32_t)pos;
+}
+
+// ---------------------------------------------------------------------------
+// Pairwise merge passes by MERGE PATH for categories of many tiles: a workgroup
+// produces one tile-sized slice of a merged pair of runs.  Two searches along
+// the slice's diagonals tell which pieces of the two runs feed it; the pieces
+// are staged in LDS with coalesced loads, every thread then finds its own
+// diagonal in LDS and merges 12 elements sequentially.  Ties take the element
+// of the left run (it holds the earlier input positions), so the pass is
+// stable with key comparisons only.  Per pass every element is read once and
+// written once, instead of one 12-step search per element and other tile.
+#define MP_PER 12       // outputs per thread: 256 * 12 = SEG_TILE
+
+// number of elements of A among the first o outputs of merge(A, B)
+template <class KA, class KB>
+__device__ __forceinline__ int32_t merge_split(KA A, int32_t na, KB B, int32_t nb, int32_t o)
+{
+    int32_t lo = max(0, o - nb), hi = min(o, na);
+    while (lo < hi) {
+        const int32_t mid = (lo + hi) >> 1;
+        if (A[mid] <= B[o - mid - 1]) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void seg_mpass_kernel(SegArgs a, int pass, int last)
+{
+    __shared__ uint64_t m_key[SEG_TILE];
+    __shared__ int32_t m_idx[SEG_TILE];
+    __shared__ int32_t m_split[2];
+    static_assert(256 * MP_PER == SEG_TILE, "one workgroup = one tile-sized slice");
+    int32_t lo = 0, hi = a.n_cat;
+    while (hi - lo > 1) {
+        const int32_t mid = (lo + hi) >> 1;
+        if (a.tile_off[mid] <= (int32_t)blockIdx.x) lo = mid; else hi = mid;
+    }
+    const int32_t k = lo;
+    const int32_t sb = a.cat_off[k], se = a.cat_off[k + 1];
+    if (se - sb <= SEG_TILE) return;
+    const int32_t tb = sb + ((int32_t)blockIdx.x - a.tile_off[k]) * SEG_TILE;
+    const int32_t len = min(SEG_TILE, se - tb);
+    if (len <= 0) return;
+    const int s = pass & 1;
+    const uint64_t *__restrict__ kin = a.key[s];
+    const int32_t *__restrict__ iin = a.idx[s];
+    const int64_t L = (int64_t)SEG_TILE << pass;
+    const int64_t base = sb + ((tb - sb) / (2 * L)) * (2 * L);
+    const int32_t a0 = (int32_t)base, a1 = (int32_t)min(base + L, (int64_t)se);
+    const int32_t b1 = (int32_t)min((int64_t)a1 + L, (int64_t)se);
+    const int32_t na = a1 - a0, nb = b1 - a1;
+    const int32_t o0 = tb - a0;
+    auto emit = [&](int32_t p, uint64_t kx, int32_t ix) {
+        if (last) {
+            if (a.order) a.order[p] = ix;
+            if (a.dst) a.dst[ix] = p;
+        } else {
+            a.key[s ^ 1][p] = kx;
+            a.idx[s ^ 1][p] = ix;
+        }
+    };
+    if (nb <= 0) {      // no partner run: the slice passes through
+        for (int32_t i = threadIdx.x; i < len; i += 256) emit(tb + i, kin[tb + i], iin[tb + i]);
+        return;
+    }
+    // ---- which pieces of the two runs make this slice
+    if (threadIdx.x == 0) m_split[0] = merge_split(kin + a0, na, kin + a1, nb, o0);
+    if (threadIdx.x == 64) m_split[1] = merge_split(kin + a0, na, kin + a1, nb, o0 + len);
+    __syncthreads();
+    const int32_t i0 = m_split[0], i1 = m_split[1];
+    const int32_t j0 = o0 - i0;
+    const int32_t pa = i1 - i0, pb = len - pa;      // piece lengths
+    for (int32_t i = threadIdx.x; i < len; i += 256) {
+        const int32_t src = i < pa ? a0 + i0 + i : a1 + j0 + (i - pa);
+        m_key[i] = kin[src];
+        m_idx[i] = iin[src];
+    }
+    __syncthreads();
+    // ---- my MP_PER outputs
+    const int32_t q0 = min(len, (int32_t)threadIdx.x * MP_PER);
+    const int32_t q1 = min(len, q0 + MP_PER);
+    if (q0 >= q1) return;
+    const uint64_t *A = m_key, *B = m_key + pa;
+    int32_t ia = merge_split(A, pa, B, pb, q0);
+    int32_t ib = q0 - ia;
+    for (int32_t q = q0; q < q1; q++) {
+        const bool takeA = ib >= pb || (ia < pa && A[ia] <= B[ib]);
+        const int32_t from = takeA ? ia : pa + ib;
+        emit(tb + q, m_key[from], m_idx[from]);
+        ia += takeA ? 1 : 0;
+        ib += takeA ? 0 : 1;
+    }
 }
 
 extern "C" size_t taoamd_sort_segments_workspace(int64_t n)
@@ -687,15 +739,13 @@ extern "C" int taoamd_sort_segments(int64_t n, int32_t n_cat,
     a.idx[0] = (int32_t *)w;  w += align256((size_t)n * 4);
     a.idx[1] = (int32_t *)w;
     seg_tile_kernel<<<(unsigned)n_tiles, SEG_THREADS, 0, s>>>(a);
-    if (max_segment > SEG_TILE && max_segment <= (int64_t)SEG_KWAY * SEG_TILE) {
+    if (max_segment > SEG_TILE && max_segment <= (int64_t)SEG_KMERGE_TILES * SEG_TILE) {
         seg_kmerge_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(a);
     } else if (max_segment > SEG_TILE) {
         int passes = 0;
         for (int64_t L = SEG_TILE; L < max_segment; L <<= 1) passes++;
-        const unsigned blocks = (unsigned)((n + 255) / 256);
         for (int p = 0; p < passes; p++)
-            seg_merge_kernel<<<blocks, 256, 0, s>>>(a, p);
-        seg_finish_kernel<<<blocks, 256, 0, s>>>(a, passes & 1);
+            seg_mpass_kernel<<<(unsigned)n_tiles, 256, 0, s>>>(a, p, p == passes - 1);
     }
     TAO_LAUNCH_CHECK();
     return TAOAMD_OK;
