@@ -94,3 +94,32 @@ def test_tao_raises_like_the_reference_without_usable_predictions():
         p["bbox"][2] = 0          # zero area: dropped by the strict filter
     with pytest.raises(ValueError, match="no predicted annotations"):
         TaoResults(Tao(gt), pred)
+
+
+def test_reference_doctest_boxes_through_the_kernels():
+    """The known answers of the reference's own doctests for
+    bb_intersect_union (tao_amodal/eval.py:21-30, non-crowd cases):
+    (i, u) = (400, 400), (100, 400), (25, 100), (400, 900) -- as IoUs of
+    one-frame tracks (track level) and of single boxes (image level)."""
+    from tao_amodal_amd import engine, flatten
+    from tao_amodal_amd.columns import DTColumns, GTColumns
+    pairs = [([0, 0, 20, 20], [0, 0, 20, 20], 400 / 400), ([0, 0, 20, 20], [0, 0, 10, 10], 100 / 400),
+             ([10, 20, 10, 10], [10, 20, 5, 5], 25 / 100), ([0, 0, 20, 20], [0, 0, 30, 30], 400 / 900)]
+    cats = [{"id": c + 1, "name": "c%d" % c, "frequency": "f"} for c in range(len(pairs))]
+    gt = {"info": {}, "categories": cats,
+          "videos": [{"id": 1, "name": "v", "neg_category_ids": [], "not_exhaustive_category_ids": []}],
+          "images": [{"id": 1, "video_id": 1, "frame_index": 0, "neg_category_ids": [],
+                      "not_exhaustive_category_ids": []}],
+          "tracks": [{"id": c + 1, "category_id": c + 1, "video_id": 1} for c in range(len(pairs))],
+          "annotations": [{"id": c + 1, "image_id": 1, "track_id": c + 1, "category_id": c + 1,
+                           "bbox": g, "area": g[2] * g[3], "visibility": 1.0, "out_of_frame": False}
+                          for c, (d, g, _) in enumerate(pairs)]}
+    preds = [{"image_id": 1, "category_id": c + 1, "bbox": d, "score": 0.9, "track_id": c + 1,
+              "video_id": 1} for c, (d, g, _) in enumerate(pairs)]
+    G, D = GTColumns.from_json(gt), DTColumns.from_json(preds)
+    want = np.array([w for _, _, w in pairs])
+    got = engine.evaluate_flat(flatten.flatten_lvis(G, D), detail=True)
+    assert np.array_equal(got["iou"], want)
+    D.track_id, _ = flatten.make_track_ids_unique(D)
+    got = engine.evaluate_flat(flatten.flatten_tao(G, D), detail=True)
+    assert np.array_equal(got["iou"], want)
