@@ -426,3 +426,39 @@ def test_fused_and_chunked_sweeps_agree():
                 torch.cuda.synchronize()
                 assert np.array_equal(ws.precision.cpu().numpy(), want["precision"]), (flat.kind, hint)
                 assert np.array_equal(ws.recall.cpu().numpy(), want["recall"]), (flat.kind, hint)
+
+
+@pytest.mark.timeout(900)
+def test_config2_full_size_properties():
+    """BASELINE.json Config 2 (200 videos x 300 frames x 50 dets, 1203
+    categories) at full size: bit-exact against the C oracle, idempotent
+    (a second pass over the same workspace gives the same tensors), and
+    consistent under the category partition (the two halves evaluated on their
+    own reproduce the halves of the whole, block for block)."""
+    import torch
+    from tao_amodal_amd import dist as tdist, engine
+    gt, dt = synth(V=200, F=300, C=1203, dets_per_frame=50)
+    fl_ = fl.flatten_lvis(gt, dt)
+    dt.track_id, _ = fl.make_track_ids_unique(dt)
+    ft_ = fl.flatten_tao(gt, dt)
+    for flat in (fl_, ft_):
+        want = orclib.run_flat(flat, detail=False)
+        dp = engine.DeviceProblem(flat, "cuda:0")
+        ws = engine.Workspace(dp)
+        engine.run(dp, ws)
+        torch.cuda.synchronize()
+        p1, r1 = ws.precision.clone(), ws.recall.clone()
+        assert np.array_equal(p1.cpu().numpy(), want["precision"])
+        assert np.array_equal(r1.cpu().numpy(), want["recall"])
+        engine.run(dp, ws)
+        torch.cuda.synchronize()
+        assert torch.equal(ws.precision, p1) and torch.equal(ws.recall, r1)
+        K = len(flat.cat_ids)
+        for rank in range(2):
+            k0, k1, _ = tdist.category_block(K, rank, 2)
+            sdp = engine.DeviceProblem(tdist.shard_by_category(flat, k0, k1), "cuda:0")
+            sws = engine.Workspace(sdp)
+            engine.run(sdp, sws)
+            torch.cuda.synchronize()
+            assert torch.equal(sws.precision[:, :, k0:k1], p1[:, :, k0:k1])
+            assert torch.equal(sws.recall[:, k0:k1], r1[:, k0:k1])
