@@ -44,7 +44,7 @@
 //    threshold is emitted;
 //  * recall thresholds are crossed at integer TP counts: cj[j] = the smallest
 //    c with fl(c / num_gt) >= rec_thrs[j] is tabulated per (category, range)
-//    by acc_cj_kernel with the reference's fp64 comparison, and the sweep
+//    (in acc_prefix_kernel / acc_fused_kernel) with the reference's fp64 comparison, and the sweep
 //    compares integers.
 #include "common.hpp"
 
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void acc_count_kernel(AccArgs a)
 // the category's chunks each, the quarters are stitched through LDS (long
 // categories -- a rank's share of a multi-GPU job -- would otherwise be one
 // serial chain of dependent loads)
-__global__ __launch_bounds__(256) void acc_prefix_kernel(AccArgs a)
+__global__ __launch_bounds__(256) void acc_prefix_kernel(AccArgs a, RecThr rec)
 {
     __shared__ uint32_t s_tp[4][WAVE], s_fp[4][WAVE];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -246,6 +246,17 @@ __global__ __launch_bounds__(256) void acc_prefix_kernel(AccArgs a)
     const int lane = lane_id();
     if (a.fused_rows > 0 && a.cat_off[k + 1] - a.cat_off[k] <= a.fused_rows)
         return;                                    // acc_fused_kernel's
+    // cj[k][r][j]: smallest TP count c with fl(c / num_gt) >= rec_thrs[j]
+    // (np.searchsorted(rc, rec_thrs, side="left") on rc = tp / num_gt,
+    // reference lvis_amodal/eval.py:386,406-408) -- tabulated here, by the
+    // word-0 workgroup of the category, for the emission sweep
+    if (word == 0)
+        for (int i = threadIdx.x; i < a.n_rng * N_REC; i += 256) {
+            const int64_t kr = (int64_t)k * a.n_rng + i / N_REC;
+            const int32_t ng = a.num_gt[kr];
+            if (ng > 0)
+                a.cj[kr * N_REC + i % N_REC] = recall_crossing(rec.v[i % N_REC], ng);
+        }
     const int32_t c0 = a.cat_chunk_off[k], c1 = a.cat_chunk_off[k + 1];
     const int32_t q = (c1 - c0 + 3) / 4;
     const int32_t lo = min(c1, c0 + wave * q), hi = min(c1, lo + q);
@@ -348,21 +359,6 @@ __global__ __launch_bounds__(256) void acc_sufmax_kernel(AccArgs a)
             const uint64_t v = a.cmax[o];
             if (pr_better((uint32_t)(later >> 32), (uint32_t)later, v)) a.cmax[o] = later;
         }
-}
-
-// cj[k][r][j]: smallest TP count c with fl(c / num_gt) >= rec_thrs[j]
-// (np.searchsorted(rc, rec_thrs, side="left") on rc = tp / num_gt,
-// reference lvis_amodal/eval.py:386,406-408)
-__global__ void acc_cj_kernel(AccArgs a, RecThr rec)
-{
-    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    const int64_t total = (int64_t)(a.k_end - a.k_begin) * a.n_rng * N_REC;
-    if (i >= total) return;
-    const int j = (int)(i % N_REC);
-    const int64_t kr = (int64_t)a.k_begin * a.n_rng + i / N_REC;
-    const int32_t ng = a.num_gt[kr];
-    if (ng <= 0) return;
-    a.cj[kr * N_REC + j] = recall_crossing(rec.v[j], ng);
 }
 
 #define EMIT_RMAX 8   // ranges that can overlap one 64-combo word
@@ -779,12 +775,8 @@ extern "C" int taoamd_accumulate_compact(int64_t n_dt, int32_t n_cat,
     const unsigned chunk_blocks = (unsigned)((nc * nw + 3) / 4);
     const unsigned cat_blocks = (unsigned)((size_t)(k_end - k_begin) * nw);
     acc_chunks_kernel<<<1, 256, 0, s>>>(a);
-    {
-        const int64_t tot = (int64_t)(k_end - k_begin) * n_rng * N_REC;
-        acc_cj_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, s>>>(a, rec_thr());
-    }
     acc_count_kernel<<<chunk_blocks, 256, 0, s>>>(a);
-    acc_prefix_kernel<<<cat_blocks, 256, 0, s>>>(a);
+    acc_prefix_kernel<<<cat_blocks, 256, 0, s>>>(a, rec_thr());
     acc_chunkmax_kernel<<<chunk_blocks, 256, 0, s>>>(a);
     acc_sufmax_kernel<<<cat_blocks, 256, 0, s>>>(a);
     acc_emit_kernel<<<chunk_blocks, 256, 0, s>>>(a);

@@ -6,7 +6,7 @@
 // 101 columns of every row to every rank would move 58 MB (image level) +
 // 194 MB (track level) per pass, most of it redundant: column j depends on j
 // only through cj[j] = the TP count at which recall first reaches
-// rec_thrs[j] (acc_cj_kernel), a function of num_gt alone.  A row with n
+// rec_thrs[j] (recall_crossing), a function of num_gt alone.  A row with n
 // ground truths has at most min(n, 100) + 1 distinct crossings, so its 101
 // columns hold at most that many distinct values ("levels"), in runs.  Track
 // level rows typically have a handful of ground-truth tracks.
