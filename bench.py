@@ -89,7 +89,12 @@ def pmc_traffic(kernel_substr):
     separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this very
     command); None when no profile is present."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
+    import re
+
+    def version(path):      # r01_v11_pmc.json -> (1, 11): numeric, not lexical
+        m = re.search(r"r(\d+)_v(\d+)_pmc", os.path.basename(path))
+        return (int(m.group(1)), int(m.group(2))) if m else (-1, -1)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), key=version)
     if not files:
         return None
     with open(files[-1]) as f:
