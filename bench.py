@@ -362,7 +362,7 @@ def main():
                        "parallelism": ("single GPU" if not use_dist else
                                        "%s-sharded x%d" % (args.shard, world))},
             "roofline": roof, "roofline_other": roof_other, "cpu_baseline": cpu,
-            "stages_ms": stages, "streams": "serial" if (args.serial or (use_dist and not by_category))
+            "stages_ms": stages, "streams": "serial" if args.serial else "2 (image-level || track-level)" if (use_dist and not by_category)
             else "4 (image-level || track-level, ranges/sort || IoU) + RCCL all_gather" if use_dist
             else "4 (image-level || track-level, ranges/sort || IoU)",
             "host_launch_ms_per_step": round(host_ms, 4),

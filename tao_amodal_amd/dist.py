@@ -409,22 +409,36 @@ class CategoryPlan:
 
 
 class ExchangePlan:
-    """Both evaluators of one rank (what bench.py steps)."""
+    """Both evaluators of one rank, unit-partitioned (`bench.py --shard unit`);
+    the two passes run on their own HIP streams."""
 
     def __init__(self, dpl, dpt, rank, world, device, backend=None, group=None):
         from . import engine
+        self.device = torch.device(device)
         backend = backend or HipBackend()
         self.lvis = ShardedEval(dpl, engine.Workspace(dpl), rank, world, backend,
                                 group)
         self.tao = ShardedEval(dpt, engine.Workspace(dpt), rank, world, backend,
                                group)
+        self.streams = None
+        if self.device.type == "cuda":
+            self.streams = [torch.cuda.Stream(self.device) for _ in range(2)]
 
     def pair_frames(self):
         return int(self.tao.ws.pair_frames.item())
 
     def step(self):
-        self.lvis.step()
-        self.tao.step()
+        if self.streams is None:
+            self.lvis.step()
+            self.tao.step()
+            return
+        cur = torch.cuda.current_stream(self.device)
+        for s, ev in zip(self.streams, (self.lvis, self.tao)):
+            s.wait_stream(cur)
+            with torch.cuda.stream(s):
+                ev.step()
+        for s in self.streams:
+            cur.wait_stream(s)
 
 
 def step(plan):
