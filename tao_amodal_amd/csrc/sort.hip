@@ -360,7 +360,22 @@ __device__ __forceinline__ void seg_passes(SegLds &L, int base, int n, int p0, i
     for (int pass = p0; pass < p1; pass++) {
         for (int i = threadIdx.x; i < 4 * RS_BINS; i += SEG_THREADS)
             (&L.wcnt[0][0])[i] = 0;
+        if (threadIdx.x == 0) L.flag = 0;
         __syncthreads();
+        // a byte that is the same for every element (the sign / exponent byte
+        // of scores in (0,1)) moves nothing: found out with one vote, before
+        // any ranking work
+        {
+            const uint32_t ref = (uint32_t)(L.key[base] >> (8 * pass)) & 255u;
+            bool differs = false;
+#pragma unroll
+            for (int r = 0; r < SEG_ROUNDS; r++)
+                if (r < rounds && w0 + r * WAVE + lane < n)
+                    differs |= ((uint32_t)(kr[r] >> (8 * pass)) & 255u) != ref;
+            if (__ballot(differs) != 0 && lane == 0) L.flag = 2;
+        }
+        __syncthreads();
+        if (L.flag != 2) { __syncthreads(); continue; }
         uint32_t rank[SEG_ROUNDS];
 #pragma unroll
         for (int r = 0; r < SEG_ROUNDS; r++) {
