@@ -265,10 +265,13 @@ def masked_mean(s):
 
 
 # ------------------------------------------------------------------ LVISEval
-def lvis_eval(gt, preds):
+def lvis_eval(gt, preds, use_cats=True):
     """Image-level evaluation.  gt: parsed annotation dict; preds: list of
     dicts (a private deep copy is taken).  L/eval.py:59-145, L/lvis.py:38-97,
-    L/results.py:10-71."""
+    L/results.py:10-71.  ``use_cats=False`` restates params.use_cats = 0
+    (L/eval.py:125-128,147-166,314-317): one cell per image, category -1;
+    the reference's summarize() then fails on the frequency groups
+    (IndexError), so "results" / "printed" are None."""
     gt = copy.deepcopy(gt)
     preds = copy.deepcopy(preds)
     imgs = {im["id"]: im for im in gt["images"]}
@@ -311,16 +314,22 @@ def lvis_eval(gt, preds):
         cell_dt[im, c].append(d)
 
     cells = OrderedDict()
+    eval_cats = cat_ids if use_cats else [-1]
     for im in img_ids:
-        for c in cat_ids:
-            G, D = cell_gt.get((im, c), []), cell_dt.get((im, c), [])
+        for c in eval_cats:
+            if use_cats:
+                G, D = cell_gt.get((im, c), []), cell_dt.get((im, c), [])
+            else:               # _get_gt_dt: the per-category lists, joined
+                G = [g for cc in cat_ids for g in cell_gt.get((im, cc), [])]
+                D = [d for cc in cat_ids for d in cell_dt.get((im, cc), [])]
             if not G and not D:
                 continue
             D = [D[i] for i in stable_desc([d["score"] for d in D])]
             ious = bb_iou_matrix([d["bbox"] for d in D],
                                  [g["bbox"] for g in G])
-            nel = c in imgs[im]["not_exhaustive_category_ids"]
-            dt_mask = np.array([d["area"] < 0 or d["area"] > 1e5 ** 2 or nel
+            nel_list = imgs[im]["not_exhaustive_category_ids"]
+            dt_mask = np.array([d["area"] < 0 or d["area"] > 1e5 ** 2
+                                or d["category_id"] in nel_list
                                 for d in D], dtype=bool)
             ranges = []
             for a, rng in enumerate(VIS_RNG):
@@ -362,14 +371,14 @@ def lvis_eval(gt, preds):
             cells[im, c] = {"ious": ious, "ranges": ranges}
 
     # ---------------------------------------------------------- accumulate
-    T, R, K, A = len(IOU_THRS), len(REC_THRS), len(cat_ids), len(VIS_RNG)
+    T, R, K, A = len(IOU_THRS), len(REC_THRS), len(eval_cats), len(VIS_RNG)
     precision = -np.ones((T, R, K, A))
     recall = -np.ones((T, K, A))
     pointers = {}
     by_cat = defaultdict(list)
     for (im, c), cell in cells.items():
         by_cat[c].append(cell)
-    for k, c in enumerate(cat_ids):
+    for k, c in enumerate(eval_cats):
         for a in range(A):
             E = [cell["ranges"][a] for cell in by_cat.get(c, [])]
             if not E:
@@ -402,6 +411,10 @@ def lvis_eval(gt, preds):
             s = s[:, :, aidx]
         return masked_mean(s)
 
+    if not use_cats:
+        return {"img_ids": img_ids, "cat_ids": eval_cats, "cells": cells,
+                "precision": precision, "recall": recall, "pointers": pointers,
+                "results": None, "freq_groups": freq_groups, "printed": None}
     res = OrderedDict()
     for suffix, vis in (("", "all"), ("-HO", "highly-occluded"),
                         ("-PO", "partially-occluded"),

@@ -9,7 +9,9 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(HERE, "libtao_amodal_hip.so")
+# TAOAMD_LIBRARY: another build of the same C ABI (A/B timing of kernel
+# variants on one GPU box); the default is the in-tree library
+SO_PATH = os.environ.get("TAOAMD_LIBRARY") or os.path.join(HERE, "libtao_amodal_hip.so")
 
 OK = 0
 N_THR, N_REC = 10, 101

@@ -662,28 +662,63 @@ struct FinArgs {
     double *precision, *recall;
 };
 
+// One workgroup: 64 (k, r) rows x 64 (t, j) columns.  Rows without evaluated
+// ground truth (most of them: a category rarely has tracks in every area x
+// duration range) are never read.  The output, 8 bytes x 1010 x K x A, is the
+// traffic that cannot be avoided; a wavefront stores 64 consecutive rows of
+// one column (512 B) at a time.  Measured alone at Config 2's track-level
+// shape (1203 x 21 rows, one in six live): 53 us, a plain fill of the same
+// buffer 34 us, the 32 x 32 tiling this replaces 83 us.  Tried and slower:
+// row windows shifted to 128-byte lines (64 us), dead rows stored ahead of the
+// barrier (72 us, partial lines), lanes gathering their own row without LDS
+// (56 us sparse, 122 us dense), 128/256-row tiles.
+#define FIN_RT 64
+#define FIN_CT 64
+
 __global__ __launch_bounds__(256) void acc_finalize_kernel(FinArgs a)
 {
-    __shared__ double tile[32][33];
+    __shared__ double tile[FIN_RT][FIN_CT + 1];
     const int64_t KR = (int64_t)a.n_cat * a.n_rng;
     const int64_t COLS = (int64_t)N_THR * N_REC;
-    const int64_t row0 = (int64_t)blockIdx.x * 32;   // (k, r) rows of val
-    const int64_t col0 = (int64_t)blockIdx.y * 32;   // (t, j) columns of val
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-    for (int i = ty; i < 32; i += 8) {
-        const int64_t row = row0 + i, col = col0 + tx;
-        double v = -1.0;
-        if (row < KR && col < COLS && a.num_gt[row] > 0) v = a.val[row * COLS + col];
-        tile[i][tx] = v;
+    const int64_t row0 = (int64_t)blockIdx.x * FIN_RT;   // (k, r) rows of val
+    const int64_t col0 = (int64_t)blockIdx.y * FIN_CT;   // (t, j) columns of val
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int ncol = (int)min((int64_t)FIN_CT, COLS - col0);
+    const int64_t orow = row0 + lane;                    // lane = row of the tile
+    const bool olive = orow < KR && a.num_gt[orow] > 0;
+    const uint64_t live_rows = __ballot(olive);          // same in every wavefront
+    // rows i = wave (mod 4) are mine to fetch; only the live ones are read,
+    // four loads in flight per step (one row in six is live at Config 2: a
+    // wavefront has two or three to fetch, and waiting for them one by one is
+    // what the kernel's time was)
+    static_assert(FIN_RT == 64 && FIN_CT == 64, "one mask word, one lane per column");
+    if (live_rows != 0) {
+        uint64_t m = live_rows & (0x1111111111111111ull << wave);
+        const int64_t col = col0 + lane;
+        const double *__restrict__ src = a.val + row0 * COLS + (col < COLS ? col : 0);
+        while (m != 0) {
+            int idx[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                idx[q] = m != 0 ? __builtin_ctzll(m) : -1;
+                if (m != 0) m &= m - 1;
+            }
+            double v[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                v[q] = idx[q] >= 0 ? src[(int64_t)idx[q] * COLS] : 0.0;
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (idx[q] >= 0) tile[idx[q]][lane] = v[q];
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    for (int i = ty; i < 32; i += 8) {
-        const int64_t col = col0 + i, row = row0 + tx;
-        if (row < KR && col < COLS) a.precision[col * KR + row] = tile[tx][i];
-    }
+    if (orow < KR)
+        for (int c = wave; c < ncol; c += 4)
+            a.precision[(col0 + c) * KR + orow] = olive ? tile[lane][c] : -1.0;
     // recall: the first column-block also transposes rec[KR][T]
     if (blockIdx.y == 0) {
-        for (int i = threadIdx.x; i < 32 * N_THR; i += 256) {
+        for (int i = threadIdx.x; i < FIN_RT * N_THR; i += 256) {
             const int64_t row = row0 + i / N_THR;
             const int t = i % N_THR;
             if (row < KR)
@@ -795,7 +830,8 @@ extern "C" int taoamd_finalize(int32_t n_cat, int32_t n_rng,
     f.n_cat = n_cat; f.n_rng = n_rng; f.num_gt = num_gt; f.val = val; f.rec = rec;
     f.precision = precision; f.recall = recall;
     const int64_t KR = (int64_t)n_cat * n_rng;
-    dim3 grid((unsigned)((KR + 31) / 32), (unsigned)((N_THR * N_REC + 31) / 32));
+    dim3 grid((unsigned)((KR + FIN_RT - 1) / FIN_RT),
+              (unsigned)((N_THR * N_REC + FIN_CT - 1) / FIN_CT));
     acc_finalize_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(f);
     TAO_LAUNCH_CHECK();
     return TAOAMD_OK;

@@ -98,23 +98,24 @@ class LVISEval:
             raise NotImplementedError(
                 "only iou_type='bbox' runs on the HIP path (segm is "
                 "SURVEY.md 8(f) rank 3)")
-        if not self.params.use_cats:
-            raise NotImplementedError("use_cats=0 is SURVEY.md 8(f) rank 2")
         self.params.img_ids = list(np.unique(self.params.img_ids))
+        use_cats = bool(self.params.use_cats)
         with timed("flatten"):
+            # use_cats = 0: class-agnostic cells, one per image (reference
+            # eval.py:125-128,147-166)
             flat = flatten.flatten_lvis(self.lvis_gt.columns,
                                         self.lvis_dt.columns_dt,
-                                        self.lvis_dt.max_dets)
+                                        self.lvis_dt.max_dets, use_cats=use_cats)
         self.flat = flat
         self.freq_groups = self._prepare_freq_group()
         self._run = GpuRun(flat, self.device)
         self._run.evaluate()
         view = CellView(self._run, flat.img_ids, 0, "image_id", "visibility_rng",
                         self.params.visibility_rng)
-        self.ious = LazyIous(view, self.params.img_ids, self.params.cat_ids)
+        cats = self.params.cat_ids if use_cats else [-1]
+        self.ious = LazyIous(view, self.params.img_ids, cats)
         self.eval_imgs = _EvalImgs(view, len(self.params.img_ids),
-                                   len(self.params.visibility_rng),
-                                   len(self.params.cat_ids))
+                                   len(self.params.visibility_rng), len(cats))
 
     def _prepare_freq_group(self):
         groups = [[] for _ in self.params.img_count_lbl]
@@ -131,7 +132,9 @@ class LVISEval:
         n_rng = len(self.params.visibility_rng)
         self.eval = {
             "params": self.params,
-            "counts": [N_THR, N_REC, len(self.params.cat_ids), n_rng],
+            "counts": [N_THR, N_REC,
+                       len(self.params.cat_ids) if self.params.use_cats else 1,
+                       n_rng],
             "date": now(),
             "precision": self._run.precision,
             "recall": self._run.recall,

@@ -286,7 +286,13 @@ def _cells(keys_gt, keys_dt):
 # ---------------------------------------------------------------------------
 # image level (LVISEval)
 # ---------------------------------------------------------------------------
-def flatten_lvis(gt: GTColumns, dt: DTColumns, max_dets=MAX_DETS):
+def flatten_lvis(gt: GTColumns, dt: DTColumns, max_dets=MAX_DETS,
+                 use_cats=True):
+    """Cell tables of LVISEval (L/eval.py:59-110).  ``use_cats=False`` builds
+    the class-agnostic problem of ``params.use_cats = 0`` (L/eval.py:125-128,
+    147-166): one cell per image holding every ground truth / every kept
+    detection of the image, category-major (the federated filter and the
+    not-exhaustive flags still use the real categories), one output category."""
     if len(dt) == 0:
         raise IndexError("list index out of range")  # L/results.py:42
     img_ids = np.unique(gt.img_id)
@@ -331,13 +337,22 @@ def flatten_lvis(gt: GTColumns, dt: DTColumns, max_dets=MAX_DETS):
     order = order[is_present | is_neg]
 
     # ---- cells
-    keys_g = g_cat * U + g_img
-    keys_d = d_cat[order] * U + d_img[order]
-    # detections: by cell, then descending score, stable in visiting order
-    o2 = sort_key_score(keys_d, d_score[order])
+    if use_cats:
+        keys_g = g_cat * U + g_img
+        keys_d = d_cat[order] * U + d_img[order]
+        # detections: by cell, then descending score, stable in visiting order
+        o2 = sort_key_score(keys_d, d_score[order])
+        og = sort_key_score(keys_g)
+    else:
+        keys_g = g_img.copy()
+        keys_d = d_img[order].copy()
+        # the image's per-category lists one after the other (ascending
+        # category), then the stable sort by score of compute_iou
+        o2 = np.lexsort((np.arange(len(order)), d_cat[order], -d_score[order],
+                         keys_d))
+        og = np.lexsort((np.arange(len(g_sel)), g_cat, keys_g))
     order = order[o2]
     keys_d = keys_d[o2]
-    og = sort_key_score(keys_g)
     g_sel, keys_g = g_sel[og], keys_g[og]
     cell_keys, g_cell, d_cell, g_off, d_off = _cells(keys_g, keys_d)
 
@@ -353,11 +368,13 @@ def flatten_lvis(gt: GTColumns, dt: DTColumns, max_dets=MAX_DETS):
 
     f = Flat()
     f.kind = "lvis"
-    f.img_ids, f.cat_ids = img_ids, cat_ids
-    f.cat_freq = _freq_of(gt, cat_ids)
+    f.use_cats = bool(use_cats)
+    f.img_ids = img_ids
+    f.cat_ids = cat_ids if use_cats else np.array([-1], dtype=np.int64)
+    f.cat_freq = _freq_of(gt, cat_ids)      # of the real categories, always
     f.n_cells = len(cell_keys)
     f.cell_unit = (cell_keys % U).astype(I32)       # image index
-    f.cell_cat = (cell_keys // U).astype(I32)
+    f.cell_cat = (cell_keys // U).astype(I32)       # all zero without categories
     f.cell_dt_off = d_off.astype(I32)
     f.cell_gt_off = g_off.astype(I32)
     f.dt_box = LazyRows(dt.bbox, keep[order])

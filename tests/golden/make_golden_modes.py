@@ -2,7 +2,10 @@
 (SURVEY.md 8(f) rank 2): iou_3d_type in {avg_iou, imagenetvid} and
 use_cats = 0.  Same conventions as make_golden.py; writes
 tests/golden/<name>/tao_modes.json.gz (per-cell IoUs) and tao_modes.npz
-(precision / recall, categories that are not all -1)."""
+(precision / recall, categories that are not all -1); and of the reference
+LVISEval with use_cats = 0 (evaluate + accumulate; its summarize() raises
+IndexError on the frequency groups): lvis_nocats.json.gz (per-image IoUs,
+per-range dt_matches / dt_ignore / gt_ignore) and lvis_nocats.npz."""
 import gzip
 import json
 import logging
@@ -52,6 +55,44 @@ def run(name):
     print(name, {m: float(arrays[m + "_results"][0]) for m in MODES})
 
 
+def run_lvis_nocats(name):
+    ref_lvis, _ = refenv.import_reference()
+    out = os.path.join(HERE, name)
+    le = ref_lvis.LVISEval(os.path.join(out, "gt.json"),
+                           os.path.join(out, "pred.json"), "bbox")
+    le.params.use_cats = 0
+    le.evaluate()
+    le.accumulate()
+    try:
+        le.summarize()
+        summarize_error = ""
+    except Exception as e:          # noqa: BLE001 -- the behaviour is the datum
+        summarize_error = type(e).__name__
+    cells = [{"key": int(k[0]), "ious": np.asarray(v).tolist()}
+             for k, v in le.ious.items()
+             if not (isinstance(v, list) and len(v) == 0)]
+    per_rng = []
+    for e in le.eval_imgs:
+        if e is None:
+            continue
+        per_rng.append({"image_id": int(e["image_id"]),
+                        "rng": [float(x) for x in e["visibility_rng"]],
+                        "dt_ids": [int(x) for x in e["dt_ids"]],
+                        "gt_ids": [int(x) for x in e["gt_ids"]],
+                        "dt_matches": np.asarray(e["dt_matches"]).astype(int).tolist(),
+                        "dt_ignore": np.asarray(e["dt_ignore"]).astype(int).tolist(),
+                        "gt_ignore": np.asarray(e["gt_ignore"]).astype(int).tolist()})
+    np.savez_compressed(os.path.join(out, "lvis_nocats.npz"),
+                        precision=le.eval["precision"], recall=le.eval["recall"])
+    with gzip.GzipFile(os.path.join(out, "lvis_nocats.json.gz"), "wb", mtime=0) as f:
+        f.write(json.dumps({"cells": cells, "eval_imgs": per_rng,
+                            "summarize_error": summarize_error},
+                           separators=(",", ":")).encode())
+    p = le.eval["precision"]
+    print(name, "lvis nocats", p.shape, float(np.mean(p[p > -1])), summarize_error)
+
+
 if __name__ == "__main__":
     for n in sys.argv[1:] or ["f1", "f2", "f4"]:
         run(n)
+        run_lvis_nocats(n)

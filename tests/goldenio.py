@@ -62,3 +62,12 @@ def load_modes(name):
         out[m] = ({tuple(c["key"]): np.asarray(c["ious"], dtype=float)
                    for c in cells[m]}, p, r, z[m + "_results"])
     return out
+
+
+def load_lvis_nocats(name):
+    """Golden LVISEval outputs with params.use_cats = 0: (cells {image_id:
+    ious}, eval_imgs list, precision, recall, summarize_error)."""
+    z = np.load(path(name, "lvis_nocats.npz"))
+    j = load_json_gz(name, "lvis_nocats.json.gz")
+    cells = {int(c["key"]): np.asarray(c["ious"], dtype=float) for c in j["cells"]}
+    return cells, j["eval_imgs"], z["precision"], z["recall"], j["summarize_error"]

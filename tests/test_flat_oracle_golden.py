@@ -160,3 +160,15 @@ def test_tao_other_modes_flatten_and_c_oracle(name, mode):
             assert np.allclose(got, want, rtol=0, atol=1e-12), key
     assert np.array_equal(out["precision"].reshape(p.shape), p)
     assert np.array_equal(out["recall"].reshape(r.shape), r)
+
+
+@pytest.mark.parametrize("name", MODE_FIXTURES)
+def test_lvis_without_categories_flatten_and_c_oracle(name):
+    """flatten_lvis(use_cats=False): one cell per image, category-major then
+    score order (reference L/eval.py:147-166), against the reference's own
+    LVISEval run with params.use_cats = 0."""
+    import nocats_check
+    gtj, predj = load_inputs(name)
+    f = fl.flatten_lvis(GTColumns.from_json(gtj), DTColumns.from_json(predj),
+                        use_cats=False)
+    nocats_check.check(f, orclib.run_flat(f), name)

@@ -291,6 +291,50 @@ def test_tao_other_modes_hip_vs_oracle_and_reference(name, mode):
     assert np.array_equal(got["precision"], want["precision"])
 
 
+@pytest.mark.parametrize("name", MODE_FIXTURES)
+def test_lvis_without_categories_hip_vs_reference(name):
+    """LVISEval with params.use_cats = 0 through the class API: evaluate +
+    accumulate equal the reference's golden run (IoUs, every match / ignore
+    decision, precision, recall); summarize() fails on the frequency groups
+    like the reference's (IndexError); and the HIP results equal the C
+    oracle's bit for bit."""
+    import nocats_check
+    from goldenio import load_lvis_nocats
+    from tao_amodal_amd.evaluation.lvis_amodal import LVIS, LVISEval, LVISResults
+    gtj, predj = load_inputs(name)
+    gt = LVIS(gtj)
+    ev = LVISEval(gt, LVISResults(gt, predj), "bbox")
+    ev.params.use_cats = 0
+    ev.evaluate()
+    ev.accumulate()
+    cells, eval_imgs, p, r, err = load_lvis_nocats(name)
+    assert np.array_equal(ev.eval["precision"], p)
+    assert np.array_equal(ev.eval["recall"], r)
+    assert ev.eval["counts"] == [10, 101, 1, 6]
+    with pytest.raises(IndexError):
+        ev.summarize()
+    for im, w in cells.items():
+        assert np.array_equal(ev.ious[im, -1], w)
+    live = [e for e in ev.eval_imgs if e is not None]
+    assert len(live) == len(eval_imgs) and len(ev.eval_imgs) == 6 * len(ev.params.img_ids)
+    for e, w in zip(live, eval_imgs):
+        assert e["image_id"] == w["image_id"] and e["category_id"] == -1
+        assert e["dt_ids"] == w["dt_ids"] and e["gt_ids"] == w["gt_ids"]
+        assert np.array_equal(e["dt_matches"], np.asarray(w["dt_matches"]).reshape(e["dt_matches"].shape))
+        assert np.array_equal(e["dt_ignore"].astype(int), np.asarray(w["dt_ignore"]).reshape(e["dt_ignore"].shape))
+    f = fl.flatten_lvis(gt.columns, DTColumns.from_json(predj), use_cats=False)
+    got = _engine().evaluate_flat(f, detail=True)
+    nocats_check.check(f, got, name)
+    _compare_with_oracle(f, got)
+
+
+def test_lvis_without_categories_synthetic_hip_vs_c_oracle():
+    gt, dt = synth(seed=77, V=4, F=12, C=30, dets_per_frame=40, n_present=6)
+    f = fl.flatten_lvis(gt, dt, use_cats=False)
+    assert f.n_cells <= 48 and len(f.cat_ids) == 1
+    _compare_with_oracle(f, _engine().evaluate_flat(f, detail=True))
+
+
 def test_other_modes_on_merge_kernel():
     gt, dt = synth(seed=41, V=1, F=1100, C=6, dets_per_frame=20,
                    gt_tracks_per_video=24, n_present=2, n_neg=1)

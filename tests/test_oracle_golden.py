@@ -135,3 +135,48 @@ def test_tao_oracle_other_modes_match_reference(name, mode):
     assert np.array_equal(got["precision"], p)
     assert np.array_equal(got["recall"], r)
     assert [float(v) for v in got["results"].values()] == res.tolist()
+
+
+from goldenio import load_lvis_nocats
+
+
+@pytest.mark.parametrize("name", MODE_FIXTURES)
+def test_lvis_oracle_without_categories_matches_reference(name):
+    """params.use_cats = 0 of LVISEval: per-image
+    IoUs, every range's matches and ignore flags, precision, recall."""
+    gt, pred = load_inputs(name)
+    got = pyoracle.lvis_eval(gt, pred, use_cats=False)
+    cells, eval_imgs, p, r, err = load_lvis_nocats(name)
+    assert err == "IndexError" and got["results"] is None
+    # (the reference stores [] where an image has only GT or only detections)
+    assert set(k[0] for k, c in got["cells"].items()
+               if np.asarray(c["ious"]).size) == set(cells)
+    for (im, c), cell in got["cells"].items():
+        assert c == -1
+        g = np.asarray(cell["ious"], dtype=float)
+        if g.size:
+            assert np.array_equal(g, cells[im].reshape(g.shape)), im
+    # eval_imgs is range-major, image-minor (L/eval.py:138-143), None dropped;
+    # the first and the out-of-frame range share the bounds [0, 1]
+    A = len(pyoracle.VIS_RNG)
+    per = len(eval_imgs) // A
+    want = {(e["image_id"], i // per): e for i, e in enumerate(eval_imgs)}
+    n = 0
+
+    def same(mine, ref):
+        mine = np.asarray(mine).astype(int)
+        return np.array_equal(mine, np.asarray(ref).reshape(mine.shape))
+
+    for (im, c), cell in got["cells"].items():
+        for a, e in enumerate(cell["ranges"]):
+            w = want[im, a]
+            assert w["rng"] == [float(x) for x in pyoracle.VIS_RNG[a]]
+            assert [int(x) for x in e["dt_ids"]] == w["dt_ids"]
+            assert [int(x) for x in e["gt_ids"]] == w["gt_ids"]
+            assert same(e["dt_matches"], w["dt_matches"]), (im, a)
+            assert same(e["dt_ignore"], w["dt_ignore"]), (im, a)
+            assert same(e["gt_ignore"], w["gt_ignore"]), (im, a)
+            n += 1
+    assert n == len(eval_imgs)
+    assert np.array_equal(got["precision"], p)
+    assert np.array_equal(got["recall"], r)
