@@ -265,13 +265,18 @@ def masked_mean(s):
 
 
 # ------------------------------------------------------------------ LVISEval
-def lvis_eval(gt, preds, use_cats=True):
+def lvis_eval(gt, preds, use_cats=True, iou_type="bbox"):
     """Image-level evaluation.  gt: parsed annotation dict; preds: list of
     dicts (a private deep copy is taken).  L/eval.py:59-145, L/lvis.py:38-97,
     L/results.py:10-71.  ``use_cats=False`` restates params.use_cats = 0
     (L/eval.py:125-128,147-166,314-317): one cell per image, category -1;
     the reference's summarize() then fails on the frequency groups
-    (IndexError), so "results" / "printed" are None."""
+    (IndexError), so "results" / "printed" are None.  ``iou_type="segm"``
+    (L/eval.py:54-58,70-73,179-191; L/results.py:42-62; L/lvis.py:171-193)
+    compares run-length masks (oracle/rle.py) instead of boxes; the result
+    then carries "gt_rle" / "dt_rle" = the compressed text of every mask
+    compared."""
+    from . import rle as _rle
     gt = copy.deepcopy(gt)
     preds = copy.deepcopy(preds)
     imgs = {im["id"]: im for im in gt["images"]}
@@ -281,9 +286,22 @@ def lvis_eval(gt, preds, use_cats=True):
     cat_set = set(cat_ids)
 
     preds = limit_dets_per_image(preds)
-    for k, p in enumerate(preds):
-        p["area"] = p["bbox"][2] * p["bbox"][3]
-        p["id"] = k + 1
+    if "bbox" in preds[0]:                       # L/results.py:42-52
+        for k, p in enumerate(preds):
+            x1, y1, w_, h_ = p["bbox"]
+            if "segmentation" not in p:
+                p["segmentation"] = [[x1, y1, x1, y1 + h_, x1 + w_, y1 + h_,
+                                      x1 + w_, y1]]
+            p["area"] = w_ * h_
+            p["id"] = k + 1
+    elif "segmentation" in preds[0]:             # L/results.py:54-62
+        for k, p in enumerate(preds):
+            m = _rle.fr_string(p["segmentation"]["counts"],
+                               *p["segmentation"]["size"])
+            p["area"] = _rle.area(m)
+            if "bbox" not in p:
+                p["bbox"] = _rle.to_bbox(m)
+            p["id"] = k + 1
     assert set(p["image_id"] for p in preds) <= set(imgs), \
         "Results do not correspond to current LVIS set."
 
@@ -301,6 +319,13 @@ def lvis_eval(gt, preds, use_cats=True):
 
     gts = select(gt["annotations"])
     dts = select(preds)
+    if iou_type == "segm":                       # _to_mask, L/eval.py:54-58
+        for a in gts + dts:
+            im = imgs[a["image_id"]]
+            a["_rle"] = _rle.ann_to_rle(a["segmentation"], im["height"],
+                                        im["width"])
+    elif iou_type != "bbox":
+        raise ValueError("Unknown iou_type for iou computation.")
     cell_gt, cell_dt = defaultdict(list), defaultdict(list)
     present = defaultdict(set)
     for g in gts:
@@ -325,8 +350,12 @@ def lvis_eval(gt, preds, use_cats=True):
             if not G and not D:
                 continue
             D = [D[i] for i in stable_desc([d["score"] for d in D])]
-            ious = bb_iou_matrix([d["bbox"] for d in D],
-                                 [g["bbox"] for g in G])
+            if iou_type == "segm":
+                ious = _rle.iou_matrix([d["_rle"] for d in D],
+                                       [g["_rle"] for g in G])
+            else:
+                ious = bb_iou_matrix([d["bbox"] for d in D],
+                                     [g["bbox"] for g in G])
             nel_list = imgs[im]["not_exhaustive_category_ids"]
             dt_mask = np.array([d["area"] < 0 or d["area"] > 1e5 ** 2
                                 or d["category_id"] in nel_list
@@ -430,10 +459,17 @@ def lvis_eval(gt, preds, use_cats=True):
                 "highly-and-partially-occluded", "out-of-frame"):
         # L/eval.py:497-499 -- the key uses only the first letter of the label
         res["AR{}@{}".format(vis[0], MAX_DETS)] = summ("ar", vis=vis)
-    return {"img_ids": img_ids, "cat_ids": cat_ids, "cells": cells,
-            "precision": precision, "recall": recall, "pointers": pointers,
-            "results": res, "freq_groups": freq_groups,
-            "printed": lvis_lines(res)}
+    out = {"img_ids": img_ids, "cat_ids": cat_ids, "cells": cells,
+           "precision": precision, "recall": recall, "pointers": pointers,
+           "results": res, "freq_groups": freq_groups,
+           "printed": lvis_lines(res)}
+    if iou_type == "segm":
+        kept = [d for lst in cell_dt.values() for d in lst]
+        out["gt_rle"] = {g["id"]: _rle.to_string(g["_rle"]) for g in gts}
+        out["dt_rle"] = {d["id"]: _rle.to_string(d["_rle"]) for d in kept}
+        out["dt_area"] = {p["id"]: float(p["area"]) for p in preds}
+        out["dt_bbox"] = {p["id"]: [float(v) for v in p["bbox"]] for p in preds}
+    return out
 
 
 def lvis_lines(results):

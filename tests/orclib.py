@@ -150,3 +150,98 @@ def run_flat(f, detail=True, iou_3d_type="3d_iou"):
                 iou=iou if f.kind == "tao" else ious_out, pairs=pairs,
                 matched=matched, ignored=ignored, match_gt=mg,
                 precision=prec, recall=rec, order=order, num_gt=num_gt)
+
+
+# ---------------------------------------------------------------------------
+# the reference's own run-length mask code (oracle/_ref, compiled from the
+# vendored maskApi.c where it lies) -- pins oracle/rle.py
+# ---------------------------------------------------------------------------
+class _RefRLE(C.Structure):
+    _fields_ = [("h", C.c_ulong), ("w", C.c_ulong), ("m", C.c_ulong),
+                ("cnts", C.POINTER(C.c_uint))]
+
+
+def _ref():
+    r = C.CDLL(REF_SO)
+    r.rleToString.restype = C.c_void_p
+    return r
+
+
+def _ref_make(r, mask):
+    R = _RefRLE()
+    c = np.asarray(mask["counts"], dtype=np.uint32)
+    r.rleInit(C.byref(R), C.c_ulong(mask["h"]), C.c_ulong(mask["w"]),
+              C.c_ulong(len(c)), c.ctypes.data_as(C.POINTER(C.c_uint)))
+    return R
+
+
+def _ref_take(r, R):
+    out = {"h": int(R.h), "w": int(R.w), "counts": [int(R.cnts[i]) for i in range(R.m)]}
+    r.rleFree(C.byref(R))
+    return out
+
+
+def ref_rle_fr_poly(xy, h, w):
+    r = _ref()
+    R = _RefRLE()
+    xy = np.ascontiguousarray(xy, dtype=np.float64)
+    r.rleFrPoly(C.byref(R), _p(xy), C.c_ulong(len(xy) // 2), C.c_ulong(h), C.c_ulong(w))
+    return _ref_take(r, R)
+
+
+def ref_rle_merge(masks, intersect=False):
+    r = _ref()
+    arr = (_RefRLE * len(masks))(*[_ref_make(r, m) for m in masks])
+    M = _RefRLE()
+    r.rleMerge(arr, C.byref(M), C.c_ulong(len(masks)), C.c_int(int(intersect)))
+    out = _ref_take(r, M)
+    for R in arr:
+        r.rleFree(C.byref(R))
+    return out
+
+
+def ref_rle_iou(dts, gts):
+    r = _ref()
+    D = (_RefRLE * len(dts))(*[_ref_make(r, m) for m in dts])
+    G = (_RefRLE * len(gts))(*[_ref_make(r, m) for m in gts])
+    o = np.zeros(len(dts) * len(gts))
+    crowd = np.zeros(max(len(gts), 1), dtype=np.uint8)
+    r.rleIou(D, G, C.c_ulong(len(dts)), C.c_ulong(len(gts)), _p(crowd), _p(o))
+    for R in list(D) + list(G):
+        r.rleFree(C.byref(R))
+    return o.reshape((len(dts), len(gts)), order="F")
+
+
+def ref_rle_to_bbox(mask):
+    r = _ref()
+    R = _ref_make(r, mask)
+    bb = np.zeros(4)
+    r.rleToBbox(C.byref(R), _p(bb), C.c_ulong(1))
+    r.rleFree(C.byref(R))
+    return bb.tolist()
+
+
+def ref_rle_area(mask):
+    r = _ref()
+    R = _ref_make(r, mask)
+    a = C.c_uint(0)
+    r.rleArea(C.byref(R), C.c_ulong(1), C.byref(a))
+    r.rleFree(C.byref(R))
+    return int(a.value)
+
+
+def ref_rle_to_string(mask):
+    r = _ref()
+    R = _ref_make(r, mask)
+    ptr = r.rleToString(C.byref(R))
+    s = C.string_at(ptr).decode("ascii")
+    C.CDLL(None).free(C.c_void_p(ptr))
+    r.rleFree(C.byref(R))
+    return s
+
+
+def ref_rle_fr_string(s, h, w):
+    r = _ref()
+    R = _RefRLE()
+    r.rleFrString(C.byref(R), C.c_char_p(s.encode("ascii")), C.c_ulong(h), C.c_ulong(w))
+    return _ref_take(r, R)
