@@ -125,14 +125,37 @@ int taoamd_tao_ranges(int64_t n_gt, const double *gt_area,
                       uint32_t *gt_rng, uint32_t *dt_rng, int32_t *num_gt,
                       void *stream);
 
+/* ---- IoU of run-length masks (iou_type="segm") -------------------------------
+ * iou[cell_iou_off[c] + d*G + g] for every cell c, iscrowd = 0: replaces
+ * mask_utils.iou(dt, gt, iscrowd) on RLE objects (L/eval.py:179-191 ->
+ * C/maskApi.c rleIou:77-96).  Masks are CSR run lists (column-major run
+ * lengths, zeros first) with their frame size hw[n][2] = (height, width) and
+ * tight box bb[n][4] = (x, y, w, h) as taoamd_rle_copy (tao_amodal_ingest.h)
+ * produces them; row i belongs to detection / ground truth i of the cell
+ * tables (n_dt / n_gt rows, dt_total / gt_total runs in all).  0 where the
+ * tight boxes do not overlap, -1 where the frames differ, else |d & g| / |d | g|
+ * (an empty intersection over a union of 1).  Workspace:
+ * taoamd_rle_iou_workspace(n_dt, dt_total, n_gt, gt_total) bytes (per-run
+ * prefix sums, rebuilt by every call). */
+size_t taoamd_rle_iou_workspace(int64_t n_dt, int64_t dt_total, int64_t n_gt,
+                                int64_t gt_total);
+int taoamd_rle_iou(int64_t n_cells, const int32_t *cell_dt_off,
+                   const int32_t *cell_gt_off, const int64_t *cell_iou_off,
+                   int64_t n_dt, int64_t dt_total, const int64_t *dt_off,
+                   const uint32_t *dt_runs, const int32_t *dt_hw,
+                   const double *dt_bb, int64_t n_gt, int64_t gt_total,
+                   const int64_t *gt_off, const uint32_t *gt_runs,
+                   const int32_t *gt_hw, const double *gt_bb, double *iou,
+                   void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- 3D IoU of track pairs --------------------------------------------------
  * iou[cell_iou_off[c] + d*G + g] for every cell c (G = its GT track count).
  * Tracks are CSR lists of (timeline position, box) sorted by position.
  * pair_frames (optional, int64[1], zeroed by the call) receives the number of
  * same-frame box pairs evaluated (the unit of BASELINE.json's metric).
  * cell_span (optional, int32[n_cells], device) = 1 + the largest timeline
- * position used by the cell.  Cells with at most 16 GT tracks and
- * (G + 1) * span <= 12288 take the dense-timeline kernel (track rows in LDS;
+ * position used by the cell.  Cells with at most 8 GT tracks and
+ * (G + 1) * ceil(span / 64) <= 1024 take the dense-timeline kernel (track rows in LDS;
  * per chunk of 32 positions the per-frame terms are formed in parallel and
  * then added in order by one lane per track pair); the others the two-pointer
  * merge kernel.

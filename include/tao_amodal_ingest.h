@@ -64,6 +64,44 @@ void taoamd_gt_free(void *handle);
 int taoamd_host_sort_key_score(int64_t n, const int64_t *key, const double *score,
                                int64_t *order);
 
+/* ---- run-length masks (csrc/rle.cpp): the host side of iou_type="segm"
+ * A batch collects masks in the order they are added and keeps them back to
+ * back; taoamd_rle_copy hands out the CSR arrays the device kernel
+ * taoamd_rle_iou (tao_amodal_hip.h) reads.  What the calls replace:
+ *   add_polygons  LVIS.ann_to_rle on a polygon list: frPyObjects + merge
+ *                 (lvis_amodal/lvis.py:171-186; pycocotools _mask.pyx frPoly /
+ *                 merge over maskApi.c rleFrPoly:161-202, rleMerge:49-71).
+ *                 part_off[n_parts+1] delimits the parts inside xy (in
+ *                 doubles; a part of 2k or 2k+1 numbers has k vertices).
+ *   add_counts    an uncompressed RLE {"size", "counts": [...]} (lvis.py:
+ *                 187-189, frUncompressedRLE)
+ *   add_string    a compressed RLE {"size", "counts": "..."} (lvis.py:190-192,
+ *                 maskApi.c rleFrString:217-230)
+ *   copy          also mask_utils.area / toBbox (lvis_amodal/results.py:56-59;
+ *                 rleArea:72-75, rleToBbox:133-147): area[n], bbox[n][4]
+ *                 (x, y, w, h); hw[n][2] = (height, width).  Any output
+ *                 pointer may be NULL.
+ *   string        the compressed text of one mask (rleToString:203-215) --
+ *                 what ann["segmentation"]["counts"] holds after _to_mask;
+ *                 returns its length, writes at most cap-1 characters + NUL.
+ * add_* return the index of the new mask, or -1 for arguments no mask can be
+ * made of (no part, a part without a vertex, a frame of 2^32 pixels or more).
+ * A batch is not thread safe; different batches are independent. */
+void *taoamd_rle_new(void);
+void taoamd_rle_free(void *handle);
+int64_t taoamd_rle_count(void *handle);
+int64_t taoamd_rle_total(void *handle);           /* runs in all masks */
+int64_t taoamd_rle_add_polygons(void *handle, int32_t n_parts,
+                                const int64_t *part_off, const double *xy,
+                                int64_t height, int64_t width);
+int64_t taoamd_rle_add_counts(void *handle, const uint32_t *counts, int64_t m,
+                              int64_t height, int64_t width);
+int64_t taoamd_rle_add_string(void *handle, const char *text, int64_t height,
+                              int64_t width);
+int taoamd_rle_copy(void *handle, int64_t *off, uint32_t *counts, int32_t *hw,
+                    uint32_t *area, double *bbox);
+int64_t taoamd_rle_string(void *handle, int64_t index, char *buf, int64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

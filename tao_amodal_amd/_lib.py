@@ -47,6 +47,10 @@ SIGNATURES = {
     "taoamd_accumulate_compact": (C.c_int, [_i64, _i32, _i32, _vp, _vp, _vp,
                                             _vp, _i32, _i32, _i32, _vp, _vp,
                                             _vp, _sz, _vp]),
+    "taoamd_rle_iou_workspace": (_sz, [_i64, _i64, _i64, _i64]),
+    "taoamd_rle_iou": (C.c_int, [_i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp,
+                                 _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp,
+                                 _sz, _vp]),
     "taoamd_finalize": (C.c_int, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "taoamd_exchange_chunk_bytes": (_sz, [_i32, _i32, _i64]),
     "taoamd_exchange_workspace": (_sz, [_i32, _i32, _i32]),

@@ -79,7 +79,7 @@ class HipBackend:
         if dp.n_dt == 0:
             return
         t, lib = dp.t, self.lib
-        fused = dp.kind == "lvis"
+        fused = dp.kind == "lvis" and not dp.mask_iou
         base = records.data_ptr()
         _lib.check(lib.taoamd_match(
             dp.n_cells, _ptr(t["cell_dt_off"]), _ptr(t["cell_gt_off"]),
@@ -472,8 +472,8 @@ def shard_flat(flat, c0, c1):
     f = Flat()
     d0, d1 = int(flat.cell_dt_off[c0]), int(flat.cell_dt_off[c1])
     g0, g1 = int(flat.cell_gt_off[c0]), int(flat.cell_gt_off[c1])
-    per_dt = ["dt_score", "dt_flags", "dt_id", "dt_cat", "dt_cell"]
-    per_gt = ["gt_flags", "gt_id", "gt_cat", "gt_cell"]
+    per_dt = ["dt_score", "dt_flags", "dt_id", "dt_cat", "dt_cell", "dt_row"]
+    per_gt = ["gt_flags", "gt_id", "gt_cat", "gt_cell", "gt_row"]
     if flat.kind == "lvis":
         per_dt += ["dt_box"]
         per_gt += ["gt_box", "gt_vis"]
@@ -489,6 +489,9 @@ def shard_flat(flat, c0, c1):
             f[k] = v[c0:c1]
         elif k in ("cell_dt_off", "cell_gt_off", "cell_iou_off"):
             f[k] = (v[c0:c1 + 1] - v[c0]).astype(v.dtype)
+        elif k == "masks":        # run-length masks (segm): CSR per row
+            f[k] = None if v is None else {"dt": v["dt"].slice(d0, d1),
+                                           "gt": v["gt"].slice(g0, g1)}
         elif not k.startswith(("dt_frame", "gt_frame")):
             f[k] = v
     f.dt_cell = f.dt_cell - c0

@@ -132,6 +132,30 @@ class DeviceProblem:
         self.t = {}
         for n in names:
             self.t[n] = _to_device(flat[n], self.device)
+        # iou_type="segm": run-length masks, row i = detection / ground truth
+        # i of the tables (masks.MaskArrays); the IoU then comes from
+        # taoamd_rle_iou instead of the boxes
+        masks = flat.get("masks") if self.kind == "lvis" else None
+        self.mask_iou = masks is not None
+        self.rle_total = {}
+        if self.mask_iou:
+            self.rle_total = {k: int(masks[k].off[-1]) for k in ("dt", "gt")}
+            for side, n_rows in (("dt", self.n_dt), ("gt", self.n_gt)):
+                m = masks[side]
+                if len(m) != n_rows:
+                    raise _lib.TaoAmdError(
+                        "%d %s masks for %d rows" % (len(m), side, n_rows))
+                self.t[side + "_rle_off"] = torch.from_numpy(m.off).to(self.device)
+                self.t[side + "_rle_runs"] = torch.from_numpy(
+                    np.ascontiguousarray(m.counts if len(m.counts) else
+                                         np.zeros(1, np.uint32)).view(np.int32)
+                ).to(self.device)
+                self.t[side + "_rle_hw"] = torch.from_numpy(
+                    np.ascontiguousarray(m.hw).reshape(-1, 2) if len(m) else
+                    np.zeros((1, 2), np.int32)).to(self.device)
+                self.t[side + "_rle_bb"] = torch.from_numpy(
+                    np.ascontiguousarray(m.bbox).reshape(-1, 4) if len(m) else
+                    np.zeros((1, 4))).to(self.device)
         gt_cat_off = np.zeros(self.n_cat + 1, dtype=np.int32)
         np.cumsum(np.bincount(flat.gt_cat, minlength=self.n_cat),
                   out=gt_cat_off[1:])
@@ -211,6 +235,12 @@ class Workspace:
             self.iou = torch.empty(max(dp.n_iou, 1), dtype=torch.float64,
                                    device=dev)
             self.pair_frames = torch.zeros(1, dtype=torch.int64, device=dev)
+        elif dp.mask_iou:
+            self.iou = torch.empty(max(dp.n_iou, 1), dtype=torch.float64,
+                                   device=dev)
+            self.rle_bytes = lib.taoamd_rle_iou_workspace(
+                dp.n_dt, dp.rle_total["dt"], dp.n_gt, dp.rle_total["gt"])
+            self.rle_ws = buf(self.rle_bytes)
         self.match_gt = None
         self.ious_out = None
         if detail:
@@ -254,7 +284,24 @@ def stage_sort(dp, ws):
         "taoamd_sort_by_cat_score")
 
 
+def stage_mask_iou(dp, ws):
+    """IoU of the run-length masks of every cell (iou_type="segm")."""
+    if not dp.mask_iou or dp.n_iou == 0:
+        return
+    lib, t, s = _lib.load(), dp.t, _stream()
+    _lib.check(lib.taoamd_rle_iou(
+        dp.n_cells, _ptr(t["cell_dt_off"]), _ptr(t["cell_gt_off"]),
+        _ptr(t["cell_iou_off"]), dp.n_dt, dp.rle_total["dt"],
+        _ptr(t["dt_rle_off"]), _ptr(t["dt_rle_runs"]), _ptr(t["dt_rle_hw"]),
+        _ptr(t["dt_rle_bb"]), dp.n_gt, dp.rle_total["gt"],
+        _ptr(t["gt_rle_off"]), _ptr(t["gt_rle_runs"]), _ptr(t["gt_rle_hw"]),
+        _ptr(t["gt_rle_bb"]), _ptr(ws.iou), _ptr(ws.rle_ws), ws.rle_bytes, s),
+        "taoamd_rle_iou")
+
+
 def stage_track_iou(dp, ws):
+    if dp.kind == "lvis":
+        return stage_mask_iou(dp, ws)        # the image level's pre-match IoU
     if dp.kind != "tao" or dp.n_iou == 0:
         return
     lib, t, s = _lib.load(), dp.t, _stream()
@@ -272,7 +319,7 @@ def stage_match(dp, ws, scatter=True):
     if dp.n_dt == 0:        # nothing was detected: every cell is GT-only
         return
     lib, t, s = _lib.load(), dp.t, _stream()
-    fused = dp.kind == "lvis"
+    fused = dp.kind == "lvis" and not dp.mask_iou
     _lib.check(lib.taoamd_match(
         dp.n_cells, _ptr(t["cell_dt_off"]), _ptr(t["cell_gt_off"]),
         _ptr(t["cell_iou_off"]), dp.max_g,
@@ -438,6 +485,7 @@ def run_forked(dp, ws, aux, head_only=False):
     if dp.kind == "lvis":
         with torch.cuda.stream(aux):
             stage_ranges(dp, ws)
+            stage_mask_iou(dp, ws)
         stage_sort(dp, ws)
     else:
         with torch.cuda.stream(aux):
@@ -525,6 +573,8 @@ def evaluate_flat(flat, device="cuda", detail=False, iou_3d_type="3d_iou"):
         out["pairs"] = int(ws.pair_frames.item())
     if detail:
         out["match_gt"] = ws.match_gt[:n].cpu().numpy()
-        if dp.kind == "lvis":
+        if dp.kind == "lvis" and not dp.mask_iou:
             out["iou"] = ws.ious_out[:dp.n_iou].cpu().numpy()
+    if dp.mask_iou:
+        out["iou"] = ws.iou[:dp.n_iou].cpu().numpy()
     return out

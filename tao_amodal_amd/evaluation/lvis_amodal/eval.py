@@ -94,10 +94,8 @@ class LVISEval:
     def evaluate(self):
         self.logger.info("Running per image evaluation.")
         self.logger.info("Evaluate annotation type *{}*".format(self.params.iou_type))
-        if self.params.iou_type != "bbox":
-            raise NotImplementedError(
-                "only iou_type='bbox' runs on the HIP path (segm is "
-                "SURVEY.md 8(f) rank 3)")
+        if self.params.iou_type not in ("bbox", "segm"):
+            raise ValueError("Unknown iou_type for iou computation.")
         self.params.img_ids = list(np.unique(self.params.img_ids))
         use_cats = bool(self.params.use_cats)
         with timed("flatten"):
@@ -106,6 +104,9 @@ class LVISEval:
             flat = flatten.flatten_lvis(self.lvis_gt.columns,
                                         self.lvis_dt.columns_dt,
                                         self.lvis_dt.max_dets, use_cats=use_cats)
+        if self.params.iou_type == "segm":
+            with timed("masks"):
+                flat.masks = self._masks(flat)
         self.flat = flat
         self.freq_groups = self._prepare_freq_group()
         self._run = GpuRun(flat, self.device)
@@ -116,6 +117,39 @@ class LVISEval:
         self.ious = LazyIous(view, self.params.img_ids, cats)
         self.eval_imgs = _EvalImgs(view, len(self.params.img_ids),
                                    len(self.params.visibility_rng), len(cats))
+
+    def _masks(self, flat):
+        """_to_mask (reference eval.py:54-58, 70-73) for the annotations that
+        are evaluated: every ground truth / detection of the cell tables goes
+        through ann_to_rle (lvis.py:171-193) into a native mask batch; a
+        detection without "segmentation" gets the polygon of its box
+        (results.py:48-49)."""
+        from ...masks import MaskBatch
+        imgs = self.lvis_gt.imgs
+        anns = self.lvis_gt.dataset["annotations"]
+        out = {}
+        batch = MaskBatch()
+        for row in flat.gt_row.tolist():
+            a = anns[row]
+            im = imgs[a["image_id"]]
+            batch.add(a["segmentation"], im["height"], im["width"])
+        out["gt"] = batch.arrays()
+        batch.close()
+        raw = self.lvis_dt.raw_results
+        batch = MaskBatch()
+        for row in flat.dt_row.tolist():
+            r = raw[row]
+            im = imgs[r["image_id"]]
+            if "segmentation" in r:
+                seg = r["segmentation"]
+            else:
+                x1, y1, w, h = r["bbox"]
+                x2, y2 = x1 + w, y1 + h
+                seg = [[x1, y1, x1, y2, x2, y2, x2, y1]]
+            batch.add(seg, im["height"], im["width"])
+        out["dt"] = batch.arrays()
+        batch.close()
+        return out
 
     def _prepare_freq_group(self):
         groups = [[] for _ in self.params.img_count_lbl]

@@ -25,15 +25,26 @@ class LVISResults(LVIS):
             raise TypeError("Unsupported type {} of lvis_gt.".format(lvis_gt))
         self.logger = logging.getLogger(__name__)
         self.logger.info("Loading and preparing results.")
+        self._raw, self._raw_path = None, None
         if isinstance(results, DTColumns):
             self.columns_dt = results
         elif isinstance(results, str):
-            self.columns_dt = DTColumns.from_json(results)
+            self._raw_path = results
+            try:
+                self.columns_dt = DTColumns.from_json(results)
+            except (KeyError, ValueError):
+                # no "bbox": results given as masks (reference results.py:54)
+                self.columns_dt = self._from_masks(self.raw_results)
         else:
             self.logger.warning(
                 "Assuming user provided the results in correct format.")
             assert isinstance(results, list), "results is not a list."
-            self.columns_dt = DTColumns.from_json(results)
+            self._raw = results
+            if results and "bbox" not in results[0] \
+                    and "segmentation" in results[0]:
+                self.columns_dt = self._from_masks(results)
+            else:
+                self.columns_dt = DTColumns.from_json(results)
         self.max_dets = max_dets
         if len(self.columns_dt) == 0:
             raise IndexError("list index out of range")  # results.py:42
@@ -44,6 +55,46 @@ class LVISResults(LVIS):
         self._index = None
         self._columns = None
         self._dataset = None
+
+    @property
+    def raw_results(self):
+        """The prediction dicts (parsed on demand: only iou_type="segm" and
+        mask-only results look at anything but the columns)."""
+        if self._raw is None:
+            if self._raw_path is None:
+                raise ValueError("the prediction dicts are not available: "
+                                 "LVISResults was built from columns")
+            import json
+            with open(self._raw_path, "r") as f:
+                self._raw = json.load(f)
+            assert isinstance(self._raw, list), "results is not a list."
+        return self._raw
+
+    @staticmethod
+    def _from_masks(results):
+        """Results that bring a compressed RLE instead of a box: area and,
+        where absent, bbox come from the mask (reference results.py:54-60:
+        mask_utils.area / toBbox)."""
+        from ...masks import MaskBatch
+        batch = MaskBatch()
+        for r in results:
+            seg = r["segmentation"]
+            batch.add({"size": seg["size"], "counts": seg["counts"]}, 0, 0)
+        arr = batch.arrays()
+        batch.close()
+        i64 = np.int64
+        bbox = np.array([r["bbox"] if "bbox" in r else arr.bbox[k]
+                         for k, r in enumerate(results)],
+                        dtype=np.float64).reshape(-1, 4)
+        cols = DTColumns(
+            image_id=np.asarray([r["image_id"] for r in results], dtype=i64),
+            category_id=np.asarray([r["category_id"] for r in results], dtype=i64),
+            bbox=bbox,
+            score=np.asarray([r["score"] for r in results], dtype=np.float64),
+            track_id=np.asarray([r.get("track_id", -1) for r in results], dtype=i64),
+            video_id=np.asarray([r.get("video_id", -1) for r in results], dtype=i64))
+        cols.area = arr.area.astype(np.float64)
+        return cols
 
     @property
     def dataset(self):

@@ -310,7 +310,11 @@ def flatten_lvis(gt: GTColumns, dt: DTColumns, max_dets=MAX_DETS,
     d_img = _lookup(img_ids, d_image)
     if (d_img < 0).any():
         raise AssertionError("Results do not correspond to current LVIS set.")
-    d_area = (dt.bbox[:, 2] * dt.bbox[:, 3])[keep]
+    # area = w * h of the box (L/results.py:51); results that come as masks
+    # only bring the mask's area instead (L/results.py:56, DTColumns.area)
+    d_area = (dt.bbox[:, 2] * dt.bbox[:, 3])[keep] \
+        if getattr(dt, "area", None) is None else \
+        np.asarray(dt.area, dtype=np.float64)[keep]
 
     # ---- ground truth selection (sorted image order, dataset order inside)
     a_img = _lookup(img_ids, gt.ann_img)
@@ -378,6 +382,8 @@ def flatten_lvis(gt: GTColumns, dt: DTColumns, max_dets=MAX_DETS,
     f.cell_dt_off = d_off.astype(I32)
     f.cell_gt_off = g_off.astype(I32)
     f.dt_box = LazyRows(dt.bbox, keep[order])
+    f.dt_row = keep[order]          # row of the prediction list
+    f.gt_row = g_sel                # row of dataset["annotations"]
     f.dt_score = np.ascontiguousarray(d_score[order])
     f.dt_flags = d_flags
     f.dt_id = d_id[order]
@@ -544,7 +550,11 @@ def flatten_tao(gt: GTColumns, dt: DTColumns, max_dets=MAX_DETS,
     d_img = _lookup(img_ids, d_image)
     if (d_img < 0).any():
         raise AssertionError("Results do not correspond to current Tao set.")
-    d_area = (dt.bbox[:, 2] * dt.bbox[:, 3])[keep]
+    # area = w * h of the box (L/results.py:51); results that come as masks
+    # only bring the mask's area instead (L/results.py:56, DTColumns.area)
+    d_area = (dt.bbox[:, 2] * dt.bbox[:, 3])[keep] \
+        if getattr(dt, "area", None) is None else \
+        np.asarray(dt.area, dtype=np.float64)[keep]
     # track score over *all* kept boxes of the track (T/results.py:88-98)
     trk_score = np.empty(len(u))
     by_trk = np.argsort(inv, kind="stable")

@@ -1,0 +1,105 @@
+"""The product's native run-length masks (csrc/rle.cpp through
+tao_amodal_amd.masks) against the oracle (oracle/rle.py, itself pinned to the
+reference C) and against the masks the reference evaluator built for golden
+fixture F6."""
+import gzip
+import json
+
+import numpy as np
+import pytest
+
+from goldenio import path
+from oracle import rle
+from tao_amodal_amd.masks import MaskBatch
+
+
+def _rand_poly(rng, h, w, spread=0.6):
+    k = int(rng.integers(3, 10))
+    cx, cy = rng.uniform(0, w), rng.uniform(0, h)
+    return np.c_[cx + rng.uniform(-w * spread, w * spread, k),
+                 cy + rng.uniform(-h * spread, h * spread, k)].ravel()
+
+
+def test_polygons_unions_text_area_bbox_equal_the_oracle():
+    rng = np.random.default_rng(3)
+    b = MaskBatch()
+    want = []
+    for it in range(400):
+        h, w = int(rng.integers(4, 70)), int(rng.integers(4, 90))
+        parts = [_rand_poly(rng, h, w) for _ in range(int(rng.integers(1, 4)))]
+        if it % 4 == 0:
+            parts = [np.round(p) for p in parts]
+        if it % 6 == 0:
+            parts[0][2:4] = parts[0][0:2]                    # repeated vertex
+        if it % 5 == 0:
+            parts[0] = np.r_[parts[0], 3.0]                  # odd length: ignored
+        segm = [p.tolist() for p in parts]
+        assert b.add(segm, h, w) == it
+        want.append(rle.ann_to_rle(segm, h, w))
+    a = b.arrays()
+    assert len(a) == len(want)
+    for i, m in enumerate(want):
+        assert a.mask(i) == m, i
+        assert int(a.area[i]) == rle.area(m)
+        assert a.bbox[i].tolist() == rle.to_bbox(m)
+        assert b.text(i) == rle.to_string(m)
+
+
+def test_uncompressed_and_compressed_forms():
+    rng = np.random.default_rng(4)
+    b = MaskBatch()
+    for it in range(100):
+        h, w = int(rng.integers(4, 40)), int(rng.integers(4, 40))
+        m = rle.fr_poly(_rand_poly(rng, h, w).tolist(), h, w)
+        i = b.add({"size": [h, w], "counts": m["counts"]}, 7, 7)   # keeps its own size
+        j = b.add({"size": [h, w], "counts": rle.to_string(m)}, 7, 7)
+        k = b.add({"size": [h, w], "counts": rle.to_string(m).encode()}, 7, 7)
+        a = b.arrays()
+        assert a.mask(i) == m and a.mask(j) == m and a.mask(k) == m
+    empty = b.add({"size": [5, 6], "counts": [30]}, 5, 6)
+    full = b.add({"size": [5, 6], "counts": [0, 30]}, 5, 6)
+    a = b.arrays()
+    assert a.bbox[empty].tolist() == [0, 0, 0, 0] and a.area[empty] == 0
+    assert a.bbox[full].tolist() == [0, 0, 6, 5] and a.area[full] == 30
+
+
+def test_rejected_inputs_raise_like_the_reference():
+    b = MaskBatch()
+    with pytest.raises(TypeError):
+        b.add([[1, 2, 3, 4]], 10, 10)        # taken for a box list (_mask.pyx:284)
+    with pytest.raises(Exception):
+        b.add([[1, 2]], 10, 10)
+    assert len(b) == 0
+
+
+@pytest.mark.parametrize("which", ["pred", "pred_rle"])
+def test_masks_of_fixture_f6_equal_the_reference(which):
+    with gzip.open(path("f6", "lvis_segm.json.gz")) as f:
+        w = json.load(f)[which]
+    gt = json.load(open(path("f6", "gt.json")))
+    pred = json.load(open(path("f6", which + ".json")))
+    imgs = {im["id"]: im for im in gt["images"]}
+    b = MaskBatch()
+    ids = []
+    for a in gt["annotations"]:
+        if str(a["id"]) in w["gt_rle"]:
+            im = imgs[a["image_id"]]
+            ids.append(("g", a["id"]))
+            b.add(a["segmentation"], im["height"], im["width"])
+    from oracle import pyoracle
+    pred = pyoracle.limit_dets_per_image(pred)   # ids = 1-based positions after it
+    for k, p in enumerate(pred):
+        if str(k + 1) in w["dt_rle"]:
+            im = imgs[p["image_id"]]
+            x, y, bw, bh = p.get("bbox", [0, 0, 0, 0])
+            segm = p.get("segmentation", [[x, y, x, y + bh, x + bw, y + bh, x + bw, y]])
+            ids.append(("d", k + 1))
+            b.add(segm, im["height"], im["width"])
+    arr = b.arrays()
+    assert len(ids) == len(w["gt_rle"]) + len(w["dt_rle"])
+    for i, (side, ident) in enumerate(ids):
+        ref = w["gt_rle" if side == "g" else "dt_rle"][str(ident)]
+        assert b.text(i) == ref, (side, ident)
+        if side == "d" and which == "pred_rle":
+            assert float(arr.area[i]) == w["dt_area"][str(ident)]
+            assert arr.bbox[i].tolist() == w["dt_bbox"][str(ident)]
