@@ -51,6 +51,9 @@
 using namespace taoamd;
 
 #define ACC_CH 256
+#ifndef ACC_INLINE_CHUNKS
+#define ACC_INLINE_CHUNKS 64    // categories up to 16384 rows scan their chunks inline
+#endif
 #define ACC_EPS 2.220446049250313e-16  // np.spacing(1)
 
 // (tp, n) pairs packed as tp << 32 | n.  better(a, b): pair a gives a larger
@@ -89,6 +92,7 @@ struct AccArgs {
     double *rec;                 // [n_cat][n_rng][N_THR]
     int32_t k_begin, k_end;      // categories swept by this call
     int32_t fused_rows;          // categories up to this many rows take acc_fused_kernel
+    int32_t inline_scans;        // short categories: no acc_prefix / acc_sufmax launches
 };
 
 __global__ __launch_bounds__(256) void acc_chunks_kernel(AccArgs a)
@@ -100,7 +104,11 @@ __global__ __launch_bounds__(256) void acc_chunks_kernel(AccArgs a)
     // (categories short enough for acc_fused_kernel get no chunks here)
     auto chunks_of = [&](int k) {
         const int32_t rows = a.cat_off[k + 1] - a.cat_off[k];
-        return (a.fused_rows > 0 && rows <= a.fused_rows) ? 0 : (rows + ACC_CH - 1) / ACC_CH;
+        if (a.fused_rows > 0 && rows <= a.fused_rows) return 0;
+        // without acc_prefix_kernel nobody visits a category that has no
+        // chunk: one of no rows carries its recall 0 / precision 0
+        if (a.inline_scans && rows == 0) return 1;
+        return (rows + ACC_CH - 1) / ACC_CH;
     };
     for (int k = lo; k < hi; k++) s += chunks_of(k);
     part[threadIdx.x] = s;
@@ -299,13 +307,33 @@ __global__ __launch_bounds__(256) void acc_prefix_kernel(AccArgs a, RecThr rec)
     }
 }
 
+// INLINE: the category is short (the host says so): the chunk adds up the
+// counts of the chunks before it by itself -- at most ACC_INLINE_CHUNKS - 1
+// loads per lane, which is cheaper than a launch between two dependent
+// kernels (acc_prefix_kernel) on the critical chain of the step.
+template <bool INLINE>
 __global__ __launch_bounds__(256) void acc_chunkmax_kernel(AccArgs a)
 {
     const ChunkInfo ci = chunk_info(a);
     if (!ci.valid) return;
     const int lane = lane_id();
     const int64_t o = ((int64_t)ci.c * a.n_words + ci.word) * WAVE + lane;
-    uint32_t tp0 = a.pre_tp[o], n0 = tp0 + a.pre_fp[o];
+    uint32_t tp0, n0;
+    if (INLINE) {
+        uint32_t fp0 = 0;
+        tp0 = 0;
+        for (int32_t c = a.cat_chunk_off[ci.k]; c < ci.c; c++) {
+            const int64_t oc = ((int64_t)c * a.n_words + ci.word) * WAVE + lane;
+            tp0 += a.cnt_tp[oc];
+            fp0 += a.cnt_fp[oc];
+        }
+        a.pre_tp[o] = tp0;
+        a.pre_fp[o] = fp0;
+        n0 = tp0 + fp0;
+    } else {
+        tp0 = a.pre_tp[o];
+        n0 = tp0 + a.pre_fp[o];
+    }
     uint64_t best = PR_ZERO;
     const int64_t tb = (((int64_t)ci.c * a.n_words + ci.word) * ACC_BLK) * WAVE + lane;
     for (int blk = 0; blk * WAVE < ci.len; blk++) {
@@ -324,6 +352,15 @@ __global__ __launch_bounds__(256) void acc_chunkmax_kernel(AccArgs a)
         n0 += (uint32_t)__popcll(TF);
     }
     a.cmax[o] = best;
+    if (INLINE && ci.last) {                        // recall of the whole category
+        const int combo = ci.word * WAVE + lane;
+        if (combo < a.n_rng * N_THR) {
+            const int r = combo / N_THR, t = combo - r * N_THR;
+            const int64_t kr = (int64_t)ci.k * a.n_rng + r;
+            const int32_t ng = a.num_gt[kr];
+            if (ng > 0) a.rec[kr * N_THR + t] = (double)tp0 / (double)ng;
+        }
+    }
 }
 
 // reverse exclusive maximum over the chunks of a category; one workgroup per
@@ -363,7 +400,11 @@ __global__ __launch_bounds__(256) void acc_sufmax_kernel(AccArgs a)
 
 #define EMIT_RMAX 8   // ranges that can overlap one 64-combo word
 
-__global__ __launch_bounds__(256) void acc_emit_kernel(AccArgs a)
+// INLINE (short categories): the recall crossings are tabulated here and the
+// envelope of the later chunks is gathered here, instead of by
+// acc_prefix_kernel / acc_sufmax_kernel.
+template <bool INLINE>
+__global__ __launch_bounds__(256) void acc_emit_kernel(AccArgs a, RecThr rec)
 {
     __shared__ int32_t s_cj[4][EMIT_RMAX][N_REC];
     const ChunkInfo ci = chunk_info(a);
@@ -379,8 +420,9 @@ __global__ __launch_bounds__(256) void acc_emit_kernel(AccArgs a)
     for (int q = r_lo; q <= r_hi; q++) {
         const bool has = a.num_gt[(int64_t)ci.k * a.n_rng + q] > 0;
         for (int j = lane; j < N_REC; j += WAVE)
-            s_cj[wave][q - r_lo][j] =
-                has ? a.cj[((int64_t)ci.k * a.n_rng + q) * N_REC + j] : 0;
+            s_cj[wave][q - r_lo][j] = !has ? 0 : INLINE
+                ? recall_crossing(rec.v[j], a.num_gt[(int64_t)ci.k * a.n_rng + q])
+                : a.cj[((int64_t)ci.k * a.n_rng + q) * N_REC + j];
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -390,7 +432,16 @@ __global__ __launch_bounds__(256) void acc_emit_kernel(AccArgs a)
     const int64_t o = ((int64_t)ci.c * a.n_words + ci.word) * WAVE + lane;
     uint32_t tp = a.pre_tp[o] + a.cnt_tp[o];
     uint32_t n = tp + a.pre_fp[o] + a.cnt_fp[o];
-    uint64_t run = a.cmax[o];
+    uint64_t run;
+    if (INLINE) {
+        run = PR_ZERO;
+        for (int32_t c = a.cat_chunk_off[ci.k + 1] - 1; c > ci.c; c--) {
+            const uint64_t v = a.cmax[((int64_t)c * a.n_words + ci.word) * WAVE + lane];
+            if (pr_better((uint32_t)(v >> 32), (uint32_t)v, run)) run = v;
+        }
+    } else {
+        run = a.cmax[o];
+    }
     double *__restrict__ out =
         a.val + (((int64_t)ci.k * a.n_rng + r) * N_THR + t) * N_REC;
     // thresholds already reached by the TP count at the end of this chunk:
@@ -409,7 +460,9 @@ __global__ __launch_bounds__(256) void acc_emit_kernel(AccArgs a)
         // a lane's row is contiguous: the wavefront writes the tails row by
         // row with coalesced stores instead of every lane walking its own row
         // (64 scattered 8-byte stores per step).
-        const int jz = live ? jcur : N_REC;
+        // (a category without detections: precision 0 everywhere it has
+        // evaluated GT, reference lvis_amodal/eval.py:412-417)
+        const int jz = live ? (ci.len == 0 ? 0 : jcur) : N_REC;
         for (int l = 0; l < WAVE; l++) {
             const int jl = __builtin_amdgcn_readlane(jz, l);
             if (jl >= N_REC) continue;
@@ -466,7 +519,7 @@ __global__ __launch_bounds__(256) void acc_emit_kernel(AccArgs a)
             } while (cnext > (int32_t)tp);
         }
     }
-    if (live && ci.first && jcur > 0) {
+    if (live && ci.first && jcur > 0 && ci.len > 0) {
         const double v = pr_value(run);
         while (jcur > 0) {
             out[jcur - 1] = v;
@@ -784,6 +837,7 @@ extern "C" int taoamd_accumulate_compact(int64_t n_dt, int32_t n_cat,
     a.cat_off = cat_off; a.matched = matched; a.ignored = ignored;
     a.num_gt = num_gt; a.val = val; a.rec = rec;
     a.k_begin = k_begin; a.k_end = k_end;
+    a.inline_scans = 0;
     // every category fits one workgroup (the host says so): the fused
     // single-launch sweep.  Mixing the two paths per category was measured
     // slower than the chunked path alone when long categories exist (image
@@ -796,6 +850,10 @@ extern "C" int taoamd_accumulate_compact(int64_t n_dt, int32_t n_cat,
         return TAOAMD_OK;
     }
     a.fused_rows = 0;
+    // categories of at most ACC_INLINE_CHUNKS chunks: the two per-category
+    // scan kernels are folded into their consumers (four launches on the
+    // chain instead of six; all or nothing, like the fused sweep)
+    a.inline_scans = max_segment > 0 && max_segment <= ACC_INLINE_CHUNKS * ACC_CH;
     unsigned char *w = (unsigned char *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     const size_t nc = (size_t)a.n_chunks_max, nw = (size_t)a.n_words;
     a.cat_chunk_off = (int32_t *)w; w += align256(((size_t)n_cat + 1) * 4);
@@ -811,10 +869,15 @@ extern "C" int taoamd_accumulate_compact(int64_t n_dt, int32_t n_cat,
     const unsigned cat_blocks = (unsigned)((size_t)(k_end - k_begin) * nw);
     acc_chunks_kernel<<<1, 256, 0, s>>>(a);
     acc_count_kernel<<<chunk_blocks, 256, 0, s>>>(a);
-    acc_prefix_kernel<<<cat_blocks, 256, 0, s>>>(a, rec_thr());
-    acc_chunkmax_kernel<<<chunk_blocks, 256, 0, s>>>(a);
-    acc_sufmax_kernel<<<cat_blocks, 256, 0, s>>>(a);
-    acc_emit_kernel<<<chunk_blocks, 256, 0, s>>>(a);
+    if (a.inline_scans) {
+        acc_chunkmax_kernel<true><<<chunk_blocks, 256, 0, s>>>(a);
+        acc_emit_kernel<true><<<chunk_blocks, 256, 0, s>>>(a, rec_thr());
+    } else {
+        acc_prefix_kernel<<<cat_blocks, 256, 0, s>>>(a, rec_thr());
+        acc_chunkmax_kernel<false><<<chunk_blocks, 256, 0, s>>>(a);
+        acc_sufmax_kernel<<<cat_blocks, 256, 0, s>>>(a);
+        acc_emit_kernel<false><<<chunk_blocks, 256, 0, s>>>(a, rec_thr());
+    }
     TAO_LAUNCH_CHECK();
     return TAOAMD_OK;
 }

@@ -447,19 +447,28 @@ def test_exchange_chunks_hip_vs_numpy_restatement(world):
 
 def test_fused_and_chunked_sweeps_agree():
     """taoamd_accumulate takes the fused single-launch sweep when the host says
-    every category fits one workgroup, the chunked kernels otherwise (hint 0 =
-    unknown): both must give the oracle's tables, also when a category
-    straddles the limit."""
+    every category fits one workgroup, the chunked kernels with the
+    per-category scans folded into them when every category has at most 32
+    chunks (hint 5000: above the fused limit, below 8192), the six-kernel
+    chain otherwise (hint 0 = unknown): all must give the oracle's tables,
+    also when a category straddles a limit or has ground truth but no
+    detection at all."""
     import torch
     from tao_amodal_amd import engine
-    for seed, V, F, C, dpf in ((5, 6, 40, 12, 60), (6, 4, 30, 30, 40)):
+    for seed, V, F, C, dpf in ((5, 6, 40, 12, 60), (6, 4, 30, 30, 40), (7, 5, 30, 9, 50)):
         gt, dt = synth(seed=seed, V=V, F=F, C=C, dets_per_frame=dpf, n_present=4)
+        if seed == 7:       # a category with ground truth and no detection
+            victim = np.bincount(gt.ann_cat).argmax()
+            dt = dt.take(np.flatnonzero(dt.category_id != victim))
         fl_ = fl.flatten_lvis(gt, dt)
         dt.track_id, _ = fl.make_track_ids_unique(dt)
         ft_ = fl.flatten_tao(gt, dt)
         for flat in (fl_, ft_):
             want = orclib.run_flat(flat, detail=False)
-            for hint in ("own", 0, 1 << 30):
+            if seed == 7:
+                k = int(np.flatnonzero(flat.cat_ids == victim)[0])
+                assert (np.asarray(flat.dt_cat) != k).all() and want["num_gt"][k].max() > 0
+            for hint in ("own", 0, 5000, 1 << 30):
                 dp = engine.DeviceProblem(flat, "cuda:0")
                 if hint != "own":
                     dp.acc_hint = hint
