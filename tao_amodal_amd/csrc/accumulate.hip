@@ -312,11 +312,28 @@ __global__ __launch_bounds__(256) void acc_prefix_kernel(AccArgs a, RecThr rec)
 // loads per lane, which is cheaper than a launch between two dependent
 // kernels (acc_prefix_kernel) on the critical chain of the step.
 template <bool INLINE>
-__global__ __launch_bounds__(256) void acc_chunkmax_kernel(AccArgs a)
+__global__ __launch_bounds__(256) void acc_chunkmax_kernel(AccArgs a, RecThr rec)
 {
     const ChunkInfo ci = chunk_info(a);
     if (!ci.valid) return;
     const int lane = lane_id();
+    if (INLINE) {
+        // the recall crossings (acc_prefix_kernel's table) depend on num_gt
+        // only: every wavefront of the launch tabulates an equal slice of the
+        // whole table, whatever category its chunk belongs to (tabulating a
+        // category's crossings in each of its emission wavefronts cost 33 us,
+        // in the wavefront of its first chunk 15 us: two fp64 divisions each)
+        const int64_t total = (int64_t)a.n_cat * a.n_rng * N_REC;
+        const int64_t items = (int64_t)a.cat_chunk_off[a.n_cat] * a.n_words;
+        const int64_t per = (total + items - 1) / items;
+        const int64_t lo = ((int64_t)ci.c * a.n_words + ci.word) * per;
+        const int64_t hi = min(total, lo + per);
+        for (int64_t i = lo + lane; i < hi; i += WAVE) {
+            const int64_t kr = i / N_REC;
+            const int32_t ng = a.num_gt[kr];
+            if (ng > 0) a.cj[i] = recall_crossing(rec.v[i - kr * N_REC], ng);
+        }
+    }
     const int64_t o = ((int64_t)ci.c * a.n_words + ci.word) * WAVE + lane;
     uint32_t tp0, n0;
     if (INLINE) {
@@ -400,11 +417,10 @@ __global__ __launch_bounds__(256) void acc_sufmax_kernel(AccArgs a)
 
 #define EMIT_RMAX 8   // ranges that can overlap one 64-combo word
 
-// INLINE (short categories): the recall crossings are tabulated here and the
-// envelope of the later chunks is gathered here, instead of by
-// acc_prefix_kernel / acc_sufmax_kernel.
+// INLINE (short categories): the envelope of the later chunks is gathered
+// here instead of by acc_sufmax_kernel.
 template <bool INLINE>
-__global__ __launch_bounds__(256) void acc_emit_kernel(AccArgs a, RecThr rec)
+__global__ __launch_bounds__(256) void acc_emit_kernel(AccArgs a)
 {
     __shared__ int32_t s_cj[4][EMIT_RMAX][N_REC];
     const ChunkInfo ci = chunk_info(a);
@@ -420,9 +436,8 @@ __global__ __launch_bounds__(256) void acc_emit_kernel(AccArgs a, RecThr rec)
     for (int q = r_lo; q <= r_hi; q++) {
         const bool has = a.num_gt[(int64_t)ci.k * a.n_rng + q] > 0;
         for (int j = lane; j < N_REC; j += WAVE)
-            s_cj[wave][q - r_lo][j] = !has ? 0 : INLINE
-                ? recall_crossing(rec.v[j], a.num_gt[(int64_t)ci.k * a.n_rng + q])
-                : a.cj[((int64_t)ci.k * a.n_rng + q) * N_REC + j];
+            s_cj[wave][q - r_lo][j] =
+                has ? a.cj[((int64_t)ci.k * a.n_rng + q) * N_REC + j] : 0;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -870,13 +885,13 @@ extern "C" int taoamd_accumulate_compact(int64_t n_dt, int32_t n_cat,
     acc_chunks_kernel<<<1, 256, 0, s>>>(a);
     acc_count_kernel<<<chunk_blocks, 256, 0, s>>>(a);
     if (a.inline_scans) {
-        acc_chunkmax_kernel<true><<<chunk_blocks, 256, 0, s>>>(a);
-        acc_emit_kernel<true><<<chunk_blocks, 256, 0, s>>>(a, rec_thr());
+        acc_chunkmax_kernel<true><<<chunk_blocks, 256, 0, s>>>(a, rec_thr());
+        acc_emit_kernel<true><<<chunk_blocks, 256, 0, s>>>(a);
     } else {
         acc_prefix_kernel<<<cat_blocks, 256, 0, s>>>(a, rec_thr());
-        acc_chunkmax_kernel<false><<<chunk_blocks, 256, 0, s>>>(a);
+        acc_chunkmax_kernel<false><<<chunk_blocks, 256, 0, s>>>(a, rec_thr());
         acc_sufmax_kernel<<<cat_blocks, 256, 0, s>>>(a);
-        acc_emit_kernel<false><<<chunk_blocks, 256, 0, s>>>(a, rec_thr());
+        acc_emit_kernel<false><<<chunk_blocks, 256, 0, s>>>(a);
     }
     TAO_LAUNCH_CHECK();
     return TAOAMD_OK;
