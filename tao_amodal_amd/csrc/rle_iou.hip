@@ -37,17 +37,22 @@ struct RleArgs {
     const int64_t *dt_off, *gt_off;           // CSR of the run lists
     const int32_t *dt_hw, *gt_hw;             // (height, width) per mask
     const double *dt_bb, *gt_bb;              // tight box (x, y, w, h) per mask
-    const uint2 *dt_pre, *gt_pre;             // (E, P) per run
+    const uint32_t *dt_end;                   // E per run of the detections
+    const uint2 *gt_pre;                      // (E, P) per run of the ground truths
     const uint32_t *dt_ones, *gt_ones;        // ones per mask
     double *iou;
 };
 
 // one wavefront per mask: inclusive scans of the run lengths and of the
 // lengths of the odd-numbered runs (the ones)
+// (detections are only ever the "A" of a pair: their P is not stored.  Summing
+// their boundaries inside the IoU kernel instead, lazily for the detections
+// that have a pair to walk, was measured slower: 0.56 vs 0.54 ms.)
+template <bool WITH_P>
 __global__ __launch_bounds__(256) void rle_prefix_kernel(int64_t n,
                                                          const int64_t *off,
                                                          const uint32_t *runs,
-                                                         uint2 *pre, uint32_t *ones)
+                                                         void *out, uint32_t *ones)
 {
     const int lane = lane_id();
     const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -65,7 +70,10 @@ __global__ __launch_bounds__(256) void rle_prefix_kernel(int64_t n,
         }
         e += carry_e;
         p += carry_p;
-        if (i < k) pre[b + i] = make_uint2(e, p);
+        if (i < k) {
+            if (WITH_P) ((uint2 *)out)[b + i] = make_uint2(e, p);
+            else ((uint32_t *)out)[b + i] = e;
+        }
         carry_e = __shfl(e, WAVE - 1, WAVE);
         carry_p = __shfl(p, WAVE - 1, WAVE);
     }
@@ -129,7 +137,7 @@ __device__ __forceinline__ void rle_cell(const RleArgs &a, int32_t d0, int32_t D
                 const uint32_t i = piece * (RLE_RPT * WAVE) + (uint32_t)lane * RLE_RPT + q;
                 use[q] = i < ka && ((i & 1) || i + 1 < ka);
                 // past the end: 0, a boundary that makes the walk below stand still
-                xq[q] = i < ka ? a.dt_pre[ab + i].x : 0u;
+                xq[q] = i < ka ? a.dt_end[ab + i] : 0u;
             }
         };
         load_piece(0);
@@ -234,7 +242,7 @@ static size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 extern "C" size_t taoamd_rle_iou_workspace(int64_t n_dt, int64_t dt_runs,
                                            int64_t n_gt, int64_t gt_runs)
 {
-    return up256((size_t)dt_runs * 8) + up256((size_t)gt_runs * 8) +
+    return up256((size_t)dt_runs * 4) + up256((size_t)gt_runs * 8) +
            up256((size_t)n_dt * 4) + up256((size_t)n_gt * 4) + 256;
 }
 
@@ -261,15 +269,15 @@ extern "C" int taoamd_rle_iou(int64_t n_cells, const int32_t *cell_dt_off,
     hipStream_t s = (hipStream_t)stream;
     unsigned char *w = (unsigned char *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     RleArgs a;
-    a.dt_pre = (const uint2 *)w; w += up256((size_t)dt_total * 8);
+    a.dt_end = (const uint32_t *)w; w += up256((size_t)dt_total * 4);
     a.gt_pre = (const uint2 *)w; w += up256((size_t)gt_total * 8);
     a.dt_ones = (const uint32_t *)w; w += up256((size_t)n_dt * 4);
     a.gt_ones = (const uint32_t *)w;
-    rle_prefix_kernel<<<dim3((unsigned)((n_dt + 3) / 4)), 256, 0, s>>>(
-        n_dt, dt_off, dt_runs, (uint2 *)a.dt_pre, (uint32_t *)a.dt_ones);
+    rle_prefix_kernel<false><<<dim3((unsigned)((n_dt + 3) / 4)), 256, 0, s>>>(
+        n_dt, dt_off, dt_runs, (void *)a.dt_end, (uint32_t *)a.dt_ones);
     TAO_LAUNCH_CHECK();
-    rle_prefix_kernel<<<dim3((unsigned)((n_gt + 3) / 4)), 256, 0, s>>>(
-        n_gt, gt_off, gt_runs, (uint2 *)a.gt_pre, (uint32_t *)a.gt_ones);
+    rle_prefix_kernel<true><<<dim3((unsigned)((n_gt + 3) / 4)), 256, 0, s>>>(
+        n_gt, gt_off, gt_runs, (void *)a.gt_pre, (uint32_t *)a.gt_ones);
     TAO_LAUNCH_CHECK();
     a.cell_dt_off = cell_dt_off; a.cell_gt_off = cell_gt_off;
     a.cell_iou_off = cell_iou_off;
