@@ -105,8 +105,8 @@ __device__ __forceinline__ uint32_t ones_before(const uint2 *__restrict__ tab,
 // detection the 64 lanes first test 64 ground truths at once (tight boxes,
 // frame sizes) and store the 0 / -1 results; the few pairs left are walked:
 // every lane holds up to RLE_RPT run boundaries of the detection in registers
-// (loaded once, used for all its pairs) and runs its RLE_RPT binary searches
-// in lock step, so their LDS reads overlap instead of queueing.
+// (loaded once, used for all its pairs): one binary search places the first,
+// the others follow B's runs forward.
 template <bool IN_LDS>
 __device__ __forceinline__ void rle_cell(const RleArgs &a, int32_t d0, int32_t D,
                                          int32_t g0, int32_t G,
