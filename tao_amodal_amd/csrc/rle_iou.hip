@@ -86,21 +86,6 @@ __global__ __launch_bounds__(256) void rle_prefix_kernel(int64_t n,
 #define RLE_RPT 8               // run boundaries of A a lane keeps in registers (even)
 #define RLE_GTILE 64            // ground truths looked at together (one per lane)
 
-// ones of B before pixel x; tab = B's (E, P) pairs
-__device__ __forceinline__ uint32_t ones_before(const uint2 *__restrict__ tab,
-                                                uint32_t kb, uint32_t total,
-                                                uint32_t x)
-{
-    uint32_t lo = 0, hi = kb;               // first run that ends beyond x
-    while (lo < hi) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (tab[mid].x <= x) lo = mid + 1; else hi = mid;
-    }
-    if (lo == kb) return total;
-    const uint2 e = tab[lo];
-    return e.y - ((lo & 1) ? e.x - x : 0u);
-}
-
 // One workgroup = one cell, one wavefront = one detection at a time.  For a
 // detection the 64 lanes first test 64 ground truths at once (tight boxes,
 // frame sizes) and store the 0 / -1 results; the few pairs left are walked:
