@@ -94,6 +94,13 @@ int64_t taoamd_rle_total(void *handle);           /* runs in all masks */
 int64_t taoamd_rle_add_polygons(void *handle, int32_t n_parts,
                                 const int64_t *part_off, const double *xy,
                                 int64_t height, int64_t width);
+/* n_masks polygon annotations at once (rasterised on all cores, appended in
+ * order): mask m = parts [mask_part_off[m], mask_part_off[m+1]) of part_off,
+ * frame hw[m] = (height, width); returns the index of the first new mask. */
+int64_t taoamd_rle_add_polygon_batch(void *handle, int64_t n_masks,
+                                     const int64_t *mask_part_off,
+                                     const int64_t *part_off, const double *xy,
+                                     const int32_t *hw);
 int64_t taoamd_rle_add_counts(void *handle, const uint32_t *counts, int64_t m,
                               int64_t height, int64_t width);
 int64_t taoamd_rle_add_string(void *handle, const char *text, int64_t height,

@@ -264,6 +264,37 @@ int64_t taoamd_rle_add_polygons(void *handle, int32_t n_parts,
     return b->count() - 1;
 }
 
+int64_t taoamd_rle_add_polygon_batch(void *handle, int64_t n_masks,
+                                     const int64_t *mask_part_off,
+                                     const int64_t *part_off, const double *xy,
+                                     const int32_t *hw)
+{
+    Batch *b = (Batch *)handle;
+    if (n_masks < 0) return -1;
+    for (int64_t m = 0; m < n_masks; m++) {
+        const int64_t h = hw[2 * m], w = hw[2 * m + 1];
+        if (mask_part_off[m + 1] <= mask_part_off[m] || h < 0 || w < 0 ||
+            (uint64_t)h * (uint64_t)w >= (1ull << 32))
+            return -1;
+        for (int64_t p = mask_part_off[m]; p < mask_part_off[m + 1]; p++)
+            if (part_off[p + 1] - part_off[p] < 2) return -1;
+    }
+    // the masks are independent: rasterise them on all cores, append in order
+    std::vector<Mask> made((size_t)n_masks);
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int64_t m = 0; m < n_masks; m++) {
+        std::vector<Mask> parts;
+        for (int64_t p = mask_part_off[m]; p < mask_part_off[m + 1]; p++)
+            parts.push_back(from_polygon(xy + part_off[p],
+                                         (part_off[p + 1] - part_off[p]) / 2,
+                                         hw[2 * m], hw[2 * m + 1]));
+        made[(size_t)m] = unite(parts);
+    }
+    const int64_t first = b->count();
+    for (const Mask &m : made) b->push(m);
+    return first;
+}
+
 int64_t taoamd_rle_add_counts(void *handle, const uint32_t *counts, int64_t m,
                               int64_t height, int64_t width)
 {

@@ -128,27 +128,31 @@ class LVISEval:
         imgs = self.lvis_gt.imgs
         anns = self.lvis_gt.dataset["annotations"]
         out = {}
-        batch = MaskBatch()
-        for row in flat.gt_row.tolist():
-            a = anns[row]
-            im = imgs[a["image_id"]]
-            batch.add(a["segmentation"], im["height"], im["width"])
-        out["gt"] = batch.arrays()
-        batch.close()
-        raw = self.lvis_dt.raw_results
-        batch = MaskBatch()
-        for row in flat.dt_row.tolist():
-            r = raw[row]
-            im = imgs[r["image_id"]]
-            if "segmentation" in r:
-                seg = r["segmentation"]
-            else:
-                x1, y1, w, h = r["bbox"]
-                x2, y2 = x1 + w, y1 + h
-                seg = [[x1, y1, x1, y2, x2, y2, x2, y1]]
-            batch.add(seg, im["height"], im["width"])
-        out["dt"] = batch.arrays()
-        batch.close()
+
+        def gt_items():
+            for row in flat.gt_row.tolist():
+                a = anns[row]
+                im = imgs[a["image_id"]]
+                yield a["segmentation"], im["height"], im["width"]
+
+        def dt_items(raw):
+            for row in flat.dt_row.tolist():
+                r = raw[row]
+                im = imgs[r["image_id"]]
+                if "segmentation" in r:
+                    seg = r["segmentation"]
+                else:
+                    x1, y1, w, h = r["bbox"]
+                    x2, y2 = x1 + w, y1 + h
+                    seg = [[x1, y1, x1, y2, x2, y2, x2, y1]]
+                yield seg, im["height"], im["width"]
+
+        for side, items in (("gt", gt_items()),
+                            ("dt", dt_items(self.lvis_dt.raw_results))):
+            batch = MaskBatch()
+            batch.add_many(items)       # polygons: one native call, all cores
+            out[side] = batch.arrays()
+            batch.close()
         return out
 
     def _prepare_freq_group(self):

@@ -37,6 +37,8 @@ def _load():
         lib.taoamd_rle_total.argtypes = [vp]
         lib.taoamd_rle_add_polygons.restype = i64
         lib.taoamd_rle_add_polygons.argtypes = [vp, C.c_int32, vp, vp, i64, i64]
+        lib.taoamd_rle_add_polygon_batch.restype = i64
+        lib.taoamd_rle_add_polygon_batch.argtypes = [vp, i64, vp, vp, vp, vp]
         lib.taoamd_rle_add_counts.restype = i64
         lib.taoamd_rle_add_counts.argtypes = [vp, vp, i64, i64, i64]
         lib.taoamd_rle_add_string.restype = i64
@@ -119,6 +121,40 @@ class MaskBatch:
         if k < 0:
             raise ValueError("cannot make a run-length mask of %r" % (segm,))
         return int(k)
+
+    def add_many(self, items):
+        """Append the masks of many annotations: items = iterable of (segm,
+        height, width).  Runs of polygon annotations go to the library in one
+        call (rasterised on all cores); the other forms one by one.  Same
+        results and order as add() in a loop."""
+        lib = self.lib
+        xy, part_off, mask_part_off, hw = [], [0], [0], []
+
+        def flush():
+            if not hw:
+                return
+            a_xy = np.asarray(xy, dtype=np.float64)
+            a_po = np.asarray(part_off, dtype=np.int64)
+            a_mo = np.asarray(mask_part_off, dtype=np.int64)
+            a_hw = np.asarray(hw, dtype=np.int32).reshape(-1, 2)
+            k = lib.taoamd_rle_add_polygon_batch(
+                self.h, len(a_hw), a_mo.ctypes.data, a_po.ctypes.data,
+                a_xy.ctypes.data, a_hw.ctypes.data)
+            if k < 0:
+                raise ValueError("cannot make run-length masks of a polygon batch")
+            del xy[:], part_off[1:], mask_part_off[1:], hw[:]
+
+        for segm, height, width in items:
+            if isinstance(segm, list) and len(segm[0]) > 4:
+                for p in segm:
+                    xy.extend(p)
+                    part_off.append(len(xy))
+                mask_part_off.append(len(part_off) - 1)
+                hw.append((int(height), int(width)))
+            else:
+                flush()
+                self.add(segm, height, width)     # (also raises for bad input)
+        flush()
 
     def arrays(self):
         n, tot = len(self), int(self.lib.taoamd_rle_total(self.h))

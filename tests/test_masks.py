@@ -138,3 +138,36 @@ def test_category_shards_slice_the_masks_with_the_cells():
         seen_d += len(md)
         seen_g += len(mg)
     assert seen_d == len(f.dt_id) and seen_g == len(f.gt_id)
+
+
+def test_add_many_equals_add_in_a_loop():
+    """The batched entry point (polygon runs rasterised on all cores in one
+    call) gives the masks of add() one by one, in the same order, also when
+    polygon annotations alternate with the two RLE forms."""
+    rng = np.random.default_rng(12)
+    items = []
+    for it in range(300):
+        h, w = int(rng.integers(4, 70)), int(rng.integers(4, 90))
+        kind = it % 7
+        if kind == 5:
+            m = rle.fr_poly(_rand_poly(rng, h, w).tolist(), h, w)
+            items.append(({"size": [h, w], "counts": m["counts"]}, h, w))
+        elif kind == 6:
+            m = rle.fr_poly(_rand_poly(rng, h, w).tolist(), h, w)
+            items.append(({"size": [h, w], "counts": rle.to_string(m)}, h, w))
+        else:
+            parts = [_rand_poly(rng, h, w).tolist() for _ in range(int(rng.integers(1, 4)))]
+            if kind == 4:
+                parts[0] = parts[0] + [1.5]             # odd length
+            items.append((parts, h, w))
+    one, many = MaskBatch(), MaskBatch()
+    for seg, h, w in items:
+        one.add(seg, h, w)
+    many.add_many(iter(items))
+    a, b = one.arrays(), many.arrays()
+    assert len(a) == len(b) == len(items)
+    for name in ("off", "counts", "hw", "area", "bbox"):
+        assert np.array_equal(getattr(a, name), getattr(b, name)), name
+    bad = MaskBatch()
+    with pytest.raises(TypeError):
+        bad.add_many([([[1, 2, 3, 4, 5, 6]], 5, 5), ([[1, 2, 3, 4]], 5, 5)])
