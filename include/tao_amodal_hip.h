@@ -153,25 +153,65 @@ int taoamd_rle_iou(int64_t n_cells, const int32_t *cell_dt_off,
  * Tracks are CSR lists of (timeline position, box) sorted by position.
  * pair_frames (optional, int64[1], zeroed by the call) receives the number of
  * same-frame box pairs evaluated (the unit of BASELINE.json's metric).
- * cell_span (optional, int32[n_cells], device) = 1 + the largest timeline
- * position used by the cell.  Cells with at most 8 GT tracks and
- * (G + 1) * ceil(span / 64) <= 1024 take the dense-timeline kernel (track rows in LDS;
- * per chunk of 32 positions the per-frame terms are formed in parallel and
- * then added in order by one lane per track pair); the others the two-pointer
- * merge kernel.
- * all_dense: non-zero when the host knows every non-empty cell qualifies, so
- * the merge kernel launch is skipped.
  * mode: 0 = 3d_iou (sum inter / sum union, the CLI's), 1 = avg_iou (mean of
  * the per-frame IoU over the union of frames, T/eval.py:99-117), 2 =
- * imagenetvid (fraction of frames with inter > 0.5 union, T/eval.py:51-70). */
+ * imagenetvid (fraction of frames with inter > 0.5 union, T/eval.py:51-70).
+ *
+ * taoamd_track_iou is the plan-less form: one lane per track pair walks the two
+ * CSR lists with a two-pointer merge (slow; any input).
+ *
+ * taoamd_track_iou_planned is the fast form.  It reads the tracks from the
+ * PADDED frame table built by taoamd_track_pad and follows a launch plan built
+ * by taoamd_track_iou_plan_host, one wavefront per task:
+ *   tasks      int32[n_tasks][4] {first row, rows (<= 36), first pair, pairs (<= 64)}
+ *   task_rows  int32  the tasks' tracks: t for detection track t, n_dt + t for
+ *              GT track t (= the row of trk_meta)
+ *   task_pairs int32  detection row | GT row << 8 (rows local to the task)
+ *   task_out   int64  index of the pair's result in `iou`
+ * A task stages its tracks' frames in LDS chunk by chunk of the timeline and
+ * adds the per-frame terms in ascending timeline order, one lane per pair.
+ * Both forms give bit-identical results. */
 int taoamd_track_iou(int64_t n_cells, const int32_t *cell_dt_off,
                      const int32_t *cell_gt_off, const int64_t *cell_iou_off,
                      int64_t n_pairs, const int32_t *dt_frame_off,
                      const int32_t *dt_frame_pos, const double *dt_frame_box,
                      const int32_t *gt_frame_off, const int32_t *gt_frame_pos,
-                     const double *gt_frame_box, const int32_t *cell_span,
-                     int32_t all_dense, int32_t mode, double *iou,
+                     const double *gt_frame_box, int32_t mode, double *iou,
                      int64_t *pair_frames, void *stream);
+int taoamd_track_iou_planned(int64_t n_tasks, const int32_t *tasks,
+                             const int32_t *task_rows, const int32_t *task_pairs,
+                             const int64_t *task_out, const double *padded,
+                             const int32_t *trk_meta, int32_t mode, double *iou,
+                             int64_t *pair_frames, void *stream);
+
+/* Padded frame table of a set of CSR tracks: track t owns the slots
+ * meta[t].base_minus_first + p for p = first .. last (its first and last
+ * timeline position); a slot holds the frame's box (x, y, w, h) or, where the
+ * track has no frame, the far box (1e300, 1e300, 0, 0), against which every
+ * intersection is exactly 0.  meta (int32[n_trk][4], device, filled by the
+ * caller) = {first, last, base - first, 1 for a detection track / 0 for GT}; a
+ * track without frames has first > last.  The call fills the slots
+ * [slot_first, slot_first + n_slots) of `padded` (double[.][4]) with far boxes
+ * and then scatters the n_frames frames.  One call per track set (detections,
+ * ground truth) into disjoint slot ranges of ONE table whose slot 0 is a far
+ * box (reserve it: slot_first = 0 for the first set, its tracks based at 1). */
+int taoamd_track_pad(int64_t n_trk, int64_t n_frames, const int32_t *frame_off,
+                     const int32_t *frame_pos, const double *frame_box,
+                     const int32_t *meta, int64_t slot_first, int64_t n_slots,
+                     double *padded, void *stream);
+
+/* Launch plan of taoamd_track_iou_planned from HOST copies of the cell offsets
+ * and of trk_meta (detection tracks first, then GT tracks).  Call with
+ * tasks_host == NULL to get sizes[0..2] = tasks, task_rows entries, task_pairs
+ * entries; then with buffers of 4 * sizes[0], sizes[1], sizes[2] int32 and
+ * sizes[2] int64.  Every (detection track, GT track) pair of every cell lands
+ * in exactly one task.  Synchronous, host only. */
+int taoamd_track_iou_plan_host(int64_t n_cells, const int32_t *cell_dt_off_host,
+                               const int32_t *cell_gt_off_host,
+                               const int64_t *cell_iou_off_host,
+                               const int32_t *trk_meta_host, int64_t *sizes,
+                               int32_t *tasks_host, int32_t *task_rows_host,
+                               int32_t *task_pairs_host, int64_t *task_out_host);
 
 /* ---- greedy assignment --------------------------------------------------------
  * If dt_box/gt_box are non-NULL the IoU matrix of each cell is computed on the

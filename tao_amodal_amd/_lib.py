@@ -36,8 +36,13 @@ SIGNATURES = {
     "taoamd_sort_segments": (C.c_int, [_i64, _i32, _vp, _vp, _i32, _i32, _vp,
                                        _vp, _vp, _vp, _vp, _sz, _vp]),
     "taoamd_track_iou": (C.c_int, [_i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp,
-                                   _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp,
-                                   _vp]),
+                                   _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
+    "taoamd_track_iou_planned": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp,
+                                           _i32, _vp, _vp, _vp]),
+    "taoamd_track_pad": (C.c_int, [_i64, _i64, _vp, _vp, _vp, _vp, _i64, _i64,
+                                   _vp, _vp]),
+    "taoamd_track_iou_plan_host": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp,
+                                             _vp, _vp, _vp, _vp]),
     "taoamd_match": (C.c_int, [_i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32,
                                _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp,
                                _vp, _vp, _vp, _i32, _vp, _i32, _vp]),

@@ -2,8 +2,7 @@
 //
 //   bb_iou_kernel       one thread per (d, g) entry of a single bbIou matrix
 //   *_ranges_kernel     per-GT / per-detection range masks + num_gt histogram
-//   track_iou_kernel    one lane per (dt track, gt track) pair, two-pointer
-//                       merge over the tracks' frame lists
+//   (the 3D track IoU lives in track_iou.hip)
 //   match_kernel        one wavefront per (cell, 64-combo word): lane = one
 //                       (range, IoU threshold) combo running the sequential
 //                       greedy of the reference; the IoU tile of the cell
@@ -161,347 +160,6 @@ __global__ __launch_bounds__(256) void count_gt_kernel(
         num_gt[(int64_t)k * n_rng + threadIdx.x] =
             part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] +
             part[3][threadIdx.x];
-}
-
-// ------------------------------------------------------------------ 3D IoU
-// upper_bound(off, n+1 entries, p) - 1: the cell whose pair range holds p
-__device__ __forceinline__ int64_t find_cell(const int64_t *__restrict__ off,
-                                             int64_t n_cells, int64_t p)
-{
-    int64_t lo = 0, hi = n_cells;  // invariant: off[lo] <= p < off[hi]
-    while (hi - lo > 1) {
-        int64_t mid = (lo + hi) >> 1;
-        if (off[mid] <= p) lo = mid; else hi = mid;
-    }
-    return lo;
-}
-
-__device__ __forceinline__ bool dense_cell(int32_t span, int32_t D, int32_t G);
-
-// A track's frame list read through a 3-deep register queue: the loads of
-// frame p+2 are issued when frame p becomes current, so the two-pointer merge
-// below never waits on a load it has just issued (the merge is a chain of
-// data-dependent steps; without the queue every step pays two serialized
-// memory round trips).
-struct FrameQueue {
-    const int32_t *__restrict__ pos;
-    const double4 *__restrict__ box;
-    int32_t p, e;
-    int32_t f0, f1, f2;
-    double4 b0, b1, b2;
-
-    __device__ __forceinline__ void load(int32_t q, int32_t &f, double4 &b) const
-    {
-        if (q < e) { f = pos[q]; b = box[q]; } else { f = INT32_MAX; }
-    }
-    __device__ __forceinline__ void init(const int32_t *pos_, const double *box_,
-                                         int32_t start, int32_t end)
-    {
-        pos = pos_; box = reinterpret_cast<const double4 *>(box_);
-        p = start; e = end;
-        b0 = b1 = b2 = make_double4(0, 0, 0, 0);
-        load(p, f0, b0); load(p + 1, f1, b1); load(p + 2, f2, b2);
-    }
-    __device__ __forceinline__ void advance()
-    {
-        p++;
-        f0 = f1; b0 = b1;
-        f1 = f2; b1 = b2;
-        load(p + 2, f2, b2);
-    }
-};
-
-__global__ __launch_bounds__(256) void track_iou_kernel(
-    int64_t n_cells, const int32_t *__restrict__ cell_dt_off,
-    const int32_t *__restrict__ cell_gt_off,
-    const int64_t *__restrict__ cell_iou_off, int64_t n_pairs,
-    const int32_t *__restrict__ dfoff, const int32_t *__restrict__ dfpos,
-    const double *__restrict__ dfbox, const int32_t *__restrict__ gfoff,
-    const int32_t *__restrict__ gfpos, const double *__restrict__ gfbox,
-    double *__restrict__ iou, unsigned long long *__restrict__ pair_frames,
-    const int32_t *__restrict__ cell_span, int mode)
-{
-    int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    unsigned long long common = 0;
-    bool mine = p < n_pairs;
-    int64_t c = 0;
-    if (mine) {
-        c = find_cell(cell_iou_off, n_cells, p);
-        // cells with a short timeline are done by track_iou_dense_kernel
-        if (cell_span != nullptr &&
-            dense_cell(cell_span[c], cell_dt_off[c + 1] - cell_dt_off[c],
-                       cell_gt_off[c + 1] - cell_gt_off[c]))
-            mine = false;
-    }
-    if (mine) {
-        const int32_t G = cell_gt_off[c + 1] - cell_gt_off[c];
-        const int64_t local = p - cell_iou_off[c];
-        const int32_t d = (int32_t)(local / G), g = (int32_t)(local - (int64_t)d * G);
-        const int32_t td = cell_dt_off[c] + d, tg = cell_gt_off[c] + g;
-        FrameQueue qd, qg;
-        qd.init(dfpos, dfbox, dfoff[td], dfoff[td + 1]);
-        qg.init(gfpos, gfbox, gfoff[tg], gfoff[tg + 1]);
-        double i = 0.0, u = 0.0, acc = 0.0, cnt = 0.0;
-        // ascending timeline order; per frame exactly the arithmetic of
-        // reference tao_amodal/eval.py:32-48 and :87-94
-        while (qd.f0 != INT32_MAX || qg.f0 != INT32_MAX) {
-            const double4 B = qd.b0, A = qg.b0;
-            cnt += 1.0;
-            if (qd.f0 == qg.f0) {
-                double w = fmin(B.x + B.z, A.x + A.z) - fmax(B.x, A.x);
-                double h = fmin(B.y + B.w, A.y + A.w) - fmax(B.y, A.y);
-                w = w > 0 ? w : 0.0;
-                h = h > 0 ? h : 0.0;
-                const double i_ = w * h;
-                const double u_ = B.z * B.w + A.z * A.w - i_;
-                i += i_;
-                u += u_;
-                if (mode == 1) acc += u_ > 0 ? i_ / u_ : 0.0;
-                if (mode == 2 && i_ > 0.5 * u_) acc += 1.0;
-                common++;
-                qd.advance();
-                qg.advance();
-            } else if (qg.f0 < qd.f0) {
-                u += A.z * A.w;
-                qg.advance();
-            } else {
-                u += B.z * B.w;
-                qd.advance();
-            }
-        }
-        iou[p] = mode == 0 ? (u > 0 ? i / u : 0.0) : acc / cnt;
-    }
-    if (pair_frames != nullptr) {
-        for (int s = WAVE / 2; s > 0; s >>= 1)
-            common += __shfl_down(common, s, WAVE);
-        if (lane_id() == 0 && common) atomicAdd(pair_frames, common);
-    }
-}
-
-// Dense-timeline variant (the common case: videos with a few hundred frames).
-// One workgroup per cell.  LDS holds, per track -- the GT tracks of the cell
-// and a group of its detection tracks -- a presence bitmap over the timeline
-// plus the frame count before each 64-position word (frame at position p =
-// first + count before its word + popcount of the bits below p).  The
-// timeline is processed in chunks of TD_CH positions, two phases per chunk:
-//   A  one work item per (detection track, position): fetch the detection
-//      frame at that position (consecutive items = consecutive frames of one
-//      track: coalesced) and, per GT track, the GT frame; form the term
-//          both: (da + ga - i_, i_)   dt only: (da, 0)   gt only: (ga, 0)
-//          neither: (0, 0)
-//      with the reference's per-frame arithmetic (tao_amodal/eval.py:32-48,
-//      87-94) and park it in LDS as terms[position][pair].  Every load is
-//      independent of every other: the memory system sees them all at once.
-//   B  lane = (detection track, GT track) pair: add the chunk's terms in
-//      ascending position -- two fp64 adds per position, operands from LDS,
-//      no global memory on the serial chain.
-// Adding (0, 0) for an empty position is exact (u, i >= +0), so the sequence
-// of roundings equals the two-pointer merge over the union of frames.
-#define TD_BM_WORDS 1024       // 64-bit words of presence bitmaps: (G + detection tracks) * ceil(span / 64)
-#define TD_CH 16               // timeline positions per chunk
-#define TD_PAIRS 64            // track pairs per detection-track group
-#define TD_GMAX 8              // GT tracks of a dense cell
-#define TD_IT 2                // phase-A items per thread and batch
-
-__device__ __forceinline__ bool dense_cell(int32_t span, int32_t D, int32_t G)
-{
-    return D > 0 && G > 0 && G <= TD_GMAX &&
-           (int64_t)(G + 1) * ((span + 63) / 64) <= TD_BM_WORDS;
-}
-
-__global__ __launch_bounds__(256) void track_iou_dense_kernel(
-    const int32_t *__restrict__ cell_dt_off,
-    const int32_t *__restrict__ cell_gt_off,
-    const int64_t *__restrict__ cell_iou_off,
-    const int32_t *__restrict__ cell_span,
-    const int32_t *__restrict__ dfoff, const int32_t *__restrict__ dfpos,
-    const double *__restrict__ dfbox, const int32_t *__restrict__ gfoff,
-    const int32_t *__restrict__ gfpos, const double *__restrict__ gfbox,
-    double *__restrict__ iou, unsigned long long *__restrict__ pair_frames,
-    int mode)
-{
-    // presence bitmap of every staged track over the timeline + frames before
-    // each 64-position word: frame at position p = first + pre[w] + popcount(
-    // bits of word w below p) -- 1/16 of the LDS a position -> frame table takes
-    __shared__ uint64_t bm[TD_BM_WORDS];
-    __shared__ uint16_t pre[TD_BM_WORDS];
-    __shared__ double2 terms[TD_CH][TD_PAIRS + 1];
-    __shared__ double4 gbox[2][TD_GMAX * TD_CH];   // GT frames of this / the next chunk
-    // frame offsets of the staged tracks: [0, G] GT, [TD_PAIRS, TD_PAIRS + nd] detections
-    __shared__ int32_t first[2 * TD_PAIRS + 2];
-    const int64_t c = blockIdx.x;
-    const int32_t d0 = cell_dt_off[c], D = cell_dt_off[c + 1] - d0;
-    const int32_t g0 = cell_gt_off[c], G = cell_gt_off[c + 1] - g0;
-    const int32_t span = cell_span[c];
-    if (!dense_cell(span, D, G)) return;
-    const int64_t ioff = cell_iou_off[c];
-    const int nw = (span + 63) >> 6;                 // bitmap words per track
-    const int rows = TD_BM_WORDS / nw;
-    const int DG = min(min(D, rows - G), TD_PAIRS / G);
-    uint64_t *__restrict__ gbm = bm, *__restrict__ dbm = bm + G * nw;
-    uint16_t *__restrict__ gpre = pre, *__restrict__ dpre = pre + G * nw;
-    // frame index inside the track of timeline position p, or -1
-    auto frame_at = [nw](const uint64_t *b, const uint16_t *pr, int track, int p) -> int {
-        const int w = track * nw + (p >> 6);
-        const uint64_t word = b[w], bit = 1ull << (p & 63);
-        return (word & bit) ? (int)pr[w] + __popcll(word & (bit - 1)) : -1;
-    };
-    const double4 *__restrict__ DB = reinterpret_cast<const double4 *>(dfbox);
-    const double4 *__restrict__ GB = reinterpret_cast<const double4 *>(gfbox);
-    // position -> frame rows.  The frames of the cell's tracks are one
-    // contiguous run of the CSR arrays: the rows are filled by a flat loop
-    // over that run (one round trip for the offsets, one for the positions)
-    // instead of track by track.
-    for (int t = threadIdx.x; t < G * nw; t += 256) gbm[t] = 0;
-    for (int g = threadIdx.x; g <= G; g += 256) first[g] = gfoff[g0 + g];
-    __syncthreads();
-    for (int32_t j = first[0] + (int32_t)threadIdx.x; j < first[G]; j += 256) {
-        int g = 0;
-        while (g + 1 < G && first[g + 1] <= j) g++;
-        const int32_t p = gfpos[j];
-        atomicOr((unsigned long long *)&gbm[g * nw + (p >> 6)], 1ull << (p & 63));
-    }
-    __syncthreads();
-    for (int g = threadIdx.x; g < G; g += 256) {
-        int acc = 0;
-        for (int w = 0; w < nw; w++) {
-            gpre[g * nw + w] = (uint16_t)acc;
-            acc += __popcll(gbm[g * nw + w]);
-        }
-    }
-    unsigned long long common = 0;
-    for (int32_t db = 0; db < D; db += DG) {
-        const int nd = min(DG, D - db);
-        __syncthreads();
-        for (int t = threadIdx.x; t < nd * nw; t += 256) dbm[t] = 0;
-        for (int dl = threadIdx.x; dl <= nd; dl += 256)
-            first[TD_PAIRS + dl] = dfoff[d0 + db + dl];
-        __syncthreads();
-        for (int32_t k = first[TD_PAIRS] + (int32_t)threadIdx.x; k < first[TD_PAIRS + nd];
-             k += 256) {
-            int lo = 0, hi = nd;            // last dl with first[dl] <= k
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (first[TD_PAIRS + mid] <= k) lo = mid; else hi = mid;
-            }
-            const int32_t p = dfpos[k];
-            atomicOr((unsigned long long *)&dbm[lo * nw + (p >> 6)], 1ull << (p & 63));
-        }
-        __syncthreads();
-        for (int dl = threadIdx.x; dl < nd; dl += 256) {
-            int acc = 0;
-            for (int w = 0; w < nw; w++) {
-                dpre[dl * nw + w] = (uint16_t)acc;
-                acc += __popcll(dbm[dl * nw + w]);
-            }
-        }
-        // GT frames of chunk 0 (later chunks are staged one chunk ahead,
-        // inside phase A)
-        if ((int)threadIdx.x < G * TD_CH) {
-            const int g = threadIdx.x / TD_CH, pp = threadIdx.x % TD_CH;
-            double4 A = make_double4(0, 0, -1.0, 0);   // w < 0: absent
-            if (pp < span) {
-                const int rg = frame_at(gbm, gpre, g, pp);
-                if (rg >= 0) A = GB[first[g] + rg];
-            }
-            gbox[0][g * TD_CH + pp] = A;
-        }
-        __syncthreads();
-        double u = 0.0, i = 0.0;   // running sums of pair = threadIdx.x
-        const int pairs = nd * G;
-        for (int32_t p0 = 0; p0 < span; p0 += TD_CH) {
-            const int np = min(TD_CH, span - p0);
-            const int cur = (p0 / TD_CH) & 1;
-            // GT frames of the NEXT chunk: the load is issued here, together
-            // with the detection-box loads of phase A, and parked in the
-            // other half of gbox at the end of the phase (one global round
-            // trip and one barrier per chunk instead of two)
-            double4 An = make_double4(0, 0, -1.0, 0);   // w < 0: absent
-            const bool stage = (int)threadIdx.x < G * TD_CH && p0 + TD_CH < span;
-            if (stage) {
-                const int g = threadIdx.x / TD_CH, pp = threadIdx.x % TD_CH;
-                if (p0 + TD_CH + pp < span) {
-                    const int rg = frame_at(gbm, gpre, g, p0 + TD_CH + pp);
-                    if (rg >= 0) An = GB[first[g] + rg];
-                }
-            }
-            // ---- phase A: item = (detection track, position): consecutive
-            // threads read consecutive frames of one track (coalesced); the
-            // TD_IT box loads of a thread are issued together
-            for (int base = threadIdx.x; base < nd * TD_CH; base += 256 * TD_IT) {
-                int32_t kd[TD_IT];
-                bool hd[TD_IT];
-                double4 B[TD_IT];
-#pragma unroll
-                for (int q = 0; q < TD_IT; q++) {
-                    const int it = base + q * 256;
-                    const int dl0 = it / TD_CH, pp0 = it % TD_CH;
-                    const bool ok = dl0 < nd && pp0 < np;
-                    const int dl = ok ? dl0 : 0, pp = ok ? pp0 : 0;
-                    const int rd = frame_at(dbm, dpre, dl, p0 + pp);
-                    hd[q] = ok && rd >= 0;
-                    kd[q] = hd[q] ? first[TD_PAIRS + dl] + rd : 0;
-                }
-#pragma unroll
-                for (int q = 0; q < TD_IT; q++) B[q] = DB[kd[q]];
-#pragma unroll
-                for (int q = 0; q < TD_IT; q++) {
-                    const int it = base + q * 256;
-                    const int dl = it / TD_CH, pp = it % TD_CH;
-                    if (dl < nd && pp < np) {
-                        const double da = B[q].z * B[q].w;
-                        for (int g = 0; g < G; g++) {
-                            const double4 A = gbox[cur][g * TD_CH + pp];
-                            const bool hg = !(A.z < 0);
-                            double w = fmin(B[q].x + B[q].z, A.x + A.z) - fmax(B[q].x, A.x);
-                            double h = fmin(B[q].y + B[q].w, A.y + A.w) - fmax(B[q].y, A.y);
-                            w = w > 0 ? w : 0.0;
-                            h = h > 0 ? h : 0.0;
-                            const double i_ = w * h;
-                            const double ga = A.z * A.w;
-                            const bool both = hd[q] && hg;
-                            const double u_ = da + ga - i_;
-                            double tx, ty;
-                            if (mode == 0) {            // (union, intersection)
-                                tx = hd[q] ? (hg ? u_ : da) : (hg ? ga : 0.0);
-                                ty = both ? i_ : 0.0;
-                            } else {                    // (score term, frame count)
-                                ty = (hd[q] || hg) ? 1.0 : 0.0;
-                                if (mode == 1) tx = both ? (u_ > 0 ? i_ / u_ : 0.0) : 0.0;
-                                else tx = (both && i_ > 0.5 * u_) ? 1.0 : 0.0;
-                            }
-                            terms[pp][dl * G + g] = make_double2(tx, ty);
-                            common += both ? 1 : 0;
-                        }
-                    }
-                }
-            }
-            if (stage) gbox[cur ^ 1][threadIdx.x] = An;   // index = g * TD_CH + pp
-            __syncthreads();
-            // ---- phase B
-            if ((int)threadIdx.x < pairs) {
-#pragma unroll 8
-                for (int pp = 0; pp < np; pp++) {
-                    const double2 t = terms[pp][threadIdx.x];
-                    u += t.x;
-                    i += t.y;
-                }
-            }
-            __syncthreads();
-        }
-        if ((int)threadIdx.x < pairs) {
-            const int dl = threadIdx.x / G, g = threadIdx.x - dl * G;
-            // mode 0: u = sum of unions, i = sum of intersections;
-            // modes 1/2: u = sum of per-frame scores, i = number of frames
-            iou[ioff + (int64_t)(db + dl) * G + g] =
-                mode == 0 ? (u > 0 ? i / u : 0.0) : u / i;
-        }
-    }
-    if (pair_frames != nullptr) {
-        for (int s_ = WAVE / 2; s_ > 0; s_ >>= 1)
-            common += __shfl_down(common, s_, WAVE);
-        if (lane_id() == 0 && common) atomicAdd(pair_frames, common);
-    }
 }
 
 // ------------------------------------------------------------------- greedy
@@ -1006,38 +664,6 @@ extern "C" int taoamd_tao_ranges(int64_t n_gt, const double *gt_area,
     if (grouped)
         count_gt_kernel<<<(unsigned)n_cat, 256, 0, s>>>(
             n_cat, TAOAMD_TAO_RNG, gt_cat_off, gt_rng, num_gt);
-    TAO_LAUNCH_CHECK();
-    return TAOAMD_OK;
-}
-
-extern "C" int taoamd_track_iou(int64_t n_cells, const int32_t *cell_dt_off,
-                                const int32_t *cell_gt_off,
-                                const int64_t *cell_iou_off, int64_t n_pairs,
-                                const int32_t *dt_frame_off,
-                                const int32_t *dt_frame_pos,
-                                const double *dt_frame_box,
-                                const int32_t *gt_frame_off,
-                                const int32_t *gt_frame_pos,
-                                const double *gt_frame_box,
-                                const int32_t *cell_span, int32_t all_dense,
-                                int32_t mode, double *iou, int64_t *pair_frames,
-                                void *stream)
-{
-    hipStream_t s = (hipStream_t)stream;
-    if (mode < 0 || mode > 2) return TAOAMD_ERR_ARG;
-    if (pair_frames) TAO_HIP(hipMemsetAsync(pair_frames, 0, 8, s));
-    if (n_pairs == 0) return TAOAMD_OK;
-    if (cell_span != nullptr)
-        track_iou_dense_kernel<<<(unsigned)n_cells, 256, 0, s>>>(
-            cell_dt_off, cell_gt_off, cell_iou_off, cell_span, dt_frame_off,
-            dt_frame_pos, dt_frame_box, gt_frame_off, gt_frame_pos,
-            gt_frame_box, iou, (unsigned long long *)pair_frames, mode);
-    if (cell_span == nullptr || !all_dense)
-        track_iou_kernel<<<(unsigned)((n_pairs + 255) / 256), 256, 0, s>>>(
-            n_cells, cell_dt_off, cell_gt_off, cell_iou_off, n_pairs,
-            dt_frame_off, dt_frame_pos, dt_frame_box, gt_frame_off,
-            gt_frame_pos, gt_frame_box, iou, (unsigned long long *)pair_frames,
-            cell_span, mode);
     TAO_LAUNCH_CHECK();
     return TAOAMD_OK;
 }

@@ -1,0 +1,593 @@
+// 3D IoU of track pairs (reference tao_amodal/eval.py:15-117, 306-335), gfx950.
+//
+//   track_iou_task_kernel  the planned path: one wavefront per task (<= 36
+//                          tracks, <= 64 track pairs), frames staged in LDS
+//                          chunk by chunk of the timeline from the padded frame
+//                          table, lane = pair adds the per-frame terms in order
+//   track_pad_*            CSR frame lists -> padded frame table
+//   track_iou_kernel       plan-less fallback: lane per pair, two-pointer merge
+//
+// fp64 elementwise / compare work, bound by instruction issue and HBM; nothing
+// is shaped into a GEMM.
+#include <algorithm>
+#include <vector>
+
+#include "common.hpp"
+
+using namespace taoamd;
+
+// ------------------------------------------------------------------ 3D IoU
+// upper_bound(off, n+1 entries, p) - 1: the cell whose pair range holds p
+__device__ __forceinline__ int64_t find_cell(const int64_t *__restrict__ off,
+                                             int64_t n_cells, int64_t p)
+{
+    int64_t lo = 0, hi = n_cells;  // invariant: off[lo] <= p < off[hi]
+    while (hi - lo > 1) {
+        int64_t mid = (lo + hi) >> 1;
+        if (off[mid] <= p) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// A track's frame list read through a 3-deep register queue: the loads of
+// frame p+2 are issued when frame p becomes current, so the two-pointer merge
+// below never waits on a load it has just issued (the merge is a chain of
+// data-dependent steps; without the queue every step pays two serialized
+// memory round trips).
+struct FrameQueue {
+    const int32_t *__restrict__ pos;
+    const double4 *__restrict__ box;
+    int32_t p, e;
+    int32_t f0, f1, f2;
+    double4 b0, b1, b2;
+
+    __device__ __forceinline__ void load(int32_t q, int32_t &f, double4 &b) const
+    {
+        if (q < e) { f = pos[q]; b = box[q]; } else { f = INT32_MAX; }
+    }
+    __device__ __forceinline__ void init(const int32_t *pos_, const double *box_,
+                                         int32_t start, int32_t end)
+    {
+        pos = pos_; box = reinterpret_cast<const double4 *>(box_);
+        p = start; e = end;
+        b0 = b1 = b2 = make_double4(0, 0, 0, 0);
+        load(p, f0, b0); load(p + 1, f1, b1); load(p + 2, f2, b2);
+    }
+    __device__ __forceinline__ void advance()
+    {
+        p++;
+        f0 = f1; b0 = b1;
+        f1 = f2; b1 = b2;
+        load(p + 2, f2, b2);
+    }
+};
+
+__global__ __launch_bounds__(256) void track_iou_kernel(
+    int64_t n_cells, const int32_t *__restrict__ cell_dt_off,
+    const int32_t *__restrict__ cell_gt_off,
+    const int64_t *__restrict__ cell_iou_off, int64_t n_pairs,
+    const int32_t *__restrict__ dfoff, const int32_t *__restrict__ dfpos,
+    const double *__restrict__ dfbox, const int32_t *__restrict__ gfoff,
+    const int32_t *__restrict__ gfpos, const double *__restrict__ gfbox,
+    double *__restrict__ iou, unsigned long long *__restrict__ pair_frames,
+    int mode)
+{
+    int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    unsigned long long common = 0;
+    bool mine = p < n_pairs;
+    int64_t c = 0;
+    if (mine) {
+        c = find_cell(cell_iou_off, n_cells, p);
+    }
+    if (mine) {
+        const int32_t G = cell_gt_off[c + 1] - cell_gt_off[c];
+        const int64_t local = p - cell_iou_off[c];
+        const int32_t d = (int32_t)(local / G), g = (int32_t)(local - (int64_t)d * G);
+        const int32_t td = cell_dt_off[c] + d, tg = cell_gt_off[c] + g;
+        FrameQueue qd, qg;
+        qd.init(dfpos, dfbox, dfoff[td], dfoff[td + 1]);
+        qg.init(gfpos, gfbox, gfoff[tg], gfoff[tg + 1]);
+        double i = 0.0, u = 0.0, acc = 0.0, cnt = 0.0;
+        // ascending timeline order; per frame exactly the arithmetic of
+        // reference tao_amodal/eval.py:32-48 and :87-94
+        while (qd.f0 != INT32_MAX || qg.f0 != INT32_MAX) {
+            const double4 B = qd.b0, A = qg.b0;
+            cnt += 1.0;
+            if (qd.f0 == qg.f0) {
+                double w = fmin(B.x + B.z, A.x + A.z) - fmax(B.x, A.x);
+                double h = fmin(B.y + B.w, A.y + A.w) - fmax(B.y, A.y);
+                w = w > 0 ? w : 0.0;
+                h = h > 0 ? h : 0.0;
+                const double i_ = w * h;
+                const double u_ = B.z * B.w + A.z * A.w - i_;
+                i += i_;
+                u += u_;
+                if (mode == 1) acc += u_ > 0 ? i_ / u_ : 0.0;
+                if (mode == 2 && i_ > 0.5 * u_) acc += 1.0;
+                common++;
+                qd.advance();
+                qg.advance();
+            } else if (qg.f0 < qd.f0) {
+                u += A.z * A.w;
+                qg.advance();
+            } else {
+                u += B.z * B.w;
+                qd.advance();
+            }
+        }
+        iou[p] = mode == 0 ? (u > 0 ? i / u : 0.0) : acc / cnt;
+    }
+    if (pair_frames != nullptr) {
+        for (int s = WAVE / 2; s > 0; s >>= 1)
+            common += __shfl_down(common, s, WAVE);
+        if (lane_id() == 0 && common) atomicAdd(pair_frames, common);
+    }
+}
+
+// Task variant (the path every planned call takes).  A task = one wavefront =
+// up to TT_ROWS tracks (of one or several cells) and up to 64 (detection
+// track, GT track) pairs among them; the workgroup IS the wavefront, so
+// nothing in here waits for another wave and 6 tasks are resident per CU
+// (24 KB of LDS each).
+//
+// Tracks are read from the PADDED frame table (taoamd_track_pad): the frames
+// of a track occupy consecutive slots first .. last of the timeline, a
+// position the track skips holds the "far box" (x = y = 1e300, w = h = 0), and
+// so does slot 0 of the table.  The frame of track t at position p is
+// padded[basem_t + p] -- no cursor, no search, no dependence between chunks:
+// the loads of chunk k + 1 are issued before the arithmetic of chunk k and
+// land in registers meanwhile.
+//
+// The timeline is walked in chunks of TT_P positions.  Per chunk:
+//   stage   16 consecutive lanes = 16 consecutive positions of one track
+//           (512 contiguous bytes; positions outside first .. last read slot
+//           0); the boxes are parked in LDS as (x1, y1, x2 = x + w,
+//           y2 = y + h, area = w * h) at [track][position - p0].  Rows that
+//           do not reach into the chunk are not touched (wiped once if they
+//           held frames before); the plan lists a task's tracks by first
+//           position, so whole rounds of four rows drop out.
+//   add     lane = (detection track, GT track) pair walks the 16 positions in
+//           ascending order: i_ = max(min(x2) - max(x1), 0) * max(.., 0),
+//           u_ = (da + ga) - i_, u += u_, i += i_  -- the reference's
+//           per-frame arithmetic (tao_amodal/eval.py:32-48, 87-94) with no
+//           case split: against the far box the intersection is exactly 0 and
+//           the union term is exactly the other box's area (x + 0 = x), and
+//           two far boxes give (0, 0), whose addition is exact (u, i >= +0).
+//           So the sequence of roundings equals the reference's walk over the
+//           union of the two tracks' frames in timeline order.
+// Chunks in which no track of the task has a frame are skipped; chunks that
+// only hold GT frames add the areas alone.
+#ifndef TT_P
+#define TT_P 16                  // timeline positions per chunk (8 or 16)
+#endif
+#define TT_ROWS 36               // tracks of a task
+#define TT_RS (5 * TT_P + 2)     // doubles per row: rows 16-byte aligned, 36 / 20 banks apart
+#define TT_GROUPS (64 / TT_P)    // rows served by one round of the wavefront
+#define TT_ROUNDS ((TT_ROWS + TT_GROUPS - 1) / TT_GROUPS)
+#define TT_SLOTS (TT_ROUNDS * TT_GROUPS)
+#define TT_FAR 1e300
+#ifndef TT_AHEAD
+#define TT_AHEAD 1               // chunks between a load and its use
+#endif
+
+// v_max_f64 / v_min_f64 as such: fmax() / fmin() make the compiler canonicalise
+// every operand it cannot prove free of signalling NaNs (one extra v_max_f64
+// per value read from LDS: 8 of 21 fp64 instructions per position)
+__device__ __forceinline__ double tt_max(double a, double b)
+{
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double tt_min(double a, double b)
+{
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double tt_pos(double a)       // max(a, 0)
+{
+    double r;
+    asm("v_max_f64 %0, %1, 0" : "=v"(r) : "v"(a));
+    return r;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(64) void track_iou_task_kernel(
+    const int4 *__restrict__ tasks, const int32_t *__restrict__ task_rows,
+    const int32_t *__restrict__ task_pairs, const int64_t *__restrict__ task_out,
+    const double4 *__restrict__ padded, const int4 *__restrict__ trk_meta,
+    double *__restrict__ iou, unsigned long long *__restrict__ pair_frames)
+{
+    __shared__ __align__(16) double rows[TT_ROWS * TT_RS];
+    __shared__ int4 meta[TT_SLOTS];
+    __shared__ uint32_t rmask[TT_SLOTS];  // positions of the chunk that hold a frame
+
+    const int lane = threadIdx.x, grp = lane / TT_P, j = lane % TT_P;
+    const int4 tk = tasks[blockIdx.x];    // {first row, rows, first pair, pairs}
+    const int n_rows = tk.y, n_pairs = tk.w;
+
+    // ---- {first, last, base - first, is detection} of the task's tracks
+    int32_t p_lo = INT32_MAX, p_hi = -1;
+    if (lane < TT_SLOTS) {
+        int4 m = make_int4(INT32_MAX, -1, 0, 0);       // no track: never in range
+        if (lane < n_rows) m = trk_meta[task_rows[tk.x + lane]];
+        if (m.y >= m.x) {
+            p_lo = m.x;
+            p_hi = m.y;
+        }
+        meta[lane] = m;
+        rmask[lane] = 0;
+    }
+    int32_t pr = 0;
+    int64_t out = 0;
+    if (lane < n_pairs) {
+        pr = task_pairs[tk.z + lane];
+        out = task_out[tk.z + lane];
+    }
+    for (int s = lane; s < TT_ROWS * TT_P; s += 64) {
+        double *rb = rows + (s / TT_P) * TT_RS + (s % TT_P);
+        rb[0] = rb[TT_P] = rb[2 * TT_P] = rb[3 * TT_P] = TT_FAR;
+        rb[4 * TT_P] = 0.0;
+    }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+        p_lo = min(p_lo, __shfl_xor(p_lo, s));
+        p_hi = max(p_hi, __shfl_xor(p_hi, s));
+    }
+    __syncthreads();     // one wave: a compiler-level fence, no s_barrier
+    // lane (grp, j) serves position j of the rows grp, TT_GROUPS + grp, ...
+    int32_t F[TT_ROUNDS], L[TT_ROUNDS], M[TT_ROUNDS];
+    uint32_t isdt = 0;
+#pragma unroll
+    for (int q = 0; q < TT_ROUNDS; q++) {
+        const int4 m = meta[TT_GROUPS * q + grp];
+        F[q] = m.x;
+        L[q] = m.y;
+        M[q] = m.z;
+        isdt |= (uint32_t)(m.w & 1) << q;
+    }
+    // TT_AHEAD register sets: the loads of chunk k + TT_AHEAD are issued when
+    // chunk k is staged.  Every round loads (lanes out of range read slot 0),
+    // so the number of loads in flight is known at compile time and a chunk
+    // waits for ITS loads only (s_waitcnt vmcnt(n > 0)).
+    double4 B[TT_AHEAD][TT_ROUNDS];
+    uint32_t wiped = ~0u;        // bit q: the slots of round q's row hold far boxes
+
+    auto issue = [&](double4 *Bx, int32_t pc) {
+        const int32_t p = pc + j;
+#pragma unroll
+        for (int q = 0; q < TT_ROUNDS; q++) {
+            const bool in = p >= F[q] && p <= L[q];
+            Bx[q] = padded[in ? M[q] + p : 0];      // slot 0: the far box
+        }
+    };
+    uint64_t any, anydt;
+    auto stage = [&](const double4 *Bx, int32_t pc) {
+        any = 0;
+        anydt = 0;
+#pragma unroll
+        for (int q = 0; q < TT_ROUNDS; q++) {
+            const int r = TT_GROUPS * q + grp;
+            const bool ov = F[q] < pc + TT_P && L[q] >= pc;     // same for the row's 16 lanes
+            const bool act = ov || !((wiped >> q) & 1u);
+            if (__ballot(act) == 0) continue;
+            const double4 b = Bx[q];
+            const bool present = b.x != TT_FAR;
+            const uint64_t ball = __ballot(present);
+            any |= ball;
+            anydt |= __ballot(present && ((isdt >> q) & 1u));
+            if (act) {
+                double *rb = rows + r * TT_RS + j;
+                rb[0] = b.x;
+                rb[TT_P] = b.y;
+                rb[2 * TT_P] = b.x + b.z;
+                rb[3 * TT_P] = b.y + b.w;
+                rb[4 * TT_P] = b.z * b.w;
+                if (j == 0) rmask[r] = (uint32_t)(ball >> (TT_P * grp)) & ((1u << TT_P) - 1);
+            }
+            wiped = ov ? wiped & ~(1u << q) : wiped | (1u << q);
+        }
+    };
+
+    double u = 0.0, i = 0.0;
+    unsigned long long common = 0;
+    const int rowd = pr & 0xFF, rowg = (pr >> 8) & 0xFF;
+    const double *__restrict__ dr = rows + rowd * TT_RS;
+    const double *__restrict__ gr = rows + rowg * TT_RS;
+    auto add = [&]() {
+        if (any == 0 || lane >= n_pairs) return;
+        if (MODE == 0) {
+            if (anydt != 0) {
+                // two positions per 16-byte LDS read of every field
+                const double2 *__restrict__ d2 = reinterpret_cast<const double2 *>(dr);
+                const double2 *__restrict__ g2 = reinterpret_cast<const double2 *>(gr);
+#pragma unroll
+                for (int pp = 0; pp < TT_P / 2; pp++) {
+                    const double2 dx1 = d2[pp], gx1 = g2[pp];
+                    const double2 dy1 = d2[TT_P / 2 + pp], gy1 = g2[TT_P / 2 + pp];
+                    const double2 dx2 = d2[TT_P + pp], gx2 = g2[TT_P + pp];
+                    const double2 dy2 = d2[3 * TT_P / 2 + pp], gy2 = g2[3 * TT_P / 2 + pp];
+                    const double2 da = d2[2 * TT_P + pp], ga = g2[2 * TT_P + pp];
+                    {
+                        const double w = tt_pos(tt_min(dx2.x, gx2.x) - tt_max(dx1.x, gx1.x));
+                        const double h = tt_pos(tt_min(dy2.x, gy2.x) - tt_max(dy1.x, gy1.x));
+                        const double i_ = w * h;
+                        const double u_ = da.x + ga.x - i_;
+                        u += u_;
+                        i += i_;
+                    }
+                    {
+                        const double w = tt_pos(tt_min(dx2.y, gx2.y) - tt_max(dx1.y, gx1.y));
+                        const double h = tt_pos(tt_min(dy2.y, gy2.y) - tt_max(dy1.y, gy1.y));
+                        const double i_ = w * h;
+                        const double u_ = da.y + ga.y - i_;
+                        u += u_;
+                        i += i_;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int pp = 0; pp < TT_P; pp++) u += gr[4 * TT_P + pp];
+            }
+            common += __popc(rmask[rowd] & rmask[rowg]);
+        } else {
+            // avg_iou / imagenetvid: u = sum of per-frame scores, i = frames
+            const uint32_t dm = rmask[rowd], gm = rmask[rowg];
+#pragma unroll
+            for (int pp = 0; pp < TT_P; pp++) {
+                const bool both = ((dm & gm) >> pp) & 1u, either = ((dm | gm) >> pp) & 1u;
+                const double x1 = tt_max(dr[pp], gr[pp]);
+                const double y1 = tt_max(dr[TT_P + pp], gr[TT_P + pp]);
+                const double x2 = tt_min(dr[2 * TT_P + pp], gr[2 * TT_P + pp]);
+                const double y2 = tt_min(dr[3 * TT_P + pp], gr[3 * TT_P + pp]);
+                const double w = tt_pos(x2 - x1), h = tt_pos(y2 - y1);
+                const double i_ = w * h;
+                const double u_ = dr[4 * TT_P + pp] + gr[4 * TT_P + pp] - i_;
+                double tx;
+                if (MODE == 1) tx = both ? (u_ > 0 ? i_ / u_ : 0.0) : 0.0;
+                else tx = (both && i_ > 0.5 * u_) ? 1.0 : 0.0;
+                u += tx;
+                i += either ? 1.0 : 0.0;
+            }
+            common += __popc(dm & gm);
+        }
+    };
+
+    int32_t p0 = p_lo & ~(TT_P - 1);
+    if (p_hi >= 0) {
+#pragma unroll
+        for (int a = 0; a < TT_AHEAD; a++) issue(B[a], p0 + a * TT_P);
+    }
+    while (p0 <= p_hi) {
+#pragma unroll
+        for (int a = 0; a < TT_AHEAD; a++) {      // register set a <-> chunk parity
+            stage(B[a], p0);
+            issue(B[a], p0 + TT_AHEAD * TT_P);    // travels while the next chunks are added up
+            __syncthreads();
+            add();
+            __syncthreads();
+            p0 += TT_P;
+        }
+    }
+    if (lane < n_pairs)
+        iou[out] = MODE == 0 ? (u > 0 ? i / u : 0.0) : u / i;
+    if (pair_frames != nullptr) {
+        for (int s_ = WAVE / 2; s_ > 0; s_ >>= 1)
+            common += __shfl_down(common, s_, WAVE);
+        if (lane == 0 && common) atomicAdd(pair_frames, common);
+    }
+}
+
+// Frames of CSR tracks -> slots of the padded table (pre-filled with far boxes)
+__global__ void track_pad_kernel(int64_t n_frames, int64_t n_trk,
+                                 const int32_t *__restrict__ foff,
+                                 const int32_t *__restrict__ fpos,
+                                 const double4 *__restrict__ fbox,
+                                 const int4 *__restrict__ meta,
+                                 double4 *__restrict__ padded)
+{
+    const int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (k >= n_frames) return;
+    int64_t lo = 0, hi = n_trk;       // track of frame k: foff[lo] <= k < foff[hi]
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (foff[mid] <= k) lo = mid; else hi = mid;
+    }
+    padded[(int64_t)meta[lo].z + fpos[k]] = fbox[k];
+}
+
+__global__ void track_pad_fill_kernel(int64_t n, double4 *__restrict__ padded)
+{
+    const int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (k < n) padded[k] = make_double4(TT_FAR, TT_FAR, 0.0, 0.0);
+}
+
+extern "C" int taoamd_track_iou(int64_t n_cells, const int32_t *cell_dt_off,
+                                const int32_t *cell_gt_off,
+                                const int64_t *cell_iou_off, int64_t n_pairs,
+                                const int32_t *dt_frame_off,
+                                const int32_t *dt_frame_pos,
+                                const double *dt_frame_box,
+                                const int32_t *gt_frame_off,
+                                const int32_t *gt_frame_pos,
+                                const double *gt_frame_box, int32_t mode,
+                                double *iou, int64_t *pair_frames, void *stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (mode < 0 || mode > 2) return TAOAMD_ERR_ARG;
+    if (pair_frames) TAO_HIP(hipMemsetAsync(pair_frames, 0, 8, s));
+    if (n_pairs == 0) return TAOAMD_OK;
+    track_iou_kernel<<<(unsigned)((n_pairs + 255) / 256), 256, 0, s>>>(
+        n_cells, cell_dt_off, cell_gt_off, cell_iou_off, n_pairs, dt_frame_off,
+        dt_frame_pos, dt_frame_box, gt_frame_off, gt_frame_pos, gt_frame_box,
+        iou, (unsigned long long *)pair_frames, mode);
+    TAO_LAUNCH_CHECK();
+    return TAOAMD_OK;
+}
+
+extern "C" int taoamd_track_iou_planned(int64_t n_tasks, const int32_t *tasks,
+                                        const int32_t *task_rows,
+                                        const int32_t *task_pairs,
+                                        const int64_t *task_out,
+                                        const double *padded,
+                                        const int32_t *trk_meta, int32_t mode,
+                                        double *iou, int64_t *pair_frames,
+                                        void *stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (mode < 0 || mode > 2 || n_tasks < 0) return TAOAMD_ERR_ARG;
+    if (pair_frames) TAO_HIP(hipMemsetAsync(pair_frames, 0, 8, s));
+    if (n_tasks == 0) return TAOAMD_OK;
+    if (!tasks || !task_rows || !task_pairs || !task_out || !padded || !trk_meta || !iou)
+        return TAOAMD_ERR_ARG;
+    unsigned long long *pf = (unsigned long long *)pair_frames;
+#define TT_LAUNCH(M)                                                           \
+    track_iou_task_kernel<M><<<(unsigned)n_tasks, 64, 0, s>>>(                 \
+        (const int4 *)tasks, task_rows, task_pairs, task_out,                  \
+        (const double4 *)padded, (const int4 *)trk_meta, iou, pf)
+    if (mode == 0) TT_LAUNCH(0);
+    else if (mode == 1) TT_LAUNCH(1);
+    else TT_LAUNCH(2);
+#undef TT_LAUNCH
+    TAO_LAUNCH_CHECK();
+    return TAOAMD_OK;
+}
+
+extern "C" int taoamd_track_pad(int64_t n_trk, int64_t n_frames,
+                                const int32_t *frame_off,
+                                const int32_t *frame_pos,
+                                const double *frame_box, const int32_t *meta,
+                                int64_t slot_first, int64_t n_slots,
+                                double *padded, void *stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (n_trk < 0 || n_frames < 0 || n_slots < 0 || slot_first < 0)
+        return TAOAMD_ERR_ARG;
+    if (n_slots > 0) {
+        if (!padded) return TAOAMD_ERR_ARG;
+        track_pad_fill_kernel<<<(unsigned)((n_slots + 255) / 256), 256, 0, s>>>(
+            n_slots, (double4 *)padded + slot_first);
+    }
+    if (n_frames > 0) {
+        if (!frame_off || !frame_pos || !frame_box || !meta || !padded)
+            return TAOAMD_ERR_ARG;
+        track_pad_kernel<<<(unsigned)((n_frames + 255) / 256), 256, 0, s>>>(
+            n_frames, n_trk, frame_off, frame_pos, (const double4 *)frame_box,
+            (const int4 *)meta, (double4 *)padded);
+    }
+    TAO_LAUNCH_CHECK();
+    return TAOAMD_OK;
+}
+
+// ---------------------------------------------------------------- the plan
+// Cells are visited by descending end of their timeline (tasks that run
+// longest start first, and the cells that share a task have similar spans);
+// the detection tracks of a cell by first position.  A task is filled track
+// by track: a detection track brings one pair per GT track of its cell's GT
+// block (<= 32 tracks), the block's rows are added when the task does not
+// hold them yet; a task is closed when the next track would exceed 64 pairs or
+// TT_ROWS rows -- so a big cell spills into the next task and the tail of one
+// cell shares a wavefront with the head of the next.
+extern "C" int taoamd_track_iou_plan_host(
+    int64_t n_cells, const int32_t *cell_dt_off, const int32_t *cell_gt_off,
+    const int64_t *cell_iou_off, const int32_t *trk_meta, int64_t *sizes,
+    int32_t *tasks, int32_t *task_rows, int32_t *task_pairs, int64_t *task_out)
+{
+    if (n_cells < 0 || !cell_dt_off || !cell_gt_off || !cell_iou_off ||
+        !trk_meta || !sizes)
+        return TAOAMD_ERR_ARG;
+    const bool fill = tasks != nullptr;
+    if (fill && (!task_rows || !task_pairs || !task_out)) return TAOAMD_ERR_ARG;
+    const int64_t n_dt = cell_dt_off[n_cells];
+    auto first_of = [&](int64_t t) { return trk_meta[4 * t]; };
+    auto last_of = [&](int64_t t) { return trk_meta[4 * t + 1]; };
+    std::vector<int64_t> order;
+    std::vector<int32_t> cell_hi(n_cells, -1);
+    for (int64_t c = 0; c < n_cells; c++) {
+        if (cell_dt_off[c + 1] <= cell_dt_off[c] || cell_gt_off[c + 1] <= cell_gt_off[c])
+            continue;
+        int32_t hi = -1;
+        for (int64_t t = cell_dt_off[c]; t < cell_dt_off[c + 1]; t++)
+            hi = std::max(hi, last_of(t));
+        for (int64_t t = cell_gt_off[c]; t < cell_gt_off[c + 1]; t++)
+            hi = std::max(hi, last_of(n_dt + t));
+        cell_hi[c] = hi;
+        order.push_back(c);
+    }
+    std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) {
+        return cell_hi[a] > cell_hi[b];
+    });
+    int64_t nt = 0, nr = 0, np = 0;
+    // the open task
+    int32_t rows[TT_ROWS], n_rows = 0, n_pairs = 0;
+    int32_t pair_d[64], pair_g[64];
+    int64_t pair_out[64];
+    auto close = [&]() {
+        if (n_pairs == 0) { n_rows = 0; return; }
+        if (fill) {
+            // rows by first position (stable), pairs renumbered
+            int32_t perm[TT_ROWS], inv[TT_ROWS];
+            for (int r = 0; r < n_rows; r++) perm[r] = r;
+            std::stable_sort(perm, perm + n_rows, [&](int32_t a, int32_t b) {
+                return first_of(rows[a]) < first_of(rows[b]);
+            });
+            for (int r = 0; r < n_rows; r++) inv[perm[r]] = r;
+            tasks[4 * nt] = (int32_t)nr;
+            tasks[4 * nt + 1] = n_rows;
+            tasks[4 * nt + 2] = (int32_t)np;
+            tasks[4 * nt + 3] = n_pairs;
+            for (int r = 0; r < n_rows; r++) task_rows[nr + r] = rows[perm[r]];
+            for (int k = 0; k < n_pairs; k++) {
+                task_pairs[np + k] = inv[pair_d[k]] | (inv[pair_g[k]] << 8);
+                task_out[np + k] = pair_out[k];
+            }
+        }
+        nt++;
+        nr += n_rows;
+        np += n_pairs;
+        n_rows = n_pairs = 0;
+    };
+    std::vector<int32_t> dts;
+    for (int64_t c : order) {
+        const int32_t d0 = cell_dt_off[c], D = cell_dt_off[c + 1] - d0;
+        const int32_t g0 = cell_gt_off[c], G = cell_gt_off[c + 1] - g0;
+        dts.resize(D);
+        for (int32_t d = 0; d < D; d++) dts[d] = d;
+        std::stable_sort(dts.begin(), dts.end(), [&](int32_t a, int32_t b) {
+            return first_of(d0 + a) < first_of(d0 + b);
+        });
+        const int32_t gblocks = (G + 31) / 32;
+        for (int32_t gb = 0; gb < gblocks; gb++) {
+            const int32_t ga = (int32_t)((int64_t)gb * G / gblocks);
+            const int32_t ng = (int32_t)((int64_t)(gb + 1) * G / gblocks) - ga;
+            int32_t grow0 = -1;          // the block's first row in the open task
+            for (int32_t k = 0; k < D; k++) {
+                const int32_t d = dts[k];
+                if (n_pairs + ng > 64 || n_rows + (grow0 < 0 ? ng : 0) + 1 > TT_ROWS) {
+                    close();
+                    grow0 = -1;
+                }
+                if (grow0 < 0) {
+                    grow0 = n_rows;
+                    for (int32_t g = 0; g < ng; g++)
+                        rows[n_rows++] = (int32_t)(n_dt + g0 + ga + g);
+                }
+                rows[n_rows] = d0 + d;
+                for (int32_t g = 0; g < ng; g++) {
+                    pair_d[n_pairs] = n_rows;
+                    pair_g[n_pairs] = grow0 + g;
+                    pair_out[n_pairs] = cell_iou_off[c] + (int64_t)d * G + ga + g;
+                    n_pairs++;
+                }
+                n_rows++;
+            }
+        }
+    }
+    close();
+    if (nr >= INT32_MAX || np >= INT32_MAX) return TAOAMD_ERR_ARG;
+    sizes[0] = nt;
+    sizes[1] = nr;
+    sizes[2] = np;
+    return TAOAMD_OK;
+}

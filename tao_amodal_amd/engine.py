@@ -85,6 +85,57 @@ def match_plan(d_cnt, g_cnt, cap_d=64, cap_g=64, cap_cell_g=8):
     return np.asarray(groups, dtype=np.int32).reshape(-1, 2), singles
 
 
+def track_meta(flat):
+    """{first, last, base - first, is detection} of every track (detection
+    tracks first, then GT) for the padded frame table: track t owns the slots
+    base .. base + last - first; slot 0 is the table's far box.  Returns the
+    int32 table, the slot range of either side and the table size."""
+    metas, sides, n_slots = [], {}, 1
+    for side in ("dt", "gt"):
+        off = np.asarray(flat[side + "_frame_off"], dtype=np.int64)
+        pos = np.asarray(flat[side + "_frame_pos"], dtype=np.int64)
+        has = off[1:] > off[:-1]
+        first = np.ones(len(off) - 1, dtype=np.int64)
+        last = np.zeros(len(off) - 1, dtype=np.int64)
+        first[has] = pos[off[:-1][has]]
+        last[has] = pos[off[1:][has] - 1]
+        span = np.where(has, last - first + 1, 0)
+        base = n_slots + np.cumsum(span) - span
+        metas.append(np.stack([first, last, base - first,
+                               np.full_like(first, side == "dt")], 1))
+        total = int(span.sum())
+        # the first set also fills slot 0
+        sides[side] = (n_slots - (side == "dt"), total + (side == "dt"))
+        n_slots += total
+    return np.concatenate(metas), sides, n_slots
+
+
+def track_iou_plan(flat, meta):
+    """Launch plan of taoamd_track_iou_planned (one wavefront per task: up to
+    36 tracks, up to 64 track pairs).  Returns tasks[n, 4], task_rows,
+    task_pairs (int32) and task_out (int64)."""
+    import ctypes as C
+    lib = _lib.load()
+    d_off = np.ascontiguousarray(flat.cell_dt_off, dtype=np.int32)
+    g_off = np.ascontiguousarray(flat.cell_gt_off, dtype=np.int32)
+    i_off = np.ascontiguousarray(flat.cell_iou_off, dtype=np.int64)
+    meta = np.ascontiguousarray(meta, dtype=np.int32)
+    sizes = np.zeros(3, dtype=np.int64)
+    args = (len(d_off) - 1, d_off.ctypes.data, g_off.ctypes.data,
+            i_off.ctypes.data, meta.ctypes.data, sizes.ctypes.data)
+    _lib.check(lib.taoamd_track_iou_plan_host(*args, None, None, None, None),
+               "taoamd_track_iou_plan_host")
+    tasks = np.zeros((int(sizes[0]), 4), dtype=np.int32)
+    rows = np.zeros(int(sizes[1]), dtype=np.int32)
+    pairs = np.zeros(int(sizes[2]), dtype=np.int32)
+    out = np.zeros(int(sizes[2]), dtype=np.int64)
+    if sizes[0]:
+        _lib.check(lib.taoamd_track_iou_plan_host(
+            *args, tasks.ctypes.data, rows.ctypes.data, pairs.ctypes.data,
+            out.ctypes.data), "taoamd_track_iou_plan_host")
+    return tasks, rows, pairs, out
+
+
 class DeviceProblem:
     """A flattened problem (flatten.Flat) resident in HBM."""
 
@@ -123,12 +174,7 @@ class DeviceProblem:
         else:
             names += ["dt_area", "dt_len", "gt_area", "gt_len", "gt_nhp",
                       "dt_frame_off", "dt_frame_pos", "dt_frame_box",
-                      "gt_frame_off", "gt_frame_pos", "gt_frame_box",
-                      "cell_span"]
-            live = (d_cnt > 0) & (g_cnt > 0)
-            fits = (g_cnt <= 8) & ((g_cnt + 1) * ((flat.cell_span.astype(np.int64)
-                                                    + 63) // 64) <= 1024)
-            self.all_dense = int(bool(np.all(fits[live])))
+                      "gt_frame_off", "gt_frame_pos", "gt_frame_box"]
         self.t = {}
         for n in names:
             self.t[n] = _to_device(flat[n], self.device)
@@ -178,6 +224,9 @@ class DeviceProblem:
             runs[:, 2] = flat.cell_gt_off[c0]
             runs[:, 3] = flat.cell_gt_off[c1] - flat.cell_gt_off[c0]
         self.t["groups"] = torch.from_numpy(runs).to(self.device)
+        self.n_tasks = 0
+        if self.kind == "tao":
+            self._plan_track_iou(flat)
         # per detection {first GT of its cell, GT count, position in the cell,
         # cell}: resolved here, on the device, from the uploaded cell tables
         cell = self.t["dt_cell"].long()
@@ -196,8 +245,50 @@ class DeviceProblem:
         self.t["tile_off"] = torch.from_numpy(tile_off).to(self.device)
         self.cat_off_host = cat_off
 
+    def _plan_track_iou(self, flat):
+        """Padded frame table + launch plan of taoamd_track_iou_planned."""
+        lib = _lib.load()
+        for k in ("tasks", "task_rows", "task_pairs", "task_out", "padded",
+                  "trk_meta"):
+            self.t[k] = None
+        if self.device.type != "cuda":     # host-side plumbing tests: no kernels
+            return
+        meta, sides, n_slots = track_meta(flat)
+        n_frames = len(flat.dt_frame_pos) + len(flat.gt_frame_pos)
+        self.n_slots = n_slots
+        # tracks that are mostly holes would blow the table up: such inputs
+        # take the two-pointer merge kernel instead (no plan)
+        if n_slots > 4 * n_frames + (1 << 20) or n_slots >= 2 ** 31 - 1:
+            return
+        tasks, rows, pairs, out = track_iou_plan(flat, meta)
+        self.n_tasks = len(tasks)
+        if self.n_tasks == 0:
+            return
+        dev = self.device
+        self.t["tasks"] = torch.from_numpy(tasks).to(dev)
+        self.t["task_rows"] = torch.from_numpy(rows).to(dev)
+        self.t["task_pairs"] = torch.from_numpy(pairs).to(dev)
+        self.t["task_out"] = torch.from_numpy(out).to(dev)
+        self.t["trk_meta"] = torch.from_numpy(
+            np.ascontiguousarray(meta, dtype=np.int32)).to(dev)
+        self.t["padded"] = torch.empty((n_slots, 4), dtype=torch.float64,
+                                       device=dev)
+        n_dt = len(flat.dt_frame_off) - 1
+        with torch.cuda.device(dev):
+            for side, row0 in (("dt", 0), ("gt", n_dt)):
+                slot0, slots = sides[side]
+                n_trk = len(flat[side + "_frame_off"]) - 1
+                _lib.check(lib.taoamd_track_pad(
+                    n_trk, len(flat[side + "_frame_pos"]),
+                    _ptr(self.t[side + "_frame_off"]),
+                    _ptr(self.t[side + "_frame_pos"]),
+                    _ptr(self.t[side + "_frame_box"]),
+                    self.t["trk_meta"].data_ptr() + 16 * row0, slot0, slots,
+                    _ptr(self.t["padded"]), _stream()), "taoamd_track_pad")
+
     def input_bytes(self):
-        return sum(v.numel() * v.element_size() for v in self.t.values())
+        return sum(v.numel() * v.element_size() for v in self.t.values()
+                   if v is not None)
 
 
 class Workspace:
@@ -305,14 +396,20 @@ def stage_track_iou(dp, ws):
     if dp.kind != "tao" or dp.n_iou == 0:
         return
     lib, t, s = _lib.load(), dp.t, _stream()
+    if t["tasks"] is not None:
+        _lib.check(lib.taoamd_track_iou_planned(
+            dp.n_tasks, _ptr(t["tasks"]), _ptr(t["task_rows"]),
+            _ptr(t["task_pairs"]), _ptr(t["task_out"]), _ptr(t["padded"]),
+            _ptr(t["trk_meta"]), dp.iou_mode, _ptr(ws.iou),
+            _ptr(ws.pair_frames), s), "taoamd_track_iou_planned")
+        return
     _lib.check(lib.taoamd_track_iou(
         dp.n_cells, _ptr(t["cell_dt_off"]), _ptr(t["cell_gt_off"]),
         _ptr(t["cell_iou_off"]), dp.n_iou, _ptr(t["dt_frame_off"]),
         _ptr(t["dt_frame_pos"]), _ptr(t["dt_frame_box"]),
         _ptr(t["gt_frame_off"]), _ptr(t["gt_frame_pos"]),
-        _ptr(t["gt_frame_box"]), _ptr(t["cell_span"]), dp.all_dense,
-        dp.iou_mode, _ptr(ws.iou), _ptr(ws.pair_frames), s),
-        "taoamd_track_iou")
+        _ptr(t["gt_frame_box"]), dp.iou_mode, _ptr(ws.iou),
+        _ptr(ws.pair_frames), s), "taoamd_track_iou")
 
 
 def stage_match(dp, ws, scatter=True):

@@ -78,20 +78,73 @@ def test_synthetic_hip_vs_c_oracle(seed, V, F, C, dpf):
     _compare_with_oracle(f, _engine().evaluate_flat(f, detail=True))
 
 
-def test_long_timelines_take_the_merge_kernel_and_gt_groups():
-    """More than 8 GT tracks (or presence bitmaps beyond 1024 words) -> two-pointer merge kernel; otherwise the
-    dense-timeline kernel, with detection tracks staged in several groups
-    when the cell has many of them."""
+def _drop_frames(gt, dt, seed, keep=0.6):
+    """Tracks with holes: a random subset of the boxes of both files."""
+    rng = np.random.default_rng(seed)
+    dt = dt.take(np.flatnonzero(rng.random(len(dt)) < keep))
+    sel = np.flatnonzero(rng.random(len(gt.ann_id)) < keep)
+    kw = {k: getattr(gt, k) for k in gt.FIELDS}
+    for k in gt.FIELDS:
+        if k.startswith("ann_"):
+            kw[k] = kw[k][sel]
+    return GTColumns(**kw), dt
+
+
+def _check_plan(f, meta, tasks, rows, pairs, out):
+    """Every (detection track, GT track) pair of every cell in exactly one
+    task, each pair's rows hold its two tracks, sizes within the kernel's."""
+    n_dt = len(f.dt_flags)
+    seen = np.zeros(int(f.cell_iou_off[-1]), dtype=np.int32)
+    cell_of = np.repeat(np.arange(f.n_cells), np.diff(f.cell_iou_off))
+    for r0, nr, p0, npair in tasks:
+        assert 0 < nr <= 36 and 0 < npair <= 64
+        trk = rows[r0:r0 + nr]
+        assert len(set(trk.tolist())) == nr
+        assert (np.diff(meta[trk, 0]) >= 0).all()        # by first position
+        pr, o = pairs[p0:p0 + npair], out[p0:p0 + npair]
+        td, tg = trk[pr & 0xFF], trk[(pr >> 8) & 0xFF]
+        assert (td < n_dt).all() and (tg >= n_dt).all()
+        c = cell_of[o]
+        G = (f.cell_gt_off[c + 1] - f.cell_gt_off[c]).astype(np.int64)
+        want = f.cell_iou_off[c] + (td - f.cell_dt_off[c]) * G + \
+            (tg - n_dt - f.cell_gt_off[c])
+        assert np.array_equal(o, want)
+        seen[o] += 1
+    assert (seen == 1).all()
+
+
+@pytest.mark.parametrize("seed,V,F,G,dpf", [
+    (31, 1, 1100, 24, 40), (32, 2, 200, 40, 40), (34, 2, 200, 14, 40),
+    (33, 1, 300, 8, 40), (35, 2, 150, 18, 40), (36, 1, 90, 70, 20),
+    (37, 2, 37, 3, 300), (38, 3, 16, 1, 120), (39, 1, 17, 33, 30)])
+def test_track_iou_tasks(seed, V, F, G, dpf):
+    """Long timelines, one to seventy GT tracks per cell (GT blocks), cells
+    with hundreds of detection tracks (several groups), timelines that end
+    mid-chunk, tracks with holes: the task kernel, the plan-less merge kernel
+    and the oracle agree bit for bit."""
     from tao_amodal_amd import engine
-    for seed, V, F, G, dense in ((31, 1, 1100, 24, False), (32, 2, 200, 40, False),
-                                 (34, 2, 200, 14, True), (33, 1, 300, 8, True),
-                                 (35, 2, 150, 18, False)):
-        gt, dt = synth(seed=seed, V=V, F=F, C=6, dets_per_frame=40,
-                       gt_tracks_per_video=G, n_present=2, n_neg=1)
+    gt, dt = synth(seed=seed, V=V, F=F, C=6, dets_per_frame=dpf,
+                   gt_tracks_per_video=G, n_present=2, n_neg=1)
+    for holes in (False, True):
+        if holes:
+            gt, dt = _drop_frames(gt, dt, seed)
         dt.track_id, _ = fl.make_track_ids_unique(dt)
         f = fl.flatten_tao(gt, dt)
-        assert bool(engine.DeviceProblem(f).all_dense) == dense
-        _compare_with_oracle(f, _engine().evaluate_flat(f, detail=True))
+        meta = engine.track_meta(f)[0]
+        _check_plan(f, meta, *engine.track_iou_plan(f, meta))
+        got = _engine().evaluate_flat(f, detail=True)
+        _compare_with_oracle(f, got)
+        for mode in ("avg_iou", "imagenetvid"):
+            want, _ = orclib.track_iou(f, mode)
+            g2 = _engine().evaluate_flat(f, iou_3d_type=mode)
+            assert np.array_equal(g2["iou"], want)
+        # without a plan: the two-pointer merge kernel
+        dp = engine.DeviceProblem(f)
+        dp.t["tasks"] = None
+        ws = engine.Workspace(dp)
+        engine.stage_track_iou(dp, ws)
+        assert np.array_equal(ws.iou[:dp.n_iou].cpu().numpy(), got["iou"])
+        assert int(ws.pair_frames.item()) == got["pairs"]
 
 
 def test_cells_with_more_than_64_ground_truths():
