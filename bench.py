@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- headline benchmark of the MI355X evaluation hot path.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config 2|3s|5s]
 
 One "step" = one pass of the hot path over one batch of synthetic input that
 is already resident in HBM: for BOTH evaluators (image-level LVISEval and
@@ -9,17 +9,31 @@ track-level TaoEval) range masks -> (category, -score) sort -> [3D track IoU]
 -> IoU + greedy match at 10 thresholds x {6 | 20} ranges -> accumulate
 (precision[T,R,K,A] and recall materialised in the reference layout).
 
-Workload at N=1: BASELINE.json configs[1], "Synthetic 200 videos x 300 frames
-x 50 dets" with 1203 categories (SURVEY.md 8(d) Config 2).  For N>1 every
-rank evaluates its own 200-video shard (weak scaling): match runs per rank,
-then one RCCL exchange routes each category's records to its owner rank,
-which sorts and accumulates them; an all-reduce(max) assembles the tensors.
+Workloads (BASELINE.json configs):
+    --config 2   "Synthetic 200 videos x 300 frames x 50 dets" (default; the
+                 configuration the metric is quoted on that fits one GPU)
+    --config 3s  stand-in for the full validation set (its JSONs are not in the
+                 container): 2000 videos x 300 frames x 50 dets, 1203 categories
+    --config 5s  stand-in for the stress set on ONE GPU: 10 000 videos x 1 frame
+                 x 1000 dets (10 M boxes; the top-300 cut per image is part of
+                 the host flatten time reported in host_s)
+
+N > 1 (one process per GPU, RCCL): launched by the driver's torchrun, or --
+when WORLD_SIZE is not set -- by this script itself, which spawns N ranks and
+fails loudly if the box has fewer GPUs.  Every rank holds one shard of the
+configuration (weak scaling); `--shard category` (default) gives every rank a
+contiguous category block of the whole set and assembles the result tables
+with one run-length packed all_gather per evaluator, `--shard unit` keeps the
+ranks' own videos and routes the per-detection records to the category owners
+with one all_to_all (tao_amodal_amd/dist.py).
 
 Prints ONE JSON line on rank 0 (see the driver contract in the task text).
 """
 import argparse
 import json
+import math
 import os
+import subprocess
 import sys
 import time
 
@@ -29,17 +43,29 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8 TB/s spec
+MIN_TIMED_S = 0.25        # floor of the timed region, whatever --steps says
+PROBE_EVERY = 8           # steps between two per-kernel event probes
+
+CONFIGS = {
+    "2": dict(videos=200, frames=300, dets=50,
+              name="SYNTH Config 2"),
+    "3s": dict(videos=2000, frames=300, dets=50,
+               name="SYNTH Config 3 stand-in (full-validation scale)"),
+    "5s": dict(videos=10000, frames=1, dets=1000,
+               name="SYNTH Config 5 stand-in (stress, top-300 cut per image)"),
+}
 
 
 def parse():
     p = argparse.ArgumentParser()
-    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--gpus", type=int, default=None)
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=3)
-    p.add_argument("--videos", type=int, default=200)
-    p.add_argument("--frames", type=int, default=300)
-    p.add_argument("--dets", type=int, default=50)
+    p.add_argument("--config", choices=sorted(CONFIGS), default="2")
+    p.add_argument("--videos", type=int, default=None)
+    p.add_argument("--frames", type=int, default=None)
+    p.add_argument("--dets", type=int, default=None)
     p.add_argument("--cats", type=int, default=1203)
     p.add_argument("--seed", type=int, default=20240807)
     p.add_argument("--cpu-sample-videos", type=int, default=200,
@@ -47,10 +73,6 @@ def parse():
                         "oracle for cpu_baseline (rank 0, N=1 only)")
     p.add_argument("--no-cpu", action="store_true")
     p.add_argument("--no-verify", action="store_true")
-    p.add_argument("--graph", action="store_true",
-                   help="replay the step from captured hipGraphs instead of "
-                        "launching the kernels (experimental: slower than the "
-                        "stream launches on one GPU, see DESIGN.md)")
     p.add_argument("--serial", action="store_true",
                    help="run the two evaluator passes back to back on one stream")
     p.add_argument("--shard", choices=["category", "unit"], default="category",
@@ -63,76 +85,175 @@ def parse():
                         "the printed value counts this rank's pairs only)")
     p.add_argument("--force-dist", action="store_true",
                    help="take the multi-GPU code path even with one rank")
-    return p.parse_args()
+    a = p.parse_args()
+    cfg = CONFIGS[a.config]
+    for k in ("videos", "frames", "dets"):
+        if getattr(a, k) is None:
+            setattr(a, k, cfg[k])
+    return a
 
 
-def algorithmic_bytes_match(dp):
-    """Compulsory HBM traffic of ONE launch of the fused LVIS IoU+match
-    kernel (DESIGN.md 'Kernels'): boxes 32 B, range masks 4 B, flags 1 B per
-    detection and GT; scatter index 4 B, cell index 4 B and 2 x 8 B output
-    words per detection; 2 x 4 B CSR entries per cell."""
-    return (dp.n_dt * (32 + 4 + 1 + 4 + 4 + 16 * dp.n_words)
-            + dp.n_gt * (32 + 4 + 1) + dp.n_cells * 8)
+# --------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` without a torchrun around it
+# --------------------------------------------------------------------------
+def self_spawn(n):
+    """Start n ranks of this very command (one per GPU) and wait for them."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < n:
+        sys.stderr.write("bench.py: --gpus %d asked for, %d GPU(s) visible on "
+                         "this box -- refusing to run fewer ranks than asked\n"
+                         % (n, have))
+        sys.exit(2)
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable] + sys.argv, env=env))
+    rc = 0
+    for p in procs:
+        rc = p.wait() or rc
+    if rc:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    sys.exit(rc)
 
 
-def algorithmic_bytes_track_iou(dp):
-    """ONE launch of the 3D-IoU kernel: every frame of every track once
-    (4 B timeline position + 32 B box), 4 B per track offset, 8 B per pair
-    written, 20 B of cell tables per cell."""
-    frames = dp.t["dt_frame_pos"].numel() + dp.t["gt_frame_pos"].numel()
-    return frames * 36 + (dp.n_dt + dp.n_gt) * 4 + dp.n_iou * 8 + dp.n_cells * 20
+# --------------------------------------------------------------------------
+# algorithmic (compulsory) HBM bytes of ONE launch of every kernel of the
+# step, DESIGN.md "Kernels": each datum the kernel needs moved once
+# --------------------------------------------------------------------------
+def kernel_models(dp, ws):
+    T, R = 10, 101
+    K, A, nw = dp.n_cat, dp.n_rng, dp.n_words
+    n_dt, n_gt, n_cells = dp.n_dt, dp.n_gt, dp.n_cells
+    rows = 16 * nw * n_dt                          # matched + ignored words
+    live = int((ws.num_gt > 0).sum().item())       # (category, range) rows with GT
+    table = 8 * T * R                              # one row of val / precision
+    seg = np.diff(dp.cat_off_host).astype(np.int64)
+    tile = 3072
+    n_multi = int(seg[seg > tile].sum())
+    m = {}
+    if dp.kind == "lvis":
+        m["lvis_ranges_kernel"] = n_gt * (8 + 1 + 4 + 4) + n_dt * (1 + 4)
+        m["match_group_kernel"] = (n_dt * (32 + 4 + 1 + 4 + 4 + 16 * nw)
+                                   + n_gt * (32 + 4 + 1) + n_cells * 8)
+    else:
+        m["tao_ranges_kernel"] = n_gt * (8 + 4 + 4 + 1 + 4 + 4) + n_dt * (8 + 4 + 1 + 4)
+        m["match_group_kernel"] = (n_dt * (4 + 1 + 4 + 4 + 16 * nw) + dp.n_iou * 8
+                                   + n_gt * (4 + 1) + n_cells * 8)
+        frames = dp.t["dt_frame_pos"].numel() + dp.t["gt_frame_pos"].numel()
+        if dp.t.get("tasks") is not None:
+            m["track_iou_task_kernel"] = (
+                frames * 32 + dp.n_iou * 8 + dp.n_tasks * 16
+                + dp.t["task_rows"].numel() * (4 + 16)
+                + dp.t["task_pairs"].numel() * (4 + 8))
+        m["track_iou_kernel"] = frames * 36 + (n_dt + n_gt) * 4 + dp.n_iou * 8
+    m["count_gt_kernel"] = n_gt * 4 + K * A * 4
+    m["seg_tile_kernel"] = n_dt * (8 + 8)           # score in; order + dst (or key + index) out
+    m["seg_kmerge_kernel"] = n_multi * (12 + 8)     # key + index in; order + dst out
+    m["seg_mpass_kernel"] = n_multi * 24
+    m["acc_count_kernel"] = rows
+    m["acc_chunkmax_kernel"] = rows
+    m["acc_emit_kernel"] = rows + live * table
+    m["acc_fused_kernel"] = rows + live * table
+    m["acc_finalize_kernel"] = live * table + K * A * (table + 8 * T)
+    grids = {"seg_tile_kernel": dp.n_tiles * 256,
+             "seg_mpass_kernel": dp.n_tiles * 256,
+             "seg_kmerge_kernel": (n_dt + 255) // 256 * 256,
+             "acc_finalize_kernel": ((K * A + 63) // 64) * ((T * R + 63) // 64) * 256}
+    return m, grids
 
 
-def pmc_traffic(kernel_substr):
-    """HBM bytes per launch of the dominant kernel from the newest committed
-    PMC summary (profiles/*_pmc.json, written by tools/prof_summary.py from
-    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this very
-    command); None when no profile is present."""
+def step_algorithmic_bytes(dpl, dpt):
+    """B_alg of one step (both evaluators)."""
+    frames = dpt.t["dt_frame_pos"].numel() + dpt.t["gt_frame_pos"].numel()
+    fixed = 8 * 10 * (101 + 1) * dpl.n_cat * (dpl.n_rng + dpt.n_rng)
+    return (32 * (dpl.n_dt + dpl.n_gt) + 32 * frames + (8 + 1 + 16) * dpl.n_dt
+            + (8 + 4 + 64) * dpt.n_dt + 17 * (dpl.n_cells + dpt.n_cells) + fixed)
+
+
+def pmc_traffic(kernel, grid, workload):
+    """HBM bytes per launch of `kernel` from the newest committed PMC summary
+    of THIS workload (profiles/*_pmc.json written by tools/prof_summary.py
+    from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this very
+    command); None when no summary of the workload is present."""
     import glob
     import re
 
-    def version(path):      # r01_v11_pmc.json -> (1, 11): numeric, not lexical
-        m = re.search(r"r(\d+)_v(\d+)_pmc", os.path.basename(path))
-        return (int(m.group(1)), int(m.group(2))) if m else (-1, -1)
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), key=version)
-    if not files:
+    def version(path):      # r02_v3_pmc.json -> (2, 3): numeric, not lexical
+        mm = re.search(r"r(\d+)_v(\d+)", os.path.basename(path))
+        return (int(mm.group(1)), int(mm.group(2))) if mm else (-1, -1)
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")),
+                       key=version, reverse=True):
+        with open(path) as f:
+            d = json.load(f)
+        if d.get("workload") != workload:
+            continue
+        for name, ents in d["kernels"].items():
+            if not re.match(r"(void )?%s\b" % re.escape(kernel), name):
+                continue
+            ents = [e for e in ents if e.get("hbm_bytes_corrected") is not None]
+            if grid is not None and len(ents) > 1:
+                ents = [e for e in ents if e.get("grid") == grid] or ents
+            if len(ents) == 1:
+                return {"bytes": ents[0]["hbm_bytes_corrected"],
+                        "source": os.path.basename(path)}
         return None
-    with open(files[-1]) as f:
-        ks = json.load(f)["kernels"]
-    for name, v in ks.items():
-        if kernel_substr in name:
-            return v["hbm_bytes_corrected"]
     return None
 
 
 def main():
     args = parse()
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and (args.gpus or 1) > 1:
+        self_spawn(args.gpus)
+    world = int(world_env or "1")
+    if args.gpus is not None and args.gpus != world:
+        sys.stderr.write("bench.py: --gpus %d but the launcher started %d "
+                         "rank(s)\n" % (args.gpus, world))
+        sys.exit(2)
     # stdout carries exactly one JSON line: RCCL and the HIP runtime print
     # banners to the C-level stdout, so fd 1 is pointed at stderr for the run
     # and the line goes to the saved descriptor
     sys.stdout.flush()
     real_stdout = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1 or args.force_dist:
+    if world > 1 or args.force_dist:
         # the category-partitioned step keeps 4 compute streams + the RCCL
         # stream busy; with the default of 4 hardware queues per process they
         # alias and serialise (measured 1.25 -> 0.94 ms/step with 8)
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     import torch.distributed as dist
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     use_dist = world > 1 or args.force_dist
+    if torch.cuda.device_count() <= local:
+        sys.stderr.write("bench.py: rank %d needs GPU %d, %d visible\n"
+                         % (rank, local, torch.cuda.device_count()))
+        sys.exit(2)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    ranks_verified = None
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local))
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+                                device_id=dev)
+        ones = torch.ones(1, dtype=torch.int64, device=dev)
+        dist.all_reduce(ones)
+        ranks_verified = int(ones.item())
+        assert dist.get_world_size() == world and ranks_verified == world, \
+            "RCCL group has %d ranks, %d asked for" % (ranks_verified, world)
 
-    from tao_amodal_amd import engine, flatten
+    from tao_amodal_amd import _lib, engine, flatten
     from tao_amodal_amd.synth import synth
 
     by_category = use_dist and args.shard == "category"
@@ -142,8 +263,8 @@ def main():
         data_world, data_rank = (int(x) for x in args.emulate.split(":"))
     t0 = time.time()
     if by_category:
-        # weak scaling: the data set grows with the number of ranks (one
-        # 200-video shard per rank) and every rank evaluates its category
+        # weak scaling: the data set grows with the number of ranks (one shard
+        # of the configuration per rank) and every rank evaluates its category
         # block of the WHOLE set, so the work per GPU stays fixed
         from tao_amodal_amd.columns import DTColumns, GTColumns
         parts = [synth(seed=args.seed + r, V=args.videos, F=args.frames,
@@ -158,6 +279,7 @@ def main():
                        C=args.cats, dets_per_frame=args.dets,
                        video_id_base=rank * args.videos)
     t_gen = time.time() - t0
+    n_boxes_in = len(dt)
     t0 = time.time()
     fl = flatten.flatten_lvis(gt, dt)
     dt.track_id, _ = flatten.make_track_ids_unique(dt)
@@ -193,86 +315,108 @@ def main():
 
         def step():
             overlap.run_pair(dpl, wsl, dpt, wst)
-        if args.graph:
-            # the launch sequence of a step is fixed: capture it once (stream
-            # forks become parallel branches), a step is two hipGraph launches
-            graphed = engine.GraphedPair(overlap, dpl, wsl, dpt, wst)
-            step = graphed.run
+
+    def bracket():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    probe = None
-    if not use_dist and not args.serial and not args.graph:
-        probe = engine.StageProbe()      # events on the kernels' streams
+    # ---- how many repetitions of the K steps make the timed region >= 0.25 s
+    bracket()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        # (the two dominant kernels are bracketed with events on every 4th
-        # step only: an event pair costs a few microseconds of stream time)
-        engine.PROBE = probe if i % 4 == 0 else None
+    for _ in range(args.steps):
         step()
-    host_ms = (time.perf_counter() - t0) / args.steps * 1e3   # launch side only
-    torch.cuda.synchronize()
+    bracket()
+    calib = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
     if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
+        dist.all_reduce(calib, op=dist.ReduceOp.MAX)
+    reps = max(1, int(math.ceil(MIN_TIMED_S / max(float(calib.item()), 1e-6))))
+    timed_steps = reps * args.steps
+
+    # ---- the timed region: reps x K steps between two barrier + synchronize
+    _lib.kernel_timings()                  # forget anything recorded so far
+    bracket()
+    t0 = time.perf_counter()
+    for i in range(timed_steps):
+        # (every kernel of every PROBE_EVERY-th step is bracketed with events
+        # on its own stream: two event records per launch cost host time)
+        probing = rank == 0 and i % PROBE_EVERY == PROBE_EVERY // 2
+        if probing:
+            _lib.kernel_timing(True)
+        step()
+        if probing:
+            _lib.kernel_timing(False)
+    host_ms = (time.perf_counter() - t0) / timed_steps * 1e3   # launch side only
+    bracket()
     elapsed = time.perf_counter() - t0
-    engine.PROBE = None
-    in_step_ms = probe.mean_ms() if probe is not None else {}
     if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    in_step = _lib.kernel_timings() if rank == 0 else {}
 
     # ---- pairs: exact counts from the cell tables / the kernel's counter
     p_l = dpl.n_pairs
-    if args.graph and not use_dist:   # the counter's memset node is unreliable under replay
-        engine.stage_track_iou(dpt, wst)
-        p_t = int(wst.pair_frames.item())
-    else:
-        p_t = int(plan.pair_frames()) if use_dist else int(wst.pair_frames.item())
+    p_t = int(plan.pair_frames()) if use_dist else int(wst.pair_frames.item())
     pairs = torch.tensor([p_l + p_t], dtype=torch.int64, device=dev)
     if use_dist:
         dist.all_reduce(pairs)
     total_pairs = int(pairs.item())
-    ms_per_step = elapsed / args.steps * 1e3
-    value = total_pairs * args.steps / elapsed / 1e6
+    ms_per_step = elapsed / timed_steps * 1e3
+    value = total_pairs * timed_steps / elapsed / 1e6
 
-    # ---- stage breakdown + dominant-kernel roofline (HIP events on the
-    # stream the kernels run on), measured outside the timed region
-    stages, roof, roof_other = None, None, None
+    workload = ("%s: %d videos x %d frames x %d dets/frame, %d categories per "
+                "GPU; LVISEval + TaoEval passes"
+                % (CONFIGS[args.config]["name"] if (args.videos, args.frames, args.dets)
+                   == tuple(CONFIGS[args.config][k] for k in ("videos", "frames", "dets"))
+                   else "SYNTH custom", args.videos, args.frames, args.dets,
+                   args.cats))
+
+    # ---- per-kernel durations inside the timed steps -> dominant kernel
+    stages, roof, roof_other, kernels_ms, step_roof = None, None, None, None, None
     if rank == 0:
-        stages = engine.time_stages(dpl, wsl, dpt, wst, reps=max(args.steps, 10))
-        # the two single-kernel stages; `roofline` reports the one that takes
-        # longer (the dominant kernel of the step), `roofline_other` the other
-        cands = []
-        for name, sym, probe_key, iso_ms, alg in (
-                ("match_group_kernel<fused> (LVIS box IoU + greedy match)",
-                 "match_group_kernel<true>", "lvis:match", stages["lvis"]["match"],
-                 algorithmic_bytes_match(dpl)),
-                ("track_iou_dense_kernel (TAO 3D track IoU)",
-                 "track_iou_dense_kernel", "tao:track_iou",
-                 stages["tao"]["track_iou"], algorithmic_bytes_track_iou(dpt))):
-            # launch duration inside the timed (overlapped) steps when it was
-            # probed there, else the isolated stage time
-            k_ms = in_step_ms.get(probe_key, iso_ms)
-            ach = alg / (k_ms * 1e-3) / 1e9
-            cands.append({"bound": "hbm", "kernel": name,
-                          "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
-                          "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
-                          "traffic": pmc_traffic(sym),
-                          "alg_bytes_per_launch": int(alg),
-                          "kernel_ms": round(k_ms, 4),
-                          "kernel_ms_isolated": round(iso_ms, 4),
-                          "timed": "HIP events on the kernel's stream inside the "
-                                   "timed steps" if probe_key in in_step_ms else
-                                   "HIP events, stages run back to back after the "
-                                   "timed steps"})
+        stages = engine.time_stages(dpl, wsl, dpt, wst, reps=10)
+        models = {}
+        for side, dp, ws in (("lvis", dpl, wsl), ("tao", dpt, wst)):
+            mm, gg = kernel_models(dp, ws)
+            for k, v in mm.items():
+                models[side + ":" + k] = (v, gg.get(k))
+        cands, kernels_ms = [], {}
+        probed = max(1, len(range(PROBE_EVERY // 2, timed_steps, PROBE_EVERY)))
+        for name, (tot, calls) in in_step.items():
+            k_ms = tot / calls
+            kernels_ms[name] = round(k_ms, 4)
+            alg, grid = models.get(name, (None, None))
+            ent = {"bound": "hbm", "kernel": name, "achieved": None,
+                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
+                   "traffic": None, "alg_bytes_per_launch": alg,
+                   "kernel_ms": round(k_ms, 4),
+                   "launches_per_step": round(calls / probed, 2),
+                   "timed": "HIP events on the kernel's stream inside the timed "
+                            "steps (every %dth step, %d launches)"
+                            % (PROBE_EVERY, calls)}
+            if alg:
+                ach = alg / (k_ms * 1e-3) / 1e9
+                ent["achieved"] = round(ach, 2)
+                ent["frac"] = round(ach / HBM_PEAK_GBS, 5)
+                tr = pmc_traffic(name.split(":", 1)[1], grid, workload)
+                if tr:
+                    ent["traffic"] = tr["bytes"]
+                    ent["traffic_source"] = tr["source"]
+            cands.append(ent)
         cands.sort(key=lambda c: -c["kernel_ms"])
-        roof, roof_other = cands[0], cands[1]
+        if cands:
+            roof = cands[0]
+            roof_other = cands[1:4]
+        if not use_dist:
+            b = step_algorithmic_bytes(dpl, dpt)
+            ach = b / (ms_per_step * 1e-3) / 1e9
+            step_roof = {"alg_bytes_per_step": int(b), "achieved": round(ach, 2),
+                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
+                         "note": "SURVEY 8(d) B_alg of both passes / ms_per_step"}
 
     # ---- multi-GPU: every rank checks the assembled tables against what the
     # owners computed.  Own block: the plain single-GPU pass over this rank's
@@ -303,27 +447,54 @@ def main():
         flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         exchange_ok = bool(flag.item())
+    elif use_dist and not args.emulate:
+        # unit partition: all ranks must hold identical assembled tables
+        ok = True
+        for ev in (plan.lvis, plan.tao):
+            own = torch.stack([ev.precision.view(torch.int64).sum(),
+                               ev.recall.view(torch.int64).sum()])
+            lo, hi = own.clone(), own.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            ok &= bool(torch.equal(lo, hi))
+        exchange_ok = ok
 
     # ---- verification + CPU baseline (C oracle = "port"), rank 0, N=1
-    cpu, verified = None, None
+    cpu, cpu_all, verified = None, None, None
     if not use_dist and rank == 0 and not args.no_cpu:
         import orclib
         nv = min(args.cpu_sample_videos, args.videos)
+        if args.frames * args.dets < 3000:        # stress shape: many tiny videos
+            nv = min(args.videos, max(nv, 3000000 // max(args.frames * args.dets, 1)))
         sgt, sdt = synth(seed=args.seed, V=nv, F=args.frames, C=args.cats,
                          dets_per_frame=args.dets)
         sfl = flatten.flatten_lvis(sgt, sdt)
         sdt.track_id, _ = flatten.make_track_ids_unique(sdt)
         sft = flatten.flatten_tao(sgt, sdt)
+        orclib.set_threads(1)
         t0 = time.perf_counter()
         ol = orclib.run_flat(sfl, detail=False)
         ot = orclib.run_flat(sft, detail=False)
         t_cpu = time.perf_counter() - t0
         sp = sfl.n_pairs + ot["pairs"]
+        what = ("%d of the %d videos of the same workload (%d box pairs, %.1f s) "
+                "through oracle/tao_oracle.c, %s")
         cpu = {"value": round(sp / t_cpu / 1e6, 4), "unit": "Mpair/s", "cores": 1,
                "kind": "port",
-               "sample": "%d of the %d videos of the same workload (%d box pairs, "
-                         "%.1f s) through oracle/tao_oracle.c, single thread"
-                         % (nv, args.videos, sp, t_cpu)}
+               "sample": what % (nv, args.videos, sp, t_cpu, "single thread")}
+        cores = orclib.set_threads(0)
+        t0 = time.perf_counter()
+        ol2 = orclib.run_flat(sfl, detail=False)
+        ot2 = orclib.run_flat(sft, detail=False)
+        t_all = time.perf_counter() - t0
+        orclib.set_threads(1)
+        same = (np.array_equal(ol2["precision"], ol["precision"])
+                and np.array_equal(ot2["precision"], ot["precision"])
+                and np.array_equal(ot2["iou"], ot["iou"]))
+        cpu_all = {"value": round(sp / t_all / 1e6, 4), "unit": "Mpair/s",
+                   "cores": cores, "kind": "port", "equals_single_thread": bool(same),
+                   "sample": what % (nv, args.videos, sp, t_all,
+                                     "OpenMP over cells / categories, %d threads" % cores)}
         if not args.no_verify:
             gl = engine.evaluate_flat(sfl, dev)
             gtt = engine.evaluate_flat(sft, dev)
@@ -351,23 +522,26 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "SYNTH Config 2: %d videos x %d frames x %d "
-                                   "dets/frame, %d categories per GPU; LVISEval + "
-                                   "TaoEval passes" % (args.videos, args.frames,
-                                                       args.dets, args.cats),
+            "config": {"workload": workload,
                        "pairs_per_step": total_pairs,
                        "lvis_pairs_rank0": p_l, "tao_pairs_rank0": p_t,
+                       "boxes_in_rank0": n_boxes_in,
                        "detections_rank0": dpl.n_dt, "tracks_rank0": dpt.n_dt,
                        "cells_rank0": [dpl.n_cells, dpt.n_cells],
                        "parallelism": ("single GPU" if not use_dist else
                                        "%s-sharded x%d" % (args.shard, world))},
-            "roofline": roof, "roofline_other": roof_other, "cpu_baseline": cpu,
-            "stages_ms": stages, "streams": "serial" if args.serial else "2 (image-level || track-level)" if (use_dist and not by_category)
+            "timed_steps": timed_steps,
+            "timed_region_s": round(elapsed, 4),
+            "roofline": roof, "roofline_other": roof_other,
+            "step_roofline": step_roof,
+            "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all,
+            "kernels_ms": kernels_ms, "stages_ms": stages,
+            "streams": "serial" if args.serial else "2 (image-level || track-level)" if (use_dist and not by_category)
             else "4 (image-level || track-level, ranges/sort || IoU) + RCCL all_gather" if use_dist
             else "4 (image-level || track-level, ranges/sort || IoU)",
             "host_launch_ms_per_step": round(host_ms, 4),
-            "hip_graph": bool(args.graph and not args.serial and not use_dist),
             "bit_exact_vs_oracle": verified,
+            "ranks_verified": ranks_verified,
             "exchange_verified": exchange_ok,
             "exchange_chunk_bytes": ([plan.lvis.chunk_bytes, plan.tao.chunk_bytes]
                                      if by_category else None),

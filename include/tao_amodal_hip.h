@@ -89,6 +89,22 @@ const char *taoamd_strerror(int status);
 const char *taoamd_last_error(void);
 int taoamd_version(void);
 
+/* Per-kernel timing for bench.py's roofline: while enabled, every kernel the
+ * library launches is bracketed by two HIP events recorded on the stream it
+ * is launched on (costs two event records per launch; off by default).
+ * taoamd_kernel_timing_collect waits for the recorded events, adds up the
+ * launch durations by kernel name and forgets them: names = NUL-separated
+ * list in launch order of first appearance, total_ms / calls per name;
+ * *n_kernels = number of distinct names.  A call always consumes the records
+ * (give room for 64 names).  Host pointers; synchronous. */
+int taoamd_kernel_timing_enable(int on);
+/* prefix ("label:") of the names recorded by this thread from now on, e.g. the
+ * evaluator a pass belongs to; NULL or "" = none */
+int taoamd_kernel_timing_label(const char *label);
+int taoamd_kernel_timing_collect(char *names_host, size_t names_bytes,
+                                 double *total_ms_host, int64_t *calls_host,
+                                 int32_t max_kernels, int32_t *n_kernels_host);
+
 /* Exact bit patterns of np.linspace(.5,.95,10) / np.linspace(0,1,101)
  * (L/eval.py:560-565).  Host pointers. */
 int taoamd_thresholds_host(double *iou_thrs, double *rec_thrs);

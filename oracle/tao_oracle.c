@@ -34,6 +34,7 @@
  * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off; no fast-math).
  */
 #include <math.h>
+#include <omp.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -154,6 +155,13 @@ void orc_tao_ranges(int64_t n_gt, const double *gt_area,
  * mode 1: avg_iou      mean_f (inter_f / union_f)      (eval.py:99-117), sum
  *                      taken left to right in timeline order
  * mode 2: imagenetvid  #{f: inter_f > 0.5 union_f} / #frames (eval.py:51-70) */
+/* Threads used by the cell / category loops below (OpenMP).  1 = the plain
+ * scalar port (default); bench.py's all-cores baseline raises it.  Cells and
+ * categories are independent, so the results do not depend on it. */
+static int g_threads = 1;
+void orc_set_threads(int n) { g_threads = n > 0 ? n : 1; }
+int orc_max_threads(void) { return omp_get_max_threads(); }
+
 int64_t orc_track_iou(int64_t n_cells, const int32_t *cell_dt_off,
                       const int32_t *cell_gt_off, const int64_t *cell_iou_off,
                       const int32_t *dt_foff, const int32_t *dt_fpos,
@@ -162,6 +170,7 @@ int64_t orc_track_iou(int64_t n_cells, const int32_t *cell_dt_off,
                       int mode, double *iou)
 {
     int64_t pairs = 0;
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : pairs) num_threads(g_threads)
     for (int64_t c = 0; c < n_cells; c++) {
         int32_t d0 = cell_dt_off[c], D = cell_dt_off[c + 1] - d0;
         int32_t g0 = cell_gt_off[c], G = cell_gt_off[c + 1] - g0;
@@ -232,6 +241,7 @@ void orc_match(int64_t n_cells, const int32_t *cell_dt_off,
     orc_thresholds(thr, rec);
     int n_combo = n_rng * N_THR;
     int n_words = (n_combo + 63) / 64;
+#pragma omp parallel for schedule(dynamic, 256) num_threads(g_threads)
     for (int64_t c = 0; c < n_cells; c++) {
         int32_t d0 = cell_dt_off[c], D = cell_dt_off[c + 1] - d0;
         int32_t g0 = cell_gt_off[c], G = cell_gt_off[c + 1] - g0;
@@ -318,8 +328,11 @@ static void msort(int64_t *x, int64_t *tmp, int64_t n)
 {
     if (n < 2) return;
     int64_t h = n / 2;
+#pragma omp task if (n > 65536)
     msort(x, tmp, h);
-    msort(x + h, tmp, n - h);
+#pragma omp task if (n > 65536)
+    msort(x + h, tmp + h, n - h);
+#pragma omp taskwait
     int64_t i = 0, j = h, k = 0;
     while (i < h && j < n)
         tmp[k++] = before(x[j], x[i]) ? x[j++] : x[i++];
@@ -359,18 +372,33 @@ void orc_accumulate(int64_t n_dt, int32_t n_cat, int n_rng,
     for (int64_t i = 0; i < n_dt; i++) order[i] = i;
     s_cat = dt_cat;
     s_score = dt_score;
+#pragma omp parallel num_threads(g_threads)
+#pragma omp single
     msort(order, tmp, n_dt);
     if (order_out) memcpy(order_out, order, sizeof(int64_t) * (size_t)n_dt);
-    double *pr = (double *)malloc(sizeof(double) * (size_t)(n_dt + 1));
-    double *rc = (double *)malloc(sizeof(double) * (size_t)(n_dt + 1));
     const double eps = 2.220446049250313e-16; /* np.spacing(1) */
     /* categories without detections still get precision 0 / recall 0 when
      * they have evaluated GT, hence the walk over all categories */
-    int64_t pos = 0;
+    int64_t *cat_b = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n_cat + 1));
+    {
+        int64_t pos = 0;
+        for (int32_t k = 0; k < n_cat; k++) {
+            cat_b[k] = pos;
+            while (pos < n_dt && dt_cat[order[pos]] == k) pos++;
+        }
+        cat_b[n_cat] = pos;
+    }
+    int64_t longest = 0;
+    for (int32_t k = 0; k < n_cat; k++)
+        if (cat_b[k + 1] - cat_b[k] > longest) longest = cat_b[k + 1] - cat_b[k];
+#pragma omp parallel num_threads(g_threads)
+    {
+    double *pr = (double *)malloc(sizeof(double) * (size_t)(longest + 1));
+    double *rc = (double *)malloc(sizeof(double) * (size_t)(longest + 1));
+#pragma omp for schedule(dynamic, 4)
     for (int32_t k = 0; k < n_cat; k++) {
-        int64_t b = pos;
-        while (pos < n_dt && dt_cat[order[pos]] == k) pos++;
-        int64_t n = pos - b;
+        int64_t b = cat_b[k];
+        int64_t n = cat_b[k + 1] - b;
         for (int r = 0; r < n_rng; r++) {
             int32_t ng = num_gt[(int64_t)k * n_rng + r];
             if (ng == 0) continue;
@@ -402,5 +430,7 @@ void orc_accumulate(int64_t n_dt, int32_t n_cat, int n_rng,
             }
         }
     }
-    free(pr); free(rc); free(order); free(tmp); free(num_gt);
+    free(pr); free(rc);
+    }
+    free(cat_b); free(order); free(tmp); free(num_gt);
 }

@@ -26,6 +26,9 @@ SIGNATURES = {
     "taoamd_last_error": (C.c_char_p, []),
     "taoamd_version": (C.c_int, []),
     "taoamd_thresholds_host": (C.c_int, [_vp, _vp]),
+    "taoamd_kernel_timing_enable": (C.c_int, [C.c_int]),
+    "taoamd_kernel_timing_label": (C.c_int, [C.c_char_p]),
+    "taoamd_kernel_timing_collect": (C.c_int, [_vp, _sz, _vp, _vp, _i32, _vp]),
     "taoamd_bb_iou": (C.c_int, [_vp, _vp, _sz, _sz, _vp, _vp, _vp]),
     "taoamd_bb_iou_host": (C.c_int, [_vp, _vp, _sz, _sz, _vp, _vp]),
     "taoamd_lvis_ranges": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _i64, _vp,
@@ -101,6 +104,38 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+TIMING = False     # kernel_timing(True): engine passes label their launches
+
+
+def kernel_timing(on):
+    """Switch the library's per-kernel event timing on / off."""
+    global TIMING
+    TIMING = bool(on)
+    check(load().taoamd_kernel_timing_enable(int(TIMING)),
+          "taoamd_kernel_timing_enable")
+
+
+def kernel_timing_label(label):
+    load().taoamd_kernel_timing_label(label.encode() if label else None)
+
+
+def kernel_timings():
+    """{kernel name: (total ms, launches)} recorded since the last call
+    (synchronises with the recorded events)."""
+    import numpy as np
+    names = C.create_string_buffer(8192)
+    ms = np.zeros(128)
+    calls = np.zeros(128, dtype=np.int64)
+    n = C.c_int32(0)
+    check(load().taoamd_kernel_timing_collect(
+        C.addressof(names), len(names), ms.ctypes.data, calls.ctypes.data, 128,
+        C.addressof(n)), "taoamd_kernel_timing_collect")
+    out, raw = {}, names.raw.split(b"\0")
+    for k in range(n.value):
+        out[raw[k].decode()] = (float(ms[k]), int(calls[k]))
+    return out
 
 
 def check(status, what):

@@ -859,8 +859,8 @@ extern "C" int taoamd_accumulate_compact(int64_t n_dt, int32_t n_cat,
     // level, Config 2: 0.23 vs 0.18 ms), so it is all or nothing.
     a.fused_rows = ACC_FUSED_WAVES / a.n_words * ACC_CH;
     if (max_segment > 0 && max_segment <= a.fused_rows) {
-        acc_fused_kernel<<<(unsigned)(k_end - k_begin), ACC_FUSED_WAVES * WAVE, 0, s>>>(
-            a, rec_thr());
+        TAO_TIMED("acc_fused_kernel", s, acc_fused_kernel<<<(unsigned)(k_end - k_begin), ACC_FUSED_WAVES * WAVE, 0, s>>>(
+            a, rec_thr()));
         TAO_LAUNCH_CHECK();
         return TAOAMD_OK;
     }
@@ -882,16 +882,16 @@ extern "C" int taoamd_accumulate_compact(int64_t n_dt, int32_t n_cat,
     a.cj = (int32_t *)w;
     const unsigned chunk_blocks = (unsigned)((nc * nw + 3) / 4);
     const unsigned cat_blocks = (unsigned)((size_t)(k_end - k_begin) * nw);
-    acc_chunks_kernel<<<1, 256, 0, s>>>(a);
-    acc_count_kernel<<<chunk_blocks, 256, 0, s>>>(a);
+    TAO_TIMED("acc_chunks_kernel", s, acc_chunks_kernel<<<1, 256, 0, s>>>(a));
+    TAO_TIMED("acc_count_kernel", s, acc_count_kernel<<<chunk_blocks, 256, 0, s>>>(a));
     if (a.inline_scans) {
-        acc_chunkmax_kernel<true><<<chunk_blocks, 256, 0, s>>>(a, rec_thr());
-        acc_emit_kernel<true><<<chunk_blocks, 256, 0, s>>>(a);
+        TAO_TIMED("acc_chunkmax_kernel", s, acc_chunkmax_kernel<true><<<chunk_blocks, 256, 0, s>>>(a, rec_thr()));
+        TAO_TIMED("acc_emit_kernel", s, acc_emit_kernel<true><<<chunk_blocks, 256, 0, s>>>(a));
     } else {
-        acc_prefix_kernel<<<cat_blocks, 256, 0, s>>>(a, rec_thr());
-        acc_chunkmax_kernel<false><<<chunk_blocks, 256, 0, s>>>(a, rec_thr());
-        acc_sufmax_kernel<<<cat_blocks, 256, 0, s>>>(a);
-        acc_emit_kernel<false><<<chunk_blocks, 256, 0, s>>>(a);
+        TAO_TIMED("acc_prefix_kernel", s, acc_prefix_kernel<<<cat_blocks, 256, 0, s>>>(a, rec_thr()));
+        TAO_TIMED("acc_chunkmax_kernel", s, acc_chunkmax_kernel<false><<<chunk_blocks, 256, 0, s>>>(a, rec_thr()));
+        TAO_TIMED("acc_sufmax_kernel", s, acc_sufmax_kernel<<<cat_blocks, 256, 0, s>>>(a));
+        TAO_TIMED("acc_emit_kernel", s, acc_emit_kernel<false><<<chunk_blocks, 256, 0, s>>>(a));
     }
     TAO_LAUNCH_CHECK();
     return TAOAMD_OK;
@@ -910,7 +910,7 @@ extern "C" int taoamd_finalize(int32_t n_cat, int32_t n_rng,
     const int64_t KR = (int64_t)n_cat * n_rng;
     dim3 grid((unsigned)((KR + FIN_RT - 1) / FIN_RT),
               (unsigned)((N_THR * N_REC + FIN_CT - 1) / FIN_CT));
-    acc_finalize_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(f);
+    TAO_TIMED("acc_finalize_kernel", (hipStream_t)stream, acc_finalize_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(f));
     TAO_LAUNCH_CHECK();
     return TAOAMD_OK;
 }

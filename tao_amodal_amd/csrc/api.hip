@@ -2,6 +2,11 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
 #include "common.hpp"
 
 namespace taoamd {
@@ -35,7 +40,120 @@ const RecThr &rec_thr()
     return t;
 }
 
+// ---- per-kernel timing: event pairs on the launch streams, reduced on demand
+bool g_timing_on = false;
+struct TimedLaunch {
+    const char *name;
+    hipEvent_t a, b;
+};
+static std::mutex g_timing_mu;
+static std::vector<TimedLaunch> g_timed;
+static std::vector<hipEvent_t> g_event_pool;
+static thread_local TimedLaunch g_open;
+static thread_local std::string g_label;
+static std::map<std::string, const char *> g_names;      // interned "label:kernel"
+
+static const char *intern(const std::string &nm)
+{
+    std::lock_guard<std::mutex> lk(g_timing_mu);
+    auto it = g_names.find(nm);
+    if (it != g_names.end()) return it->second;
+    char *c = strdup(nm.c_str());
+    g_names[nm] = c;
+    return c;
+}
+
+static hipEvent_t take_event()
+{
+    std::lock_guard<std::mutex> lk(g_timing_mu);
+    if (!g_event_pool.empty()) {
+        hipEvent_t e = g_event_pool.back();
+        g_event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+void timing_begin(const char *name, hipStream_t s)
+{
+    g_open.name = g_label.empty() ? name : intern(g_label + ":" + name);
+    g_open.a = take_event();
+    g_open.b = take_event();
+    (void)hipEventRecord(g_open.a, s);
+}
+
+void timing_end(hipStream_t s)
+{
+    (void)hipEventRecord(g_open.b, s);
+    std::lock_guard<std::mutex> lk(g_timing_mu);
+    g_timed.push_back(g_open);
+}
+
 }  // namespace taoamd
+
+extern "C" int taoamd_kernel_timing_enable(int on)
+{
+    taoamd::g_timing_on = on != 0;
+    return TAOAMD_OK;
+}
+
+extern "C" int taoamd_kernel_timing_label(const char *label)
+{
+    taoamd::g_label = label ? label : "";
+    return TAOAMD_OK;
+}
+
+extern "C" int taoamd_kernel_timing_collect(char *names, size_t names_bytes,
+                                            double *total_ms, int64_t *calls,
+                                            int32_t max_kernels,
+                                            int32_t *n_kernels)
+{
+    using namespace taoamd;
+    if (!n_kernels || max_kernels < 0) return TAOAMD_ERR_ARG;
+    std::vector<TimedLaunch> taken;
+    {
+        std::lock_guard<std::mutex> lk(g_timing_mu);
+        taken.swap(g_timed);
+    }
+    std::map<std::string, std::pair<double, int64_t>> agg;
+    std::vector<std::string> order;
+    for (const TimedLaunch &t : taken) {
+        TAO_HIP(hipEventSynchronize(t.b));
+        float ms = 0.f;
+        TAO_HIP(hipEventElapsedTime(&ms, t.a, t.b));
+        auto it = agg.find(t.name);
+        if (it == agg.end()) {
+            order.push_back(t.name);
+            agg[t.name] = {ms, 1};
+        } else {
+            it->second.first += ms;
+            it->second.second += 1;
+        }
+    }
+    {
+        std::lock_guard<std::mutex> lk(g_timing_mu);
+        for (const TimedLaunch &t : taken) {
+            g_event_pool.push_back(t.a);
+            g_event_pool.push_back(t.b);
+        }
+    }
+    *n_kernels = (int32_t)order.size();
+    size_t used = 0;
+    int32_t k = 0;
+    for (const std::string &nm : order) {
+        if (k >= max_kernels) break;
+        if (!names || !total_ms || !calls || used + nm.size() + 1 > names_bytes)
+            return TAOAMD_ERR_ARG;
+        memcpy(names + used, nm.c_str(), nm.size() + 1);   // NUL-separated list
+        used += nm.size() + 1;
+        total_ms[k] = agg[nm].first;
+        calls[k] = agg[nm].second;
+        k++;
+    }
+    return TAOAMD_OK;
+}
 
 extern "C" const char *taoamd_strerror(int status)
 {

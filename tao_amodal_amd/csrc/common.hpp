@@ -33,6 +33,30 @@ const RecThr &rec_thr();
         }                                                 \
     } while (0)
 
+// Optional per-kernel timing (taoamd_kernel_timing_*): a launch wrapped in
+// TAO_TIMED is bracketed by two HIP events recorded on ITS stream while timing
+// is switched on; switched off (the default) the wrapper costs one load.
+extern bool g_timing_on;
+void timing_begin(const char *name, hipStream_t s);
+void timing_end(hipStream_t s);
+struct KernelTimer {
+    hipStream_t s;
+    bool on;
+    KernelTimer(const char *name, hipStream_t s_) : s(s_), on(g_timing_on)
+    {
+        if (on) timing_begin(name, s);
+    }
+    ~KernelTimer()
+    {
+        if (on) timing_end(s);
+    }
+};
+#define TAO_TIMED(name, stream, ...)                      \
+    do {                                                  \
+        taoamd::KernelTimer tao_timer_(name, stream);     \
+        __VA_ARGS__;                                      \
+    } while (0)
+
 #define TAO_LAUNCH_CHECK()                                \
     do {                                                  \
         hipError_t e_ = hipGetLastError();                \

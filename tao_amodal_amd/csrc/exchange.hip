@@ -289,9 +289,9 @@ extern "C" int taoamd_exchange_sizes(int32_t block_cats, int32_t n_rng,
     hipStream_t s = (hipStream_t)stream;
     ExWs w = carve(workspace, rows, world);
     NumSrc src{(const unsigned char *)num_gt, (int64_t)BR * 4, rows, BR};
-    ex_levels_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, s>>>(src, 0, rows, w,
-                                                                rec_thr());
-    ex_offsets_kernel<<<world, 1024, 0, s>>>(0, BR, INT64_MAX, w, nullptr);
+    TAO_TIMED("ex_levels_kernel", s, ex_levels_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, s>>>(src, 0, rows, w,
+                                                                rec_thr()));
+    TAO_TIMED("ex_offsets_kernel", s, ex_offsets_kernel<<<world, 1024, 0, s>>>(0, BR, INT64_MAX, w, nullptr));
     TAO_LAUNCH_CHECK();
     TAO_HIP(hipMemcpyAsync(totals, w.totals, (size_t)world * 8,
                            hipMemcpyDeviceToDevice, s));
@@ -319,9 +319,9 @@ extern "C" int taoamd_exchange_pack(int32_t n_cat, int32_t n_rng,
     const int64_t r0 = (int64_t)rank * BR;
     // the local table is addressed by global row: one "block" spanning it all
     NumSrc src{(const unsigned char *)num_gt, 0, valid, (int32_t)0x7fffffff};
-    ex_levels_kernel<<<(unsigned)((BR + 3) / 4), 256, 0, s>>>(src, r0, r0 + BR, w,
-                                                              rec_thr());
-    ex_offsets_kernel<<<1, 1024, 0, s>>>(rank, BR, capacity, w, overflow);
+    TAO_TIMED("ex_levels_kernel", s, ex_levels_kernel<<<(unsigned)((BR + 3) / 4), 256, 0, s>>>(src, r0, r0 + BR, w,
+                                                              rec_thr()));
+    TAO_TIMED("ex_offsets_kernel", s, ex_offsets_kernel<<<1, 1024, 0, s>>>(rank, BR, capacity, w, overflow));
     const Chunk c = chunk_layout(block_cats, n_rng, capacity);
     PackArgs a;
     a.row0 = r0; a.block_rows = BR; a.valid_rows = valid;
@@ -331,7 +331,7 @@ extern "C" int taoamd_exchange_pack(int32_t n_cat, int32_t n_rng,
     a.levels = (double *)((unsigned char *)chunk + c.hdr_bytes + c.rec_bytes);
     a.capacity = capacity; a.w = w;
     const int64_t threads = (int64_t)BR * N_THR * N_REC;
-    ex_pack_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>(a);
+    TAO_TIMED("ex_pack_kernel", s, ex_pack_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>(a));
     TAO_LAUNCH_CHECK();
     return TAOAMD_OK;
 }
@@ -356,8 +356,8 @@ extern "C" int taoamd_exchange_unpack(int32_t n_cat, int32_t n_rng,
     UnpackArgs a;
     a.w = carve(workspace, rows, world);
     NumSrc src{(const unsigned char *)chunks, (int64_t)c.bytes, rows, BR};
-    ex_levels_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, s>>>(src, 0, rows, a.w,
-                                                                rec_thr());
+    TAO_TIMED("ex_levels_kernel", s, ex_levels_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, s>>>(src, 0, rows, a.w,
+                                                                rec_thr()));
     a.n_cat = n_cat; a.n_rng = n_rng; a.block_rows = BR;
     a.chunks = (const unsigned char *)chunks;
     a.chunk_bytes = c.bytes; a.hdr_bytes = c.hdr_bytes; a.rec_bytes = c.rec_bytes;
@@ -365,7 +365,7 @@ extern "C" int taoamd_exchange_unpack(int32_t n_cat, int32_t n_rng,
     a.precision = precision; a.recall = recall; a.overflow = overflow;
     const int64_t KR = (int64_t)n_cat * n_rng;
     dim3 grid((unsigned)((KR + 31) / 32), (unsigned)((N_THR * N_REC + 31) / 32));
-    ex_unpack_kernel<<<grid, 256, 0, s>>>(a);
+    TAO_TIMED("ex_unpack_kernel", s, ex_unpack_kernel<<<grid, 256, 0, s>>>(a));
     TAO_LAUNCH_CHECK();
     return TAOAMD_OK;
 }

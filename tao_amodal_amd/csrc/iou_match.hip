@@ -586,7 +586,7 @@ extern "C" int taoamd_bb_iou(const double *dt, const double *gt, size_t m,
     if (!dt || !gt || !o) return TAOAMD_ERR_ARG;
     size_t total = m * n;
     unsigned blocks = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    bb_iou_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(dt, gt, m, n, iscrowd, o);
+    TAO_TIMED("bb_iou_kernel", (hipStream_t)stream, bb_iou_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(dt, gt, m, n, iscrowd, o));
     TAO_LAUNCH_CHECK();
     return TAOAMD_OK;
 }
@@ -631,13 +631,13 @@ extern "C" int taoamd_lvis_ranges(int64_t n_gt, const double *gt_vis,
         TAO_HIP(hipMemsetAsync(num_gt, 0, sizeof(int32_t) * (size_t)n_cat * TAOAMD_LVIS_RNG, s));
     int64_t n = n_gt > n_dt ? n_gt : n_dt;
     if (n > 0) {
-        lvis_ranges_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(
+        TAO_TIMED("lvis_ranges_kernel", s, lvis_ranges_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(
             n_gt, gt_vis, gt_flags, gt_cat, n_dt, dt_flags, gt_rng, dt_rng,
-            grouped ? nullptr : num_gt);
+            grouped ? nullptr : num_gt));
     }
     if (grouped)
-        count_gt_kernel<<<(unsigned)n_cat, 256, 0, s>>>(
-            n_cat, TAOAMD_LVIS_RNG, gt_cat_off, gt_rng, num_gt);
+        TAO_TIMED("count_gt_kernel", s, count_gt_kernel<<<(unsigned)n_cat, 256, 0, s>>>(
+            n_cat, TAOAMD_LVIS_RNG, gt_cat_off, gt_rng, num_gt));
     TAO_LAUNCH_CHECK();
     return TAOAMD_OK;
 }
@@ -657,13 +657,13 @@ extern "C" int taoamd_tao_ranges(int64_t n_gt, const double *gt_area,
         TAO_HIP(hipMemsetAsync(num_gt, 0, sizeof(int32_t) * (size_t)n_cat * TAOAMD_TAO_RNG, s));
     int64_t n = n_gt > n_dt ? n_gt : n_dt;
     if (n > 0) {
-        tao_ranges_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(
+        TAO_TIMED("tao_ranges_kernel", s, tao_ranges_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(
             n_gt, gt_area, gt_len, gt_nhp, gt_flags, gt_cat, n_dt, dt_area,
-            dt_len, dt_flags, gt_rng, dt_rng, grouped ? nullptr : num_gt);
+            dt_len, dt_flags, gt_rng, dt_rng, grouped ? nullptr : num_gt));
     }
     if (grouped)
-        count_gt_kernel<<<(unsigned)n_cat, 256, 0, s>>>(
-            n_cat, TAOAMD_TAO_RNG, gt_cat_off, gt_rng, num_gt);
+        TAO_TIMED("count_gt_kernel", s, count_gt_kernel<<<(unsigned)n_cat, 256, 0, s>>>(
+            n_cat, TAOAMD_TAO_RNG, gt_cat_off, gt_rng, num_gt));
     TAO_LAUNCH_CHECK();
     return TAOAMD_OK;
 }
@@ -706,22 +706,22 @@ extern "C" int taoamd_match(int64_t n_cells, const int32_t *cell_dt_off,
     hipStream_t s = (hipStream_t)stream;
     if (planned && n_groups > 0) {
         const unsigned gb = (unsigned)(((int64_t)n_groups * a.n_words + 3) / 4);
-        if (fused) match_group_kernel<true><<<gb, 256, 0, s>>>(a, iou_thr());
-        else match_group_kernel<false><<<gb, 256, 0, s>>>(a, iou_thr());
+        if (fused) TAO_TIMED("match_group_kernel", s, match_group_kernel<true><<<gb, 256, 0, s>>>(a, iou_thr()));
+        else TAO_TIMED("match_group_kernel", s, match_group_kernel<false><<<gb, 256, 0, s>>>(a, iou_thr()));
     }
     const int64_t cells = planned ? n_singles : n_cells;
     const int64_t items = cells * a.n_words;
     if (items > 0) {
         const unsigned blocks = (unsigned)((items + 3) / 4);
-        if (fused) match_kernel<true><<<blocks, 256, 0, s>>>(a, iou_thr());
-        else match_kernel<false><<<blocks, 256, 0, s>>>(a, iou_thr());
+        if (fused) TAO_TIMED("match_kernel", s, match_kernel<true><<<blocks, 256, 0, s>>>(a, iou_thr()));
+        else TAO_TIMED("match_kernel", s, match_kernel<false><<<blocks, 256, 0, s>>>(a, iou_thr()));
         if (max_gt_per_cell > WAVE) {
             const int32_t cap = (max_gt_per_cell + 31) / 32 * 32;
             const size_t lds = (size_t)cap * 8 + (size_t)(cap / 32) * WAVE * 4;
             if (fused)
-                match_big_kernel<true><<<(unsigned)items, 64, lds, s>>>(a, iou_thr(), cap);
+                TAO_TIMED("match_big_kernel", s, match_big_kernel<true><<<(unsigned)items, 64, lds, s>>>(a, iou_thr(), cap));
             else
-                match_big_kernel<false><<<(unsigned)items, 64, lds, s>>>(a, iou_thr(), cap);
+                TAO_TIMED("match_big_kernel", s, match_big_kernel<false><<<(unsigned)items, 64, lds, s>>>(a, iou_thr(), cap));
         }
     }
     TAO_LAUNCH_CHECK();
@@ -759,9 +759,9 @@ extern "C" int taoamd_gather_rows(int64_t n, int32_t n_words,
     if (n_words < 1 || src_stride < n_words) return TAOAMD_ERR_ARG;
     const int64_t total = n * n_words;
     unsigned blocks = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    gather_rows_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(
+    TAO_TIMED("gather_rows_kernel", (hipStream_t)stream, gather_rows_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(
         n, n_words, src_matched, src_ignored, src_stride, order, dst_matched,
-        dst_ignored);
+        dst_ignored));
     TAO_LAUNCH_CHECK();
     return TAOAMD_OK;
 }

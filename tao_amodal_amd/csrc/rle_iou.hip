@@ -258,18 +258,18 @@ extern "C" int taoamd_rle_iou(int64_t n_cells, const int32_t *cell_dt_off,
     a.gt_pre = (const uint2 *)w; w += up256((size_t)gt_total * 8);
     a.dt_ones = (const uint32_t *)w; w += up256((size_t)n_dt * 4);
     a.gt_ones = (const uint32_t *)w;
-    rle_prefix_kernel<false><<<dim3((unsigned)((n_dt + 3) / 4)), 256, 0, s>>>(
-        n_dt, dt_off, dt_runs, (void *)a.dt_end, (uint32_t *)a.dt_ones);
+    TAO_TIMED("rle_prefix_kernel", s, rle_prefix_kernel<false><<<dim3((unsigned)((n_dt + 3) / 4)), 256, 0, s>>>(
+        n_dt, dt_off, dt_runs, (void *)a.dt_end, (uint32_t *)a.dt_ones));
     TAO_LAUNCH_CHECK();
-    rle_prefix_kernel<true><<<dim3((unsigned)((n_gt + 3) / 4)), 256, 0, s>>>(
-        n_gt, gt_off, gt_runs, (void *)a.gt_pre, (uint32_t *)a.gt_ones);
+    TAO_TIMED("rle_prefix_kernel", s, rle_prefix_kernel<true><<<dim3((unsigned)((n_gt + 3) / 4)), 256, 0, s>>>(
+        n_gt, gt_off, gt_runs, (void *)a.gt_pre, (uint32_t *)a.gt_ones));
     TAO_LAUNCH_CHECK();
     a.cell_dt_off = cell_dt_off; a.cell_gt_off = cell_gt_off;
     a.cell_iou_off = cell_iou_off;
     a.dt_off = dt_off; a.gt_off = gt_off;
     a.dt_hw = dt_hw; a.gt_hw = gt_hw; a.dt_bb = dt_bb; a.gt_bb = gt_bb;
     a.iou = iou;
-    rle_iou_kernel<<<dim3((unsigned)n_cells), RLE_THREADS, 0, s>>>(a);
+    TAO_TIMED("rle_iou_kernel", s, rle_iou_kernel<<<dim3((unsigned)n_cells), RLE_THREADS, 0, s>>>(a));
     TAO_LAUNCH_CHECK();
     return TAOAMD_OK;
 }

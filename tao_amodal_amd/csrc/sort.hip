@@ -267,14 +267,14 @@ extern "C" int taoamd_sort_by_cat_score(int64_t n, const int32_t *dt_cat,
     b.sel = b.skip + RS_PASSES;
     TAO_HIP(hipMemsetAsync(b.digit_total, 0, RS_PASSES * RS_BINS * 4, s));
     unsigned init_blocks = (unsigned)(b.n_blocks < 2048 ? b.n_blocks : 2048);
-    rs_init_kernel<<<init_blocks, RS_THREADS, 0, s>>>(b, dt_score);
-    rs_plan_kernel<<<1, RS_BINS, 0, s>>>(b);
+    TAO_TIMED("rs_init_kernel", s, rs_init_kernel<<<init_blocks, RS_THREADS, 0, s>>>(b, dt_score));
+    TAO_TIMED("rs_plan_kernel", s, rs_plan_kernel<<<1, RS_BINS, 0, s>>>(b));
     for (int p = 0; p < RS_PASSES; p++) {
-        rs_hist_kernel<<<b.n_blocks, RS_THREADS, 0, s>>>(b, p);
-        rs_scan_kernel<<<RS_BINS, RS_THREADS, 0, s>>>(b, p);
-        rs_scatter_kernel<<<b.n_blocks, RS_THREADS, 0, s>>>(b, p);
+        TAO_TIMED("rs_hist_kernel", s, rs_hist_kernel<<<b.n_blocks, RS_THREADS, 0, s>>>(b, p));
+        TAO_TIMED("rs_scan_kernel", s, rs_scan_kernel<<<RS_BINS, RS_THREADS, 0, s>>>(b, p));
+        TAO_TIMED("rs_scatter_kernel", s, rs_scatter_kernel<<<b.n_blocks, RS_THREADS, 0, s>>>(b, p));
     }
-    rs_finish_kernel<<<init_blocks, 256, 0, s>>>(b, order, dst);
+    TAO_TIMED("rs_finish_kernel", s, rs_finish_kernel<<<init_blocks, 256, 0, s>>>(b, order, dst));
     TAO_LAUNCH_CHECK();
     return TAOAMD_OK;
 }
@@ -753,14 +753,14 @@ extern "C" int taoamd_sort_segments(int64_t n, int32_t n_cat,
     a.key[1] = (uint64_t *)w; w += align256((size_t)n * 8);
     a.idx[0] = (int32_t *)w;  w += align256((size_t)n * 4);
     a.idx[1] = (int32_t *)w;
-    seg_tile_kernel<<<(unsigned)n_tiles, SEG_THREADS, 0, s>>>(a);
+    TAO_TIMED("seg_tile_kernel", s, seg_tile_kernel<<<(unsigned)n_tiles, SEG_THREADS, 0, s>>>(a));
     if (max_segment > SEG_TILE && max_segment <= (int64_t)SEG_KMERGE_TILES * SEG_TILE) {
-        seg_kmerge_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(a);
+        TAO_TIMED("seg_kmerge_kernel", s, seg_kmerge_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(a));
     } else if (max_segment > SEG_TILE) {
         int passes = 0;
         for (int64_t L = SEG_TILE; L < max_segment; L <<= 1) passes++;
         for (int p = 0; p < passes; p++)
-            seg_mpass_kernel<<<(unsigned)n_tiles, 256, 0, s>>>(a, p, p == passes - 1);
+            TAO_TIMED("seg_mpass_kernel", s, seg_mpass_kernel<<<(unsigned)n_tiles, 256, 0, s>>>(a, p, p == passes - 1));
     }
     TAO_LAUNCH_CHECK();
     return TAOAMD_OK;

@@ -418,10 +418,10 @@ extern "C" int taoamd_track_iou(int64_t n_cells, const int32_t *cell_dt_off,
     if (mode < 0 || mode > 2) return TAOAMD_ERR_ARG;
     if (pair_frames) TAO_HIP(hipMemsetAsync(pair_frames, 0, 8, s));
     if (n_pairs == 0) return TAOAMD_OK;
-    track_iou_kernel<<<(unsigned)((n_pairs + 255) / 256), 256, 0, s>>>(
+    TAO_TIMED("track_iou_kernel", s, track_iou_kernel<<<(unsigned)((n_pairs + 255) / 256), 256, 0, s>>>(
         n_cells, cell_dt_off, cell_gt_off, cell_iou_off, n_pairs, dt_frame_off,
         dt_frame_pos, dt_frame_box, gt_frame_off, gt_frame_pos, gt_frame_box,
-        iou, (unsigned long long *)pair_frames, mode);
+        iou, (unsigned long long *)pair_frames, mode));
     TAO_LAUNCH_CHECK();
     return TAOAMD_OK;
 }
@@ -443,9 +443,10 @@ extern "C" int taoamd_track_iou_planned(int64_t n_tasks, const int32_t *tasks,
         return TAOAMD_ERR_ARG;
     unsigned long long *pf = (unsigned long long *)pair_frames;
 #define TT_LAUNCH(M)                                                           \
-    track_iou_task_kernel<M><<<(unsigned)n_tasks, 64, 0, s>>>(                 \
-        (const int4 *)tasks, task_rows, task_pairs, task_out,                  \
-        (const double4 *)padded, (const int4 *)trk_meta, iou, pf)
+    TAO_TIMED("track_iou_task_kernel", s,                                      \
+              track_iou_task_kernel<M><<<(unsigned)n_tasks, 64, 0, s>>>(       \
+                  (const int4 *)tasks, task_rows, task_pairs, task_out,        \
+                  (const double4 *)padded, (const int4 *)trk_meta, iou, pf))
     if (mode == 0) TT_LAUNCH(0);
     else if (mode == 1) TT_LAUNCH(1);
     else TT_LAUNCH(2);
@@ -466,15 +467,15 @@ extern "C" int taoamd_track_pad(int64_t n_trk, int64_t n_frames,
         return TAOAMD_ERR_ARG;
     if (n_slots > 0) {
         if (!padded) return TAOAMD_ERR_ARG;
-        track_pad_fill_kernel<<<(unsigned)((n_slots + 255) / 256), 256, 0, s>>>(
-            n_slots, (double4 *)padded + slot_first);
+        TAO_TIMED("track_pad_fill_kernel", s, track_pad_fill_kernel<<<(unsigned)((n_slots + 255) / 256), 256, 0, s>>>(
+            n_slots, (double4 *)padded + slot_first));
     }
     if (n_frames > 0) {
         if (!frame_off || !frame_pos || !frame_box || !meta || !padded)
             return TAOAMD_ERR_ARG;
-        track_pad_kernel<<<(unsigned)((n_frames + 255) / 256), 256, 0, s>>>(
+        TAO_TIMED("track_pad_kernel", s, track_pad_kernel<<<(unsigned)((n_frames + 255) / 256), 256, 0, s>>>(
             n_frames, n_trk, frame_off, frame_pos, (const double4 *)frame_box,
-            (const int4 *)meta, (double4 *)padded);
+            (const int4 *)meta, (double4 *)padded));
     }
     TAO_LAUNCH_CHECK();
     return TAOAMD_OK;

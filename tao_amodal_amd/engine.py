@@ -446,6 +446,8 @@ STAGES = (("ranges", stage_ranges), ("sort", stage_sort),
 
 def run(dp, ws):
     """Launch one evaluator pass on the current stream (asynchronous)."""
+    if _lib.TIMING:
+        _lib.kernel_timing_label(dp.kind)
     for _, fn in STAGES:
         fn(dp, ws)
 
@@ -582,6 +584,8 @@ def run_forked(dp, ws, aux, head_only=False):
     track level  (ranges, sort) || 3D IoU -> match -> accumulate."""
     cur = torch.cuda.current_stream(dp.device)
     aux.wait_stream(cur)
+    if _lib.TIMING:
+        _lib.kernel_timing_label(dp.kind)
     if dp.kind == "lvis":
         with torch.cuda.stream(aux):
             stage_ranges(dp, ws)

@@ -27,6 +27,14 @@ def lib():
     return _lib
 
 
+def set_threads(n):
+    """OpenMP threads of the oracle's cell / category loops (1 = the scalar
+    port; 0 = all host cores).  Returns the number now in use."""
+    n = int(n) if n else int(lib().orc_max_threads())
+    lib().orc_set_threads(C.c_int(n))
+    return n
+
+
 def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 

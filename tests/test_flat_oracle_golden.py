@@ -172,3 +172,26 @@ def test_lvis_without_categories_flatten_and_c_oracle(name):
     f = fl.flatten_lvis(GTColumns.from_json(gtj), DTColumns.from_json(predj),
                         use_cats=False)
     nocats_check.check(f, orclib.run_flat(f), name)
+
+
+def test_oracle_threads_do_not_change_results():
+    """The all-cores CPU baseline of bench.py = the same oracle with OpenMP
+    over cells / categories: bit-identical to the single-thread run."""
+    import orclib
+    from tao_amodal_amd.synth import synth
+    gt, dt = synth(seed=5, V=6, F=25, C=40, dets_per_frame=30)
+    fl_ = fl.flatten_lvis(gt, dt)
+    dt.track_id, _ = fl.make_track_ids_unique(dt)
+    ft_ = fl.flatten_tao(gt, dt)
+    try:
+        for f in (fl_, ft_):
+            orclib.set_threads(1)
+            a = orclib.run_flat(f)
+            assert orclib.set_threads(0) >= 1
+            b = orclib.run_flat(f)
+            for k in ("matched", "ignored", "precision", "recall", "order", "num_gt"):
+                assert np.array_equal(a[k], b[k]), k
+            if f.kind == "tao":
+                assert np.array_equal(a["iou"], b["iou"]) and a["pairs"] == b["pairs"]
+    finally:
+        orclib.set_threads(1)
