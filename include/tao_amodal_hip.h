@@ -267,10 +267,67 @@ int taoamd_match(int64_t n_cells, const int32_t *cell_dt_off,
                  int32_t n_groups, const int32_t *singles, int32_t n_singles,
                  void *stream);
 
+/* ---- cell-table build, detection side (csrc/flatten.hip) ----------------------
+ * The per-box half of what the reference does with dicts in L/results.py:20-84,
+ * L/lvis.py:90-96, L/eval.py:59-110 (and the T/ counterparts): the host keeps
+ * the ground-truth half and everything that is O(cells) (flatten_dev.py).
+ *
+ * taoamd_flat_map     image / category ids -> their positions in the sorted
+ *                     unique id lists of the ground truth (-1 = unknown),
+ *                     area = w * h unless `area_in` is given,
+ *                     boxes per image (img_count[n_img + 1]) and their
+ *                     exclusive scan (img_start[n_img + 1]); status[0] = boxes
+ *                     of unknown images, status[1] = most boxes in one image
+ * taoamd_flat_rank_drop   dropped[d] = 1 for boxes beyond the best max_dets of
+ *                     their image; `order` = the stable sort by (image, -score)
+ * taoamd_flat_filter  key[d] = cat * n_unit + unit for boxes that survive the
+ *                     known-category, 0 < area < inf and federated filters
+ *                     (the cell has ground truth: key in sorted gkeys; or the
+ *                     category is in the unit's negative list), INT32_MAX for
+ *                     the others; flags[d] = DT_IGNORE_UNMATCHED when the
+ *                     category is in the unit's not-exhaustive list (or, with
+ *                     area_flag, the area is outside [0, 1e10]); *n_keep =
+ *                     survivors.  unit_row[unit] = row of the CSR lists
+ * taoamd_flat_gather  rows of the first n_keep entries of `order` (the stable
+ *                     sort by (key, -score)): source row, score, flags, key,
+ *                     category = key / n_unit, box (optional)
+ * taoamd_flat_runs    runs of equal values of a sorted key array: run_id[i],
+ *                     run_key[r], run_start[r], *n_runs
+ * taoamd_flat_remap   out[i] = map[id[i]] */
+int taoamd_flat_map(int64_t n, const int64_t *image_id, const int64_t *category_id,
+                    const double *bbox, const double *area_in, int64_t n_img,
+                    const int64_t *img_ids, int64_t n_cat, const int64_t *cat_ids,
+                    int32_t *img, int32_t *cat, double *area, int32_t *img_count,
+                    int32_t *img_start, int32_t *status, void *stream);
+int taoamd_flat_rank_drop(int64_t n, const int32_t *order, const int32_t *img,
+                          const int32_t *img_start, int32_t max_dets,
+                          uint8_t *dropped, void *stream);
+int taoamd_flat_filter(int64_t n, const int32_t *unit, const int32_t *cat,
+                       const double *area, const int64_t *category_id,
+                       const uint8_t *dropped, int32_t n_unit, int64_t n_gkeys,
+                       const int32_t *gkeys, const int32_t *unit_row,
+                       const int64_t *neg_off, const int64_t *neg_val,
+                       const int64_t *nel_off, const int64_t *nel_val,
+                       int32_t area_flag, int32_t *key, uint8_t *flags,
+                       int32_t *n_keep, void *stream);
+int taoamd_flat_gather(int64_t n_keep, const int32_t *order, const double *score,
+                       const uint8_t *flags, const int32_t *key,
+                       const double *bbox, int32_t n_unit, int32_t *dt_row,
+                       double *dt_score, uint8_t *dt_flags, int32_t *dt_key,
+                       int32_t *dt_cat, double *dt_box, void *stream);
+size_t taoamd_flat_runs_workspace(int64_t n);
+int taoamd_flat_runs(int64_t n, const int32_t *sorted_key, int32_t *run_id,
+                     int32_t *run_key, int32_t *run_start, int32_t *n_runs,
+                     void *workspace, size_t workspace_bytes, void *stream);
+int taoamd_flat_remap(int64_t n, const int32_t *id, const int32_t *map,
+                      int32_t *out, void *stream);
+
 /* ---- stable sort by (category asc, score desc) ---------------------------------
  * order[p] = detection at sorted position p; dst[d] = sorted position of
  * detection d (either may be NULL).  Ties keep input order, i.e. the
- * reference's concatenation order.  Workspace: taoamd_sort_workspace(n). */
+ * reference's concatenation order.  dt_cat: any non-negative int32 key;
+ * dt_score may be NULL (integer key alone).  Workspace:
+ * taoamd_sort_workspace(n). */
 size_t taoamd_sort_workspace(int64_t n);
 int taoamd_sort_by_cat_score(int64_t n, const int32_t *dt_cat,
                              const double *dt_score, int32_t *order,

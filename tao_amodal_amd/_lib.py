@@ -46,6 +46,17 @@ SIGNATURES = {
                                    _vp, _vp]),
     "taoamd_track_iou_plan_host": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp,
                                              _vp, _vp, _vp, _vp]),
+    "taoamd_flat_map": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp,
+                                  _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "taoamd_flat_rank_drop": (C.c_int, [_i64, _vp, _vp, _vp, _i32, _vp, _vp]),
+    "taoamd_flat_filter": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _i32, _i64,
+                                     _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp,
+                                     _vp, _vp]),
+    "taoamd_flat_gather": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _i32, _vp,
+                                     _vp, _vp, _vp, _vp, _vp, _vp]),
+    "taoamd_flat_runs_workspace": (_sz, [_i64]),
+    "taoamd_flat_runs": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "taoamd_flat_remap": (C.c_int, [_i64, _vp, _vp, _vp, _vp]),
     "taoamd_match": (C.c_int, [_i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32,
                                _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp,
                                _vp, _vp, _vp, _i32, _vp, _i32, _vp]),

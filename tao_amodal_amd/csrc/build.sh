@@ -8,7 +8,7 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 OUT=../libtao_amodal_hip.so
 $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared \
     -ffp-contract=off -fno-fast-math -Wall -Wno-unused-result \
-    api.hip iou_match.hip track_iou.hip sort.hip accumulate.hip exchange.hip rle_iou.hip -o $OUT "$@"
+    api.hip iou_match.hip track_iou.hip flatten.hip sort.hip accumulate.hip exchange.hip rle_iou.hip -o $OUT "$@"
 echo "built $(realpath $OUT)"
 # host-only: columnar JSON ingest, run-length masks (no GPU code)
 g++ -O3 -std=c++17 -fPIC -shared -fopenmp -Wall -ffp-contract=off ingest.cpp rle.cpp -o ../libtao_amodal_ingest.so

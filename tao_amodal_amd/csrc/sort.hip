@@ -7,7 +7,9 @@
 // order, so any stable sort on the key (category, -score) reproduces it.
 //
 // Key digits, least significant first: 8 x 8 bits of the order-preserving
-// transform of -score (descending), then 2 x 8 bits of the category index.
+// transform of -score (descending), then 4 x 8 bits of the category index
+// (any non-negative int32: the flatten stage sorts by cell keys with it; a
+// NULL score sorts by the integer key alone).
 // A pass whose digit is the same for every element (e.g. the sign/exponent
 // byte of scores in (0,1)) is detected from the global digit histograms and
 // skipped on the device without host involvement.
@@ -24,7 +26,7 @@ using namespace taoamd;
 #define RS_ITEMS 8                           // rounds of 64 per wave
 #define RS_TILE (RS_THREADS * RS_ITEMS)      // 2048 elements per block
 #define RS_BINS 256
-#define RS_PASSES 10
+#define RS_PASSES 12
 
 struct SortBufs {
     uint64_t *key[2];
@@ -63,7 +65,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_init_kernel(
     __syncthreads();
     for (int64_t i = blockIdx.x * (int64_t)RS_THREADS + threadIdx.x; i < b.n;
          i += (int64_t)gridDim.x * RS_THREADS) {
-        uint64_t k = desc_key(score[i]);
+        uint64_t k = score ? desc_key(score[i]) : 0;
         b.key[0][i] = k;
         b.idx[0][i] = (int32_t)i;
 #pragma unroll
@@ -249,7 +251,7 @@ extern "C" int taoamd_sort_by_cat_score(int64_t n, const int32_t *dt_cat,
 {
     if (n == 0) return TAOAMD_OK;
     if (n > 0x7fffffff) return TAOAMD_ERR_TOO_LARGE;
-    if (!dt_cat || !dt_score || !workspace) return TAOAMD_ERR_ARG;
+    if (!dt_cat || !workspace) return TAOAMD_ERR_ARG;
     if (workspace_bytes < taoamd_sort_workspace(n)) return TAOAMD_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     unsigned char *w = (unsigned char *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);

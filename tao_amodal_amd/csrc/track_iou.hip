@@ -124,51 +124,52 @@ __global__ __launch_bounds__(256) void track_iou_kernel(
     }
 }
 
-// Task variant (the path every planned call takes).  A task = one wavefront =
-// up to TT_ROWS tracks (of one or several cells) and up to 64 (detection
-// track, GT track) pairs among them; the workgroup IS the wavefront, so
-// nothing in here waits for another wave and 6 tasks are resident per CU
-// (24 KB of LDS each).
+// Task variant (the path every planned call takes).  A task = up to TT_ROWS
+// tracks (of one or several cells) and up to 64 (detection track, GT track)
+// pairs among them, run by a workgroup of TWO wavefronts with separate jobs:
+//
+//   stager  (wave 0) fetches the tracks' frames and parks them in LDS,
+//   adder   (wave 1) lane = track pair, adds the per-frame terms in order.
+//
+// They meet at one barrier per chunk of TT_P timeline positions; the frames
+// live in two LDS buffers, so the stager fills chunk k + 1 while the adder
+// walks chunk k, and the loads of chunks k + 2 and k + 3 are in flight
+// meanwhile (two register sets).  The adder's instruction stream -- the one that bounds the
+// kernel: 13 fp64 operations per pair and position, a chain of dependent adds
+// -- therefore never waits for global memory or for the staging arithmetic.
+// 24 KB of LDS per task: 6 tasks = 12 wavefronts per CU.
 //
 // Tracks are read from the PADDED frame table (taoamd_track_pad): the frames
 // of a track occupy consecutive slots first .. last of the timeline, a
 // position the track skips holds the "far box" (x = y = 1e300, w = h = 0), and
 // so does slot 0 of the table.  The frame of track t at position p is
-// padded[basem_t + p] -- no cursor, no search, no dependence between chunks:
-// the loads of chunk k + 1 are issued before the arithmetic of chunk k and
-// land in registers meanwhile.
+// padded[basem_t + p] -- no cursor, no search, no dependence between chunks.
 //
-// The timeline is walked in chunks of TT_P positions.  Per chunk:
-//   stage   16 consecutive lanes = 16 consecutive positions of one track
-//           (512 contiguous bytes; positions outside first .. last read slot
-//           0); the boxes are parked in LDS as (x1, y1, x2 = x + w,
-//           y2 = y + h, area = w * h) at [track][position - p0].  Rows that
-//           do not reach into the chunk are not touched (wiped once if they
-//           held frames before); the plan lists a task's tracks by first
-//           position, so whole rounds of four rows drop out.
-//   add     lane = (detection track, GT track) pair walks the 16 positions in
-//           ascending order: i_ = max(min(x2) - max(x1), 0) * max(.., 0),
-//           u_ = (da + ga) - i_, u += u_, i += i_  -- the reference's
+//   stage   TT_P consecutive lanes = TT_P consecutive positions of one track
+//           (contiguous bytes; positions outside first .. last read slot 0);
+//           the boxes are parked as (x1, y1, x2 = x + w, y2 = y + h, area =
+//           w * h) at [track][position - p0].  Rows that do not reach into
+//           the chunk are not touched (wiped once if they held frames
+//           before); the plan lists a task's tracks by first position, so
+//           whole rounds of rows drop out.
+//   add     i_ = max(min(x2) - max(x1), 0) * max(.., 0), u_ = (da + ga) - i_,
+//           u += u_, i += i_ in ascending position -- the reference's
 //           per-frame arithmetic (tao_amodal/eval.py:32-48, 87-94) with no
 //           case split: against the far box the intersection is exactly 0 and
 //           the union term is exactly the other box's area (x + 0 = x), and
 //           two far boxes give (0, 0), whose addition is exact (u, i >= +0).
 //           So the sequence of roundings equals the reference's walk over the
 //           union of the two tracks' frames in timeline order.
-// Chunks in which no track of the task has a frame are skipped; chunks that
-// only hold GT frames add the areas alone.
-#ifndef TT_P
-#define TT_P 16                  // timeline positions per chunk (8 or 16)
-#endif
+// Chunks in which no track of the task has a frame are skipped by the adder;
+// chunks that only hold GT frames add the areas alone.
+#define TT_P 8                   // timeline positions per chunk
 #define TT_ROWS 36               // tracks of a task
-#define TT_RS (5 * TT_P + 2)     // doubles per row: rows 16-byte aligned, 36 / 20 banks apart
-#define TT_GROUPS (64 / TT_P)    // rows served by one round of the wavefront
+#define TT_RS (5 * TT_P + 2)     // doubles per row: rows 16-byte aligned, 20 banks apart
+#define TT_GROUPS (64 / TT_P)    // rows served by one round of the stager
 #define TT_ROUNDS ((TT_ROWS + TT_GROUPS - 1) / TT_GROUPS)
 #define TT_SLOTS (TT_ROUNDS * TT_GROUPS)
 #define TT_FAR 1e300
-#ifndef TT_AHEAD
-#define TT_AHEAD 1               // chunks between a load and its use
-#endif
+#define TT_SETS 2                // chunks between a load and its use (even)
 
 // v_max_f64 / v_min_f64 as such: fmax() / fmin() make the compiler canonicalise
 // every operand it cannot prove free of signalling NaNs (one extra v_max_f64
@@ -192,113 +193,164 @@ __device__ __forceinline__ double tt_pos(double a)       // max(a, 0)
     return r;
 }
 
+// The chunk barrier of the two waves.  __syncthreads() would also drain the
+// stager's global loads (its fence covers global memory: s_waitcnt vmcnt(0)),
+// i.e. wait at every chunk for the prefetch that was just issued; the waves
+// only exchange LDS data, so LDS traffic is all the barrier has to order.
+__device__ __forceinline__ void tt_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 template <int MODE>
-__global__ __launch_bounds__(64) void track_iou_task_kernel(
+__global__ __launch_bounds__(128) void track_iou_task_kernel(
     const int4 *__restrict__ tasks, const int32_t *__restrict__ task_rows,
     const int32_t *__restrict__ task_pairs, const int64_t *__restrict__ task_out,
     const double4 *__restrict__ padded, const int4 *__restrict__ trk_meta,
     double *__restrict__ iou, unsigned long long *__restrict__ pair_frames)
 {
-    __shared__ __align__(16) double rows[TT_ROWS * TT_RS];
+    __shared__ __align__(16) double rows[2][TT_ROWS * TT_RS];
     __shared__ int4 meta[TT_SLOTS];
-    __shared__ uint32_t rmask[TT_SLOTS];  // positions of the chunk that hold a frame
+    __shared__ uint32_t rmask[2][TT_SLOTS];   // positions of the chunk that hold a frame
+    __shared__ uint32_t flags[2][2];          // {any frame, any detection frame} of the chunk
+    __shared__ int32_t span[2];               // first chunk start, last position
 
-    const int lane = threadIdx.x, grp = lane / TT_P, j = lane % TT_P;
-    const int4 tk = tasks[blockIdx.x];    // {first row, rows, first pair, pairs}
+    const int lane = threadIdx.x & 63;
+    const bool stager = threadIdx.x < 64;     // wave-uniform
+    const int4 tk = tasks[blockIdx.x];        // {first row, rows, first pair, pairs}
     const int n_rows = tk.y, n_pairs = tk.w;
 
-    // ---- {first, last, base - first, is detection} of the task's tracks
-    int32_t p_lo = INT32_MAX, p_hi = -1;
-    if (lane < TT_SLOTS) {
-        int4 m = make_int4(INT32_MAX, -1, 0, 0);       // no track: never in range
-        if (lane < n_rows) m = trk_meta[task_rows[tk.x + lane]];
-        if (m.y >= m.x) {
-            p_lo = m.x;
-            p_hi = m.y;
+    if (stager) {
+        // ---- {first, last, base - first, is detection} of the task's tracks
+        int32_t p_lo = INT32_MAX, p_hi = -1;
+        if (lane < TT_SLOTS) {
+            int4 m = make_int4(INT32_MAX, -1, 0, 0);       // no track: never in range
+            if (lane < n_rows) m = trk_meta[task_rows[tk.x + lane]];
+            if (m.y >= m.x) {
+                p_lo = m.x;
+                p_hi = m.y;
+            }
+            meta[lane] = m;
+            rmask[0][lane] = rmask[1][lane] = 0;
         }
-        meta[lane] = m;
-        rmask[lane] = 0;
+        for (int s = lane; s < 2 * TT_ROWS * TT_P; s += 64) {
+            const int b = s / (TT_ROWS * TT_P), t = s % (TT_ROWS * TT_P);
+            double *rb = rows[b] + (t / TT_P) * TT_RS + (t % TT_P);
+            rb[0] = rb[TT_P] = rb[2 * TT_P] = rb[3 * TT_P] = TT_FAR;
+            rb[4 * TT_P] = 0.0;
+        }
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) {
+            p_lo = min(p_lo, __shfl_xor(p_lo, s));
+            p_hi = max(p_hi, __shfl_xor(p_hi, s));
+        }
+        if (lane == 0) {
+            span[0] = p_lo & ~(TT_P - 1);
+            span[1] = p_hi;
+        }
     }
+    __syncthreads();
+    const int32_t p_first = span[0], p_hi = span[1];
+    const int n_chunks = p_hi < 0 ? 0 : (p_hi - p_first) / TT_P + 1;
+
+    if (stager) {
+        const int grp = lane / TT_P, j = lane % TT_P;
+        // lane (grp, j) serves position j of the rows grp, TT_GROUPS + grp, ...
+        int32_t F[TT_ROUNDS], L[TT_ROUNDS], M[TT_ROUNDS];
+        uint32_t isdt = 0;
+#pragma unroll
+        for (int q = 0; q < TT_ROUNDS; q++) {
+            const int4 m = meta[TT_GROUPS * q + grp];
+            F[q] = m.x;
+            L[q] = m.y;
+            M[q] = m.z;
+            isdt |= (uint32_t)(m.w & 1) << q;
+        }
+        // TT_SETS register sets: the loads of chunk k + TT_SETS are issued when
+        // chunk k has been staged.  Every round loads (lanes out of range read
+        // slot 0), so the number of loads in flight is known at compile time
+        // and a chunk waits for ITS loads only (s_waitcnt vmcnt(n > 0)).
+        double4 B[TT_SETS][TT_ROUNDS];
+        uint32_t wiped[2] = {~0u, ~0u};   // bit q: round q's row holds far boxes in buffer b
+
+        auto issue = [&](double4 *Bx, int32_t pc) {
+            const int32_t p = pc + j;
+#pragma unroll
+            for (int q = 0; q < TT_ROUNDS; q++) {
+                const bool in = p >= F[q] && p <= L[q];
+                Bx[q] = padded[in ? M[q] + p : 0];      // slot 0: the far box
+            }
+        };
+        auto stage = [&](const double4 *Bx, int32_t pc, int b) {
+            uint64_t any = 0, anydt = 0;
+            uint32_t wp = wiped[b];
+#pragma unroll
+            for (int q = 0; q < TT_ROUNDS; q++) {
+                const int r = TT_GROUPS * q + grp;
+                const bool ov = F[q] < pc + TT_P && L[q] >= pc;   // same for the row's lanes
+                const bool act = ov || !((wp >> q) & 1u);
+                if (__ballot(act) == 0) continue;
+                const double4 bx = Bx[q];
+                const bool present = bx.x != TT_FAR;
+                const uint64_t ball = __ballot(present);
+                any |= ball;
+                anydt |= __ballot(present && ((isdt >> q) & 1u));
+                if (act) {
+                    double *rb = rows[b] + r * TT_RS + j;
+                    rb[0] = bx.x;
+                    rb[TT_P] = bx.y;
+                    rb[2 * TT_P] = bx.x + bx.z;
+                    rb[3 * TT_P] = bx.y + bx.w;
+                    rb[4 * TT_P] = bx.z * bx.w;
+                    if (j == 0)
+                        rmask[b][r] = (uint32_t)(ball >> (TT_P * grp)) & ((1u << TT_P) - 1);
+                }
+                wp = ov ? wp & ~(1u << q) : wp | (1u << q);
+            }
+            wiped[b] = wp;
+            if (lane == 0) {
+                flags[b][0] = any != 0;
+                flags[b][1] = anydt != 0;
+            }
+        };
+        // chunk c lives in register set c % TT_SETS and in LDS buffer c & 1
+#pragma unroll
+        for (int c = 0; c < TT_SETS; c++) issue(B[c], p_first + c * TT_P);
+        if (n_chunks > 0) stage(B[0], p_first, 0);
+        issue(B[0], p_first + TT_SETS * TT_P);
+        tt_barrier();
+        for (int k = 0; k < n_chunks; k += TT_SETS) {
+#pragma unroll
+            for (int a = 1; a <= TT_SETS; a++) {
+                // the adder is on chunk k + a - 1: fill the other buffer with
+                // chunk k + a
+                const int c = k + a;
+                if (c - 1 >= n_chunks) break;
+                if (c < n_chunks) stage(B[a % TT_SETS], p_first + c * TT_P, a & 1);
+                issue(B[a % TT_SETS], p_first + (c + TT_SETS) * TT_P);
+                tt_barrier();
+            }
+        }
+        return;
+    }
+
+    // ---- adder
     int32_t pr = 0;
     int64_t out = 0;
     if (lane < n_pairs) {
         pr = task_pairs[tk.z + lane];
         out = task_out[tk.z + lane];
     }
-    for (int s = lane; s < TT_ROWS * TT_P; s += 64) {
-        double *rb = rows + (s / TT_P) * TT_RS + (s % TT_P);
-        rb[0] = rb[TT_P] = rb[2 * TT_P] = rb[3 * TT_P] = TT_FAR;
-        rb[4 * TT_P] = 0.0;
-    }
-#pragma unroll
-    for (int s = 32; s > 0; s >>= 1) {
-        p_lo = min(p_lo, __shfl_xor(p_lo, s));
-        p_hi = max(p_hi, __shfl_xor(p_hi, s));
-    }
-    __syncthreads();     // one wave: a compiler-level fence, no s_barrier
-    // lane (grp, j) serves position j of the rows grp, TT_GROUPS + grp, ...
-    int32_t F[TT_ROUNDS], L[TT_ROUNDS], M[TT_ROUNDS];
-    uint32_t isdt = 0;
-#pragma unroll
-    for (int q = 0; q < TT_ROUNDS; q++) {
-        const int4 m = meta[TT_GROUPS * q + grp];
-        F[q] = m.x;
-        L[q] = m.y;
-        M[q] = m.z;
-        isdt |= (uint32_t)(m.w & 1) << q;
-    }
-    // TT_AHEAD register sets: the loads of chunk k + TT_AHEAD are issued when
-    // chunk k is staged.  Every round loads (lanes out of range read slot 0),
-    // so the number of loads in flight is known at compile time and a chunk
-    // waits for ITS loads only (s_waitcnt vmcnt(n > 0)).
-    double4 B[TT_AHEAD][TT_ROUNDS];
-    uint32_t wiped = ~0u;        // bit q: the slots of round q's row hold far boxes
-
-    auto issue = [&](double4 *Bx, int32_t pc) {
-        const int32_t p = pc + j;
-#pragma unroll
-        for (int q = 0; q < TT_ROUNDS; q++) {
-            const bool in = p >= F[q] && p <= L[q];
-            Bx[q] = padded[in ? M[q] + p : 0];      // slot 0: the far box
-        }
-    };
-    uint64_t any, anydt;
-    auto stage = [&](const double4 *Bx, int32_t pc) {
-        any = 0;
-        anydt = 0;
-#pragma unroll
-        for (int q = 0; q < TT_ROUNDS; q++) {
-            const int r = TT_GROUPS * q + grp;
-            const bool ov = F[q] < pc + TT_P && L[q] >= pc;     // same for the row's 16 lanes
-            const bool act = ov || !((wiped >> q) & 1u);
-            if (__ballot(act) == 0) continue;
-            const double4 b = Bx[q];
-            const bool present = b.x != TT_FAR;
-            const uint64_t ball = __ballot(present);
-            any |= ball;
-            anydt |= __ballot(present && ((isdt >> q) & 1u));
-            if (act) {
-                double *rb = rows + r * TT_RS + j;
-                rb[0] = b.x;
-                rb[TT_P] = b.y;
-                rb[2 * TT_P] = b.x + b.z;
-                rb[3 * TT_P] = b.y + b.w;
-                rb[4 * TT_P] = b.z * b.w;
-                if (j == 0) rmask[r] = (uint32_t)(ball >> (TT_P * grp)) & ((1u << TT_P) - 1);
-            }
-            wiped = ov ? wiped & ~(1u << q) : wiped | (1u << q);
-        }
-    };
-
+    const int rowd = pr & 0xFF, rowg = (pr >> 8) & 0xFF;
     double u = 0.0, i = 0.0;
     unsigned long long common = 0;
-    const int rowd = pr & 0xFF, rowg = (pr >> 8) & 0xFF;
-    const double *__restrict__ dr = rows + rowd * TT_RS;
-    const double *__restrict__ gr = rows + rowg * TT_RS;
-    auto add = [&]() {
-        if (any == 0 || lane >= n_pairs) return;
+    auto add = [&](int b) {
+        if (!flags[b][0] || lane >= n_pairs) return;
+        const double *__restrict__ dr = rows[b] + rowd * TT_RS;
+        const double *__restrict__ gr = rows[b] + rowg * TT_RS;
+        const uint32_t dm = rmask[b][rowd], gm = rmask[b][rowg];
         if (MODE == 0) {
-            if (anydt != 0) {
+            if (flags[b][1]) {
                 // two positions per 16-byte LDS read of every field
                 const double2 *__restrict__ d2 = reinterpret_cast<const double2 *>(dr);
                 const double2 *__restrict__ g2 = reinterpret_cast<const double2 *>(gr);
@@ -330,10 +382,8 @@ __global__ __launch_bounds__(64) void track_iou_task_kernel(
 #pragma unroll
                 for (int pp = 0; pp < TT_P; pp++) u += gr[4 * TT_P + pp];
             }
-            common += __popc(rmask[rowd] & rmask[rowg]);
         } else {
             // avg_iou / imagenetvid: u = sum of per-frame scores, i = frames
-            const uint32_t dm = rmask[rowd], gm = rmask[rowg];
 #pragma unroll
             for (int pp = 0; pp < TT_P; pp++) {
                 const bool both = ((dm & gm) >> pp) & 1u, either = ((dm | gm) >> pp) & 1u;
@@ -350,25 +400,16 @@ __global__ __launch_bounds__(64) void track_iou_task_kernel(
                 u += tx;
                 i += either ? 1.0 : 0.0;
             }
-            common += __popc(dm & gm);
         }
+        common += __popc(dm & gm);
     };
-
-    int32_t p0 = p_lo & ~(TT_P - 1);
-    if (p_hi >= 0) {
-#pragma unroll
-        for (int a = 0; a < TT_AHEAD; a++) issue(B[a], p0 + a * TT_P);
-    }
-    while (p0 <= p_hi) {
-#pragma unroll
-        for (int a = 0; a < TT_AHEAD; a++) {      // register set a <-> chunk parity
-            stage(B[a], p0);
-            issue(B[a], p0 + TT_AHEAD * TT_P);    // travels while the next chunks are added up
-            __syncthreads();
-            add();
-            __syncthreads();
-            p0 += TT_P;
-        }
+    tt_barrier();
+    for (int k = 0; k < n_chunks; k += 2) {
+        add(0);
+        tt_barrier();
+        if (k + 1 >= n_chunks) break;
+        add(1);
+        tt_barrier();
     }
     if (lane < n_pairs)
         iou[out] = MODE == 0 ? (u > 0 ? i / u : 0.0) : u / i;
@@ -444,7 +485,7 @@ extern "C" int taoamd_track_iou_planned(int64_t n_tasks, const int32_t *tasks,
     unsigned long long *pf = (unsigned long long *)pair_frames;
 #define TT_LAUNCH(M)                                                           \
     TAO_TIMED("track_iou_task_kernel", s,                                      \
-              track_iou_task_kernel<M><<<(unsigned)n_tasks, 64, 0, s>>>(       \
+              track_iou_task_kernel<M><<<(unsigned)n_tasks, 128, 0, s>>>(       \
                   (const int4 *)tasks, task_rows, task_pairs, task_out,        \
                   (const double4 *)padded, (const int4 *)trk_meta, iou, pf))
     if (mode == 0) TT_LAUNCH(0);

@@ -149,9 +149,11 @@ class DeviceProblem:
         self.n_words = (self.n_rng * N_THR + 63) // 64
         self.n_cells = int(flat.n_cells)
         self.n_cat = len(flat.cat_ids)
-        self.n_dt = len(flat.dt_flags)
-        self.n_gt = len(flat.gt_flags)
+        self.n_dt = int(flat.cell_dt_off[-1])
+        self.n_gt = int(flat.cell_gt_off[-1])
         self.n_pairs = int(flat.n_pairs)
+        # tables a device-side build (flatten_dev.DeviceFlat) already holds in HBM
+        on_dev = getattr(flat, "dev", {})
         d_cnt = np.diff(flat.cell_dt_off).astype(np.int64)
         g_cnt = np.diff(flat.cell_gt_off).astype(np.int64)
         self.max_g = int(g_cnt.max()) if self.n_cells else 0
@@ -162,9 +164,21 @@ class DeviceProblem:
         iou_off = np.zeros(self.n_cells + 1, dtype=np.int64)
         np.cumsum(d_cnt * g_cnt, out=iou_off[1:])
         self.n_iou = int(iou_off[-1])
-        cat_off = np.zeros(self.n_cat + 1, dtype=np.int32)
-        np.cumsum(np.bincount(flat.dt_cat, minlength=self.n_cat),
-                  out=cat_off[1:])
+        # category-major cells (flatten.py): every category is one run of
+        # cells, of detections and of ground truths
+        cell_cat = np.asarray(flat.cell_cat)
+        self.grouped = bool(np.all(np.diff(cell_cat) >= 0))
+        if self.grouped:
+            first = np.searchsorted(cell_cat, np.arange(self.n_cat + 1), "left")
+            cat_off = np.asarray(flat.cell_dt_off)[first].astype(np.int32)
+            gt_cat_off = np.asarray(flat.cell_gt_off)[first].astype(np.int32)
+        else:
+            cat_off = np.zeros(self.n_cat + 1, dtype=np.int32)
+            np.cumsum(np.bincount(flat.dt_cat, minlength=self.n_cat),
+                      out=cat_off[1:])
+            gt_cat_off = np.zeros(self.n_cat + 1, dtype=np.int32)
+            np.cumsum(np.bincount(flat.gt_cat, minlength=self.n_cat),
+                      out=gt_cat_off[1:])
         groups, singles = match_plan(d_cnt, g_cnt)
         self.n_groups, self.n_singles = len(groups), len(singles)
         names = ["cell_dt_off", "cell_gt_off", "dt_score", "dt_flags",
@@ -177,7 +191,8 @@ class DeviceProblem:
                       "gt_frame_off", "gt_frame_pos", "gt_frame_box"]
         self.t = {}
         for n in names:
-            self.t[n] = _to_device(flat[n], self.device)
+            self.t[n] = on_dev[n].to(self.device) if n in on_dev else \
+                _to_device(flat[n], self.device)
         # iou_type="segm": run-length masks, row i = detection / ground truth
         # i of the tables (masks.MaskArrays); the IoU then comes from
         # taoamd_rle_iou instead of the boxes
@@ -202,12 +217,6 @@ class DeviceProblem:
                 self.t[side + "_rle_bb"] = torch.from_numpy(
                     np.ascontiguousarray(m.bbox).reshape(-1, 4) if len(m) else
                     np.zeros((1, 4))).to(self.device)
-        gt_cat_off = np.zeros(self.n_cat + 1, dtype=np.int32)
-        np.cumsum(np.bincount(flat.gt_cat, minlength=self.n_cat),
-                  out=gt_cat_off[1:])
-        # category-major tables (flatten.py): every category is one run
-        self.grouped = bool(np.all(np.diff(flat.dt_cat) >= 0)
-                            and np.all(np.diff(flat.gt_cat) >= 0))
         self.max_segment = int(np.diff(cat_off).max()) if self.n_cat else 0
         # hint for the sweep: longest category (0 = unknown -> chunked kernels)
         self.acc_hint = self.max_segment

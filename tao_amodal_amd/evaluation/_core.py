@@ -237,3 +237,33 @@ class LazyPointers(Mapping):
 
 def now():
     return datetime.datetime.now().strftime("%Y-%m-%d %H:%M:%S")
+
+
+def require_default_params(params, fresh, id_fields):
+    """The kernels evaluate every image / video and category of the ground
+    truth at the reference's default thresholds and ranges (compiled in).  The
+    reference lets a caller edit ``params`` before ``evaluate()``; edits this
+    path cannot honour must not pass silently, so they raise.  ``fresh`` is a
+    newly built Params of the same kind, ``id_fields`` maps a params field to
+    the ids the ground truth defines (``use_cats`` and ``iou_3d_type`` ARE
+    honoured)."""
+    for name, want in id_fields.items():
+        got = np.unique(np.asarray(getattr(params, name)))
+        if not np.array_equal(got, np.unique(np.asarray(want))):
+            raise NotImplementedError(
+                "params.%s restricts the evaluation to a subset; the HIP path "
+                "evaluates the whole ground truth (filter the inputs instead)"
+                % name)
+    for name in ("iou_thrs", "rec_thrs"):
+        if not np.array_equal(np.asarray(getattr(params, name), dtype=np.float64),
+                              getattr(fresh, name)):
+            raise NotImplementedError(
+                "params.%s differs from the reference defaults, which are "
+                "compiled into the kernels" % name)
+    for name in ("visibility_rng", "area_rng", "time_rng"):
+        if hasattr(fresh, name) and \
+                np.asarray(getattr(params, name), dtype=np.float64).tolist() != \
+                np.asarray(getattr(fresh, name), dtype=np.float64).tolist():
+            raise NotImplementedError(
+                "params.%s differs from the reference defaults, which are "
+                "compiled into the kernels" % name)

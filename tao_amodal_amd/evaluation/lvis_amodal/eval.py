@@ -12,6 +12,7 @@ import numpy as np
 
 from ... import flatten
 from .._core import (N_REC, N_THR, CellView, GpuRun, LazyIous, LazyPointers,
+                     require_default_params,
                      masked_mean, now, timed)
 from .lvis import LVIS
 from .results import LVISResults
@@ -97,6 +98,10 @@ class LVISEval:
         if self.params.iou_type not in ("bbox", "segm"):
             raise ValueError("Unknown iou_type for iou computation.")
         self.params.img_ids = list(np.unique(self.params.img_ids))
+        require_default_params(
+            self.params, Params(self.params.iou_type),
+            {"img_ids": self.lvis_gt.get_img_ids(),
+             "cat_ids": self.lvis_gt.get_cat_ids()})
         use_cats = bool(self.params.use_cats)
         with timed("flatten"):
             # use_cats = 0: class-agnostic cells, one per image (reference

@@ -10,6 +10,7 @@ from collections.abc import Mapping
 import numpy as np
 
 from .._core import (N_REC, N_THR, CellView, GpuRun, LazyIous, LazyPointers,
+                     require_default_params,
                      masked_mean, now, timed)
 from .results import TaoResults
 from .tao import Tao
@@ -109,6 +110,10 @@ class TaoEval:
         if self.params.iou_3d_type not in ("3d_iou", "avg_iou", "imagenetvid"):
             raise ValueError("Unknown iou_3d_type %r" % self.params.iou_3d_type)
         self.params.vid_ids = list(np.unique(self.params.vid_ids))
+        require_default_params(
+            self.params, Params(self.params.iou_type),
+            {"vid_ids": self.tao_gt.get_vid_ids(),
+             "cat_ids": self.tao_gt.get_cat_ids()})
         if not self.params.use_cats:
             # class-agnostic cells (reference eval.py:257-260,293-303)
             from ... import flatten

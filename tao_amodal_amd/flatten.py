@@ -235,8 +235,13 @@ class LazyRows:
 
 class Flat(dict):
     """A bag of arrays with attribute access."""
-    __getattr__ = dict.__getitem__
     __setattr__ = dict.__setitem__
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
 
 
 DENSE_TABLE_MAX = 1 << 28     # entries of a boolean membership table (256 MB)
@@ -286,6 +291,44 @@ def _cells(keys_gt, keys_dt):
 # ---------------------------------------------------------------------------
 # image level (LVISEval)
 # ---------------------------------------------------------------------------
+def lvis_gt_side(gt):
+    """Ground-truth half of the image-level tables: sorted unique image and
+    category ids, the dataset row of every image (dict semantics: the last one
+    with an id wins), and the selected annotations in sorted-image order,
+    dataset order inside (L/lvis.py:34-61,90-96)."""
+    img_ids = np.unique(gt.img_id)
+    cat_ids = np.unique(gt.cat_id)
+    # the reference keeps images in a dict keyed by id: last one wins
+    img_row = np.full(len(img_ids), -1, dtype=np.int64)
+    img_row[_lookup(img_ids, gt.img_id)] = np.arange(len(gt.img_id))
+    a_img = _lookup(img_ids, gt.ann_img)
+    a_cat = _lookup(cat_ids, gt.ann_cat)
+    alias = _last_with_same_id(gt.ann_id)
+    g_sel = np.flatnonzero(a_img >= 0)
+    g_sel = g_sel[np.argsort(a_img[g_sel], kind="stable")]
+    g_sel = g_sel[(a_cat[g_sel] >= 0) & (gt.ann_area[g_sel] > 0)
+                  & (gt.ann_area[g_sel] < np.inf)]
+    g_sel = alias[g_sel]
+    G = Flat()
+    G.img_ids, G.cat_ids, G.img_row = img_ids, cat_ids, img_row
+    G.g_sel, G.g_img, G.g_cat = g_sel, a_img[g_sel], a_cat[g_sel]
+    return G
+
+
+def lvis_gt_tables(f, gt, g_sel, keys_g, U):
+    """Ground-truth columns of a flattened image-level problem (rows g_sel,
+    already in final order)."""
+    f.gt_row = g_sel                # row of dataset["annotations"]
+    f.gt_box = np.ascontiguousarray(gt.ann_bbox[g_sel])
+    f.gt_vis = np.ascontiguousarray(gt.ann_vis[g_sel])
+    f.gt_flags = (np.where(gt.ann_ignore[g_sel] != 0, GT_IGNORE, 0)
+                  | np.where(gt.ann_oof[g_sel] != 0, GT_OOF, 0)
+                  | np.where(gt.ann_id[g_sel] == 0, GT_ID_HIDDEN, 0)
+                  ).astype(np.uint8)
+    f.gt_id = gt.ann_id[g_sel]
+    f.gt_cat = (keys_g // U).astype(I32)
+
+
 def flatten_lvis(gt: GTColumns, dt: DTColumns, max_dets=MAX_DETS,
                  use_cats=True):
     """Cell tables of LVISEval (L/eval.py:59-110).  ``use_cats=False`` builds
@@ -295,12 +338,10 @@ def flatten_lvis(gt: GTColumns, dt: DTColumns, max_dets=MAX_DETS,
     not-exhaustive flags still use the real categories), one output category."""
     if len(dt) == 0:
         raise IndexError("list index out of range")  # L/results.py:42
-    img_ids = np.unique(gt.img_id)
-    cat_ids = np.unique(gt.cat_id)
+    G = lvis_gt_side(gt)
+    img_ids, cat_ids, img_row = G.img_ids, G.cat_ids, G.img_row
+    g_sel, g_img, g_cat = G.g_sel, G.g_img, G.g_cat
     K = len(cat_ids)
-    # the reference keeps images in a dict keyed by id: last one wins
-    img_row = np.full(len(img_ids), -1, dtype=np.int64)
-    img_row[_lookup(img_ids, gt.img_id)] = np.arange(len(gt.img_id))
 
     keep = limit_dets_per_image(dt, max_dets)
     # columns of the kept detections (the boxes are gathered once, at the end)
@@ -315,17 +356,6 @@ def flatten_lvis(gt: GTColumns, dt: DTColumns, max_dets=MAX_DETS,
     d_area = (dt.bbox[:, 2] * dt.bbox[:, 3])[keep] \
         if getattr(dt, "area", None) is None else \
         np.asarray(dt.area, dtype=np.float64)[keep]
-
-    # ---- ground truth selection (sorted image order, dataset order inside)
-    a_img = _lookup(img_ids, gt.ann_img)
-    a_cat = _lookup(cat_ids, gt.ann_cat)
-    alias = _last_with_same_id(gt.ann_id)
-    g_sel = np.flatnonzero(a_img >= 0)
-    g_sel = g_sel[np.argsort(a_img[g_sel], kind="stable")]
-    g_sel = g_sel[(a_cat[g_sel] >= 0) & (gt.ann_area[g_sel] > 0)
-                  & (gt.ann_area[g_sel] < np.inf)]
-    g_sel = alias[g_sel]
-    g_img, g_cat = a_img[g_sel], a_cat[g_sel]
 
     # ---- detection selection + federated filter
     d_cat = _lookup(cat_ids, d_catid)

@@ -106,3 +106,34 @@ def test_product_path_refuses_to_run_without_gpu():
     ev = LVISEval(path("f1", "gt.json"), path("f1", "pred.json"), "bbox")
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ev.run()
+
+
+@pytest.mark.parametrize("edit", [
+    ("img_ids", lambda v: v[:1]), ("cat_ids", lambda v: v[:1]),
+    ("iou_thrs", lambda v: v[:3]), ("rec_thrs", lambda v: v[::2]),
+    ("visibility_rng", lambda v: v[:2])])
+def test_lvis_params_edits_the_kernels_cannot_honour_raise(edit):
+    """The reference lets a caller restrict / change params before evaluate();
+    this path evaluates the whole ground truth at the compiled-in thresholds,
+    so such edits must raise instead of silently giving full-set numbers."""
+    ev = LVISEval(path("f1", "gt.json"), path("f1", "pred.json"), "bbox")
+    name, fn = edit
+    setattr(ev.params, name, fn(getattr(ev.params, name)))
+    with pytest.raises(NotImplementedError, match="params." + name):
+        ev.evaluate()
+
+
+@pytest.mark.parametrize("edit", [
+    ("vid_ids", lambda v: v[:1]), ("cat_ids", lambda v: v[1:]),
+    ("iou_thrs", lambda v: v + 0.01), ("area_rng", lambda v: v[:1]),
+    ("time_rng", lambda v: [[0, 5]])])
+def test_tao_params_edits_the_kernels_cannot_honour_raise(edit):
+    gtj, predj = load_inputs("f1")
+    dt = DTColumns.from_json(predj)
+    dt.track_id, _ = flatten.make_track_ids_unique(dt)
+    gt = Tao(gtj)
+    ev = TaoEval(gt, TaoResults(gt, dt))
+    name, fn = edit
+    setattr(ev.params, name, fn(getattr(ev.params, name)))
+    with pytest.raises(NotImplementedError, match="params." + name):
+        ev.evaluate()
