@@ -276,8 +276,10 @@ int taoamd_match(int64_t n_cells, const int32_t *cell_dt_off,
  *                     unique id lists of the ground truth (-1 = unknown),
  *                     area = w * h unless `area_in` is given,
  *                     boxes per image (img_count[n_img + 1]) and their
- *                     exclusive scan (img_start[n_img + 1]); status[0] = boxes
- *                     of unknown images, status[1] = most boxes in one image
+ *                     exclusive scan (img_start[n_img + 1]), optionally the
+ *                     first box of every image (img_first[n_img], file order;
+ *                     0x7f7f7f7f = none); status[0] = boxes of unknown images,
+ *                     status[1] = most boxes in one image
  * taoamd_flat_rank_drop   dropped[d] = 1 for boxes beyond the best max_dets of
  *                     their image; `order` = the stable sort by (image, -score)
  * taoamd_flat_filter  key[d] = cat * n_unit + unit for boxes that survive the
@@ -298,7 +300,8 @@ int taoamd_flat_map(int64_t n, const int64_t *image_id, const int64_t *category_
                     const double *bbox, const double *area_in, int64_t n_img,
                     const int64_t *img_ids, int64_t n_cat, const int64_t *cat_ids,
                     int32_t *img, int32_t *cat, double *area, int32_t *img_count,
-                    int32_t *img_start, int32_t *status, void *stream);
+                    int32_t *img_start, int32_t *img_first, int32_t *status,
+                    void *stream);
 int taoamd_flat_rank_drop(int64_t n, const int32_t *order, const int32_t *img,
                           const int32_t *img_start, int32_t max_dets,
                           uint8_t *dropped, void *stream);
@@ -315,10 +318,96 @@ int taoamd_flat_gather(int64_t n_keep, const int32_t *order, const double *score
                        const double *bbox, int32_t n_unit, int32_t *dt_row,
                        double *dt_score, uint8_t *dt_flags, int32_t *dt_key,
                        int32_t *dt_cat, double *dt_box, void *stream);
+/* Track level (T/results.py:20-132, T/tao.py:108-254, T/eval.py:196-243); see
+ * csrc/flatten.hip for the stages and flatten_dev.flatten_tao_device for the
+ * order they run in.  Sort keys travel as exact doubles, negated (the radix
+ * sort is descending in its score argument).
+ *   taoamd_flat_ordscore   score of boxes in images beyond max_dets, else 0
+ *   taoamd_flat_ordinal    ordinal[d] = place of box d inside its image in the
+ *                          post-truncation list, dropped[d] = beyond max_dets
+ *   taoamd_flat_merge_cat  merged category id + its index (-1 unknown)
+ *   taoamd_flat_split64 / _compose / _gather_cols   helpers of the sorts
+ *   taoamd_flat_track_of   trk[d] = run of its track id; status[2] = a box whose
+ *                          track spans two videos (else unchanged)
+ *   taoamd_flat_keys       list-order / visiting-order / frame / timeline keys,
+ *                          track keys of the kept and of the selected boxes
+ *   taoamd_flat_track_kept per track: score (np.mean when the boxes' scores
+ *                          differ: status[1] = 1), first kept box; status[3] =
+ *                          a box whose category differs inside its track
+ *   taoamd_flat_track_sel  per track: mean area (left to right), boxes,
+ *                          distinct images, first appearance
+ *   taoamd_flat_track_filter  federated filter on the video lists, flags, key
+ *   taoamd_flat_frames     frame lists of the final tracks
+ *   taoamd_flat_scan       exclusive scan of int32 counts (start[n] = total) */
+int taoamd_flat_ordscore(int64_t n, const int32_t *img, const int32_t *img_count,
+                         const double *score, int32_t max_dets, double *out,
+                         void *stream);
+int taoamd_flat_ordinal(int64_t n, const int32_t *order, const int32_t *img,
+                        const int32_t *img_start, int32_t max_dets,
+                        int32_t *ordinal, uint8_t *dropped, void *stream);
+int taoamd_flat_merge_cat(int64_t n, const int64_t *category_id, int64_t n_merge,
+                          const int64_t *merge_src, const int64_t *merge_dst,
+                          int64_t n_cat, const int64_t *cat_ids, int64_t *merged_id,
+                          int32_t *cat, void *stream);
+int taoamd_flat_split64(int64_t n, const int64_t *key, const int32_t *order,
+                        int32_t *lo, int32_t *hi, void *stream);
+int taoamd_flat_compose(int64_t n, const int32_t *outer, const int32_t *inner,
+                        int32_t *out, void *stream);
+int taoamd_flat_gather_cols(int64_t n, const int32_t *idx, const int32_t *src_i32,
+                            int32_t *out_i32, const double *src_f64,
+                            double *out_f64, const uint8_t *src_u8,
+                            uint8_t *out_u8, void *stream);
+int taoamd_flat_track_of(int64_t n, const int32_t *order, const int32_t *run_id,
+                         const int32_t *run_start, const int64_t *video_id,
+                         int32_t *trk, int32_t *status, void *stream);
+int taoamd_flat_keys(int64_t n, const int32_t *img, const int32_t *ordinal,
+                     const uint8_t *dropped, const int32_t *cat, const double *area,
+                     const int32_t *trk, const int32_t *img_rank,
+                     const int32_t *visit_rank, const double *img_frame,
+                     const int32_t *tl_pos, double M, double *keep_key,
+                     double *visit_key, double *frame_key, double *pos_key,
+                     int32_t *trk_keep, int32_t *trk_sel, void *stream);
+int taoamd_flat_track_kept(int64_t n_runs, const int32_t *run_trk,
+                           const int32_t *run_start, int64_t n_sorted,
+                           const int32_t *order_k, const double *score,
+                           const int64_t *merged_id, double *trk_score,
+                           int32_t *trk_first_kept, int32_t *status, void *stream);
+int taoamd_flat_track_sel(int64_t n_runs, const int32_t *run_trk,
+                          const int32_t *run_start, int64_t n_sorted,
+                          const int32_t *order_s, const double *area,
+                          const double *visit_key, const int32_t *img,
+                          double *sel_area, int32_t *sel_len, int32_t *sel_frames,
+                          double *sel_first, void *stream);
+int taoamd_flat_track_filter(int64_t n_runs, const int32_t *run_trk,
+                             const int32_t *sel_len, const int32_t *trk_first_kept,
+                             const int32_t *cat, const int64_t *merged_id,
+                             const int64_t *video_id, const int64_t *track_id,
+                             int64_t n_vid, const int64_t *vid_ids, int64_t n_gkeys,
+                             const int32_t *gkeys, const int32_t *vid_row,
+                             const int64_t *neg_off, const int64_t *neg_val,
+                             const int64_t *nel_off, const int64_t *nel_val,
+                             int32_t *key, uint8_t *flags, int32_t *n_keep,
+                             int32_t *status, void *stream);
+int taoamd_flat_frames(int64_t n_trk, const int32_t *trk_run,
+                       const int32_t *run_start, int64_t n_runs, int64_t n_sorted,
+                       const int32_t *order_s, const int32_t *img,
+                       const int32_t *tl_pos, const double *bbox,
+                       const int32_t *frame_off, int32_t *frame_pos,
+                       double *frame_box, void *stream);
+int taoamd_flat_scan(int64_t n, const int32_t *count, int32_t *start,
+                     int32_t *status2, void *stream);
 size_t taoamd_flat_runs_workspace(int64_t n);
 int taoamd_flat_runs(int64_t n, const int32_t *sorted_key, int32_t *run_id,
                      int32_t *run_key, int32_t *run_start, int32_t *n_runs,
                      void *workspace, size_t workspace_bytes, void *stream);
+int taoamd_flat_runs_by(int64_t n, const int32_t *key, const int32_t *order,
+                        int32_t *run_id, int32_t *run_key, int32_t *run_start,
+                        int32_t *n_runs, void *workspace, size_t workspace_bytes,
+                        void *stream);
+int taoamd_flat_runs64_by(int64_t n, const int64_t *key, const int32_t *order,
+                          int32_t *run_id, int64_t *run_key, int32_t *run_start,
+                          int32_t *n_runs, void *workspace, size_t workspace_bytes,
+                          void *stream);
 int taoamd_flat_remap(int64_t n, const int32_t *id, const int32_t *map,
                       int32_t *out, void *stream);
 

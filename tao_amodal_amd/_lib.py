@@ -47,7 +47,33 @@ SIGNATURES = {
     "taoamd_track_iou_plan_host": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp,
                                              _vp, _vp, _vp, _vp]),
     "taoamd_flat_map": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp,
-                                  _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+                                  _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "taoamd_flat_ordscore": (C.c_int, [_i64, _vp, _vp, _vp, _i32, _vp, _vp]),
+    "taoamd_flat_ordinal": (C.c_int, [_i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
+    "taoamd_flat_merge_cat": (C.c_int, [_i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp,
+                                        _vp, _vp]),
+    "taoamd_flat_split64": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp]),
+    "taoamd_flat_compose": (C.c_int, [_i64, _vp, _vp, _vp, _vp]),
+    "taoamd_flat_gather_cols": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                          _vp]),
+    "taoamd_flat_track_of": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "taoamd_flat_keys": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                   _vp, _vp, C.c_double, _vp, _vp, _vp, _vp, _vp,
+                                   _vp, _vp]),
+    "taoamd_flat_track_kept": (C.c_int, [_i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp,
+                                         _vp, _vp, _vp]),
+    "taoamd_flat_track_sel": (C.c_int, [_i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp,
+                                        _vp, _vp, _vp, _vp, _vp]),
+    "taoamd_flat_track_filter": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                           _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp,
+                                           _vp, _vp, _vp, _vp, _vp, _vp]),
+    "taoamd_flat_frames": (C.c_int, [_i64, _vp, _vp, _i64, _i64, _vp, _vp, _vp,
+                                     _vp, _vp, _vp, _vp, _vp]),
+    "taoamd_flat_scan": (C.c_int, [_i64, _vp, _vp, _vp, _vp]),
+    "taoamd_flat_runs_by": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz,
+                                      _vp]),
+    "taoamd_flat_runs64_by": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                        _sz, _vp]),
     "taoamd_flat_rank_drop": (C.c_int, [_i64, _vp, _vp, _vp, _i32, _vp, _vp]),
     "taoamd_flat_filter": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _i32, _i64,
                                      _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp,

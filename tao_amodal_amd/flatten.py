@@ -486,17 +486,52 @@ def _unique_frames(trk_of, pos_of, n_trk):
     return sel, off
 
 
-def flatten_tao(gt: GTColumns, dt: DTColumns, max_dets=MAX_DETS,
-                use_cats=True):
-    """``dt.track_id`` must already be unique per video (the CLI runs
-    make_track_ids_unique first; T/results.py:111-119 asserts it).
+def track_frames(tl_pos, trk_order, trk_of_ann, aoff, ann_rows, img_idx_of_ann,
+                 boxes):
+    """Frame lists of the tracks `trk_order` (final, cell order).  The
+    annotations are grouped by track (CSR `aoff`) in frame_index order."""
+    pos = tl_pos[img_idx_of_ann]
+    if len(pos) > 1:
+        rising = pos[1:] > pos[:-1]
+        rising[aoff[1:-1][aoff[1:-1] < len(pos)] - 1] = True   # track boundaries
+    if len(pos) <= 1 or rising.all():
+        # every track already lists distinct images in timeline order (the
+        # usual case): the result is just the tracks' segments, permuted
+        lens = np.diff(aoff)[trk_order]
+        off = np.zeros(len(trk_order) + 1, dtype=np.int64)
+        np.cumsum(lens, out=off[1:])
+        rows = np.repeat(aoff[:-1][trk_order] - off[:-1], lens) + \
+            np.arange(int(off[-1]))
+    else:
+        # renumber tracks to their final (cell) position, sort, keep the
+        # last annotation of every (track, image)
+        new_of_old = np.full(int(trk_of_ann.max()) + 1 if len(trk_of_ann)
+                             else 0, -1, dtype=np.int64)
+        new_of_old[trk_order] = np.arange(len(trk_order))
+        nt = new_of_old[trk_of_ann]
+        live = np.flatnonzero(nt >= 0)
+        sel, off = _unique_frames(nt[live], pos[live], len(trk_order))
+        rows = live[sel]
+    return (pos[rows].astype(I32), LazyRows(boxes, ann_rows[rows]),
+            off.astype(I32))
 
-    ``use_cats=False`` builds the class-agnostic problem of
-    ``params.use_cats = 0`` (T/eval.py:257-260,293-303): one cell per video
-    holding the tracks of all categories (category-major, as the reference
-    concatenates them), no federated filter, a single pseudo category -1."""
-    if len(dt) == 0:
-        raise IndexError("list index out of range")  # T/results.py:61
+
+def _tao_select(visit_rank, a_img_idx, a_cat_idx, a_area, a_ids):
+    """get_ann_ids(vid_ids, cat_ids) + load_anns (T/tao.py:203-254)"""
+    sel = np.flatnonzero(a_img_idx >= 0)
+    sel = sel[visit_rank[a_img_idx[sel]] >= 0]
+    sel = sel[sort_key_score(visit_rank[a_img_idx[sel]])]
+    sel = sel[(a_cat_idx[sel] >= 0) & (a_area[sel] > 0)
+              & (a_area[sel] < np.inf)]
+    return _last_with_same_id(a_ids)[sel]
+
+
+def tao_gt_side(gt):
+    """Ground-truth half of the track-level tables (T/tao.py:108-254): merged
+    categories, sorted unique ids and dataset rows (dict semantics: last one
+    wins), the per-video timeline, the CPython-set visiting order of the
+    images, and the ground-truth tracks (selected annotations grouped by
+    track in first-appearance order, frame order inside)."""
     # ---- category merge (GT annotations + tracks + predictions)
     merge_src = gt.cat_merged[:, 0] if len(gt.cat_merged) else \
         np.zeros(0, np.int64)
@@ -514,7 +549,6 @@ def flatten_tao(gt: GTColumns, dt: DTColumns, max_dets=MAX_DETS,
 
     ann_cat = merged(gt.ann_cat)
     trk_cat = merged(gt.trk_cat)
-    pred_cat = merged(dt.category_id)
 
     vid_ids = np.unique(gt.vid_id)
     cat_ids = np.unique(gt.cat_id)
@@ -559,6 +593,56 @@ def flatten_tao(gt: GTColumns, dt: DTColumns, max_dets=MAX_DETS,
     visit_rank[_lookup(img_ids, np.asarray(visit, dtype=np.int64))] = \
         np.arange(len(visit))
 
+
+    a_img = _lookup(img_ids, gt.ann_img)
+    g_sel = _tao_select(visit_rank, a_img, _lookup(cat_ids, ann_cat), gt.ann_area,
+                        gt.ann_id)
+    if len(g_sel) == 0:
+        raise ValueError("Found no groundtruth annotations for given params")
+    g_ids, g_perm, g_aoff = _group_tracks(
+        gt.ann_trk[g_sel], gt.img_frame[img_row[a_img[g_sel]]])
+    g_ann = g_sel[g_perm]                          # annotations, track-major
+    g_trk_of_ann = np.repeat(np.arange(len(g_ids)), np.diff(g_aoff))
+    g_area = _seq_track_mean(gt.ann_area[g_ann], g_aoff)
+    g_len = np.diff(g_aoff)
+    g_nhp = np.bincount(g_trk_of_ann, weights=(gt.ann_vis[g_ann] < 0.8),
+                        minlength=len(g_ids)).astype(np.int64)
+    g_row = t_rows_u[_lookup(t_keys_u, g_ids)]
+    g_vid = _lookup(vid_ids, gt.trk_vid[g_row])
+    g_cat = _lookup(cat_ids, trk_cat[g_row])
+    g_ign = gt.trk_ignore[g_row]
+    if (g_vid < 0).any():
+        raise KeyError("track refers to an unknown video")
+    T = Flat()
+    for k, v in list(locals().items()):
+        if k not in ("T", "gt", "merged") and not k.startswith("_"):
+            T[k] = v
+    return T
+
+
+def flatten_tao(gt: GTColumns, dt: DTColumns, max_dets=MAX_DETS,
+                use_cats=True):
+    """``dt.track_id`` must already be unique per video (the CLI runs
+    make_track_ids_unique first; T/results.py:111-119 asserts it).
+
+    ``use_cats=False`` builds the class-agnostic problem of
+    ``params.use_cats = 0`` (T/eval.py:257-260,293-303): one cell per video
+    holding the tracks of all categories (category-major, as the reference
+    concatenates them), no federated filter, a single pseudo category -1."""
+    if len(dt) == 0:
+        raise IndexError("list index out of range")  # T/results.py:61
+    T = tao_gt_side(gt)
+    ms, md = T.ms, T.md
+
+    def merged(c):
+        j = _lookup(ms, c)
+        return np.where(j >= 0, md[np.maximum(j, 0)], c) if len(ms) else c
+
+    pred_cat = merged(dt.category_id)
+    vid_ids, cat_ids, img_ids, K = T.vid_ids, T.cat_ids, T.img_ids, T.K
+    vid_row, img_row = T.vid_row, T.img_row
+    trk_cat, tl_pos, visit_rank = T.trk_cat, T.tl_pos, T.visit_rank
+
     # ---- predictions: TaoResults
     tid = dt.track_id
     u, first, inv = first_inverse(tid)
@@ -601,45 +685,24 @@ def flatten_tao(gt: GTColumns, dt: DTColumns, max_dets=MAX_DETS,
     dt_trk_vid = dt.video_id[keep[first]]
     dt_trk_cat = d_cat_id[first]
 
-    def select(a_img_idx, a_cat_idx, a_area, a_ids):
-        """get_ann_ids(vid_ids, cat_ids) + load_anns (T/tao.py:203-254)"""
-        sel = np.flatnonzero(a_img_idx >= 0)
-        sel = sel[visit_rank[a_img_idx[sel]] >= 0]
-        sel = sel[sort_key_score(visit_rank[a_img_idx[sel]])]
-        sel = sel[(a_cat_idx[sel] >= 0) & (a_area[sel] > 0)
-                  & (a_area[sel] < np.inf)]
-        return _last_with_same_id(a_ids)[sel]
-
-    a_img = _lookup(img_ids, gt.ann_img)
-    g_sel = select(a_img, _lookup(cat_ids, ann_cat), gt.ann_area, gt.ann_id)
-    d_sel = select(d_img, _lookup(cat_ids, d_cat_id), d_area,
-                   np.arange(1, len(keep) + 1, dtype=np.int64))
-    if len(g_sel) == 0:
-        raise ValueError("Found no groundtruth annotations for given params")
+    a_img, g_sel = T.a_img, T.g_sel
+    d_sel = _tao_select(visit_rank, d_img, _lookup(cat_ids, d_cat_id), d_area,
+                        np.arange(1, len(keep) + 1, dtype=np.int64))
     if len(d_sel) == 0:
         raise ValueError("Found no predicted annotations for given params")
 
     # ---- group into tracks
-    g_ids, g_perm, g_aoff = _group_tracks(
-        gt.ann_trk[g_sel], gt.img_frame[img_row[a_img[g_sel]]])
-    g_ann = g_sel[g_perm]                          # annotations, track-major
-    g_trk_of_ann = np.repeat(np.arange(len(g_ids)), np.diff(g_aoff))
+    g_ids, g_ann, g_aoff, g_trk_of_ann = T.g_ids, T.g_ann, T.g_aoff, T.g_trk_of_ann
     d_ids, d_perm, d_aoff = _group_tracks(
         d_track[d_sel], gt.img_frame[img_row[d_img[d_sel]]])
     d_ann = d_sel[d_perm]
     d_trk_of_ann = np.repeat(np.arange(len(d_ids)), np.diff(d_aoff))
 
-    g_area = _seq_track_mean(gt.ann_area[g_ann], g_aoff)
+    g_area, g_len, g_nhp = T.g_area, T.g_len, T.g_nhp
     d_area_t = _seq_track_mean(d_area[d_ann], d_aoff)
-    g_len = np.diff(g_aoff)
     d_len = np.diff(d_aoff)
-    g_nhp = np.bincount(g_trk_of_ann, weights=(gt.ann_vis[g_ann] < 0.8),
-                        minlength=len(g_ids)).astype(np.int64)
 
-    g_row = t_rows_u[_lookup(t_keys_u, g_ids)]
-    g_vid = _lookup(vid_ids, gt.trk_vid[g_row])
-    g_cat = _lookup(cat_ids, trk_cat[g_row])
-    g_ign = gt.trk_ignore[g_row]
+    g_row, g_vid, g_cat, g_ign = T.g_row, T.g_vid, T.g_cat, T.g_ign
     d_trow = _lookup(u, d_ids)
     d_vid_id = dt_trk_vid[d_trow]
     d_vid = _lookup(vid_ids, d_vid_id)
@@ -674,37 +737,9 @@ def flatten_tao(gt: GTColumns, dt: DTColumns, max_dets=MAX_DETS,
     cell_keys, g_cell, d_cell, g_off, d_off = _cells(keys_g, keys_d)
 
     # ---- frames per track (unique images, timeline order)
-    def frames(trk_order, trk_of_ann, aoff, ann_rows, img_idx_of_ann, boxes):
-        """Frame lists of the tracks `trk_order` (final, cell order).  The
-        annotations are grouped by track (CSR `aoff`) in frame_index order."""
-        pos = tl_pos[img_idx_of_ann]
-        if len(pos) > 1:
-            rising = pos[1:] > pos[:-1]
-            rising[aoff[1:-1][aoff[1:-1] < len(pos)] - 1] = True   # track boundaries
-        if len(pos) <= 1 or rising.all():
-            # every track already lists distinct images in timeline order (the
-            # usual case): the result is just the tracks' segments, permuted
-            lens = np.diff(aoff)[trk_order]
-            off = np.zeros(len(trk_order) + 1, dtype=np.int64)
-            np.cumsum(lens, out=off[1:])
-            rows = np.repeat(aoff[:-1][trk_order] - off[:-1], lens) + \
-                np.arange(int(off[-1]))
-        else:
-            # renumber tracks to their final (cell) position, sort, keep the
-            # last annotation of every (track, image)
-            new_of_old = np.full(int(trk_of_ann.max()) + 1 if len(trk_of_ann)
-                                 else 0, -1, dtype=np.int64)
-            new_of_old[trk_order] = np.arange(len(trk_order))
-            nt = new_of_old[trk_of_ann]
-            live = np.flatnonzero(nt >= 0)
-            sel, off = _unique_frames(nt[live], pos[live], len(trk_order))
-            rows = live[sel]
-        return (pos[rows].astype(I32), LazyRows(boxes, ann_rows[rows]),
-                off.astype(I32))
-
-    g_fpos, g_fbox, g_foff = frames(og, g_trk_of_ann, g_aoff, g_ann, a_img[g_ann],
+    g_fpos, g_fbox, g_foff = track_frames(tl_pos, og, g_trk_of_ann, g_aoff, g_ann, a_img[g_ann],
                                     gt.ann_bbox)
-    d_fpos, d_fbox, d_foff = frames(d_keep, d_trk_of_ann, d_aoff, keep[d_ann],
+    d_fpos, d_fbox, d_foff = track_frames(tl_pos, d_keep, d_trk_of_ann, d_aoff, keep[d_ann],
                                     d_img[d_ann], dt.bbox)
 
     # 1 + largest timeline position used by a cell (sizes the LDS tables of

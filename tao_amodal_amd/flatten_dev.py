@@ -76,9 +76,10 @@ def raw_columns(dt, device):
         _RAW[key] = ent
     if dev not in ent[1]:
         cols = {}
-        for name in ("image_id", "category_id", "score", "bbox"):
-            cols[name] = torch.from_numpy(
-                np.ascontiguousarray(getattr(dt, name))).to(dev, non_blocking=True)
+        for name in ("image_id", "category_id", "score", "bbox", "video_id"):
+            v = getattr(dt, name, None)
+            cols[name] = None if v is None else torch.from_numpy(
+                np.ascontiguousarray(v)).to(dev, non_blocking=True)
         area = getattr(dt, "area", None)
         cols["area"] = None if area is None else torch.from_numpy(
             np.ascontiguousarray(area, dtype=np.float64)).to(dev)
@@ -135,9 +136,10 @@ def _cells_from_runs(lib, dev, n_keep, dt_key, gkeys_sorted):
     np.cumsum(cnt, out=d_off[1:])
     dt_cell = torch.empty(max(n_keep, 1), dtype=torch.int32, device=dev)
     if nr:
+        t_map = torch.from_numpy(map_d).to(dev)     # (named: alive until launched)
         _lib.check(lib.taoamd_flat_remap(
-            n_keep, _ptr(run_id), _ptr(torch.from_numpy(map_d).to(dev)),
-            _ptr(dt_cell), _stream()), "taoamd_flat_remap")
+            n_keep, _ptr(run_id), _ptr(t_map), _ptr(dt_cell), _stream()),
+            "taoamd_flat_remap")
     return cell_keys, dt_cell[:n_keep], d_off
 
 
@@ -172,7 +174,7 @@ def flatten_lvis_device(gt, dt, device="cuda", max_dets=MAX_DETS):
             n, _ptr(raw["image_id"]), _ptr(raw["category_id"]), _ptr(raw["bbox"]),
             _ptr(raw["area"]), U, _ptr(t_img_ids), K, _ptr(t_cat_ids),
             _ptr(d_img), _ptr(d_cat), _ptr(d_area), _ptr(img_count),
-            _ptr(img_start), _ptr(status), _stream()), "taoamd_flat_map")
+            _ptr(img_start), None, _ptr(status), _stream()), "taoamd_flat_map")
         # the uploads of the small ground-truth tables travel meanwhile
         t_gkeys = up(gkeys, np.int32)
         t_img_row = up(G.img_row, np.int32)
@@ -245,4 +247,333 @@ def flatten_lvis_device(gt, dt, device="cuda", max_dets=MAX_DETS):
         pos[keep] = np.arange(len(keep))
         return pos[f.dt_row.astype(np.int64)] + 1
     f.lazy["dt_id"] = dt_id
+    return f
+
+
+class _Runs:
+    """Runs of equal keys of key[order[.]] (taoamd_flat_runs*_by)."""
+
+    def __init__(self, lib, dev, n, key, order, wide=False):
+        m = max(n, 1)
+        self.run_id = torch.empty(m, dtype=torch.int32, device=dev)
+        self.run_key = torch.empty(m, dtype=torch.int64 if wide else torch.int32,
+                                   device=dev)
+        self.run_start = torch.empty(m, dtype=torch.int32, device=dev)
+        n_runs = torch.zeros(1, dtype=torch.int32, device=dev)
+        wsb = int(lib.taoamd_flat_runs_workspace(n))
+        ws = torch.empty(max(wsb, 256), dtype=torch.uint8, device=dev)
+        fn = lib.taoamd_flat_runs64_by if wide else lib.taoamd_flat_runs_by
+        _lib.check(fn(n, _ptr(key), _ptr(order), _ptr(self.run_id),
+                      _ptr(self.run_key), _ptr(self.run_start), _ptr(n_runs),
+                      _ptr(ws), wsb, _stream()), "taoamd_flat_runs_by")
+        self.n = int(n_runs.item())
+
+
+def flatten_tao_device(gt, dt, device="cuda", max_dets=MAX_DETS):
+    """flatten.flatten_tao(gt, dt, max_dets) with the prediction side built on
+    the device (``dt.track_id`` already unique per video).  Inputs the kernels
+    do not cover raise Unsupported; inputs the reference rejects are handed to
+    flatten.flatten_tao, which raises the reference's exception."""
+    if len(dt) == 0:
+        raise IndexError("list index out of range")  # T/results.py:61
+    lib = _lib.load()
+    dev = torch.device(device)
+    T = flatten.tao_gt_side(gt)
+    vid_ids, cat_ids, img_ids = T.vid_ids, T.cat_ids, T.img_ids
+    U, K, NI, n = len(vid_ids), len(cat_ids), len(img_ids), len(dt)
+    tid_host = np.ascontiguousarray(dt.track_id, dtype=np.int64)
+    if U == 0 or K == 0 or K * U >= 2 ** 31 - 1 or n >= 2 ** 31 - 1 or \
+            int(tid_host.min()) < 0 or int(tid_host.max()) >= 2 ** 62:
+        raise Unsupported("keys do not fit")
+    keys_g = T.g_cat * U + T.g_vid
+    og = flatten.sort_key_score(keys_g)
+    keys_g = keys_g[og]
+    gkeys = np.unique(keys_g).astype(np.int32)
+    img_frame = gt.img_frame[T.img_row]
+
+    def reject():
+        # an input the reference rejects: let the numpy path word the error
+        flatten.flatten_tao(gt, dt, max_dets)
+        raise AssertionError("device flatten flagged an input flatten.py accepts")
+
+    I32_MAX = 2 ** 31 - 1
+    with torch.cuda.device(dev):
+        raw = raw_columns(dt, dev)
+        if raw["video_id"] is None:
+            raise Unsupported("predictions carry no video_id")
+        hold = []      # uploads stay referenced until the build is over: a
+        # tensor freed right after data_ptr() would be recycled by the next one
+
+        def up(a, t):
+            hold.append(torch.from_numpy(np.ascontiguousarray(a, dtype=t)).to(dev))
+            return hold[-1]
+        new = lambda m, t: torch.empty(max(int(m), 1), dtype=t, device=dev)
+        tid = up(tid_host, np.int64)        # (not cached: make_track_ids_unique rewrites it)
+        d_img, d_cat0 = new(n, torch.int32), new(n, torch.int32)
+        d_area = new(n, torch.float64)
+        img_count, img_start = new(NI + 1, torch.int32), new(NI + 1, torch.int32)
+        img_first = new(NI, torch.int32)
+        status = new(4, torch.int32)
+        t_img_ids, t_cat_ids = up(img_ids, np.int64), up(cat_ids, np.int64)
+        _lib.check(lib.taoamd_flat_map(
+            n, _ptr(raw["image_id"]), _ptr(raw["category_id"]), _ptr(raw["bbox"]),
+            _ptr(raw["area"]), NI, _ptr(t_img_ids), K, _ptr(t_cat_ids),
+            _ptr(d_img), _ptr(d_cat0), _ptr(d_area), _ptr(img_count),
+            _ptr(img_start), _ptr(img_first), _ptr(status), _stream()),
+            "taoamd_flat_map")
+        merged_id, d_cat = new(n, torch.int64), new(n, torch.int32)
+        _lib.check(lib.taoamd_flat_merge_cat(
+            n, _ptr(raw["category_id"]), len(T.ms), _ptr(up(T.ms, np.int64)),
+            _ptr(up(T.md, np.int64)), K, _ptr(t_cat_ids), _ptr(merged_id),
+            _ptr(d_cat), _stream()), "taoamd_flat_merge_cat")
+        st = status.cpu().numpy()
+        if st[0]:
+            reject()
+        max_count = int(st[1])
+        sorter = _Sorter(n, dev)
+
+        # ---- place of every box inside its image, top-max_dets cut
+        sc0 = None
+        if 0 <= max_dets < max_count:
+            sc0 = new(n, torch.float64)
+            _lib.check(lib.taoamd_flat_ordscore(
+                n, _ptr(d_img), _ptr(img_count), _ptr(raw["score"]), max_dets,
+                _ptr(sc0), _stream()), "taoamd_flat_ordscore")
+        order0 = sorter(n, d_img, sc0)
+        ordinal, dropped = new(n, torch.int32), new(n, torch.uint8)
+        _lib.check(lib.taoamd_flat_ordinal(
+            n, _ptr(order0), _ptr(d_img), _ptr(img_start), max_dets, _ptr(ordinal),
+            _ptr(dropped), _stream()), "taoamd_flat_ordinal")
+
+        # ---- tracks: runs of the boxes sorted by track id
+        lo, hi = new(n, torch.int32), None
+        wide = int(tid_host.max()) >= 2 ** 31
+        if wide:
+            hi = new(n, torch.int32)
+        _lib.check(lib.taoamd_flat_split64(n, _ptr(tid), None, _ptr(lo), None,
+                                           _stream()), "taoamd_flat_split64")
+        order_t = sorter(n, lo, None)
+        if wide:
+            _lib.check(lib.taoamd_flat_split64(n, _ptr(tid), _ptr(order_t), None,
+                                               _ptr(hi), _stream()),
+                       "taoamd_flat_split64")
+            inner = sorter(n, hi, None)
+            comp = new(n, torch.int32)
+            _lib.check(lib.taoamd_flat_compose(n, _ptr(order_t), _ptr(inner),
+                                               _ptr(comp), _stream()),
+                       "taoamd_flat_compose")
+            order_t = comp
+        tr = _Runs(lib, dev, n, tid, order_t, wide=True)
+        n_trk = tr.n
+        trk = new(n, torch.int32)
+        st2 = torch.full((4,), I32_MAX, dtype=torch.int32, device=dev)
+        st2[1] = 0
+        _lib.check(lib.taoamd_flat_track_of(
+            n, _ptr(order_t), _ptr(tr.run_id), _ptr(tr.run_start),
+            _ptr(raw["video_id"]), _ptr(trk), _ptr(st2), _stream()),
+            "taoamd_flat_track_of")
+
+        # ---- sort keys (host: first-seen rank of the images)
+        first = img_first.cpu().numpy().astype(np.int64)
+        img_rank = np.empty(NI, dtype=np.int32)
+        img_rank[np.argsort(first, kind="stable")] = np.arange(NI, dtype=np.int32)
+        M = float(1 << max(int(max_count), 1).bit_length())
+        if NI * M >= 2.0 ** 52:
+            raise Unsupported("sort keys do not fit a double")
+        keep_key, visit_key = new(n, torch.float64), new(n, torch.float64)
+        frame_key, pos_key = new(n, torch.float64), new(n, torch.float64)
+        trk_keep, trk_sel = new(n, torch.int32), new(n, torch.int32)
+        t_tl_pos = up(T.tl_pos, np.int32)
+        _lib.check(lib.taoamd_flat_keys(
+            n, _ptr(d_img), _ptr(ordinal), _ptr(dropped), _ptr(d_cat), _ptr(d_area),
+            _ptr(trk), _ptr(up(img_rank, np.int32)), _ptr(up(T.visit_rank, np.int32)),
+            _ptr(up(img_frame, np.float64)), _ptr(t_tl_pos), M, _ptr(keep_key),
+            _ptr(visit_key), _ptr(frame_key), _ptr(pos_key), _ptr(trk_keep),
+            _ptr(trk_sel), _stream()), "taoamd_flat_keys")
+
+        # ---- per track over its kept boxes in list order: score, category
+        order_k = sorter(n, trk_keep, keep_key)
+        rk = _Runs(lib, dev, n, trk_keep, order_k)
+        trk_score = torch.zeros(max(n_trk, 1), dtype=torch.float64, device=dev)
+        trk_first = torch.full((max(n_trk, 1),), -1, dtype=torch.int32, device=dev)
+        _lib.check(lib.taoamd_flat_track_kept(
+            rk.n, _ptr(rk.run_key), _ptr(rk.run_start), n, _ptr(order_k),
+            _ptr(raw["score"]), _ptr(merged_id), _ptr(trk_score), _ptr(trk_first),
+            _ptr(st2), _stream()), "taoamd_flat_track_kept")
+
+        # ---- selected boxes: visiting order, then (track, frame_index) stable
+        zeros = torch.zeros(n, dtype=torch.int32, device=dev)
+        order_v = sorter(n, zeros, visit_key)
+
+        def resort(outer, key_f64):
+            """stable sort of the list `outer` by (selected track, key)"""
+            kt, kf = new(n, torch.int32), new(n, torch.float64)
+            _lib.check(lib.taoamd_flat_gather_cols(
+                n, _ptr(outer), _ptr(trk_sel), _ptr(kt), _ptr(key_f64), _ptr(kf),
+                None, None, _stream()), "taoamd_flat_gather_cols")
+            inner = sorter(n, kt, kf)
+            out = new(n, torch.int32)
+            _lib.check(lib.taoamd_flat_compose(n, _ptr(outer), _ptr(inner), _ptr(out),
+                                               _stream()), "taoamd_flat_compose")
+            return out
+        order_s = resort(order_v, frame_key)         # frame order (T/tao.py:181-187)
+        order_p = resort(order_s, pos_key)           # timeline order, last box wins
+        rs = _Runs(lib, dev, n, trk_sel, order_s)
+        R = rs.n
+        sel_area = torch.zeros(max(R, 1), dtype=torch.float64, device=dev)
+        sel_first = torch.full((max(R, 1),), -np.inf, dtype=torch.float64, device=dev)
+        sel_len, sel_frames = new(R, torch.int32), new(R, torch.int32)
+        _lib.check(lib.taoamd_flat_track_sel(
+            R, _ptr(rs.run_key), _ptr(rs.run_start), n, _ptr(order_s), _ptr(d_area),
+            _ptr(visit_key), _ptr(d_img), _ptr(sel_area), _ptr(sel_len),
+            _ptr(sel_frames), _ptr(sel_first), _stream()), "taoamd_flat_track_sel")
+        # distinct images are counted on the timeline-ordered list
+        sel_area_p = torch.zeros(max(R, 1), dtype=torch.float64, device=dev)
+        sel_first_p = torch.zeros(max(R, 1), dtype=torch.float64, device=dev)
+        sel_len_p = new(R, torch.int32)
+        _lib.check(lib.taoamd_flat_track_sel(
+            R, _ptr(rs.run_key), _ptr(rs.run_start), n, _ptr(order_p), _ptr(d_area),
+            _ptr(visit_key), _ptr(d_img), _ptr(sel_area_p), _ptr(sel_len_p),
+            _ptr(sel_frames), _ptr(sel_first_p), _stream()), "taoamd_flat_track_sel")
+
+        # ---- federated filter, track order
+        key, flags = new(R, torch.int32), new(R, torch.uint8)
+        n_keep_t = new(1, torch.int32)
+        _lib.check(lib.taoamd_flat_track_filter(
+            R, _ptr(rs.run_key), _ptr(sel_len), _ptr(trk_first), _ptr(d_cat),
+            _ptr(merged_id), _ptr(raw["video_id"]), _ptr(tid), U,
+            _ptr(up(vid_ids, np.int64)), len(gkeys), _ptr(up(gkeys, np.int32)),
+            _ptr(up(T.vid_row, np.int32)), _ptr(up(gt.vid_neg_off, np.int64)),
+            _ptr(up(gt.vid_neg, np.int64)), _ptr(up(gt.vid_nel_off, np.int64)),
+            _ptr(up(gt.vid_nel, np.int64)), _ptr(key), _ptr(flags), _ptr(n_keep_t),
+            _ptr(st2), _stream()), "taoamd_flat_track_filter")
+        s2 = st2.cpu().numpy()
+        if s2[0] != I32_MAX or s2[2] != I32_MAX or s2[3] != I32_MAX:
+            import os
+            if os.environ.get("TAOAMD_DEBUG"):
+                print("flatten_tao_device status", s2, "R", R, "n_trk", n_trk)
+            reject()
+        required_average = bool(s2[1])
+        n_sel_tracks = int((sel_len[:R] > 0).sum().item()) if R else 0
+        if n_sel_tracks == 0:
+            raise ValueError("Found no predicted annotations for given params")
+        n_keep = int(n_keep_t.item())
+        tsorter = _Sorter(R, dev)
+        zr = torch.zeros(max(R, 1), dtype=torch.int32, device=dev)
+        order_a = tsorter(R, zr, sel_first)              # first appearance
+        ka, ta, sa = new(R, torch.int32), new(R, torch.int32), new(R, torch.float64)
+        _lib.check(lib.taoamd_flat_gather_cols(
+            R, _ptr(order_a), _ptr(key), _ptr(ka), None, None, None, None,
+            _stream()), "taoamd_flat_gather_cols")
+        # score of run r = trk_score[track of run r]
+        run_trk = torch.where(rs.run_key[:max(R, 1)] == I32_MAX,
+                              torch.zeros_like(rs.run_key[:max(R, 1)]),
+                              rs.run_key[:max(R, 1)]).contiguous()
+        run_score = new(R, torch.float64)
+        _lib.check(lib.taoamd_flat_gather_cols(
+            R, _ptr(run_trk), None, None, _ptr(trk_score), _ptr(run_score), None,
+            None, _stream()), "taoamd_flat_gather_cols")
+        _lib.check(lib.taoamd_flat_gather_cols(
+            R, _ptr(order_a), _ptr(run_trk), _ptr(ta), _ptr(run_score), _ptr(sa),
+            None, None, _stream()), "taoamd_flat_gather_cols")
+        order_b = tsorter(R, ka, sa)
+        final = new(R, torch.int32)                      # final position -> run
+        _lib.check(lib.taoamd_flat_compose(R, _ptr(order_a), _ptr(order_b),
+                                           _ptr(final), _stream()),
+                   "taoamd_flat_compose")
+
+        # ---- tables of the kept tracks in final order
+        m = max(n_keep, 1)
+        dt_key, dt_len, dt_nfr = new(m, torch.int32), new(m, torch.int32), new(m + 1, torch.int32)
+        dt_score, dt_area = new(m, torch.float64), new(m, torch.float64)
+        dt_flags, dt_first = new(m, torch.uint8), new(m, torch.int32)
+        g = lib.taoamd_flat_gather_cols
+        _lib.check(g(n_keep, _ptr(final), _ptr(key), _ptr(dt_key), _ptr(run_score),
+                     _ptr(dt_score), _ptr(flags), _ptr(dt_flags), _stream()), "gather")
+        _lib.check(g(n_keep, _ptr(final), _ptr(sel_len), _ptr(dt_len), _ptr(sel_area),
+                     _ptr(dt_area), None, None, _stream()), "gather")
+        _lib.check(g(n_keep, _ptr(final), _ptr(sel_frames), _ptr(dt_nfr), None, None,
+                     None, None, _stream()), "gather")
+        trk_of_final = new(m, torch.int32)
+        _lib.check(g(n_keep, _ptr(final), _ptr(run_trk), _ptr(trk_of_final), None, None,
+                     None, None, _stream()), "gather")
+        _lib.check(g(n_keep, _ptr(trk_of_final), _ptr(trk_first), _ptr(dt_first), None,
+                     None, None, None, _stream()), "gather")
+        frame_off = new(m + 1, torch.int32)
+        scratch = new(4, torch.int32)
+        _lib.check(lib.taoamd_flat_scan(n_keep, _ptr(dt_nfr), _ptr(frame_off),
+                                        _ptr(scratch), _stream()), "taoamd_flat_scan")
+        n_frames = int(frame_off[n_keep].item())
+        frame_pos = new(n_frames, torch.int32)
+        frame_box = torch.empty((max(n_frames, 1), 4), dtype=torch.float64, device=dev)
+        _lib.check(lib.taoamd_flat_frames(
+            n_keep, _ptr(final), _ptr(rs.run_start), R, n, _ptr(order_p), _ptr(d_img),
+            _ptr(t_tl_pos), _ptr(raw["bbox"]), _ptr(frame_off), _ptr(frame_pos),
+            _ptr(frame_box), _stream()), "taoamd_flat_frames")
+        dt_cat = torch.div(dt_key[:n_keep], U, rounding_mode="floor").to(torch.int32)
+        cell_keys, dt_cell, d_off = _cells_from_runs(lib, dev, n_keep, dt_key, gkeys)
+        dt_id = tid[dt_first[:n_keep].long()]
+
+    n_cells = len(cell_keys)
+    g_cell = np.searchsorted(cell_keys, keys_g)
+    g_off = np.zeros(n_cells + 1, dtype=np.int64)
+    np.cumsum(np.bincount(g_cell, minlength=n_cells), out=g_off[1:])
+    g_fpos, g_fbox, g_foff = flatten.track_frames(
+        T.tl_pos, og, T.g_trk_of_ann, T.g_aoff, T.g_ann, T.a_img[T.g_ann],
+        gt.ann_bbox)
+
+    f = DeviceFlat()
+    f.kind = "tao"
+    f.vid_ids, f.cat_ids = vid_ids, cat_ids
+    f.required_average = required_average
+    f.n_cells = n_cells
+    f.use_cats = True
+    f.cell_unit = (cell_keys % U).astype(I32)
+    f.cell_cat = (cell_keys // U).astype(I32)
+    f.cell_dt_off = d_off.astype(I32)
+    f.cell_gt_off = g_off.astype(I32)
+    iou_off = np.zeros(n_cells + 1, dtype=np.int64)
+    np.cumsum(np.diff(d_off) * np.diff(g_off), out=iou_off[1:])
+    f.cell_iou_off = iou_off
+    f.gt_area = np.ascontiguousarray(T.g_area[og])
+    f.gt_len = T.g_len[og].astype(I32)
+    f.gt_nhp = T.g_nhp[og].astype(I32)
+    f.gt_flags = (np.where(T.g_ign[og] != 0, flatten.GT_IGNORE, 0)
+                  | np.where(T.g_ids[og] == -1, flatten.GT_ID_HIDDEN, 0)
+                  ).astype(np.uint8)
+    f.gt_id = T.g_ids[og]
+    f.gt_cat = (keys_g // U).astype(I32)
+    f.gt_cell = g_cell.astype(I32)
+    f.gt_frame_off, f.gt_frame_pos, f.gt_frame_box = g_foff, g_fpos, g_fbox
+    f.n_pairs = int(iou_off[-1])
+    f.dev.update(dt_score=dt_score[:n_keep], dt_area=dt_area[:n_keep],
+                 dt_len=dt_len[:n_keep], dt_flags=dt_flags[:n_keep],
+                 dt_id=dt_id, dt_cat=dt_cat, dt_cell=dt_cell,
+                 dt_frame_off=frame_off[:n_keep + 1],
+                 dt_frame_pos=frame_pos[:n_frames], dt_frame_box=frame_box[:n_frames])
+
+    def track_scores():
+        # tracks with at least one box left after the top-max_dets cut
+        live = (trk_first[:n_trk] >= 0).cpu().numpy()
+        ids = tr.run_key[:n_trk].cpu().numpy()[live]
+        return dict(zip(ids.tolist(),
+                        trk_score[:n_trk].cpu().numpy()[live].tolist()))
+    f.lazy["track_scores"] = track_scores
+
+    def cell_span():
+        span = np.zeros(n_cells, dtype=np.int64)
+        for off, pos, coff in ((f.dt_frame_off, f.dt_frame_pos, d_off),
+                               (g_foff, g_fpos, g_off)):
+            off = np.asarray(off, dtype=np.int64)
+            pos = np.asarray(pos)
+            ts = np.zeros(len(off) - 1, dtype=np.int64)
+            has = np.diff(off) > 0
+            ts[has] = pos[off[1:][has] - 1].astype(np.int64) + 1
+            ne = np.diff(coff) > 0
+            cs = np.zeros(n_cells, dtype=np.int64)
+            if ne.any():
+                cs[ne] = np.maximum.reduceat(ts, coff[:-1][ne])
+            span = np.maximum(span, cs)
+        return span.astype(I32)
+    f.lazy["cell_span"] = cell_span
     return f
