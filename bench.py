@@ -281,9 +281,18 @@ def main():
     t_gen = time.time() - t0
     n_boxes_in = len(dt)
     t0 = time.time()
-    fl = flatten.flatten_lvis(gt, dt)
-    dt.track_id, _ = flatten.make_track_ids_unique(dt)
-    ft = flatten.flatten_tao(gt, dt)
+    if use_dist:
+        # (the shards are cut out of host tables: flatten.py)
+        fl = flatten.flatten_lvis(gt, dt)
+        dt.track_id, _ = flatten.make_track_ids_unique(dt)
+        ft = flatten.flatten_tao(gt, dt)
+    else:
+        # cell tables built on the device (flatten_dev / csrc/flatten.hip)
+        from tao_amodal_amd import flatten_dev
+        fl = flatten_dev.flatten_lvis(gt, dt, device=dev)
+        dt.track_id, _ = flatten.make_track_ids_unique(dt)
+        ft = flatten_dev.flatten_tao(gt, dt, device=dev)
+        torch.cuda.synchronize()
     if by_category:
         from tao_amodal_amd import dist as tdist
         k0, k1, _ = tdist.category_block(len(fl.cat_ids), data_rank, data_world)
@@ -545,8 +554,9 @@ def main():
             "exchange_verified": exchange_ok,
             "exchange_chunk_bytes": ([plan.lvis.chunk_bytes, plan.tao.chunk_bytes]
                                      if by_category else None),
-            "host_s": {"generate": round(t_gen, 2), "flatten": round(t_flat, 2),
-                       "upload": round(t_h2d, 2)},
+            "host_s": {"generate": round(t_gen, 2), "flatten": round(t_flat, 3),
+                       "flatten_on": "host (numpy)" if use_dist else "device",
+                       "upload": round(t_h2d, 3)},
         }
         real_stdout.write(json.dumps(out) + "\n")
         real_stdout.flush()

@@ -339,6 +339,9 @@ int taoamd_flat_gather(int64_t n_keep, const int32_t *order, const double *score
  *   taoamd_flat_track_filter  federated filter on the video lists, flags, key
  *   taoamd_flat_frames     frame lists of the final tracks
  *   taoamd_flat_scan       exclusive scan of int32 counts (start[n] = total) */
+/* *count = kept boxes with a negative corner or an empty side (T/results.py:100-103) */
+int taoamd_flat_count_bad(int64_t n, const double *bbox, const uint8_t *dropped,
+                          int32_t *count, void *stream);
 int taoamd_flat_ordscore(int64_t n, const int32_t *img, const int32_t *img_count,
                          const double *score, int32_t max_dets, double *out,
                          void *stream);
@@ -410,6 +413,17 @@ int taoamd_flat_runs64_by(int64_t n, const int64_t *key, const int32_t *order,
                           void *stream);
 int taoamd_flat_remap(int64_t n, const int32_t *id, const int32_t *map,
                       int32_t *out, void *stream);
+
+/* Launch plan of taoamd_match (groups / singles arguments) from HOST copies of
+ * the cell offsets: runs of consecutive small cells (each <= cap_d detections
+ * and <= cap_cell_g ground truths, a run <= cap_d detections and <= cap_g
+ * ground truths) -> groups[.][2] = {first cell, end cell}; other cells with
+ * detections -> singles.  groups == NULL: sizes only (sizes[0] groups,
+ * sizes[1] singles).  The kernels' caps are 64, 64, 8.  Synchronous, host. */
+int taoamd_match_plan_host(int64_t n_cells, const int32_t *cell_dt_off_host,
+                           const int32_t *cell_gt_off_host, int32_t cap_d,
+                           int32_t cap_g, int32_t cap_cell_g, int64_t *sizes,
+                           int32_t *groups_host, int32_t *singles_host);
 
 /* ---- stable sort by (category asc, score desc) ---------------------------------
  * order[p] = detection at sorted position p; dst[d] = sorted position of

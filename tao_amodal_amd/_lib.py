@@ -48,6 +48,7 @@ SIGNATURES = {
                                              _vp, _vp, _vp, _vp]),
     "taoamd_flat_map": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp,
                                   _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "taoamd_flat_count_bad": (C.c_int, [_i64, _vp, _vp, _vp, _vp]),
     "taoamd_flat_ordscore": (C.c_int, [_i64, _vp, _vp, _vp, _i32, _vp, _vp]),
     "taoamd_flat_ordinal": (C.c_int, [_i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
     "taoamd_flat_merge_cat": (C.c_int, [_i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp,
@@ -83,6 +84,8 @@ SIGNATURES = {
     "taoamd_flat_runs_workspace": (_sz, [_i64]),
     "taoamd_flat_runs": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "taoamd_flat_remap": (C.c_int, [_i64, _vp, _vp, _vp, _vp]),
+    "taoamd_match_plan_host": (C.c_int, [_i64, _vp, _vp, _i32, _i32, _i32, _vp,
+                                         _vp, _vp]),
     "taoamd_match": (C.c_int, [_i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32,
                                _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp,
                                _vp, _vp, _vp, _i32, _vp, _i32, _vp]),

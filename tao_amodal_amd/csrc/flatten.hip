@@ -508,6 +508,22 @@ __global__ void fl_ordinal_kernel(int64_t n, const int32_t *__restrict__ order,
     dropped[d] = im < 0 || (max_dets >= 0 && o >= max_dets);
 }
 
+// boxes of the post-truncation list with a negative corner or an empty side
+// (the warning of T/results.py:100-103)
+__global__ void fl_count_bad_kernel(int64_t n, const double4 *__restrict__ bbox,
+                                    const uint8_t *__restrict__ dropped,
+                                    int32_t *__restrict__ count)
+{
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    bool bad = false;
+    if (i < n && !dropped[i]) {
+        const double4 b = bbox[i];
+        bad = b.x < 0 || b.y < 0 || b.z <= 0 || b.w <= 0;
+    }
+    const uint64_t m = __ballot(bad);
+    if (lane_id() == 0 && m) atomicAdd(count, (int32_t)__popcll(m));
+}
+
 __global__ void fl_merge_cat_kernel(int64_t n, const int64_t *__restrict__ category_id,
                                     int64_t n_merge, const int64_t *__restrict__ msrc,
                                     const int64_t *__restrict__ mdst, int64_t n_cat,
@@ -804,6 +820,20 @@ extern "C" int taoamd_flat_ordinal(int64_t n, const int32_t *order, const int32_
     if (n == 0) return TAOAMD_OK;
     if (!order || !img || !img_start || !ordinal || !dropped) return TAOAMD_ERR_ARG;
     FL_LAUNCH1(fl_ordinal_kernel, n, n, order, img, img_start, max_dets, ordinal, dropped);
+    TAO_LAUNCH_CHECK();
+    return TAOAMD_OK;
+}
+
+extern "C" int taoamd_flat_count_bad(int64_t n, const double *bbox,
+                                     const uint8_t *dropped, int32_t *count,
+                                     void *stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (n < 0 || !count) return TAOAMD_ERR_ARG;
+    TAO_HIP(hipMemsetAsync(count, 0, sizeof(int32_t), s));
+    if (n == 0) return TAOAMD_OK;
+    if (!bbox || !dropped) return TAOAMD_ERR_ARG;
+    FL_LAUNCH1(fl_count_bad_kernel, n, n, (const double4 *)bbox, dropped, count);
     TAO_LAUNCH_CHECK();
     return TAOAMD_OK;
 }

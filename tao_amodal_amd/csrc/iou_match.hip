@@ -668,6 +668,53 @@ extern "C" int taoamd_tao_ranges(int64_t n_gt, const double *gt_area,
     return TAOAMD_OK;
 }
 
+// Launch plan of taoamd_match from HOST copies of the cell offsets: runs of
+// consecutive small cells (each <= cap_d detections and <= cap_cell_g ground
+// truths, the run <= cap_d detections and <= cap_g ground truths in total)
+// become groups {first cell, end cell} for match_group_kernel, every other
+// cell that holds detections a single.  Call with groups == NULL for the
+// sizes (sizes[0] = groups, sizes[1] = singles).
+extern "C" int taoamd_match_plan_host(int64_t n_cells, const int32_t *cell_dt_off,
+                                      const int32_t *cell_gt_off, int32_t cap_d,
+                                      int32_t cap_g, int32_t cap_cell_g,
+                                      int64_t *sizes, int32_t *groups,
+                                      int32_t *singles)
+{
+    if (n_cells < 0 || !cell_dt_off || !cell_gt_off || !sizes) return TAOAMD_ERR_ARG;
+    if ((groups == nullptr) != (singles == nullptr)) return TAOAMD_ERR_ARG;
+    int64_t ng = 0, ns = 0, c = 0;
+    auto small = [&](int64_t k) {
+        return cell_dt_off[k + 1] - cell_dt_off[k] <= cap_d &&
+               cell_gt_off[k + 1] - cell_gt_off[k] <= cap_cell_g;
+    };
+    while (c < n_cells) {
+        if (!small(c)) {
+            if (cell_dt_off[c + 1] > cell_dt_off[c]) {
+                if (singles) singles[ns] = (int32_t)c;
+                ns++;
+            }
+            c++;
+            continue;
+        }
+        int64_t e = c + 1;
+        while (e < n_cells && small(e) &&
+               cell_dt_off[e + 1] - cell_dt_off[c] <= cap_d &&
+               cell_gt_off[e + 1] - cell_gt_off[c] <= cap_g)
+            e++;
+        if (cell_dt_off[e] > cell_dt_off[c]) {
+            if (groups) {
+                groups[2 * ng] = (int32_t)c;
+                groups[2 * ng + 1] = (int32_t)e;
+            }
+            ng++;
+        }
+        c = e;
+    }
+    sizes[0] = ng;
+    sizes[1] = ns;
+    return TAOAMD_OK;
+}
+
 extern "C" int taoamd_match(int64_t n_cells, const int32_t *cell_dt_off,
                             const int32_t *cell_gt_off,
                             const int64_t *cell_iou_off,

@@ -54,35 +54,27 @@ def _to_device(v, device):
     return ent[1][dev].index_select(0, torch.from_numpy(v.index).to(dev))
 
 
-def match_plan(d_cnt, g_cnt, cap_d=64, cap_g=64, cap_cell_g=8):
+def match_plan(cell_dt_off, cell_gt_off, cap_d=64, cap_g=64, cap_cell_g=8):
     """Pack runs of consecutive small cells (<= cap_d detections and <= cap_g
     GTs in total, <= cap_cell_g GTs per cell) into groups for
-    match_group_kernel; every other cell that has detections is a 'single'."""
-    n = len(d_cnt)
-    small = (d_cnt <= cap_d) & (g_cnt <= cap_cell_g)
-    cum_d = np.zeros(n + 1, dtype=np.int64)
-    cum_g = np.zeros(n + 1, dtype=np.int64)
-    np.cumsum(d_cnt, out=cum_d[1:])
-    np.cumsum(g_cnt, out=cum_g[1:])
-    # next non-small cell at or after i
-    idx = np.where(small, n, np.arange(n))
-    nxt = np.minimum.accumulate(idx[::-1])[::-1] if n else idx
-    groups, singles = [], np.flatnonzero(~small & (d_cnt > 0)).astype(np.int32)
-    # where a group starting at cell c would end, for every c at once; the
-    # greedy segmentation then only follows that jump table
-    end = np.minimum(np.searchsorted(cum_d, cum_d[:-1] + cap_d, "right") - 1,
-                     np.searchsorted(cum_g, cum_g[:-1] + cap_g, "right") - 1)
-    end = np.maximum(np.minimum(end, nxt), np.arange(n) + 1)
-    jump = np.where(small, end, np.arange(n) + 1).tolist()
-    has_dt = (cum_d[end] > cum_d[:-1]).tolist() if n else []
-    is_small = small.tolist()
-    c = 0
-    while c < n:
-        e = jump[c]
-        if is_small[c] and has_dt[c]:
-            groups.append((c, e))
-        c = e
-    return np.asarray(groups, dtype=np.int32).reshape(-1, 2), singles
+    match_group_kernel; every other cell that has detections is a 'single'
+    (taoamd_match_plan_host)."""
+    lib = _lib.load()
+    d_off = np.ascontiguousarray(cell_dt_off, dtype=np.int32)
+    g_off = np.ascontiguousarray(cell_gt_off, dtype=np.int32)
+    sizes = np.zeros(2, dtype=np.int64)
+    args = (len(d_off) - 1, d_off.ctypes.data, g_off.ctypes.data, cap_d, cap_g,
+            cap_cell_g, sizes.ctypes.data)
+    _lib.check(lib.taoamd_match_plan_host(*args, None, None),
+               "taoamd_match_plan_host")
+    ng, ns = int(sizes[0]), int(sizes[1])
+    groups = np.zeros((max(ng, 1), 2), dtype=np.int32)
+    singles = np.zeros(max(ns, 1), dtype=np.int32)
+    if ng or ns:
+        _lib.check(lib.taoamd_match_plan_host(
+            *args, groups.ctypes.data, singles.ctypes.data),
+            "taoamd_match_plan_host")
+    return groups[:ng], singles[:ns]
 
 
 def track_meta(flat):
@@ -179,7 +171,7 @@ class DeviceProblem:
             gt_cat_off = np.zeros(self.n_cat + 1, dtype=np.int32)
             np.cumsum(np.bincount(flat.gt_cat, minlength=self.n_cat),
                       out=gt_cat_off[1:])
-        groups, singles = match_plan(d_cnt, g_cnt)
+        groups, singles = match_plan(flat.cell_dt_off, flat.cell_gt_off)
         self.n_groups, self.n_singles = len(groups), len(singles)
         names = ["cell_dt_off", "cell_gt_off", "dt_score", "dt_flags",
                  "dt_cat", "gt_flags", "gt_cat", "dt_cell"]

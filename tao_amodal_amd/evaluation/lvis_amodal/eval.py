@@ -106,9 +106,13 @@ class LVISEval:
         with timed("flatten"):
             # use_cats = 0: class-agnostic cells, one per image (reference
             # eval.py:125-128,147-166)
-            flat = flatten.flatten_lvis(self.lvis_gt.columns,
-                                        self.lvis_dt.columns_dt,
-                                        self.lvis_dt.max_dets, use_cats=use_cats)
+            # (built on the device: flatten_dev; flatten.py for the inputs it
+            # does not cover)
+            from ... import flatten_dev
+            flat = flatten_dev.flatten_lvis(self.lvis_gt.columns,
+                                            self.lvis_dt.columns_dt,
+                                            self.lvis_dt.max_dets,
+                                            use_cats=use_cats, device=self.device)
         if self.params.iou_type == "segm":
             with timed("masks"):
                 flat.masks = self._masks(flat)

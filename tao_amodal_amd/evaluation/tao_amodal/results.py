@@ -36,7 +36,6 @@ class TaoResults(Tao):
             assert isinstance(results, list), "results is not a list."
             self.columns_dt = DTColumns.from_json(results)
         self.max_dets = max_dets
-        self.ensure_unique_track_ids(self.columns_dt)
         if len(self.columns_dt) == 0:
             raise IndexError("list index out of range")  # results.py:61
         if len(self.gt.columns.cat_merged) == 0:
@@ -50,12 +49,15 @@ class TaoResults(Tao):
         # (_flat: the same tables prepared ahead of time by the CLI, which
         # builds them on a worker thread while the image-level pass runs)
         with timed("flatten"):
-            self.flat = _flat if _flat is not None else flatten.flatten_tao(
-                self.gt.columns, self.columns_dt, max_dets)
-        keep = flatten.limit_dets_per_image(self.columns_dt, max_dets)
-        b = self.columns_dt.bbox
-        bad = (b[:, 0] < 0) | (b[:, 1] < 0) | (b[:, 2] <= 0) | (b[:, 3] <= 0)
-        neg = int(np.count_nonzero(bad[keep])) if bad.any() else 0
+            self.flat = _flat if _flat is not None else self._flatten(max_dets)
+        neg = self.flat.get("neg_coords")      # counted by the device build
+        if neg is None:
+            b = self.columns_dt.bbox
+            bad = (b[:, 0] < 0) | (b[:, 1] < 0) | (b[:, 2] <= 0) | (b[:, 3] <= 0)
+            neg = 0
+            if bad.any():
+                keep = flatten.limit_dets_per_image(self.columns_dt, max_dets)
+                neg = int(np.count_nonzero(bad[keep]))
         if neg:
             self.logger.warning(
                 f"{neg} annotations had negative values in coordinates!")
@@ -64,6 +66,21 @@ class TaoResults(Tao):
                 "At least one track had annotations with different scores; "
                 "using average of individual annotation scores as track "
                 "scores.")
+
+    def _flatten(self, max_dets):
+        """Cell tables on the device; inputs the reference rejects go through
+        the numpy statement, which raises at the reference's places (one video
+        per track first, results.py:111-119)."""
+        from ... import flatten_dev
+        dev = flatten_dev._cuda(None)
+        if dev is not None:
+            try:
+                return flatten_dev.flatten_tao_device(
+                    self.gt.columns, self.columns_dt, dev, max_dets)
+            except (flatten_dev.Unsupported, flatten_dev.Rejected):
+                pass
+        self.ensure_unique_track_ids(self.columns_dt)
+        return flatten.flatten_tao(self.gt.columns, self.columns_dt, max_dets)
 
     @staticmethod
     def ensure_unique_track_ids(dt):

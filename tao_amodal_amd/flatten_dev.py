@@ -24,6 +24,12 @@ class Unsupported(Exception):
     cell keys or boxes): the caller falls back to flatten.py."""
 
 
+class Rejected(Exception):
+    """The input breaks a rule the reference asserts (a track in two videos or
+    with two categories, results of unknown images / videos): the caller runs
+    the numpy statement, which raises the reference's exception."""
+
+
 class DeviceFlat(Flat):
     """Flat whose per-detection tables live on the device (``dev``); reading
     one as an attribute downloads it once (views, tests, the oracle).  ``lazy``
@@ -272,8 +278,9 @@ class _Runs:
 def flatten_tao_device(gt, dt, device="cuda", max_dets=MAX_DETS):
     """flatten.flatten_tao(gt, dt, max_dets) with the prediction side built on
     the device (``dt.track_id`` already unique per video).  Inputs the kernels
-    do not cover raise Unsupported; inputs the reference rejects are handed to
-    flatten.flatten_tao, which raises the reference's exception."""
+    do not cover raise Unsupported, inputs the reference rejects raise Rejected
+    (``flatten_tao`` / ``flatten_lvis`` below fall back to flatten.py, which
+    words the reference's exception)."""
     if len(dt) == 0:
         raise IndexError("list index out of range")  # T/results.py:61
     lib = _lib.load()
@@ -292,9 +299,7 @@ def flatten_tao_device(gt, dt, device="cuda", max_dets=MAX_DETS):
     img_frame = gt.img_frame[T.img_row]
 
     def reject():
-        # an input the reference rejects: let the numpy path word the error
-        flatten.flatten_tao(gt, dt, max_dets)
-        raise AssertionError("device flatten flagged an input flatten.py accepts")
+        raise Rejected("predictions break a rule of TaoResults")
 
     I32_MAX = 2 ** 31 - 1
     with torch.cuda.device(dev):
@@ -344,6 +349,11 @@ def flatten_tao_device(gt, dt, device="cuda", max_dets=MAX_DETS):
         _lib.check(lib.taoamd_flat_ordinal(
             n, _ptr(order0), _ptr(d_img), _ptr(img_start), max_dets, _ptr(ordinal),
             _ptr(dropped), _stream()), "taoamd_flat_ordinal")
+
+        n_bad = new(1, torch.int32)
+        _lib.check(lib.taoamd_flat_count_bad(n, _ptr(raw["bbox"]), _ptr(dropped),
+                                             _ptr(n_bad), _stream()),
+                   "taoamd_flat_count_bad")
 
         # ---- tracks: runs of the boxes sorted by track id
         lo, hi = new(n, torch.int32), None
@@ -454,6 +464,7 @@ def flatten_tao_device(gt, dt, device="cuda", max_dets=MAX_DETS):
                 print("flatten_tao_device status", s2, "R", R, "n_trk", n_trk)
             reject()
         required_average = bool(s2[1])
+        neg_coords = int(n_bad.item())
         n_sel_tracks = int((sel_len[:R] > 0).sum().item()) if R else 0
         if n_sel_tracks == 0:
             raise ValueError("Found no predicted annotations for given params")
@@ -526,6 +537,7 @@ def flatten_tao_device(gt, dt, device="cuda", max_dets=MAX_DETS):
     f.kind = "tao"
     f.vid_ids, f.cat_ids = vid_ids, cat_ids
     f.required_average = required_average
+    f.neg_coords = neg_coords       # kept boxes with a negative corner / empty side
     f.n_cells = n_cells
     f.use_cats = True
     f.cell_unit = (cell_keys % U).astype(I32)
@@ -577,3 +589,34 @@ def flatten_tao_device(gt, dt, device="cuda", max_dets=MAX_DETS):
         return span.astype(I32)
     f.lazy["cell_span"] = cell_span
     return f
+
+
+def _cuda(device):
+    if device is None:
+        device = "cuda"
+    dev = torch.device(device)
+    return dev if dev.type == "cuda" and torch.cuda.is_available() else None
+
+
+def flatten_lvis(gt, dt, max_dets=MAX_DETS, use_cats=True, device=None):
+    """The image-level cell tables: built on the device when the input allows
+    it, by flatten.py otherwise (class-agnostic cells, > 2^31 keys, no GPU for
+    host-side tooling)."""
+    dev = _cuda(device)
+    if dev is not None and use_cats and len(dt):
+        try:
+            return flatten_lvis_device(gt, dt, dev, max_dets)
+        except Unsupported:
+            pass
+    return flatten.flatten_lvis(gt, dt, max_dets, use_cats=use_cats)
+
+
+def flatten_tao(gt, dt, max_dets=MAX_DETS, use_cats=True, device=None):
+    """The track-level cell tables (see flatten_lvis)."""
+    dev = _cuda(device)
+    if dev is not None and use_cats and len(dt):
+        try:
+            return flatten_tao_device(gt, dt, dev, max_dets)
+        except (Unsupported, Rejected):
+            pass
+    return flatten.flatten_tao(gt, dt, max_dets, use_cats=use_cats)

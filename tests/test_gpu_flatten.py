@@ -124,8 +124,10 @@ def test_tao_device_build_hands_rejected_inputs_to_the_numpy_path():
     bad = dt.take(np.arange(len(dt)))
     bad.video_id = bad.video_id.copy()
     bad.video_id[0] = bad.video_id[0] % 3 + 1 if bad.video_id[0] != 2 else 3
-    with pytest.raises(AssertionError, match="more than one video"):
+    with pytest.raises(flatten_dev.Rejected):
         flatten_dev.flatten_tao_device(gt, bad, "cuda:0")
+    with pytest.raises(AssertionError, match="more than one video"):
+        flatten_dev.flatten_tao(gt, bad, device="cuda:0")
     bad = dt.take(np.arange(len(dt)))
     bad.category_id = bad.category_id.copy()
     t = bad.track_id[0]
@@ -133,4 +135,4 @@ def test_tao_device_build_hands_rejected_inputs_to_the_numpy_path():
     if len(sel) > 1:
         bad.category_id[sel[-1]] = bad.category_id[sel[-1]] % 10 + 1
         with pytest.raises(AssertionError, match="multiple categories"):
-            flatten_dev.flatten_tao_device(gt, bad, "cuda:0")
+            flatten_dev.flatten_tao(gt, bad, device="cuda:0")

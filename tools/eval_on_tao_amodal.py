@@ -69,22 +69,13 @@ def make_track_ids_unique(dt):
     return n
 
 
-def prepare_track_level(gt_columns, dt_columns):
-    """Worker-thread body: the unique track ids and the track-level cell
-    tables, computed while the main thread runs the image-level evaluator
-    (numpy releases the GIL in its sorts / gathers).  Works on a shallow copy:
-    ``dt_columns.track_id`` is only replaced where the reference does it."""
+def prepare_track_level(dt_columns):
+    """Worker-thread body: the unique track ids (reference :44-66), computed
+    while the main thread runs the image-level evaluator (numpy releases the
+    GIL in its sorts / gathers).  ``dt_columns.track_id`` itself is only
+    replaced where the reference does it."""
     ids, _ = flatten.make_track_ids_unique(dt_columns)
-    view = DTColumns(**{f: getattr(dt_columns, f) for f in DTColumns.FIELDS})
-    view.track_id = ids
-    cache = getattr(dt_columns, "_limit_cache", None)
-    if cache is not None:
-        view._limit_cache = cache
-    try:
-        flat = flatten.flatten_tao(gt_columns, view)
-    except Exception:       # raised again, at the reference's place, by TaoResults
-        flat = None
-    return ids, flat
+    return ids
 
 
 def evaluate_predictions_on_lvis(lvis_gt, track_result, dt_columns, iou_type,
@@ -111,17 +102,13 @@ def eval_tao_track(ann_path, gt_dataset, gt_columns, dt_columns, logger,
     tao_gt = Tao(gt_dataset, columns=gt_columns)
     logger.info("Done")
     logger.info("Loading results...")
-    flat = None
     if prepared is not None:
-        from tao_amodal_amd.evaluation._core import timed
-        with timed("flatten (wait for worker)"):
-            dt_columns.track_id, flat = prepared.result()
+        dt_columns.track_id = prepared.result()
     else:
         make_track_ids_unique(dt_columns)
     logger.info("Done")
     logger.info("Building")
-    tao_eval = TaoEval(tao_gt, TaoResults(tao_gt, dt_columns, _flat=flat),
-                       logger=logger)
+    tao_eval = TaoEval(tao_gt, TaoResults(tao_gt, dt_columns), logger=logger)
     logger.info("Done")
     tao_eval.run()
     tao_eval.print_results()
@@ -161,9 +148,7 @@ def main(argv=None):
             dt_columns = dt_future.result()
         prepared = None
         if len(dt_columns):
-            flatten.limit_dets_per_image(dt_columns)    # shared by both passes
-            prepared = pool.submit(prepare_track_level, lvis_gt.columns,
-                                   dt_columns)
+            prepared = pool.submit(prepare_track_level, dt_columns)
         try:
             evaluate_predictions_on_lvis(lvis_gt, args.track_result, dt_columns,
                                          "bbox", logger)
