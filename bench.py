@@ -550,6 +550,10 @@ def main():
             else "4 (image-level || track-level, ranges/sort || IoU)",
             "host_launch_ms_per_step": round(host_ms, 4),
             "bit_exact_vs_oracle": verified,
+            "frame_order_guard": {
+                "exact_terms": bool(dpt.exact_terms),
+                "near_threshold_pairs": 0 if dpt.exact_terms or not hasattr(wst, "near_count")
+                else int(wst.near_count.item())},
             "ranks_verified": ranks_verified,
             "exchange_verified": exchange_ok,
             "exchange_chunk_bytes": ([plan.lvis.chunk_bytes, plan.tao.chunk_bytes]

@@ -210,11 +210,28 @@ int taoamd_track_iou_planned(int64_t n_tasks, const int32_t *tasks,
  * [slot_first, slot_first + n_slots) of `padded` (double[.][4]) with far boxes
  * and then scatters the n_frames frames.  One call per track set (detections,
  * ground truth) into disjoint slot ranges of ONE table whose slot 0 is a far
- * box (reserve it: slot_first = 0 for the first set, its tracks based at 1). */
+ * box (reserve it: slot_first = 0 for the first set, its tracks based at 1).
+ * `inexact` (optional, int32[1], zeroed by the caller) is set when some box has a
+ * coordinate that is not an integer below 2^20 -- with none the per-frame
+ * products and their sums are exact and taoamd_track_iou_near has nothing to do. */
 int taoamd_track_pad(int64_t n_trk, int64_t n_frames, const int32_t *frame_off,
                      const int32_t *frame_pos, const double *frame_box,
                      const int32_t *meta, int64_t slot_first, int64_t n_slots,
-                     double *padded, void *stream);
+                     double *padded, int32_t *inexact, void *stream);
+
+/* Guard of the documented frame-order deviation (frames are added in timeline
+ * order; the reference adds them in CPython set order, T/eval.py:83-94): lists
+ * the pairs whose IoU lies within max_ulp units in the last place of one of the
+ * ten IoU thresholds or of another ground truth's IoU in the same row -- the
+ * comparisons of the greedy match that a last-bit difference could flip.
+ * *count = number of such pairs (zeroed by the call), list[0 .. min(count,
+ * capacity)) = their indices into `iou`.  The host recomputes those pairs in
+ * the reference's order and patches `iou` before the match
+ * (tao_amodal_amd/engine.py: apply_iou_guard). */
+int taoamd_track_iou_near(int64_t n_cells, const int32_t *cell_gt_off,
+                          const int64_t *cell_iou_off, int64_t n_pairs,
+                          const double *iou, int32_t max_ulp, int32_t capacity,
+                          int32_t *count, int64_t *list, void *stream);
 
 /* Launch plan of taoamd_track_iou_planned from HOST copies of the cell offsets
  * and of trk_meta (detection tracks first, then GT tracks).  Call with

@@ -426,7 +426,8 @@ __global__ void track_pad_kernel(int64_t n_frames, int64_t n_trk,
                                  const int32_t *__restrict__ fpos,
                                  const double4 *__restrict__ fbox,
                                  const int4 *__restrict__ meta,
-                                 double4 *__restrict__ padded)
+                                 double4 *__restrict__ padded,
+                                 int32_t *__restrict__ inexact)
 {
     const int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (k >= n_frames) return;
@@ -435,7 +436,59 @@ __global__ void track_pad_kernel(int64_t n_frames, int64_t n_trk,
         const int64_t mid = (lo + hi) >> 1;
         if (foff[mid] <= k) lo = mid; else hi = mid;
     }
-    padded[(int64_t)meta[lo].z + fpos[k]] = fbox[k];
+    const double4 b = fbox[k];
+    padded[(int64_t)meta[lo].z + fpos[k]] = b;
+    // integer coordinates below 2^20: every per-frame product (< 2^40) and
+    // every sum of up to 2^13 of them is exact in fp64, so the order frames are
+    // added in cannot matter (taoamd_track_iou_near has nothing to guard)
+    if (inexact) {
+        const double lim = 1048576.0;
+        const bool exact = b.x == rint(b.x) && b.y == rint(b.y) && b.z == rint(b.z) &&
+                           b.w == rint(b.w) && fabs(b.x) < lim && fabs(b.y) < lim &&
+                           fabs(b.z) < lim && fabs(b.w) < lim;
+        if (!exact && *inexact == 0) atomicOr(inexact, 1);
+    }
+}
+
+// Guard of the one documented deviation: frames are added in timeline order,
+// the reference adds them in CPython set order (tao_amodal/eval.py:83-94).
+// With inexact per-frame terms the two sums may differ in the last bits, which
+// only matters where a comparison can flip: an IoU within max_ulp of one of the
+// ten thresholds, or of another GT's IoU in the same row (the greedy takes the
+// best).  Those pairs are listed; the host recomputes them in set order.
+__global__ void track_iou_near_kernel(int64_t n_cells,
+                                      const int32_t *__restrict__ cell_gt_off,
+                                      const int64_t *__restrict__ cell_iou_off,
+                                      int64_t n_pairs, const double *__restrict__ iou,
+                                      IouThr thr, int32_t max_ulp, int32_t cap,
+                                      int32_t *__restrict__ count,
+                                      int64_t *__restrict__ list)
+{
+    const int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (p >= n_pairs) return;
+    const double v = iou[p];
+    if (!(v > 0)) return;          // no intersection at all: 0 in any order
+    auto close = [max_ulp](double a, double b) {
+        const int64_t d = __double_as_longlong(a) - __double_as_longlong(b);
+        return (d < 0 ? -d : d) <= max_ulp;
+    };
+    bool near = false;
+#pragma unroll
+    for (int t = 0; t < N_THR; t++) near |= close(v, thr.v[t]);
+    if (!near) {
+        const int64_t c = find_cell(cell_iou_off, n_cells, p);
+        const int32_t G = cell_gt_off[c + 1] - cell_gt_off[c];
+        const int64_t local = p - cell_iou_off[c];
+        const int64_t row = cell_iou_off[c] + (local / G) * G;
+        for (int32_t g = 0; g < G && !near; g++) {
+            const double o = iou[row + g];
+            near = row + g != p && o > 0 && close(v, o);
+        }
+    }
+    if (near) {
+        const int32_t k = atomicAdd(count, 1);
+        if (k < cap) list[k] = p;
+    }
 }
 
 __global__ void track_pad_fill_kernel(int64_t n, double4 *__restrict__ padded)
@@ -501,7 +554,7 @@ extern "C" int taoamd_track_pad(int64_t n_trk, int64_t n_frames,
                                 const int32_t *frame_pos,
                                 const double *frame_box, const int32_t *meta,
                                 int64_t slot_first, int64_t n_slots,
-                                double *padded, void *stream)
+                                double *padded, int32_t *inexact, void *stream)
 {
     hipStream_t s = (hipStream_t)stream;
     if (n_trk < 0 || n_frames < 0 || n_slots < 0 || slot_first < 0)
@@ -516,8 +569,28 @@ extern "C" int taoamd_track_pad(int64_t n_trk, int64_t n_frames,
             return TAOAMD_ERR_ARG;
         TAO_TIMED("track_pad_kernel", s, track_pad_kernel<<<(unsigned)((n_frames + 255) / 256), 256, 0, s>>>(
             n_frames, n_trk, frame_off, frame_pos, (const double4 *)frame_box,
-            (const int4 *)meta, (double4 *)padded));
+            (const int4 *)meta, (double4 *)padded, inexact));
     }
+    TAO_LAUNCH_CHECK();
+    return TAOAMD_OK;
+}
+
+extern "C" int taoamd_track_iou_near(int64_t n_cells, const int32_t *cell_gt_off,
+                                     const int64_t *cell_iou_off, int64_t n_pairs,
+                                     const double *iou, int32_t max_ulp,
+                                     int32_t capacity, int32_t *count,
+                                     int64_t *list, void *stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (n_cells < 0 || n_pairs < 0 || max_ulp < 0 || capacity < 0 || !count)
+        return TAOAMD_ERR_ARG;
+    TAO_HIP(hipMemsetAsync(count, 0, sizeof(int32_t), s));
+    if (n_pairs == 0) return TAOAMD_OK;
+    if (!cell_gt_off || !cell_iou_off || !iou || (capacity > 0 && !list))
+        return TAOAMD_ERR_ARG;
+    TAO_TIMED("track_iou_near_kernel", s, track_iou_near_kernel<<<(unsigned)((n_pairs + 255) / 256), 256, 0, s>>>(
+        n_cells, cell_gt_off, cell_iou_off, n_pairs, iou, iou_thr(), max_ulp, capacity,
+        count, list));
     TAO_LAUNCH_CHECK();
     return TAOAMD_OK;
 }

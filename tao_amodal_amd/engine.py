@@ -226,6 +226,7 @@ class DeviceProblem:
             runs[:, 3] = flat.cell_gt_off[c1] - flat.cell_gt_off[c0]
         self.t["groups"] = torch.from_numpy(runs).to(self.device)
         self.n_tasks = 0
+        self.exact_terms = False
         if self.kind == "tao":
             self._plan_track_iou(flat)
         # per detection {first GT of its cell, GT count, position in the cell,
@@ -275,6 +276,7 @@ class DeviceProblem:
         self.t["padded"] = torch.empty((n_slots, 4), dtype=torch.float64,
                                        device=dev)
         n_dt = len(flat.dt_frame_off) - 1
+        inexact = torch.zeros(1, dtype=torch.int32, device=dev)
         with torch.cuda.device(dev):
             for side, row0 in (("dt", 0), ("gt", n_dt)):
                 slot0, slots = sides[side]
@@ -285,7 +287,10 @@ class DeviceProblem:
                     _ptr(self.t[side + "_frame_pos"]),
                     _ptr(self.t[side + "_frame_box"]),
                     self.t["trk_meta"].data_ptr() + 16 * row0, slot0, slots,
-                    _ptr(self.t["padded"]), _stream()), "taoamd_track_pad")
+                    _ptr(self.t["padded"]), _ptr(inexact), _stream()),
+                    "taoamd_track_pad")
+        # integer boxes: frame sums are exact in any order, nothing to guard
+        self.exact_terms = not bool(inexact.item())
 
     def input_bytes(self):
         return sum(v.numel() * v.element_size() for v in self.t.values()
@@ -327,6 +332,9 @@ class Workspace:
             self.iou = torch.empty(max(dp.n_iou, 1), dtype=torch.float64,
                                    device=dev)
             self.pair_frames = torch.zeros(1, dtype=torch.int64, device=dev)
+            self.near_count = torch.zeros(1, dtype=torch.int32, device=dev)
+            self.near_cap = int(min(max(dp.n_iou, 1), NEAR_CAP))
+            self.near_list = torch.empty(self.near_cap, dtype=torch.int64, device=dev)
         elif dp.mask_iou:
             self.iou = torch.empty(max(dp.n_iou, 1), dtype=torch.float64,
                                    device=dev)
@@ -413,6 +421,100 @@ def stage_track_iou(dp, ws):
         _ptr(ws.pair_frames), s), "taoamd_track_iou")
 
 
+NEAR_CAP = 1 << 16     # listed near-threshold pairs (more: the list is regrown)
+NEAR_ULP = 4           # distance to a threshold / a rival IoU that is guarded
+
+
+def stage_iou_guard(dp, ws):
+    """List the track pairs whose 3D IoU a last-bit difference could move
+    across a comparison of the match (taoamd_track_iou_near).  Nothing to do
+    for integer boxes (exact sums) and for the count-based imagenetvid IoU."""
+    if dp.kind != "tao" or dp.n_iou == 0 or dp.exact_terms or dp.iou_mode == 2:
+        return
+    lib, t = _lib.load(), dp.t
+    _lib.check(lib.taoamd_track_iou_near(
+        dp.n_cells, _ptr(t["cell_gt_off"]), _ptr(t["cell_iou_off"]), dp.n_iou,
+        _ptr(ws.iou), NEAR_ULP, ws.near_cap, _ptr(ws.near_count),
+        _ptr(ws.near_list), _stream()), "taoamd_track_iou_near")
+
+
+def apply_iou_guard(dp, ws, flat):
+    """The documented deviation, closed: the kernels add a track pair's frames
+    in timeline order, the reference in CPython set-iteration order
+    (T/eval.py:83-94).  The pairs stage_iou_guard listed are recomputed on the
+    host in the reference's order -- with Python's own sets -- and patched into
+    the IoU matrix before the match.  Returns the number of guarded pairs
+    (synchronises)."""
+    if dp.kind != "tao" or dp.n_iou == 0 or dp.exact_terms or dp.iou_mode == 2:
+        return 0
+    n = int(ws.near_count.item())
+    if n == 0:
+        return 0
+    if n > ws.near_cap:                 # regrow the list and list again
+        ws.near_cap = dp.n_iou
+        ws.near_list = torch.empty(ws.near_cap, dtype=torch.int64, device=dp.device)
+        stage_iou_guard(dp, ws)
+        n = int(ws.near_count.item())
+    pairs = ws.near_list[:n].cpu().numpy()
+    vals = set_order_iou(flat, pairs, dp.iou_mode)
+    ws.iou[torch.from_numpy(pairs).to(dp.device)] = torch.from_numpy(vals).to(dp.device)
+    return n
+
+
+def set_order_iou(flat, pairs, mode=0):
+    """3D IoU (mode 0) / average IoU (mode 1) of the listed pairs exactly as
+    the reference computes them: {image id: box} maps in annotation order, the
+    frames visited in the iteration order of
+    ``set(gt.keys()) | set(dt.keys())`` (T/eval.py:73-117)."""
+    ioff = np.asarray(flat.cell_iou_off)
+    d_off, g_off = np.asarray(flat.cell_dt_off), np.asarray(flat.cell_gt_off)
+    tl_id, tl_start = np.asarray(flat.tl_image_id), np.asarray(flat.tl_vid_start)
+    unit = np.asarray(flat.cell_unit)
+    fr = {}
+    for side in ("dt", "gt"):
+        fr[side] = (np.asarray(flat[side + "_frame_off"]),
+                    np.asarray(flat[side + "_frame_pos"]),
+                    np.asarray(flat[side + "_frame_box"]))
+    cache = {}
+
+    def track_map(side, t, v):
+        key = (side, t)
+        if key not in cache:
+            off, pos, box = fr[side]
+            a, b = int(off[t]), int(off[t + 1])
+            ids = tl_id[tl_start[v] + pos[a:b]].tolist()
+            cache[key] = dict(zip(ids, np.asarray(box[a:b]).tolist()))
+        return cache[key]
+    out = np.zeros(len(pairs))
+    cells = np.searchsorted(ioff, pairs, "right") - 1
+    for k, (p, c) in enumerate(zip(pairs.tolist(), cells.tolist())):
+        G = int(g_off[c + 1] - g_off[c])
+        local = p - int(ioff[c])
+        v = int(unit[c])
+        dmap = track_map("dt", int(d_off[c]) + local // G, v)
+        gmap = track_map("gt", int(g_off[c]) + local % G, v)
+        i = u = 0
+        ious = []
+        for im in set(gmap.keys()) | set(dmap.keys()):
+            g, d = gmap.get(im), dmap.get(im)
+            if d and g:
+                w = max(min(d[0] + d[2], g[0] + g[2]) - max(d[0], g[0]), 0)
+                h = max(min(d[1] + d[3], g[1] + g[3]) - max(d[1], g[1]), 0)
+                i_ = w * h
+                u_ = d[2] * d[3] + g[2] * g[3] - i_
+                i += i_
+                u += u_
+                ious.append(i_ / u_ if u_ > 0 else 0)
+            elif g:
+                u += g[2] * g[3]
+                ious.append(0)
+            elif d:
+                u += d[2] * d[3]
+                ious.append(0)
+        out[k] = (i / u if u > 0 else 0) if mode == 0 else float(np.mean(ious))
+    return out
+
+
 def stage_match(dp, ws, scatter=True):
     if dp.n_dt == 0:        # nothing was detected: every cell is GT-only
         return
@@ -440,8 +542,13 @@ def stage_accumulate(dp, ws):
         "taoamd_accumulate")
 
 
+def stage_track_iou_guarded(dp, ws):
+    stage_track_iou(dp, ws)
+    stage_iou_guard(dp, ws)
+
+
 STAGES = (("ranges", stage_ranges), ("sort", stage_sort),
-          ("track_iou", stage_track_iou), ("match", stage_match),
+          ("track_iou", stage_track_iou_guarded), ("match", stage_match),
           ("accumulate", stage_accumulate))
 
 
@@ -596,7 +703,7 @@ def run_forked(dp, ws, aux, head_only=False):
         with torch.cuda.stream(aux):
             stage_ranges(dp, ws)
             stage_sort(dp, ws)
-        _probed("track_iou", stage_track_iou, dp, ws)
+        _probed("track_iou", stage_track_iou_guarded, dp, ws)
     cur.wait_stream(aux)
     _probed("match", stage_match, dp, ws)
     if not head_only:
@@ -651,12 +758,28 @@ def time_stages(dpl, wsl, dpt, wst, reps=10):
     return out
 
 
+def run_guarded(dp, ws, flat, upto=None):
+    """One evaluator pass with the frame-order guard applied (one host
+    synchronisation between the 3D IoU and the match when the boxes are not
+    integers).  Returns the number of guarded pairs."""
+    if _lib.TIMING:
+        _lib.kernel_timing_label(dp.kind)
+    stage_ranges(dp, ws)
+    stage_sort(dp, ws)
+    stage_track_iou_guarded(dp, ws)
+    n = apply_iou_guard(dp, ws, flat)
+    stage_match(dp, ws)
+    if upto != "match":
+        stage_accumulate(dp, ws)
+    return n
+
+
 def evaluate_flat(flat, device="cuda", detail=False, iou_3d_type="3d_iou"):
     """Upload, run, download.  Returns a dict of numpy arrays shaped like the
     C oracle's outputs (tests compare the two field by field)."""
     dp = DeviceProblem(flat, device, iou_3d_type)
     ws = Workspace(dp, detail=detail)
-    run(dp, ws)
+    guarded = run_guarded(dp, ws, flat)
     torch.cuda.synchronize(dp.device)
     n = dp.n_dt
     out = {
@@ -676,6 +799,7 @@ def evaluate_flat(flat, device="cuda", detail=False, iou_3d_type="3d_iou"):
     if dp.kind == "tao":
         out["iou"] = ws.iou[:dp.n_iou].cpu().numpy()
         out["pairs"] = int(ws.pair_frames.item())
+        out["near_threshold_pairs"] = guarded
     if detail:
         out["match_gt"] = ws.match_gt[:n].cpu().numpy()
         if dp.kind == "lvis" and not dp.mask_iou:

@@ -64,15 +64,16 @@ class GpuRun:
             self.ws = engine.Workspace(self.dp)
             torch.cuda.synchronize(self.device)
         self._detail = None
+        self.near_threshold_pairs = 0
         self.precision = self.recall = None
 
     def evaluate(self):
         e = self.engine
         with timed("kernels"):
-            e.stage_ranges(self.dp, self.ws)
-            e.stage_sort(self.dp, self.ws)
-            e.stage_track_iou(self.dp, self.ws)
-            e.stage_match(self.dp, self.ws)
+            # (frame-order guard of the 3D IoU applied before the match:
+            # engine.apply_iou_guard; 0 pairs for integer boxes)
+            self.near_threshold_pairs = e.run_guarded(self.dp, self.ws, self.flat,
+                                                      upto="match")
             import os
             if os.environ.get("TAOAMD_TIMING"):
                 self.torch.cuda.synchronize(self.device)

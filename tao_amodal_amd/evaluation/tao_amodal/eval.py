@@ -123,6 +123,12 @@ class TaoEval:
         flat = self.flat
         self._run = GpuRun(flat, self.device, self.params.iou_3d_type)
         self._run.evaluate()
+        # track pairs whose 3D IoU was recomputed in the reference's frame
+        # order because it sits within a few ulp of a comparison of the match
+        self.near_threshold_pairs = self._run.near_threshold_pairs
+        if self.near_threshold_pairs:
+            self.logger.debug("%d track pairs near an IoU threshold recomputed "
+                              "in set order", self.near_threshold_pairs)
         P = self.params
         rngs = [(a, t) for a in P.area_rng for t in P.time_rng]
         view = CellView(self._run, flat.vid_ids, -1, "video_id", "rng", rngs)

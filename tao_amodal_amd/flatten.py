@@ -582,6 +582,9 @@ def tao_gt_side(gt):
     start = np.flatnonzero(np.r_[True, v_sorted[1:] != v_sorted[:-1]])
     tl_pos[tl_order] = np.arange(len(img_ids)) - np.repeat(
         start, np.diff(np.r_[start, len(img_ids)]))
+    # image id at (video, timeline position): tl_image_id[tl_vid_start[v] + pos]
+    tl_image_id = img_ids[tl_order]
+    tl_vid_start = np.searchsorted(v_sorted, np.arange(len(vid_ids) + 1), "left")
 
     # ---- visiting order of images: CPython set iteration (T/tao.py:224-230)
     vid_of_image_row = _lookup(vid_ids, gt.img_vid)
@@ -799,4 +802,5 @@ def flatten_tao(gt: GTColumns, dt: DTColumns, max_dets=MAX_DETS,
     f.gt_frame_off, f.gt_frame_pos, f.gt_frame_box = g_foff, g_fpos, g_fbox
     f.n_pairs = int(iou_off[-1])
     f.track_scores = dict(zip(u.tolist(), trk_score.tolist()))
+    f.tl_image_id, f.tl_vid_start = T.tl_image_id, T.tl_vid_start
     return f

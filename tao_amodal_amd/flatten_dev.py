@@ -558,6 +558,7 @@ def flatten_tao_device(gt, dt, device="cuda", max_dets=MAX_DETS):
     f.gt_cell = g_cell.astype(I32)
     f.gt_frame_off, f.gt_frame_pos, f.gt_frame_box = g_foff, g_fpos, g_fbox
     f.n_pairs = int(iou_off[-1])
+    f.tl_image_id, f.tl_vid_start = T.tl_image_id, T.tl_vid_start
     f.dev.update(dt_score=dt_score[:n_keep], dt_area=dt_area[:n_keep],
                  dt_len=dt_len[:n_keep], dt_flags=dt_flags[:n_keep],
                  dt_id=dt_id, dt_cat=dt_cat, dt_cell=dt_cell,

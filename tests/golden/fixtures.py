@@ -10,6 +10,11 @@ F4  F1 geometry with arbitrary decimal coordinates (documents the one
     tolerated deviation: frame-sum order of the 3D IoU)
 F5  shuffled image ids, colliding track ids, merged categories, >300 dets
     per image
+F7  adversarial decimal coordinates: every (detection track, GT track) pair
+    has a 3D IoU that is EXACTLY one of the ten IoU thresholds in real
+    arithmetic, so its fp64 value lands within a few ulp of the threshold and
+    the side it falls on depends on the order the frames are added in -- the
+    reference's CPython set order (T/eval.py:83-94) against timeline order
 """
 import os
 import sys
@@ -228,4 +233,57 @@ def f2():
     return gt, preds
 
 
-ALL = {"f1": f1, "f2": f2, "f3": f3, "f4": f4, "f5": f5}
+def f7():
+    rng = np.random.default_rng(77)
+    cats = [{"id": c, "name": "c%d" % c, "frequency": "rcf"[c % 3]}
+            for c in (1, 2, 3)]
+    videos, images, tracks, anns, preds = [], [], [], [], []
+    thr = [0.5, 0.55, 0.6, 0.65, 0.7, 0.75, 0.8, 0.85, 0.9, 0.95]
+    next_img, next_trk, next_dt = 1, 1, 1
+    for v in range(1, 5):
+        videos.append({"id": v, "name": "v%d" % v, "neg_category_ids": [],
+                       "not_exhaustive_category_ids": []})
+        n_fr = 8 + 3 * v
+        # ids spread so that the sets' slot order is not the timeline order
+        ids = (next_img + rng.permutation(n_fr * 37)[:n_fr]).tolist()
+        next_img += n_fr * 37
+        for f, i in enumerate(ids):
+            images.append({"id": int(i), "video_id": v, "frame_index": 30 * f,
+                           "neg_category_ids": [],
+                           "not_exhaustive_category_ids": []})
+        for g in range(6):
+            cat = 1 + g % 3
+            lo = int(rng.integers(0, n_fr - 5))
+            hi = int(rng.integers(lo + 5, n_fr + 1))
+            x = rng.integers(0, 900, hi - lo) + rng.integers(0, 100, hi - lo) / 100
+            y = rng.integers(0, 500, hi - lo) + rng.integers(0, 100, hi - lo) / 100
+            w = rng.integers(20, 300, hi - lo) + rng.integers(0, 10, hi - lo) / 10
+            # heights are multiples of 0.2: h * t has at most two decimals
+            h = rng.integers(100, 1000, hi - lo) / 5.0
+            tracks.append({"id": next_trk, "category_id": cat, "video_id": v})
+            for k in range(hi - lo):
+                box = [float(x[k]), float(y[k]), float(w[k]), float(h[k])]
+                anns.append({"id": len(anns) + 1, "image_id": int(ids[lo + k]),
+                             "track_id": next_trk, "category_id": cat,
+                             "bbox": box, "area": box[2] * box[3],
+                             "visibility": 1.0, "out_of_frame": False})
+            # detection tracks covering exactly the same frames, the same
+            # boxes with the height scaled by a threshold: IoU = t per frame
+            for t in rng.permutation(thr)[:5]:
+                score = float(rng.integers(1, 1000)) / 1000
+                for k in range(hi - lo):
+                    hh = float(np.round(h[k] * t, 2))
+                    preds.append({"image_id": int(ids[lo + k]),
+                                  "category_id": cat,
+                                  "bbox": [float(x[k]), float(y[k]), float(w[k]), hh],
+                                  "score": score, "track_id": next_dt,
+                                  "video_id": v})
+                next_dt += 1
+            next_trk += 1
+    gt = {"info": {"description": "threshold-straddling 3D IoUs"},
+          "images": images, "videos": videos, "tracks": tracks,
+          "annotations": anns, "categories": cats}
+    return gt, preds
+
+
+ALL = {"f1": f1, "f2": f2, "f3": f3, "f4": f4, "f5": f5, "f7": f7}

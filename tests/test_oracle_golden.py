@@ -2,7 +2,8 @@
 import numpy as np
 import pytest
 
-from goldenio import FIXTURES, INTEGER_FIXTURES, load_eval, load_inputs, load_json_gz
+from goldenio import (ADVERSARIAL_FIXTURES, FIXTURES, INTEGER_FIXTURES, load_eval,
+                      load_inputs, load_json_gz)
 from oracle import pyoracle
 
 
@@ -46,7 +47,7 @@ def _check_results(got, want):
         assert float(gv) == wv, k
 
 
-@pytest.mark.parametrize("name", FIXTURES)
+@pytest.mark.parametrize("name", FIXTURES + ADVERSARIAL_FIXTURES)
 def test_lvis_oracle_matches_reference(name):
     gt, pred = load_inputs(name)
     want = load_json_gz(name, "lvis.json.gz")
@@ -62,7 +63,7 @@ def test_lvis_oracle_matches_reference(name):
     assert got["freq_groups"] == want["freq_groups"]
 
 
-@pytest.mark.parametrize("name", FIXTURES)
+@pytest.mark.parametrize("name", FIXTURES + ADVERSARIAL_FIXTURES)
 def test_tao_oracle_matches_reference(name):
     gt, pred = load_inputs(name)
     want = load_json_gz(name, "tao.json.gz")
@@ -180,3 +181,20 @@ def test_lvis_oracle_without_categories_matches_reference(name):
     assert n == len(eval_imgs)
     assert np.array_equal(got["precision"], p)
     assert np.array_equal(got["recall"], r)
+
+
+def test_timeline_frame_order_flips_matches_on_the_adversarial_fixture():
+    """F7: every 3D IoU sits on a threshold in real arithmetic.  Adding the
+    frames in timeline order instead of the reference's set order moves some of
+    them across it -- the reason the HIP path guards these pairs
+    (engine.apply_iou_guard, tests/test_gpu_guard.py)."""
+    gt, pred = load_inputs("f7")
+    want = {tuple(c["key"]): c for c in load_json_gz("f7", "tao.json.gz")["cells"]}
+    pyoracle.make_track_ids_unique(pred)
+    got = pyoracle.tao_eval(gt, pred, frame_order="timeline")
+    flips = 0
+    for key, g in got["cells"].items():
+        for gr, wr in zip(g["ranges"], want[key]["ranges"]):
+            flips += int((np.asarray(gr["dt_matches"], dtype=float)
+                          != np.asarray(wr["dt_matches"], dtype=float)).sum())
+    assert flips > 0
