@@ -21,11 +21,13 @@ Workloads (BASELINE.json configs):
 N > 1 (one process per GPU, RCCL): launched by the driver's torchrun, or --
 when WORLD_SIZE is not set -- by this script itself, which spawns N ranks and
 fails loudly if the box has fewer GPUs.  Every rank holds one shard of the
-configuration (weak scaling); `--shard category` (default) gives every rank a
-contiguous category block of the whole set and assembles the result tables
-with one run-length packed all_gather per evaluator, `--shard unit` keeps the
-ranks' own videos and routes the per-detection records to the category owners
-with one all_to_all (tao_amodal_amd/dist.py).
+configuration (weak scaling).  `--shard unit` (default, the partition
+BASELINE.json names): a rank keeps its own videos, the per-detection records
+travel to the category owners in one all_to_all, are merged run by run and
+swept, and the result tables are assembled with one run-length packed
+all_gather per evaluator.  `--shard category`: every rank evaluates a
+contiguous category block of the union of all shards (no record exchange, but
+every rank flattens the whole input) (tao_amodal_amd/dist.py).
 
 Prints ONE JSON line on rank 0 (see the driver contract in the task text).
 """
@@ -75,10 +77,11 @@ def parse():
     p.add_argument("--no-verify", action="store_true")
     p.add_argument("--serial", action="store_true",
                    help="run the two evaluator passes back to back on one stream")
-    p.add_argument("--shard", choices=["category", "unit"], default="category",
-                   help="multi-GPU partition: contiguous category blocks (no "
-                        "record exchange) or the ranks' own videos (records "
-                        "meet at the category owners)")
+    p.add_argument("--shard", choices=["category", "unit"], default="unit",
+                   help="multi-GPU partition: the ranks' own videos (default; "
+                        "records meet at the category owners) or contiguous "
+                        "category blocks of one shared input (no record "
+                        "exchange, but every rank reads the whole input)")
     p.add_argument("--emulate", default=None, metavar="W:R",
                    help="with --force-dist on one GPU: run the per-rank work of "
                         "rank R of a W-rank category-sharded job (diagnostic; "
@@ -545,7 +548,7 @@ def main():
             "step_roofline": step_roof,
             "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all,
             "kernels_ms": kernels_ms, "stages_ms": stages,
-            "streams": "serial" if args.serial else "2 (image-level || track-level)" if (use_dist and not by_category)
+            "streams": "serial" if args.serial else "4 (image-level || track-level, range masks + num_gt all-reduce aside) + RCCL" if (use_dist and not by_category)
             else "4 (image-level || track-level, ranges/sort || IoU) + RCCL all_gather" if use_dist
             else "4 (image-level || track-level, ranges/sort || IoU)",
             "host_launch_ms_per_step": round(host_ms, 4),

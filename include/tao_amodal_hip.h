@@ -556,6 +556,21 @@ int taoamd_exchange_unpack(int32_t n_cat, int32_t n_rng, int32_t block_cats,
                            int32_t *overflow, void *workspace,
                            size_t workspace_bytes, void *stream);
 
+/* By-video partition, owner side.  `records` = what one all_to_all delivered:
+ * for source s the rows [src_base[s], src_base[s + 1]), each `width` int64
+ * {score bits, category, n_words matched words, n_words ignored words}, sorted
+ * by (category, -score) inside the source; run_off[s * (block_cats + 1) + kb] =
+ * offset of the run of category k0 + kb inside source s's rows; cat_base[kb] =
+ * first row of that category in the merged layout.  Writes every record's
+ * words at its place in the reference's order (stable -score sort of the
+ * sources' concatenation in rank order, L/eval.py:353-361): one binary search
+ * per other source instead of a radix sort and a gather. */
+int taoamd_exchange_merge(int64_t n_recv, int32_t world, int32_t block_cats,
+                          int32_t k0, const int64_t *records, int64_t width,
+                          int32_t n_words, const int64_t *src_base,
+                          const int64_t *run_off, const int64_t *cat_base,
+                          uint64_t *matched, uint64_t *ignored, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

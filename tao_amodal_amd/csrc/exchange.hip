@@ -369,3 +369,83 @@ extern "C" int taoamd_exchange_unpack(int32_t n_cat, int32_t n_rng,
     TAO_LAUNCH_CHECK();
     return TAOAMD_OK;
 }
+
+// ---------------------------------------------------------------------------
+// By-video partition, owner side: k-way merge of the received runs.
+//
+// Every source rank sends its records sorted by (category, -score) (the match
+// kernel writes them at their sorted place).  What an owner receives is, per
+// source, one block holding the runs of the owner's categories back to back.
+// The reference's order of a category = stable sort by -score of the
+// concatenation of the sources in rank order (tao_amodal/eval.py:508-518,
+// lvis_amodal/eval.py:353-361); inside a run that order is already there, so
+// a record's final row = its place in its own run + the number of records of
+// the OTHER sources' runs of the category that precede it (better score; on a
+// tie the lower rank) -- one binary search per other source.  The rows are
+// written straight into the sorted layout the sweep reads: no radix sort, no
+// gather pass.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t ex_desc_key(int64_t score_bits)
+{
+    double s = __longlong_as_double(score_bits) + 0.0;   // -0.0 -> +0.0
+    const uint64_t u = (uint64_t)__double_as_longlong(s);
+    const uint64_t asc = (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+    return ~asc;                                          // ascending = score descending
+}
+
+__global__ void ex_merge_kernel(int64_t n_recv, int32_t world, int32_t block_cats,
+                                int32_t k0, const int64_t *__restrict__ records,
+                                int64_t width, int32_t n_words,
+                                const int64_t *__restrict__ src_base,
+                                const int64_t *__restrict__ run_off,
+                                const int64_t *__restrict__ cat_base,
+                                uint64_t *__restrict__ matched,
+                                uint64_t *__restrict__ ignored)
+{
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n_recv) return;
+    int s = 0;
+    while (s + 1 < world && src_base[s + 1] <= i) s++;
+    const int64_t *rec = records + i * width;
+    const int32_t kb = (int32_t)rec[1] - k0;
+    const uint64_t key = ex_desc_key(rec[0]);
+    const int64_t *ro = run_off + (int64_t)s * (block_cats + 1);
+    int64_t pos = cat_base[kb] + (i - src_base[s] - ro[kb]);
+    for (int o = 0; o < world; o++) {
+        if (o == s) continue;
+        const int64_t *oo = run_off + (int64_t)o * (block_cats + 1);
+        const int64_t b = src_base[o] + oo[kb], e = src_base[o] + oo[kb + 1];
+        // records of run o that come first: key' < key, or key' == key from a lower rank
+        int64_t lo = b, hi = e;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            const uint64_t km = ex_desc_key(records[mid * width]);
+            if (km < key || (km == key && o < s)) lo = mid + 1; else hi = mid;
+        }
+        pos += lo - b;
+    }
+    for (int w = 0; w < n_words; w++) {
+        matched[pos * n_words + w] = (uint64_t)rec[2 + w];
+        ignored[pos * n_words + w] = (uint64_t)rec[2 + n_words + w];
+    }
+}
+
+extern "C" int taoamd_exchange_merge(int64_t n_recv, int32_t world, int32_t block_cats,
+                                     int32_t k0, const int64_t *records, int64_t width,
+                                     int32_t n_words, const int64_t *src_base,
+                                     const int64_t *run_off, const int64_t *cat_base,
+                                     uint64_t *matched, uint64_t *ignored, void *stream)
+{
+    if (n_recv < 0 || world < 1 || block_cats < 1 || n_words < 1 ||
+        width < 2 + 2 * (int64_t)n_words)
+        return TAOAMD_ERR_ARG;
+    if (n_recv == 0) return TAOAMD_OK;
+    if (!records || !src_base || !run_off || !cat_base || !matched || !ignored)
+        return TAOAMD_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    TAO_TIMED("ex_merge_kernel", s, ex_merge_kernel<<<(unsigned)((n_recv + 255) / 256), 256, 0, s>>>(
+        n_recv, world, block_cats, k0, records, width, n_words, src_base, run_off,
+        cat_base, matched, ignored));
+    TAO_LAUNCH_CHECK();
+    return TAOAMD_OK;
+}

@@ -21,25 +21,29 @@ is not enough for exact AP; the per-detection TP/ignore words have to meet.
 Per evaluator pass and rank:
 
   1. range masks; ``all_reduce(sum)`` of num_gt[K, n_rng]        (tiny)
-  2. [3D track IoU]; match kernel writes each detection's words straight
-     into its slot of the send buffer (rows grouped by owner rank, local
-     order kept) -- no pack pass
+  2. local segment sort (the rank's tables are category-major) || [3D track
+     IoU]; the match kernel writes each detection's words straight into the
+     send buffer AT ITS SORTED PLACE, so what a rank sends to an owner is the
+     runs of the owner's categories, each in (-score, concatenation) order
   3. ONE ``all_to_all_single`` of the records
          [score | category | matched words | ignored words]   (int64 cols)
      Category k is owned by rank k // ceil(K / world): contiguous blocks.
-  4. owner: stable (category, -score) sort of what it received.  Ranks hold
+  4. owner: k-way merge of the received runs (taoamd_exchange_merge): a
+     record's row = its place in its run + the records of the other sources'
+     runs that precede it -- one binary search per other source.  Ranks hold
      ascending, disjoint unit ranges and all_to_all delivers sources in rank
-     order, so "received order" == the reference's concatenation order and
-     the stable sort reproduces its tie-breaking exactly.
-  5. owner: gather rows into sorted order, sweep its categories
-     (taoamd_accumulate_compact) into the category-major tables
-  6. ONE in-place ``all_gather_into_tensor`` of the tables (a rank's share is
-     one contiguous block), then every rank transposes them into the
-     reference layout (taoamd_finalize).
+     order, so "lower rank first on ties" == the reference's concatenation
+     order and its stable sort is reproduced exactly.  The rows land in the
+     sorted layout the sweep reads: no radix sort, no gather pass.
+  5. owner: sweep of its categories (taoamd_accumulate_compact), result rows
+     run-length packed (taoamd_exchange_pack)
+  6. ONE in-place ``all_gather_into_tensor`` of the packed chunks, expanded
+     straight into the reference layout (taoamd_exchange_unpack) -- the same
+     tail as the category partition.
 
-Volumes at Config 2 per rank: step 3 ~ 32 B x 2.1 M records, step 6 ~ 250 MB
-/ world per rank -- far below the 7 x ~153 GB/s xGMI links, so the design
-minimises the NUMBER of collectives (2 + one tiny all-reduce per evaluator).
+Volumes at Config 2 per rank: step 3 ~ 32 B x 2.1 M records, step 6 a few MB
+-- far below the 7 x ~153 GB/s xGMI links, so the design minimises the NUMBER
+of collectives (2 + one tiny all-reduce per evaluator).
 
 The collective plumbing is backend-agnostic: ``tests/test_dist_gloo.py`` runs
 this very module with world_size 2 on CPU tensors over gloo, with the oracle
@@ -107,6 +111,13 @@ class HipBackend:
             n, _ptr(cat), _ptr(score), _ptr(order), None, _ptr(ws_buf),
             ws_bytes, self._s()), "taoamd_sort_by_cat_score")
 
+    def merge_runs(self, n_recv, world, block_cats, k0, records, width, n_words,
+                   src_base, run_off, cat_base, matched, ignored):
+        _lib.check(self.lib.taoamd_exchange_merge(
+            n_recv, world, block_cats, k0, _ptr(records), width, n_words,
+            _ptr(src_base), _ptr(run_off), _ptr(cat_base), _ptr(matched),
+            _ptr(ignored), self._s()), "taoamd_exchange_merge")
+
     def gather_rows(self, n, n_words, records, width, order, matched, ignored):
         base = records.data_ptr()
         _lib.check(self.lib.taoamd_gather_rows(
@@ -154,66 +165,78 @@ class HipBackend:
 
 
 class ShardedEval:
-    """One evaluator (LVIS or TAO side) of one rank."""
+    """One evaluator (LVIS or TAO side) of one rank when the problem is
+    partitioned BY UNIT: the rank holds the cell tables of its own images /
+    videos (category-major, flatten.py) and owns a contiguous category block
+    of the result."""
 
     def __init__(self, dp, ws, rank, world, backend, group=None):
         self.dp, self.ws, self.rank, self.world = dp, ws, rank, world
         self.be, self.group = backend, group
         dev = dp.device
-        K, nw = dp.n_cat, dp.n_words
+        K, nw, R = dp.n_cat, dp.n_words, dp.n_rng
         self.W = 2 + 2 * nw                       # int64 columns of a record
-        self.Kb = (K + world - 1) // world        # categories per owner block
-        cat = dp.t["dt_cat"].to(torch.int64)
-        owner = torch.div(cat, self.Kb, rounding_mode="floor")
-        # stable partition by owner: slot of every local detection
-        perm = torch.argsort(owner, stable=True)
-        slot = torch.empty_like(perm)
-        slot[perm] = torch.arange(dp.n_dt, device=dev)
-        self.dst = slot.to(torch.int32)
-        self.send_counts = torch.bincount(owner, minlength=world)[:world].cpu().tolist()
-        counts = torch.tensor(self.send_counts, dtype=torch.int64, device=dev)
-        rc = torch.empty_like(counts)
-        dist.all_to_all_single(rc, counts, group=group)
-        self.recv_counts = rc.cpu().tolist()
-        self.n_recv = int(sum(self.recv_counts))
+        self.k0, self.k1, self.Kb = category_block(K, rank, world)
+        Kb = self.Kb
+        # ---- who sends what: records per (owner, category of its block)
+        cnt = np.zeros(Kb * world, dtype=np.int64)
+        cnt[:K] = np.diff(dp.cat_off_host)
+        send = torch.from_numpy(cnt).to(dev)                  # [world * Kb]
+        recv = torch.empty_like(send)                         # [source][kb]
+        dist.all_to_all_single(recv, send, group=group)
+        rc = recv.cpu().numpy().reshape(world, Kb)
+        self.send_counts = cnt.reshape(world, Kb).sum(1).tolist()
+        self.recv_counts = rc.sum(1).tolist()
+        self.n_recv = int(rc.sum())
+        src_base = np.zeros(world + 1, dtype=np.int64)
+        np.cumsum(rc.sum(1), out=src_base[1:])
+        run_off = np.zeros((world, Kb + 1), dtype=np.int64)
+        np.cumsum(rc, axis=1, out=run_off[:, 1:])
+        cat_base = np.zeros(Kb + 1, dtype=np.int64)
+        np.cumsum(rc.sum(0), out=cat_base[1:])
+        cat_off = np.zeros(K + 1, dtype=np.int64)
+        hi = min(self.k0 + Kb, K)
+        cat_off[self.k0:hi + 1] = cat_base[:hi - self.k0 + 1]
+        cat_off[hi + 1:] = self.n_recv
+        self.max_segment = int(rc.sum(0).max()) if self.n_recv else 0
+        self.src_base = torch.from_numpy(src_base).to(dev)
+        self.run_off = torch.from_numpy(run_off).to(dev)
+        self.cat_base = torch.from_numpy(cat_base).to(dev)
+        self.cat_off = torch.from_numpy(cat_off.astype(np.int32)).to(dev)
         self.send = torch.zeros((max(dp.n_dt, 1), self.W), dtype=torch.int64,
                                 device=dev)
         self.recv = torch.zeros((max(self.n_recv, 1), self.W), dtype=torch.int64,
                                 device=dev)
-        # static columns: score bits and category
-        if dp.n_dt:
-            self.send[slot, 0] = dp.t["dt_score"].view(torch.int64)
-            self.send[slot, 1] = cat
-        self._exchange()
-        rcat = self.recv[:self.n_recv, 1]
-        cat_off = torch.zeros(K + 1, dtype=torch.int64, device=dev)
-        if self.n_recv:
-            cat_off[1:] = torch.cumsum(torch.bincount(rcat, minlength=K)[:K], 0)
-        self.cat_off = cat_off.to(torch.int32)
-        self.k0 = min(rank * self.Kb, K)
-        self.k1 = min((rank + 1) * self.Kb, K)
-        lib = _lib.load()
+        self._static = False          # score / category columns of `send`
         n = max(self.n_recv, 1)
-        self.rcat = torch.empty(n, dtype=torch.int32, device=dev)
-        self.rscore = torch.empty(n, dtype=torch.float64, device=dev)
-        self.order = torch.empty(n, dtype=torch.int32, device=dev)
-        self.sort_bytes = lib.taoamd_sort_workspace(self.n_recv)
-        self.sort_ws = torch.empty(max(self.sort_bytes, 256), dtype=torch.uint8,
-                                   device=dev)
         self.matched = torch.empty((n, nw), dtype=torch.int64, device=dev)
         self.ignored = torch.empty((n, nw), dtype=torch.int64, device=dev)
-        self.acc_bytes = lib.taoamd_accumulate_workspace(self.n_recv, K, dp.n_rng)
+        lib = _lib.load()
+        self.acc_bytes = lib.taoamd_accumulate_workspace(self.n_recv, K, R)
         self.acc_ws = torch.empty(max(self.acc_bytes, 256), dtype=torch.uint8,
                                   device=dev)
-        kpad = self.Kb * world
-        self.val = torch.zeros((kpad, dp.n_rng, N_THR, N_REC),
-                               dtype=torch.float64, device=dev)
-        self.rec = torch.zeros((kpad, dp.n_rng, N_THR), dtype=torch.float64,
-                               device=dev)
-        self.num_gt = torch.zeros((K, dp.n_rng), dtype=torch.int32, device=dev)
-        self.precision = torch.empty((N_THR, N_REC, K, dp.n_rng),
-                                     dtype=torch.float64, device=dev)
-        self.recall = torch.empty((N_THR, K, dp.n_rng), dtype=torch.float64,
+        self.val = torch.zeros((K, R, N_THR, N_REC), dtype=torch.float64, device=dev)
+        self.rec = torch.zeros((K, R, N_THR), dtype=torch.float64, device=dev)
+        self.num_gt = torch.zeros((K, R), dtype=torch.int32, device=dev)
+        self.num_gt_out = torch.zeros((K, R), dtype=torch.int32, device=dev)
+        self.precision = torch.empty((N_THR, N_REC, K, R), dtype=torch.float64,
+                                     device=dev)
+        self.recall = torch.empty((N_THR, K, R), dtype=torch.float64, device=dev)
+        self.overflow = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.xws = torch.empty(backend.exchange_workspace(Kb, R, world),
+                               dtype=torch.uint8, device=dev)
+        # ---- chunk capacity: levels of the largest block, from the global
+        # num_gt (the ground truth of a plan does not change between passes)
+        backend.ranges(dp, ws)
+        self.num_gt.copy_(ws.num_gt)
+        dist.all_reduce(self.num_gt, group=group)
+        table = torch.zeros((Kb * world, R), dtype=torch.int32, device=dev)
+        table[:K].copy_(self.num_gt)
+        totals = torch.zeros(world, dtype=torch.int64, device=dev)
+        backend.exchange_sizes(Kb, R, world, table, totals, self.xws)
+        self.capacity = int(totals.max().item())
+        self.chunk_bytes = backend.exchange_chunk_bytes(Kb, R, self.capacity)
+        self.chunks = torch.zeros(world * self.chunk_bytes, dtype=torch.uint8,
                                   device=dev)
 
     def _exchange(self):
@@ -222,30 +245,58 @@ class ShardedEval:
             output_split_sizes=self.recv_counts,
             input_split_sizes=self.send_counts, group=self.group)
 
-    def step(self):
+    def step(self, aux=None):
+        """`aux`: a second stream for the range masks and the num_gt
+        all-reduce, which only the sweep needs (sort, 3D IoU and match run
+        beside them)."""
         dp, ws, be = self.dp, self.ws, self.be
-        be.ranges(dp, ws)
-        self.num_gt.copy_(ws.num_gt)
-        dist.all_reduce(self.num_gt, group=self.group)
+        cur = None
+        if aux is not None:
+            cur = torch.cuda.current_stream(dp.device)
+            aux.wait_stream(cur)
+            with torch.cuda.stream(aux):
+                be.ranges(dp, ws)
+                self.num_gt.copy_(ws.num_gt)
+                dist.all_reduce(self.num_gt, group=self.group)
+        else:
+            be.ranges(dp, ws)
+            self.num_gt.copy_(ws.num_gt)
+            dist.all_reduce(self.num_gt, group=self.group)
+        be.sort_local(dp, ws)
+        if not self._static and dp.n_dt:
+            # the inputs of the exchange that no pass changes: a record's
+            # score and category, at the record's sorted place
+            slot = ws.dst[:dp.n_dt].long()
+            self.send[slot, 0] = dp.t["dt_score"].view(torch.int64)
+            self.send[slot, 1] = dp.t["dt_cat"].to(torch.int64)
+            self._static = True
         be.track_iou(dp, ws)
-        be.match_into(dp, ws, self.dst, self.send, self.W)
+        if cur is not None:
+            cur.wait_stream(aux)         # the match reads the range masks
+        be.match_into(dp, ws, ws.dst, self.send, self.W)
         self._exchange()
-        n = self.n_recv
-        if n:
-            self.rcat[:n].copy_(self.recv[:n, 1])
-            self.rscore[:n].copy_(self.recv[:n, 0].view(torch.float64))
-        be.sort(n, self.rcat, self.rscore, self.order, self.sort_ws,
-                self.sort_bytes)
-        be.gather_rows(n, dp.n_words, self.recv, self.W, self.order,
-                       self.matched, self.ignored)
-        be.accumulate_compact(n, dp.n_cat, dp.n_rng, self.cat_off, self.matched,
-                              self.ignored, self.num_gt, self.k0, self.k1,
-                              self.val, self.rec, self.acc_ws, self.acc_bytes)
-        lo, hi = self.rank * self.Kb, (self.rank + 1) * self.Kb
-        dist.all_gather_into_tensor(self.val, self.val[lo:hi], group=self.group)
-        dist.all_gather_into_tensor(self.rec, self.rec[lo:hi], group=self.group)
-        be.finalize(dp.n_cat, dp.n_rng, self.num_gt, self.val, self.rec,
-                    self.precision, self.recall)
+        be.merge_runs(self.n_recv, self.world, self.Kb, self.k0, self.recv, self.W,
+                      dp.n_words, self.src_base, self.run_off, self.cat_base,
+                      self.matched, self.ignored)
+        be.accumulate_compact(self.n_recv, dp.n_cat, dp.n_rng, self.cat_off,
+                              self.matched, self.ignored, self.num_gt, self.k0,
+                              self.k1, self.val, self.rec, self.acc_ws,
+                              self.acc_bytes, self.max_segment)
+        lo, hi = self.rank * self.chunk_bytes, (self.rank + 1) * self.chunk_bytes
+        be.exchange_pack(dp.n_cat, dp.n_rng, self.Kb, self.world, self.rank,
+                         self.num_gt, self.val, self.rec, self.chunks[lo:hi],
+                         self.capacity, self.overflow, self.xws)
+        dist.all_gather_into_tensor(self.chunks, self.chunks[lo:hi],
+                                    group=self.group)
+        be.exchange_unpack(dp.n_cat, dp.n_rng, self.Kb, self.world, self.chunks,
+                           self.capacity, self.num_gt_out, self.precision,
+                           self.recall, self.overflow, self.xws)
+
+    def check(self):
+        """Host-side guard (synchronises): the capacity held."""
+        if int(self.overflow.item()):
+            raise _lib.TaoAmdError("exchange chunk overflow: the ground truth "
+                                   "changed after the plan was built")
 
 
 def category_block(n_cat, rank, world):
@@ -414,8 +465,9 @@ class CategoryPlan:
 
 
 class ExchangePlan:
-    """Both evaluators of one rank, unit-partitioned (`bench.py --shard unit`);
-    the two passes run on their own HIP streams."""
+    """Both evaluators of one rank, unit-partitioned (`bench.py --shard unit`):
+    the image-level pass on the caller's stream, the track-level one on its
+    own, one auxiliary stream each for the range masks + num_gt all-reduce."""
 
     def __init__(self, dpl, dpt, rank, world, device, backend=None, group=None):
         from . import engine
@@ -427,7 +479,7 @@ class ExchangePlan:
                                group)
         self.streams = None
         if self.device.type == "cuda":
-            self.streams = [torch.cuda.Stream(self.device) for _ in range(2)]
+            self.streams = [torch.cuda.Stream(self.device) for _ in range(4)]
 
     def pair_frames(self):
         return int(self.tao.ws.pair_frames.item())
@@ -440,9 +492,9 @@ class ExchangePlan:
         cur = torch.cuda.current_stream(self.device)
         st = self.streams[1]            # image level on the caller's stream
         st.wait_stream(cur)
-        self.lvis.step()
+        self.lvis.step(self.streams[2])
         with torch.cuda.stream(st):
-            self.tao.step()
+            self.tao.step(self.streams[3])
         cur.wait_stream(st)
 
 
@@ -451,26 +503,8 @@ def step(plan):
 
 
 # --------------------------------------------------------------------------
-# sharding one flattened problem (class API on several GPUs)
+# cutting a cell range out of one flattened problem (category shards)
 # --------------------------------------------------------------------------
-def shard_bounds(flat, world):
-    """Contiguous unit ranges (images or videos, in sorted order) with roughly
-    equal numbers of box pairs.  Returns cell boundaries, len world + 1."""
-    d = np.diff(flat.cell_dt_off).astype(np.int64)
-    g = np.diff(flat.cell_gt_off).astype(np.int64)
-    cost = np.cumsum(d * g + d + g)
-    total = cost[-1] if len(cost) else 0
-    bounds = [0]
-    for r in range(1, world):
-        c = int(np.searchsorted(cost, total * r / world))
-        # move to the next unit boundary
-        while 0 < c < flat.n_cells and flat.cell_unit[c] == flat.cell_unit[c - 1]:
-            c += 1
-        bounds.append(max(min(c, flat.n_cells), bounds[-1]))
-    bounds.append(flat.n_cells)
-    return bounds
-
-
 def shard_flat(flat, c0, c1):
     """The sub-problem made of cells [c0, c1)."""
     from .flatten import Flat

@@ -61,6 +61,21 @@ class OracleBackend:
         order[:n] = torch.from_numpy(
             np.lexsort((np.arange(n), -(s + 0.0), c)).astype(np.int32))
 
+    def merge_runs(self, n_recv, world, block_cats, k0, records, width, n_words,
+                   src_base, run_off, cat_base, matched, ignored):
+        rec, sb = records.numpy(), src_base.numpy()
+        ro, cb = run_off.numpy(), cat_base.numpy()
+        for kb in range(block_cats):
+            idx = np.concatenate([np.arange(sb[s] + ro[s, kb], sb[s] + ro[s, kb + 1])
+                                  for s in range(world)]).astype(np.int64)
+            if len(idx) == 0:
+                continue
+            sc = np.ascontiguousarray(rec[idx, 0]).view(np.float64)
+            rows = idx[np.argsort(-(sc + 0.0), kind="stable")]
+            at = cb[kb] + np.arange(len(rows))
+            matched[at] = torch.from_numpy(rec[rows, 2:2 + n_words].copy())
+            ignored[at] = torch.from_numpy(rec[rows, 2 + n_words:2 + 2 * n_words].copy())
+
     def gather_rows(self, n, n_words, records, width, order, matched, ignored):
         o = order[:n].numpy().astype(np.int64)
         rec = records.numpy()
@@ -115,6 +130,12 @@ def _free_port():
     return port
 
 
+def _unit_parts(world):
+    from tao_amodal_amd.synth import synth
+    return [synth(seed=17 + r, V=3, F=12, C=23, dets_per_frame=30, n_present=4,
+                  video_id_base=r * 3) for r in range(world)]
+
+
 def _worker(rank, world, port, out):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path[:0] = [root, os.path.join(root, "tests")]
@@ -122,35 +143,38 @@ def _worker(rank, world, port, out):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from tao_amodal_amd import dist as tdist, engine, flatten
-    from tao_amodal_amd.synth import synth
-    gt, dt = synth(seed=17, V=6, F=12, C=23, dets_per_frame=30, n_present=4)
+    gt, dt = _unit_parts(world)[rank]          # the rank's own videos
     fl = flatten.flatten_lvis(gt, dt)
     dt.track_id, _ = flatten.make_track_ids_unique(dt)
     ft = flatten.flatten_tao(gt, dt)
     res = {}
     for name, flat in (("lvis", fl), ("tao", ft)):
-        b = tdist.shard_bounds(flat, world)
-        shard = tdist.shard_flat(flat, b[rank], b[rank + 1])
-        dp = engine.DeviceProblem(shard, "cpu")
+        dp = engine.DeviceProblem(flat, "cpu")
         ws = engine.Workspace(dp)
-        be = OracleBackend({id(dp): shard})
+        be = OracleCategoryBackend({id(dp): flat})
         ev = tdist.ShardedEval(dp, ws, rank, world, be)
         ev.step()
         ev.step()          # a second step must reproduce the first
+        ev.check()
         res[name] = (ev.precision.numpy().copy(), ev.recall.numpy().copy(),
-                     ev.num_gt.numpy().copy(), b)
+                     ev.num_gt.numpy().copy(), flat.n_pairs)
     torch.save(res, os.path.join(out, "rank%d.pt" % rank))
     dist.destroy_process_group()
 
 
 @pytest.mark.timeout(600)
-def test_two_ranks_reproduce_the_single_process_result(tmp_path):
-    world = 2
+@pytest.mark.parametrize("world", [2, 3])
+def test_unit_partition_ranks_reproduce_the_whole_problem(tmp_path, world):
+    """Every rank holds its own videos; the records meet at the category owners
+    (one all_to_all), are merged run by run and swept; every rank ends with the
+    tables a single process computes on the union."""
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world,
              join=True)
     from tao_amodal_amd import flatten
-    from tao_amodal_amd.synth import synth
-    gt, dt = synth(seed=17, V=6, F=12, C=23, dets_per_frame=30, n_present=4)
+    from tao_amodal_amd.columns import DTColumns, GTColumns
+    parts = _unit_parts(world)
+    gt = GTColumns.concat([p[0] for p in parts])
+    dt = DTColumns.concat([p[1] for p in parts])
     fl = flatten.flatten_lvis(gt, dt)
     dt.track_id, _ = flatten.make_track_ids_unique(dt)
     ft = flatten.flatten_tao(gt, dt)
@@ -160,8 +184,8 @@ def test_two_ranks_reproduce_the_single_process_result(tmp_path):
         got = torch.load(os.path.join(str(tmp_path), "rank%d.pt" % rank),
                          weights_only=False)
         for name in ("lvis", "tao"):
-            p, r, ng, b = got[name]
-            assert 0 < b[1] < b[2], "both ranks must own cells"
+            p, r, ng, n_pairs = got[name]
+            assert n_pairs > 0, "every rank must hold cells"
             assert np.array_equal(ng, want[name]["num_gt"])
             assert np.array_equal(p, want[name]["precision"]), (rank, name)
             assert np.array_equal(r, want[name]["recall"]), (rank, name)
@@ -176,16 +200,18 @@ def test_shard_flat_partitions_the_problem():
     dt.track_id, _ = flatten.make_track_ids_unique(dt)
     ft = flatten.flatten_tao(gt, dt)
     for flat in (fl, ft):
-        b = tdist.shard_bounds(flat, 3)
-        assert b[0] == 0 and b[-1] == flat.n_cells and b == sorted(b)
+        K = len(flat.cat_ids)
+        b = [int(np.searchsorted(flat.cell_cat, tdist.category_block(K, r, 3)[0]))
+             for r in range(3)] + [flat.n_cells]
+        assert b[0] == 0 and b == sorted(b)
         parts = [tdist.shard_flat(flat, b[i], b[i + 1]) for i in range(3)]
         assert sum(p.n_pairs for p in parts) == flat.n_pairs
         assert np.array_equal(np.concatenate([p.dt_id for p in parts]), flat.dt_id)
         assert np.array_equal(np.concatenate([p.gt_id for p in parts]), flat.gt_id)
-        # a unit (image / video) never straddles two shards
+        # a category never straddles two shards
         for i in range(1, 3):
             if 0 < b[i] < flat.n_cells:
-                assert flat.cell_unit[b[i]] != flat.cell_unit[b[i] - 1]
+                assert flat.cell_cat[b[i]] != flat.cell_cat[b[i] - 1]
         whole = orclib.run_flat(flat, detail=False)
         # matches of a shard equal the matching slice of the whole problem
         d_off = 0
