@@ -284,11 +284,20 @@ def main():
     t_gen = time.time() - t0
     n_boxes_in = len(dt)
     t0 = time.time()
-    if use_dist:
+    if by_category:
         # (the shards are cut out of host tables: flatten.py)
         fl = flatten.flatten_lvis(gt, dt)
         dt.track_id, _ = flatten.make_track_ids_unique(dt)
         ft = flatten.flatten_tao(gt, dt)
+    elif use_dist:
+        # a rank's own videos, tables built on the device; the visiting order
+        # comes from the image ids of ALL ranks (one all_gather)
+        from tao_amodal_amd import dist as tdist, flatten_dev
+        universe = tdist.gather_visit_universe(gt, dev)
+        fl = flatten_dev.flatten_lvis(gt, dt, device=dev)
+        dt.track_id, _ = flatten.make_track_ids_unique(dt)
+        ft = flatten_dev.flatten_tao(gt, dt, device=dev, visit_universe=universe)
+        torch.cuda.synchronize()
     else:
         # cell tables built on the device (flatten_dev / csrc/flatten.hip)
         from tao_amodal_amd import flatten_dev
@@ -562,7 +571,7 @@ def main():
             "exchange_chunk_bytes": ([plan.lvis.chunk_bytes, plan.tao.chunk_bytes]
                                      if by_category else None),
             "host_s": {"generate": round(t_gen, 2), "flatten": round(t_flat, 3),
-                       "flatten_on": "host (numpy)" if use_dist else "device",
+                       "flatten_on": "host (numpy)" if by_category else "device",
                        "upload": round(t_h2d, 3)},
         }
         real_stdout.write(json.dumps(out) + "\n")

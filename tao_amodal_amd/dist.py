@@ -299,6 +299,26 @@ class ShardedEval:
                                    "changed after the plan was built")
 
 
+def gather_visit_universe(gt, device, group=None):
+    """Image ids of the WHOLE ground truth when every rank holds the share of
+    its own videos (ranks hold ascending video ranges): the CPython set whose
+    iteration order fixes the visiting order of the track level
+    (flatten.tao_gt_side) is built from all of them, not from a rank's share."""
+    from .flatten import video_images
+    own = torch.from_numpy(np.ascontiguousarray(video_images(gt))).to(device)
+    world = dist.get_world_size(group)
+    sizes = torch.zeros(world, dtype=torch.int64, device=device)
+    sizes[dist.get_rank(group)] = own.numel()
+    dist.all_reduce(sizes, group=group)
+    m = int(sizes.max().item())
+    pad = torch.zeros(m, dtype=torch.int64, device=device)
+    pad[:own.numel()] = own
+    out = torch.empty(world * m, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(out, pad, group=group)
+    out, sizes = out.cpu().numpy().reshape(world, m), sizes.cpu().numpy()
+    return np.concatenate([out[r, :sizes[r]] for r in range(world)])
+
+
 def category_block(n_cat, rank, world):
     """Contiguous, equally sized category blocks: rank r owns [k0, k1)."""
     kb = (n_cat + world - 1) // world

@@ -526,12 +526,26 @@ def _tao_select(visit_rank, a_img_idx, a_cat_idx, a_area, a_ids):
     return _last_with_same_id(a_ids)[sel]
 
 
-def tao_gt_side(gt):
+def video_images(gt):
+    """Image ids in the order the reference collects them for its visiting set
+    (videos in sorted-id order, dataset order inside; T/tao.py:224-230)."""
+    vid_of_image_row = _lookup(np.unique(gt.vid_id), gt.img_vid)
+    by_vid = np.argsort(vid_of_image_row, kind="stable")
+    by_vid = by_vid[vid_of_image_row[by_vid] >= 0]
+    return gt.img_id[by_vid]
+
+
+def tao_gt_side(gt, visit_universe=None):
     """Ground-truth half of the track-level tables (T/tao.py:108-254): merged
     categories, sorted unique ids and dataset rows (dict semantics: last one
     wins), the per-video timeline, the CPython-set visiting order of the
     images, and the ground-truth tracks (selected annotations grouped by
-    track in first-appearance order, frame order inside)."""
+    track in first-appearance order, frame order inside).
+
+    ``visit_universe``: when ``gt`` is one rank's share of a larger ground
+    truth (by-video partition), the image ids of the WHOLE ground truth in
+    video_images() order -- the iteration order of a CPython set depends on
+    everything in it, so the visiting order must come from the full set."""
     # ---- category merge (GT annotations + tracks + predictions)
     merge_src = gt.cat_merged[:, 0] if len(gt.cat_merged) else \
         np.zeros(0, np.int64)
@@ -587,14 +601,15 @@ def tao_gt_side(gt):
     tl_vid_start = np.searchsorted(v_sorted, np.arange(len(vid_ids) + 1), "left")
 
     # ---- visiting order of images: CPython set iteration (T/tao.py:224-230)
-    vid_of_image_row = _lookup(vid_ids, gt.img_vid)
-    by_vid = np.argsort(vid_of_image_row, kind="stable")
-    by_vid = by_vid[vid_of_image_row[by_vid] >= 0]
-    video_images = gt.img_id[by_vid].tolist()
-    visit = list(set(video_images) & set(video_images))
+    own_images = video_images(gt)
+    vis_list = (own_images if visit_universe is None
+                else np.asarray(visit_universe, dtype=np.int64)).tolist()
+    visit = np.asarray(list(set(vis_list) & set(vis_list)), dtype=np.int64)
+    # (images of other ranks' videos drop out of the ranking)
+    at = _lookup(img_ids, visit)
     visit_rank = np.full(len(img_ids), -1, dtype=np.int64)
-    visit_rank[_lookup(img_ids, np.asarray(visit, dtype=np.int64))] = \
-        np.arange(len(visit))
+    mine = np.flatnonzero((at >= 0) & np.isin(visit, own_images))
+    visit_rank[at[mine]] = np.arange(len(mine))
 
 
     a_img = _lookup(img_ids, gt.ann_img)
@@ -624,7 +639,7 @@ def tao_gt_side(gt):
 
 
 def flatten_tao(gt: GTColumns, dt: DTColumns, max_dets=MAX_DETS,
-                use_cats=True):
+                use_cats=True, visit_universe=None):
     """``dt.track_id`` must already be unique per video (the CLI runs
     make_track_ids_unique first; T/results.py:111-119 asserts it).
 
@@ -634,7 +649,7 @@ def flatten_tao(gt: GTColumns, dt: DTColumns, max_dets=MAX_DETS,
     concatenates them), no federated filter, a single pseudo category -1."""
     if len(dt) == 0:
         raise IndexError("list index out of range")  # T/results.py:61
-    T = tao_gt_side(gt)
+    T = tao_gt_side(gt, visit_universe)
     ms, md = T.ms, T.md
 
     def merged(c):

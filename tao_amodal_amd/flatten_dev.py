@@ -275,7 +275,8 @@ class _Runs:
         self.n = int(n_runs.item())
 
 
-def flatten_tao_device(gt, dt, device="cuda", max_dets=MAX_DETS):
+def flatten_tao_device(gt, dt, device="cuda", max_dets=MAX_DETS,
+                       visit_universe=None):
     """flatten.flatten_tao(gt, dt, max_dets) with the prediction side built on
     the device (``dt.track_id`` already unique per video).  Inputs the kernels
     do not cover raise Unsupported, inputs the reference rejects raise Rejected
@@ -285,7 +286,7 @@ def flatten_tao_device(gt, dt, device="cuda", max_dets=MAX_DETS):
         raise IndexError("list index out of range")  # T/results.py:61
     lib = _lib.load()
     dev = torch.device(device)
-    T = flatten.tao_gt_side(gt)
+    T = flatten.tao_gt_side(gt, visit_universe)
     vid_ids, cat_ids, img_ids = T.vid_ids, T.cat_ids, T.img_ids
     U, K, NI, n = len(vid_ids), len(cat_ids), len(img_ids), len(dt)
     tid_host = np.ascontiguousarray(dt.track_id, dtype=np.int64)
@@ -612,12 +613,14 @@ def flatten_lvis(gt, dt, max_dets=MAX_DETS, use_cats=True, device=None):
     return flatten.flatten_lvis(gt, dt, max_dets, use_cats=use_cats)
 
 
-def flatten_tao(gt, dt, max_dets=MAX_DETS, use_cats=True, device=None):
+def flatten_tao(gt, dt, max_dets=MAX_DETS, use_cats=True, device=None,
+                visit_universe=None):
     """The track-level cell tables (see flatten_lvis)."""
     dev = _cuda(device)
     if dev is not None and use_cats and len(dt):
         try:
-            return flatten_tao_device(gt, dt, dev, max_dets)
+            return flatten_tao_device(gt, dt, dev, max_dets, visit_universe)
         except (Unsupported, Rejected):
             pass
-    return flatten.flatten_tao(gt, dt, max_dets, use_cats=use_cats)
+    return flatten.flatten_tao(gt, dt, max_dets, use_cats=use_cats,
+                               visit_universe=visit_universe)

@@ -358,3 +358,37 @@ def test_chunk_format_round_trip_numpy():
     assert np.array_equal(p.transpose(2, 3, 0, 1)[m], val[m])
     assert np.array_equal(r.transpose(1, 2, 0)[m], rec[m])
     assert (p.transpose(2, 3, 0, 1)[~m] == -1).all() and (r.transpose(1, 2, 0)[~m] == -1).all()
+
+
+def test_visiting_order_of_a_share_comes_from_the_whole_set():
+    """The track level visits images in CPython set-iteration order
+    (T/tao.py:224-230), which depends on EVERY id in the set.  A rank that holds
+    only its own videos must rank its images inside the set of all ranks' images
+    (flatten.tao_gt_side(visit_universe=...)): same relative order as in the
+    whole problem -- and, with ids that collide in the hash table, a different
+    one from what the share alone would give."""
+    from tao_amodal_amd import flatten
+    from tao_amodal_amd.columns import GTColumns
+    from tao_amodal_amd.synth import synth
+    rng = np.random.default_rng(3)
+    parts = []
+    for r in range(3):
+        gt, _ = synth(seed=40 + r, V=2, F=9, C=8, dets_per_frame=4, n_present=3,
+                      video_id_base=r * 2)
+        # scatter the image ids: multiples of 2^k collide in CPython's table
+        new = (rng.permutation(4000)[:len(gt.img_id)].astype(np.int64) << 12) + r
+        remap = dict(zip(gt.img_id.tolist(), new.tolist()))
+        gt.img_id = new
+        gt.ann_img = np.array([remap[i] for i in gt.ann_img.tolist()], dtype=np.int64)
+        parts.append(gt)
+    whole = GTColumns.concat(parts)
+    universe = flatten.video_images(whole)
+    Tw = flatten.tao_gt_side(whole)
+    differs = False
+    for gt in parts:
+        Tp = flatten.tao_gt_side(gt, visit_universe=universe)
+        Ta = flatten.tao_gt_side(gt)
+        in_whole = Tw.visit_rank[np.searchsorted(Tw.img_ids, Tp.img_ids)]
+        assert np.array_equal(np.argsort(in_whole), np.argsort(Tp.visit_rank))
+        differs |= not np.array_equal(np.argsort(Ta.visit_rank), np.argsort(Tp.visit_rank))
+    assert differs

@@ -139,11 +139,15 @@ def _worker(rank, world, port, mode, out):
             engine.DeviceProblem(tdist.shard_by_category(f_t, k0, k1), dev),
             rank, world, dev)
     else:
+        # a rank's own videos, tables built on the device; the visiting order
+        # of the track level from the image ids of all ranks
+        from tao_amodal_amd import flatten_dev
         parts, _, _ = _parts(world)
         gt, dt = parts[rank]
-        f_l = fl.flatten_lvis(gt, dt)
+        universe = tdist.gather_visit_universe(gt, dev)
+        f_l = flatten_dev.flatten_lvis(gt, dt, device=dev)
         dt.track_id, _ = fl.make_track_ids_unique(dt)
-        f_t = fl.flatten_tao(gt, dt)
+        f_t = flatten_dev.flatten_tao(gt, dt, device=dev, visit_universe=universe)
         plan = tdist.ExchangePlan(engine.DeviceProblem(f_l, dev),
                                   engine.DeviceProblem(f_t, dev), rank, world, dev)
     plan.step()
