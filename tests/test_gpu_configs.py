@@ -29,15 +29,27 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def _whole_problem_vs_oracle(gt, dt):
-    from tao_amodal_amd import engine
+    """The cell tables are built on the device (flatten_dev) and must equal the
+    numpy tables the oracle evaluates; the kernels run on the device tables."""
+    from tao_amodal_amd import engine, flatten_dev
     f_l = fl.flatten_lvis(gt, dt)
+    d_l = flatten_dev.flatten_lvis_device(gt, dt, "cuda:0")
     dt.track_id, _ = fl.make_track_ids_unique(dt)
     f_t = fl.flatten_tao(gt, dt)
+    d_t = flatten_dev.flatten_tao_device(gt, dt, "cuda:0")
+    for a, b, names in ((d_l, f_l, ("dt_row", "dt_score", "dt_flags", "dt_cell")),
+                        (d_t, f_t, ("dt_id", "dt_score", "dt_area", "dt_len",
+                                    "dt_frame_off", "dt_frame_pos", "dt_cell"))):
+        assert np.array_equal(a.cell_dt_off, b.cell_dt_off)
+        assert np.array_equal(a.cell_gt_off, b.cell_gt_off)
+        for k in names:
+            assert np.array_equal(np.asarray(a[k]).astype(np.asarray(b[k]).dtype),
+                                  np.asarray(b[k])), k
     orclib.set_threads(0)
     try:
-        for flat in (f_l, f_t):
+        for flat, dflat in ((f_l, d_l), (f_t, d_t)):
             want = orclib.run_flat(flat, detail=False)
-            dp = engine.DeviceProblem(flat, "cuda:0")
+            dp = engine.DeviceProblem(dflat, "cuda:0")
             ws = engine.Workspace(dp)
             engine.run(dp, ws)
             torch.cuda.synchronize()
