@@ -280,6 +280,9 @@ class DTColumns:
                 raise AssertionError("results is not a list.")
             if msg.startswith("cannot open"):
                 raise FileNotFoundError(msg)
+            if "KeyError: '" in msg:
+                # a required key is absent: what the reference's dict access raises
+                raise KeyError(msg.split("KeyError: '")[1].split("'")[0])
             raise ValueError("malformed prediction file: " + msg)
         try:
             n = lib.taoamd_pred_count(h)

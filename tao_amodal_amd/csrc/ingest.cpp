@@ -31,6 +31,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -83,6 +84,11 @@ struct Cursor {
             p += 8; v = -INFINITY; return true;
         }
         auto r = std::from_chars(s, p, v);
+        if (r.ec == std::errc::result_out_of_range && r.ptr == p) {
+            // 1e400 -> inf, 1e-400 -> 0.0, as json.load (float()) gives them
+            v = strtod(std::string(s, p).c_str(), nullptr);
+            return true;
+        }
         if (r.ec != std::errc() || r.ptr != p) { bad("malformed number"); return false; }
         return true;
     }
@@ -223,10 +229,45 @@ const char *find_elements(const char *p0, const char *e,
     return close_pos;
 }
 
+// text of a JSON string body with its escapes resolved (ASCII \uXXXX only:
+// enough for key names)
+static std::string unescape(const char *b, const char *e)
+{
+    std::string out;
+    for (const char *p = b; p < e; p++) {
+        if (*p != '\\' || p + 1 >= e) { out.push_back(*p); continue; }
+        p++;
+        switch (*p) {
+        case 'b': out.push_back('\b'); break;
+        case 'f': out.push_back('\f'); break;
+        case 'n': out.push_back('\n'); break;
+        case 'r': out.push_back('\r'); break;
+        case 't': out.push_back('\t'); break;
+        case 'u':
+            if (p + 4 < e) {
+                unsigned v = 0;
+                for (int k = 1; k <= 4; k++) {
+                    const char c = p[k];
+                    v = v * 16 + (c >= '0' && c <= '9' ? c - '0'
+                                  : c >= 'a' && c <= 'f' ? c - 'a' + 10
+                                  : c >= 'A' && c <= 'F' ? c - 'A' + 10 : 0);
+                }
+                out.push_back(v < 128 ? (char)v : '?');
+                p += 4;
+            }
+            break;
+        default: out.push_back(*p);
+        }
+    }
+    return out;
+}
+
 bool key_is(const char *b, const char *e, const char *name)
 {
     size_t n = strlen(name);
-    return (size_t)(e - b) == n && !memcmp(b, name, n);
+    if ((size_t)(e - b) == n && !memcmp(b, name, n)) return true;
+    if (!memchr(b, '\\', (size_t)(e - b))) return false;
+    return unescape(b, e) == name;        // "\u0069mage_id" is image_id too
 }
 
 // one prediction object [b, e) -> row i of the columns
@@ -247,7 +288,14 @@ bool parse_object(const char *b, const char *e, int64_t i, Columns &c, std::stri
             else if (key_is(kb, ke, "category_id")) { if (cur.integer(iv)) { c.category_id[i] = iv; has_cat = true; } }
             else if (key_is(kb, ke, "track_id")) { if (cur.integer(iv)) c.track_id[i] = iv; }
             else if (key_is(kb, ke, "video_id")) { if (cur.integer(iv)) c.video_id[i] = iv; }
-            else if (key_is(kb, ke, "score")) { if (cur.number(v)) { c.score[i] = v; has_score = true; } }
+            else if (key_is(kb, ke, "score")) {
+                cur.ws();
+                if (cur.p < cur.e && (*cur.p == 't' || *cur.p == 'f')) {
+                    c.score[i] = *cur.p == 't' ? 1.0 : 0.0;     // True == 1
+                    cur.skip();
+                    has_score = true;
+                } else if (cur.number(v)) { c.score[i] = v; has_score = true; }
+            }
             else if (key_is(kb, ke, "bbox")) {
                 if (!cur.eat('[')) cur.bad("bbox is not a list");
                 for (int k = 0; k < 4 && !cur.fail; k++) {
@@ -571,6 +619,26 @@ void *taoamd_pred_parse(const char *path, char *err, size_t errlen)
         char closer = 0;
         const char *close_pos = find_elements(p, e, el, &closer);
         if (!close_pos || closer != ']') { done(); return fail("unterminated list"); }
+        // between the objects only commas and white space may stand: a bare
+        // number or string in the list is not a prediction (json.load would
+        // hand it to the evaluator, which fails on it), and nothing but white
+        // space may follow the list
+        auto blank = [](const char *a, const char *b, bool commas) {
+            for (; a < b; a++)
+                if (!(*a == ' ' || *a == '\n' || *a == '\t' || *a == '\r' ||
+                      (commas && *a == ',')))
+                    return false;
+            return true;
+        };
+        bool clean = blank(close_pos + 1, e, false);
+        if (!clean) { done(); return fail("Extra data after the list"); }
+        const char *prev = p;
+        for (size_t i = 0; i < el.size() && clean; i++) {
+            clean = blank(prev, el[i].first, true);
+            prev = el[i].second;
+        }
+        if (clean) clean = blank(prev, close_pos, true);
+        if (!clean) { done(); return fail("list element is not an object"); }
         objs.resize(el.size());
         for (size_t i = 0; i < el.size(); i++)
             objs[i] = {(size_t)(el[i].first - buf), (size_t)(el[i].second - buf)};

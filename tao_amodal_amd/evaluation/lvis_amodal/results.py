@@ -32,7 +32,9 @@ class LVISResults(LVIS):
             self._raw_path = results
             try:
                 self.columns_dt = DTColumns.from_json(results)
-            except (KeyError, ValueError):
+            except KeyError as e:
+                if e.args != ("bbox",):
+                    raise
                 # no "bbox": results given as masks (reference results.py:54)
                 self.columns_dt = self._from_masks(self.raw_results)
         else:

@@ -63,7 +63,7 @@ def test_errors(tmp_path):
     with pytest.raises(ValueError):
         DTColumns.from_file_native(str(p))
     p.write_text('[{"image_id": 1, "category_id": 2, "score": 1}]')
-    with pytest.raises(ValueError, match="bbox"):
+    with pytest.raises(KeyError, match="bbox"):      # as the reference's r["bbox"]
         DTColumns.from_file_native(str(p))
     with pytest.raises(FileNotFoundError):
         DTColumns.from_file_native(str(tmp_path / "missing.json"))
@@ -229,3 +229,26 @@ def test_parallel_boundary_scan_with_hostile_strings(tmp_path):
     p.write_text(json.dumps(preds)[:-1])
     with pytest.raises(ValueError):
         DTColumns.from_file_native(str(p))
+
+
+def test_reader_corner_cases_of_json_load(tmp_path):
+    """What json.load accepts the reader accepts with the same values, what the
+    evaluator cannot use it rejects: out-of-range exponents (inf / 0.0 as
+    float() gives them), keys written with \\u escapes, a boolean score
+    (True == 1), bare scalars between the objects, bytes after the list."""
+    ok = tmp_path / "ok.json"
+    ok.write_text('[{"\\u0069mage_id": 3, "category_id": 2, "bbox": [1e400, 1e-400, -1e999, 2],'
+                  ' "score": true, "track_id": 1, "video_id": 1},\n'
+                  ' {"image_id": 4, "category_id": 2, "bbox": [0, 0, 1, 1], "score": false}]  \n')
+    got = DTColumns.from_file_native(str(ok))
+    want = DTColumns.from_json(json.load(open(ok)))
+    _same(got, want)
+    assert np.isinf(got.bbox[0, 0]) and got.bbox[0, 1] == 0.0 and got.bbox[0, 2] == -np.inf
+    assert got.score.tolist() == [1.0, 0.0] and got.image_id.tolist() == [3, 4]
+    for text in ('[5, {"image_id": 4, "category_id": 2, "bbox": [0, 0, 1, 1], "score": 1}]',
+                 '[{"image_id": 4, "category_id": 2, "bbox": [0, 0, 1, 1], "score": 1}, "x"]',
+                 '[{"image_id": 4, "category_id": 2, "bbox": [0, 0, 1, 1], "score": 1}] tail'):
+        bad = tmp_path / "bad.json"
+        bad.write_text(text)
+        with pytest.raises(ValueError):
+            DTColumns.from_file_native(str(bad))
