@@ -21,6 +21,17 @@ import json
 import numpy as np
 
 
+FREQ_MISSING, FREQ_OTHER = ord("?"), 0xFF
+
+
+def _freq_byte(cat):
+    if "frequency" not in cat:
+        return FREQ_MISSING
+    f = cat["frequency"]
+    return ord(f) if isinstance(f, str) and len(f) == 1 and ord(f) < 0x80 \
+        and f != "?" else FREQ_OTHER
+
+
 def _csr(lists):
     off = np.zeros(len(lists) + 1, dtype=np.int64)
     if len(lists):
@@ -129,7 +140,10 @@ class GTColumns:
         i64 = np.int64
         return cls(
             cat_id=np.asarray([c["id"] for c in cats], dtype=i64),
-            cat_freq=np.asarray([ord(c.get("frequency", "?")[0])
+            # one byte per category: the letter; FREQ_MISSING when the key is
+            # absent, FREQ_OTHER for any other text ("rare", "") -- the
+            # reference's img_count_lbl.index() fails on those
+            cat_freq=np.asarray([_freq_byte(c)
                                  for c in cats], dtype=np.uint8),
             cat_merged=np.asarray(merged, dtype=i64).reshape(-1, 2),
             vid_id=np.asarray([v["id"] for v in vids], dtype=i64),

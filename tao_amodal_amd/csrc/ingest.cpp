@@ -448,8 +448,11 @@ void parse_categories(const Ranges &r, GT &g, Fail &fl)
             else if (key_is(kb, ke, "frequency")) {
                 const char *b, *e;
                 if (c.str(b, e)) {
-                    if (e == b || *b == '\\' || (unsigned char)*b >= 0x80) c.bad("unsupported frequency string");
-                    else g.cat_freq[i] = (uint8_t)*b;
+                    // the letter; 0xFF for any other text ("rare", ""): the
+                    // reference's img_count_lbl.index() fails on those
+                    const bool letter = e - b == 1 && *b != '\\' && *b != '?' &&
+                                        (unsigned char)*b < 0x80;
+                    g.cat_freq[i] = letter ? (uint8_t)*b : (uint8_t)0xFF;
                 }
             } else if (key_is(kb, ke, "merged")) {
                 Ranges ms;

@@ -48,6 +48,8 @@ def _to_device(v, device):
     dev = torch.device(device)
     if dev not in ent[1]:
         ent[1][dev] = torch.from_numpy(np.ascontiguousarray(v.source)).to(dev)
+        if isinstance(v.source, np.ndarray):
+            v.source.setflags(write=False)     # cached by identity: no silent edits
     if len(v.index) == 0:
         return torch.zeros((0,) + tuple(v.source.shape[1:]), dtype=ent[1][dev].dtype,
                            device=dev)

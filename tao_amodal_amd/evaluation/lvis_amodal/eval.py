@@ -166,7 +166,12 @@ class LVISEval:
 
     def _prepare_freq_group(self):
         groups = [[] for _ in self.params.img_count_lbl]
+        from ...columns import FREQ_MISSING, FREQ_OTHER
         for idx, fr in enumerate(self.flat.cat_freq.tolist()):
+            if fr == FREQ_MISSING:
+                raise KeyError("frequency")       # reference: cat["frequency"]
+            if fr == FREQ_OTHER:
+                raise ValueError("category frequency is not in list")
             groups[self.params.img_count_lbl.index(chr(fr))].append(idx)
         return groups
 

@@ -168,6 +168,11 @@ def limit_dets_per_image(dt, max_dets=MAX_DETS):
         order = sort_key_score(img_rank)
     try:
         dt._limit_cache = (max_dets, n, order)
+        # the cut is reused for this DTColumns: the columns it depends on
+        # become read-only, so an in-place edit fails instead of going stale
+        for col in (dt.image_id, dt.score):
+            if isinstance(col, np.ndarray):
+                col.setflags(write=False)
     except AttributeError:
         pass
     return order

@@ -86,6 +86,10 @@ def raw_columns(dt, device):
             v = getattr(dt, name, None)
             cols[name] = None if v is None else torch.from_numpy(
                 np.ascontiguousarray(v)).to(dev, non_blocking=True)
+            if isinstance(v, np.ndarray):
+                # the device copy is reused for this DTColumns: an in-place
+                # edit of the host column must fail loudly, not go stale
+                v.setflags(write=False)
         area = getattr(dt, "area", None)
         cols["area"] = None if area is None else torch.from_numpy(
             np.ascontiguousarray(area, dtype=np.float64)).to(dev)
