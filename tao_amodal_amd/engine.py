@@ -47,7 +47,10 @@ def _to_device(v, device):
         _RAW_TABLES[key] = ent
     dev = torch.device(device)
     if dev not in ent[1]:
-        ent[1][dev] = torch.from_numpy(np.ascontiguousarray(v.source)).to(dev)
+        import warnings
+        with warnings.catch_warnings():       # (frozen by an earlier upload)
+            warnings.simplefilter("ignore")
+            ent[1][dev] = torch.from_numpy(np.ascontiguousarray(v.source)).to(dev)
         if isinstance(v.source, np.ndarray):
             v.source.setflags(write=False)     # cached by identity: no silent edits
     if len(v.index) == 0:

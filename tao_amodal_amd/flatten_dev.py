@@ -11,6 +11,7 @@ The ground-truth side (10^5 rows, dict / alias semantics) is taken from
 PyTorch only allocates; every pass is a kernel of the C ABI
 (``taoamd_flat_*``, ``taoamd_sort_by_cat_score``).
 """
+import warnings
 import weakref
 
 import numpy as np
@@ -84,8 +85,10 @@ def raw_columns(dt, device):
         cols = {}
         for name in ("image_id", "category_id", "score", "bbox", "video_id"):
             v = getattr(dt, name, None)
-            cols[name] = None if v is None else torch.from_numpy(
-                np.ascontiguousarray(v)).to(dev, non_blocking=True)
+            with warnings.catch_warnings():      # (a column frozen by an earlier
+                warnings.simplefilter("ignore")  # upload: read-only is intended)
+                cols[name] = None if v is None else torch.from_numpy(
+                    np.ascontiguousarray(v)).to(dev, non_blocking=True)
             if isinstance(v, np.ndarray):
                 # the device copy is reused for this DTColumns: an in-place
                 # edit of the host column must fail loudly, not go stale
