@@ -132,6 +132,11 @@ def self_spawn(n):
 # algorithmic (compulsory) HBM bytes of ONE launch of every kernel of the
 # step, DESIGN.md "Kernels": each datum the kernel needs moved once
 # --------------------------------------------------------------------------
+def _lib_tile():
+    from tao_amodal_amd import _lib
+    return _lib.SEGMENT_TILE
+
+
 def kernel_models(dp, ws):
     T, R = 10, 101
     K, A, nw = dp.n_cat, dp.n_rng, dp.n_words
@@ -140,7 +145,7 @@ def kernel_models(dp, ws):
     live = int((ws.num_gt > 0).sum().item())       # (category, range) rows with GT
     table = 8 * T * R                              # one row of val / precision
     seg = np.diff(dp.cat_off_host).astype(np.int64)
-    tile = 3072
+    tile = _lib_tile()
     n_multi = int(seg[seg > tile].sum())
     m = {}
     if dp.kind == "lvis":

@@ -461,7 +461,7 @@ int taoamd_sort_by_cat_score(int64_t n, const int32_t *dt_cat,
  * n_tiles its total; max_segment = host value of the longest run.  Tiles are
  * sorted in LDS, longer runs finished by rank-merge passes.
  * Workspace: taoamd_sort_segments_workspace(n). */
-#define TAOAMD_SEGMENT_TILE 3072
+#define TAOAMD_SEGMENT_TILE 2816
 size_t taoamd_sort_segments_workspace(int64_t n);
 int taoamd_sort_segments(int64_t n, int32_t n_cat, const int32_t *cat_off,
                          const int32_t *tile_off, int32_t n_tiles,
@@ -515,6 +515,16 @@ int taoamd_accumulate(int64_t n_dt, int32_t n_cat, int32_t n_rng,
                       const int32_t *num_gt, int32_t max_segment, double *precision,
                       double *recall, void *workspace, size_t workspace_bytes,
                       void *stream);
+/* The same with the rows where the match kernel left them when it ran WITHOUT
+ * `dst` (row = detection, cell order): order[p] = detection at sorted position
+ * p (taoamd_sort_segments).  The first sweep gathers the rows through it -- the
+ * match then neither waits for the sort nor scatters 16-byte rows. */
+int taoamd_accumulate_by_order(int64_t n_dt, int32_t n_cat, int32_t n_rng,
+                               const int32_t *cat_off, const int32_t *order,
+                               const uint64_t *matched, const uint64_t *ignored,
+                               const int32_t *num_gt, int32_t max_segment,
+                               double *precision, double *recall, void *workspace,
+                               size_t workspace_bytes, void *stream);
 
 /* ---- multi-GPU result exchange (category-partitioned evaluation) -------------------
  * No reference counterpart (the reference is single-process); these carry the

@@ -17,7 +17,7 @@ OK = 0
 N_THR, N_REC = 10, 101
 LVIS_RNG, TAO_RNG = 6, 20
 MAX_GT_PER_CELL = 3072
-SEGMENT_TILE = 3072
+SEGMENT_TILE = 2816
 
 _vp, _i64, _i32, _sz = C.c_void_p, C.c_int64, C.c_int32, C.c_size_t
 
@@ -117,6 +117,8 @@ SIGNATURES = {
     "taoamd_accumulate_workspace": (_sz, [_i64, _i32, _i32]),
     "taoamd_accumulate": (C.c_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _i32,
                                     _vp, _vp, _vp, _sz, _vp]),
+    "taoamd_accumulate_by_order": (C.c_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp,
+                                             _vp, _i32, _vp, _vp, _vp, _sz, _vp]),
 }
 
 _lib = None

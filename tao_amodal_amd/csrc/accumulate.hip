@@ -81,6 +81,7 @@ struct AccArgs {
     const int32_t *cat_off;
     const uint64_t *matched;
     const uint64_t *ignored;
+    const int32_t *order;    // optional: sorted position -> row of matched / ignored
     const int32_t *num_gt;
     int32_t *cat_chunk_off;  // [n_cat + 1]
     uint32_t *cnt_tp, *cnt_fp;   // [chunk][word][64] counts inside the chunk
@@ -149,15 +150,20 @@ __device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int lane)
 // Rows [base, base+n) of a chunk: lane q loads row q (coalesced), returning
 // the TP and FP words of that row; the sequential loops then broadcast row q
 // with v_readlane, so there is no memory access inside them.
-__device__ __forceinline__ void load_rows(const uint64_t *__restrict__ M,
-                                          const uint64_t *__restrict__ I,
-                                          int n_words, int base, int n, int lane,
-                                          uint64_t &tpw, uint64_t &fpw)
+// `first` = sorted position of the block's first row.  With a.order the rows
+// still lie where the match kernel produced them (cell order: its stores are
+// full wavefront runs and it does not wait for the sort) and are gathered here,
+// the one place that reads them.
+__device__ __forceinline__ void load_rows(const AccArgs &a, int64_t first, int word,
+                                          int n, int lane, uint64_t &tpw,
+                                          uint64_t &fpw)
 {
     uint64_t m = 0, i = ~0ull;
     if (lane < n) {
-        m = M[(int64_t)(base + lane) * n_words];
-        i = I[(int64_t)(base + lane) * n_words];
+        int64_t r = first + lane;
+        if (a.order) r = a.order[r];
+        m = a.matched[r * a.n_words + word];
+        i = a.ignored[r * a.n_words + word];
     }
     tpw = m & ~i;
     fpw = ~m & ~i;
@@ -218,15 +224,13 @@ __global__ __launch_bounds__(256) void acc_count_kernel(AccArgs a)
     if (!ci.valid) return;
     const int lane = lane_id();
     uint32_t tp = 0, fp = 0;
-    const uint64_t *__restrict__ M = a.matched + ci.start * a.n_words + ci.word;
-    const uint64_t *__restrict__ I = a.ignored + ci.start * a.n_words + ci.word;
     const int64_t tb = (((int64_t)ci.c * a.n_words + ci.word) * ACC_BLK) * WAVE + lane;
     for (int blk = 0; blk < ACC_BLK; blk++) {
         const int base = blk * WAVE;
         uint64_t T = 0, F = 0;
         if (base < ci.len) {
             uint64_t tpw, fpw;
-            load_rows(M, I, a.n_words, base, min(WAVE, ci.len - base), lane, tpw, fpw);
+            load_rows(a, ci.start + base, ci.word, min(WAVE, ci.len - base), lane, tpw, fpw);
             T = transpose64(tpw, lane);
             F = transpose64(fpw, lane);
         }
@@ -582,15 +586,13 @@ __global__ __launch_bounds__(ACC_FUSED_WAVES * WAVE) void acc_fused_kernel(AccAr
     uint64_t T[ACC_BLK], TF[ACC_BLK];
     uint32_t tp_own = 0, fp_own = 0;
     {
-        const uint64_t *__restrict__ M = a.matched + (int64_t)start * nw + word;
-        const uint64_t *__restrict__ I = a.ignored + (int64_t)start * nw + word;
 #pragma unroll
         for (int blk = 0; blk < ACC_BLK; blk++) {
             const int base = blk * WAVE;
             uint64_t t_ = 0, f_ = 0;
             if (base < len) {
                 uint64_t tpw, fpw;
-                load_rows(M, I, nw, base, min(WAVE, len - base), lane, tpw, fpw);
+                load_rows(a, (int64_t)start + base, word, min(WAVE, len - base), lane, tpw, fpw);
                 t_ = transpose64(tpw, lane);
                 f_ = transpose64(fpw, lane);
             }
@@ -826,15 +828,12 @@ extern "C" size_t taoamd_accumulate_workspace(int64_t n_dt, int32_t n_cat,
            align256((size_t)n_cat * n_rng * N_THR * 8);
 }
 
-extern "C" int taoamd_accumulate_compact(int64_t n_dt, int32_t n_cat,
-                                         int32_t n_rng, const int32_t *cat_off,
-                                         const uint64_t *matched,
-                                         const uint64_t *ignored,
-                                         const int32_t *num_gt, int32_t k_begin,
-                                         int32_t k_end, int32_t max_segment,
-                                         double *val, double *rec,
-                                         void *workspace, size_t workspace_bytes,
-                                         void *stream)
+static int accumulate_compact(int64_t n_dt, int32_t n_cat, int32_t n_rng,
+                              const int32_t *cat_off, const int32_t *order,
+                              const uint64_t *matched, const uint64_t *ignored,
+                              const int32_t *num_gt, int32_t k_begin, int32_t k_end,
+                              int32_t max_segment, double *val, double *rec,
+                              void *workspace, size_t workspace_bytes, void *stream)
 {
     if (n_cat <= 0 || n_rng < 1 || n_rng > 32) return TAOAMD_ERR_ARG;
     if (k_begin < 0 || k_end > n_cat || k_begin > k_end) return TAOAMD_ERR_ARG;
@@ -849,7 +848,7 @@ extern "C" int taoamd_accumulate_compact(int64_t n_dt, int32_t n_cat,
     a.n_dt = n_dt; a.n_cat = n_cat; a.n_rng = n_rng;
     a.n_words = (n_rng * N_THR + 63) / 64;
     a.n_chunks_max = max_chunks(n_dt, n_cat);
-    a.cat_off = cat_off; a.matched = matched; a.ignored = ignored;
+    a.cat_off = cat_off; a.matched = matched; a.ignored = ignored; a.order = order;
     a.num_gt = num_gt; a.val = val; a.rec = rec;
     a.k_begin = k_begin; a.k_end = k_end;
     a.inline_scans = 0;
@@ -897,6 +896,21 @@ extern "C" int taoamd_accumulate_compact(int64_t n_dt, int32_t n_cat,
     return TAOAMD_OK;
 }
 
+extern "C" int taoamd_accumulate_compact(int64_t n_dt, int32_t n_cat,
+                                         int32_t n_rng, const int32_t *cat_off,
+                                         const uint64_t *matched,
+                                         const uint64_t *ignored,
+                                         const int32_t *num_gt, int32_t k_begin,
+                                         int32_t k_end, int32_t max_segment,
+                                         double *val, double *rec,
+                                         void *workspace, size_t workspace_bytes,
+                                         void *stream)
+{
+    return accumulate_compact(n_dt, n_cat, n_rng, cat_off, nullptr, matched, ignored,
+                              num_gt, k_begin, k_end, max_segment, val, rec,
+                              workspace, workspace_bytes, stream);
+}
+
 extern "C" int taoamd_finalize(int32_t n_cat, int32_t n_rng,
                                const int32_t *num_gt, const double *val,
                                const double *rec, double *precision,
@@ -915,13 +929,12 @@ extern "C" int taoamd_finalize(int32_t n_cat, int32_t n_rng,
     return TAOAMD_OK;
 }
 
-extern "C" int taoamd_accumulate(int64_t n_dt, int32_t n_cat, int32_t n_rng,
-                                 const int32_t *cat_off,
-                                 const uint64_t *matched,
-                                 const uint64_t *ignored, const int32_t *num_gt,
-                                 int32_t max_segment, double *precision,
-                                 double *recall, void *workspace,
-                                 size_t workspace_bytes, void *stream)
+static int accumulate_all(int64_t n_dt, int32_t n_cat, int32_t n_rng,
+                          const int32_t *cat_off, const int32_t *order,
+                          const uint64_t *matched, const uint64_t *ignored,
+                          const int32_t *num_gt, int32_t max_segment,
+                          double *precision, double *recall, void *workspace,
+                          size_t workspace_bytes, void *stream)
 {
     if (n_cat <= 0 || n_rng < 1 || n_rng > 32) return TAOAMD_ERR_ARG;
     if (!workspace) return TAOAMD_ERR_ARG;
@@ -931,9 +944,38 @@ extern "C" int taoamd_accumulate(int64_t n_dt, int32_t n_cat, int32_t n_rng,
     const size_t base = base_workspace(n_dt, n_cat, n_rng);
     double *val = (double *)(w + base);
     double *rec = val + (align256(taoamd_compact_elems(n_cat, n_rng) * 8) / 8);
-    int st = taoamd_accumulate_compact(n_dt, n_cat, n_rng, cat_off, matched,
-                                       ignored, num_gt, 0, n_cat, max_segment,
-                                       val, rec, w, base, stream);
+    int st = accumulate_compact(n_dt, n_cat, n_rng, cat_off, order, matched, ignored,
+                                num_gt, 0, n_cat, max_segment, val, rec, w, base,
+                                stream);
     if (st != TAOAMD_OK) return st;
     return taoamd_finalize(n_cat, n_rng, num_gt, val, rec, precision, recall, stream);
+}
+
+extern "C" int taoamd_accumulate(int64_t n_dt, int32_t n_cat, int32_t n_rng,
+                                 const int32_t *cat_off,
+                                 const uint64_t *matched,
+                                 const uint64_t *ignored, const int32_t *num_gt,
+                                 int32_t max_segment, double *precision,
+                                 double *recall, void *workspace,
+                                 size_t workspace_bytes, void *stream)
+{
+    return accumulate_all(n_dt, n_cat, n_rng, cat_off, nullptr, matched, ignored,
+                          num_gt, max_segment, precision, recall, workspace,
+                          workspace_bytes, stream);
+}
+
+extern "C" int taoamd_accumulate_by_order(int64_t n_dt, int32_t n_cat, int32_t n_rng,
+                                          const int32_t *cat_off,
+                                          const int32_t *order,
+                                          const uint64_t *matched,
+                                          const uint64_t *ignored,
+                                          const int32_t *num_gt, int32_t max_segment,
+                                          double *precision, double *recall,
+                                          void *workspace, size_t workspace_bytes,
+                                          void *stream)
+{
+    if (!order) return TAOAMD_ERR_ARG;
+    return accumulate_all(n_dt, n_cat, n_rng, cat_off, order, matched, ignored,
+                          num_gt, max_segment, precision, recall, workspace,
+                          workspace_bytes, stream);
 }

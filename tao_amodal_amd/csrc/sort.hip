@@ -293,7 +293,7 @@ extern "C" int taoamd_sort_by_cat_score(int64_t n, const int32_t *dt_cat,
 //   seg_mpass_kernel  longer categories: log2(#tiles) pairwise merge-path
 //                     passes, the last one writes order / dst
 // ---------------------------------------------------------------------------
-#define SEG_TILE 3072
+#define SEG_TILE 2816
 #define SEG_THREADS 256
 
 struct SegArgs {
@@ -326,12 +326,12 @@ struct SegArgs {
 //   * more than SEG_LONG_MAX long runs: the tile starts over with 8 passes.
 #define SEG_RUN_MAX 64
 #define SEG_LONG_MAX 8
-#define SEG_ROUNDS (SEG_TILE / SEG_THREADS)   // 16 rounds of 64 per wavefront
+#define SEG_ROUNDS (SEG_TILE / SEG_THREADS)   // rounds of 64 per wavefront
 
 struct SegLds {
     uint64_t key[SEG_TILE];
     uint16_t pos[SEG_TILE];     // bits 0-11 input position, 14/15 run marks
-    uint32_t wcnt[4][RS_BINS];
+    uint16_t wcnt[4][RS_BINS];  // (a tile holds < 65536 elements)
     uint32_t dbase[RS_BINS];
     uint32_t wave_tot[4];
     int32_t flag;
@@ -396,7 +396,8 @@ __device__ __forceinline__ void seg_passes(SegLds &L, int base, int n, int p0, i
                 uint32_t old = 0;
                 if (ok) old = L.wcnt[wave][dig];
                 rank[r] = old + below;
-                if (ok && (peers >> lane) == 1ull) L.wcnt[wave][dig] = old + below + 1;
+                if (ok && (peers >> lane) == 1ull)
+                    L.wcnt[wave][dig] = (uint16_t)(old + below + 1);
             }
         }
         __syncthreads();
@@ -420,8 +421,9 @@ __device__ __forceinline__ void seg_passes(SegLds &L, int base, int n, int p0, i
             const uint32_t excl = before + inc - tot;
             L.dbase[d] = excl;
             // exclusive over wavefronts, in place
-            L.wcnt[0][d] = 0; L.wcnt[1][d] = c0; L.wcnt[2][d] = c0 + c1;
-            L.wcnt[3][d] = c0 + c1 + c2;
+            L.wcnt[0][d] = 0; L.wcnt[1][d] = (uint16_t)c0;
+            L.wcnt[2][d] = (uint16_t)(c0 + c1);
+            L.wcnt[3][d] = (uint16_t)(c0 + c1 + c2);
             if (tot == (uint32_t)n) L.flag = 1;
         }
         __syncthreads();
@@ -450,7 +452,7 @@ __device__ __forceinline__ void seg_passes(SegLds &L, int base, int n, int p0, i
     }
 }
 
-__global__ __launch_bounds__(SEG_THREADS) void seg_tile_kernel(SegArgs a)
+__global__ __launch_bounds__(SEG_THREADS, 5) void seg_tile_kernel(SegArgs a)
 {
     __shared__ SegLds L;
     // category owning this tile: last k with tile_off[k] <= blockIdx.x
@@ -646,7 +648,7 @@ __global__ __launch_bounds__(256) void seg_kmerge_kernel(SegArgs a)
 // of the left run (it holds the earlier input positions), so the pass is
 // stable with key comparisons only.  Per pass every element is read once and
 // written once, instead of one 12-step search per element and other tile.
-#define MP_PER 12       // outputs per thread: 256 * 12 = SEG_TILE
+#define MP_PER 11       // outputs per thread: 256 * 11 = SEG_TILE
 
 // number of elements of A among the first o outputs of merge(A, B)
 template <class KA, class KB>

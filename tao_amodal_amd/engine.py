@@ -538,6 +538,17 @@ def stage_match(dp, ws, scatter=True):
         dp.n_singles, s), "taoamd_match")
 
 
+def stage_accumulate_by_order(dp, ws):
+    """The sweep over rows the match left in cell order (stage_match(scatter=
+    False)): gathered through the sort's order[] by the first sweep."""
+    lib, t, s = _lib.load(), dp.t, _stream()
+    _lib.check(lib.taoamd_accumulate_by_order(
+        dp.n_dt, dp.n_cat, dp.n_rng, _ptr(t["cat_off"]), _ptr(ws.order),
+        _ptr(ws.matched), _ptr(ws.ignored), _ptr(ws.num_gt), dp.acc_hint,
+        _ptr(ws.precision), _ptr(ws.recall), _ptr(ws.acc_ws), ws.acc_bytes, s),
+        "taoamd_accumulate_by_order")
+
+
 def stage_accumulate(dp, ws):
     lib, t, s = _lib.load(), dp.t, _stream()
     _lib.check(lib.taoamd_accumulate(
@@ -563,6 +574,14 @@ def run(dp, ws):
         _lib.kernel_timing_label(dp.kind)
     for _, fn in STAGES:
         fn(dp, ws)
+
+
+import os as _os
+# Overlap: image-level sort beside ranges + match (see run_forked).  Off: measured
+# slower on one MI355X (0.439 vs 0.421 ms/step at Config 2: the match takes 139
+# instead of 84 us beside the sort -- the step is bound by the sum of its
+# kernels, not by the chain); TAOAMD_SORT_ASIDE=1 switches it on for A/B timing
+SORT_ASIDE = _os.environ.get("TAOAMD_SORT_ASIDE", "0") != "0"
 
 
 class Overlap:
@@ -593,7 +612,7 @@ class Overlap:
         cur = torch.cuda.current_stream(self.device)
         s_aux_l, s_aux_t = self.streams[2], self.streams[3]   # forked by run_forked
         st = self._fork(1)
-        run_forked(dpl, wsl, s_aux_l)
+        run_forked(dpl, wsl, s_aux_l, sort_aside=SORT_ASIDE)
         with torch.cuda.stream(st):
             run_forked(dpt, wst, s_aux_t)
         cur.wait_stream(st)
@@ -690,15 +709,27 @@ def _probed(name, fn, dp, ws):
         PROBE.wrap(dp.kind + ":" + name, fn, dp, ws)
 
 
-def run_forked(dp, ws, aux, head_only=False):
+def run_forked(dp, ws, aux, head_only=False, sort_aside=False):
     """One evaluator pass on the current stream, its independent head stages
     on the stream `aux` (forked from and joined to the current stream):
     image level  ranges || sort -> match -> accumulate,
-    track level  (ranges, sort) || 3D IoU -> match -> accumulate."""
+    track level  (ranges, sort) || 3D IoU -> match -> accumulate.
+    `sort_aside` (image level): sort || (ranges -> match, rows left in cell
+    order) -> accumulate gathering the rows through order[] -- the match does
+    not wait for the sort and stores full wavefront runs."""
     cur = torch.cuda.current_stream(dp.device)
     aux.wait_stream(cur)
     if _lib.TIMING:
         _lib.kernel_timing_label(dp.kind)
+    if sort_aside and dp.kind == "lvis" and not dp.mask_iou and not head_only \
+            and dp.grouped and dp.n_dt:
+        with torch.cuda.stream(aux):
+            stage_sort(dp, ws)
+        stage_ranges(dp, ws)
+        _probed("match", lambda d, w: stage_match(d, w, scatter=False), dp, ws)
+        cur.wait_stream(aux)
+        stage_accumulate_by_order(dp, ws)
+        return
     if dp.kind == "lvis":
         with torch.cuda.stream(aux):
             stage_ranges(dp, ws)

@@ -568,3 +568,24 @@ def test_config2_full_size_properties():
             torch.cuda.synchronize()
             assert torch.equal(sws.precision[:, :, k0:k1], p1[:, :, k0:k1])
             assert torch.equal(sws.recall[:, k0:k1], r1[:, k0:k1])
+
+
+def test_sort_beside_the_match_gives_the_same_tables():
+    """Overlap's image-level chain: the match leaves its rows in cell order while
+    the sort runs beside it, the first sweep gathers them through order[]
+    (taoamd_accumulate_by_order).  Same precision / recall as the chain that
+    scatters the rows to their sorted place, and as the oracle."""
+    import torch
+    from tao_amodal_amd import engine
+    gt, dt = synth(seed=21, V=8, F=40, C=60, dets_per_frame=40, n_present=5)
+    f = fl.flatten_lvis(gt, dt)
+    want = orclib.run_flat(f, detail=False)
+    dp = engine.DeviceProblem(f, "cuda:0")
+    ws = engine.Workspace(dp)
+    aux = torch.cuda.Stream("cuda:0")
+    for aside in (True, False, True):
+        ws.precision.fill_(7.0)
+        engine.run_forked(dp, ws, aux, sort_aside=aside)
+        torch.cuda.synchronize()
+        assert np.array_equal(ws.precision.cpu().numpy(), want["precision"]), aside
+        assert np.array_equal(ws.recall.cpu().numpy(), want["recall"]), aside
