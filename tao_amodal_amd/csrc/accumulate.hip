@@ -54,26 +54,6 @@ using namespace taoamd;
 #ifndef ACC_INLINE_CHUNKS
 #define ACC_INLINE_CHUNKS 64    // categories up to 16384 rows scan their chunks inline
 #endif
-#define ACC_EPS 2.220446049250313e-16  // np.spacing(1)
-
-// (tp, n) pairs packed as tp << 32 | n.  better(a, b): pair a gives a larger
-// tp / (n + eps) than pair b (see the header comment).
-__device__ __forceinline__ bool pr_better(uint32_t ta, uint32_t na, uint64_t b)
-{
-    const uint32_t tb = (uint32_t)(b >> 32), nb = (uint32_t)b;
-    const uint64_t l = (uint64_t)ta * nb, r = (uint64_t)tb * na;
-    return l > r || (l == r && na > nb);
-}
-__device__ __forceinline__ uint64_t pr_pack(uint32_t t, uint32_t n)
-{
-    return ((uint64_t)t << 32) | n;
-}
-__device__ __forceinline__ double pr_value(uint64_t p)
-{
-    const double t = (double)(uint32_t)(p >> 32), n = (double)(uint32_t)p;
-    return t / (n + ACC_EPS);   // fp + tp == n exactly
-}
-#define PR_ZERO 1ull   // (0, 1): value 0
 
 struct AccArgs {
     int64_t n_dt;
@@ -89,7 +69,7 @@ struct AccArgs {
     uint64_t *t_tp, *t_fp;       // [chunk][word][4 blocks][64] transposed TP / FP words
     uint64_t *cmax;              // chunk max as (tp << 32 | n), then reverse-exclusive max
     int32_t *cj;                 // [n_cat][n_rng][N_REC] TP count crossing each recall thr
-    double *val;                 // [n_cat][n_rng][N_THR][N_REC]
+    uint64_t *val;               // [n_cat][n_rng][N_THR][N_REC] (tp << 32 | n) records
     double *rec;                 // [n_cat][n_rng][N_THR]
     int32_t k_begin, k_end;      // categories swept by this call
     int32_t fused_rows;          // categories up to this many rows take acc_fused_kernel
@@ -225,14 +205,20 @@ __global__ __launch_bounds__(256) void acc_count_kernel(AccArgs a)
     const int lane = lane_id();
     uint32_t tp = 0, fp = 0;
     const int64_t tb = (((int64_t)ci.c * a.n_words + ci.word) * ACC_BLK) * WAVE + lane;
+    // every load of the chunk ahead of its first store: gfx9 counts loads and
+    // stores in one in-order counter (vmcnt), so a load issued after a store
+    // waits for that store's acknowledgement as well
+    uint64_t tpw[ACC_BLK], fpw[ACC_BLK];
+#pragma unroll
+    for (int blk = 0; blk < ACC_BLK; blk++)
+        load_rows(a, ci.start + blk * WAVE, ci.word,
+                  max(0, min(WAVE, ci.len - blk * WAVE)), lane, tpw[blk], fpw[blk]);
+#pragma unroll
     for (int blk = 0; blk < ACC_BLK; blk++) {
-        const int base = blk * WAVE;
         uint64_t T = 0, F = 0;
-        if (base < ci.len) {
-            uint64_t tpw, fpw;
-            load_rows(a, ci.start + base, ci.word, min(WAVE, ci.len - base), lane, tpw, fpw);
-            T = transpose64(tpw, lane);
-            F = transpose64(fpw, lane);
+        if (blk * WAVE < ci.len) {
+            T = transpose64(tpw[blk], lane);
+            F = transpose64(fpw[blk], lane);
         }
         a.t_tp[tb + (int64_t)blk * WAVE] = T;
         a.t_fp[tb + (int64_t)blk * WAVE] = F;
@@ -304,8 +290,8 @@ __global__ __launch_bounds__(256) void acc_prefix_kernel(AccArgs a, RecThr rec)
             // a category without detections still has precision 0 / recall 0
             // where it has evaluated GT (reference lvis_amodal/eval.py:412-417)
             if (c0 == c1) {
-                double *out = a.val + (kr * N_THR + t) * N_REC;
-                for (int j = 0; j < N_REC; j++) out[j] = 0.0;
+                uint64_t *out = a.val + (kr * N_THR + t) * N_REC;
+                for (int j = 0; j < N_REC; j++) out[j] = PR_ZERO;
             }
         }
     }
@@ -321,7 +307,63 @@ __global__ __launch_bounds__(256) void acc_chunkmax_kernel(AccArgs a, RecThr rec
     const ChunkInfo ci = chunk_info(a);
     if (!ci.valid) return;
     const int lane = lane_id();
+    const int64_t o = ((int64_t)ci.c * a.n_words + ci.word) * WAVE + lane;
+    uint32_t tp0, n0, pre_t = 0, pre_f = 0;
     if (INLINE) {
+        uint32_t fp0 = 0;
+        tp0 = 0;
+        for (int32_t c = a.cat_chunk_off[ci.k]; c < ci.c; c++) {
+            const int64_t oc = ((int64_t)c * a.n_words + ci.word) * WAVE + lane;
+            tp0 += a.cnt_tp[oc];
+            fp0 += a.cnt_fp[oc];
+        }
+        pre_t = tp0;
+        pre_f = fp0;
+        n0 = tp0 + fp0;
+    } else {
+        tp0 = a.pre_tp[o];
+        n0 = tp0 + a.pre_fp[o];
+    }
+    uint64_t best = PR_ZERO;
+    const int64_t tb = (((int64_t)ci.c * a.n_words + ci.word) * ACC_BLK) * WAVE + lane;
+    // (blocks past the chunk's rows hold zero words: acc_count_kernel wrote them)
+    uint64_t Tb[ACC_BLK], TFb[ACC_BLK];
+#pragma unroll
+    for (int blk = 0; blk < ACC_BLK; blk++) {
+        Tb[blk] = a.t_tp[tb + (int64_t)blk * WAVE];
+        TFb[blk] = Tb[blk] | a.t_fp[tb + (int64_t)blk * WAVE];
+    }
+#pragma unroll
+    for (int blk = 0; blk < ACC_BLK; blk++) {
+        const uint64_t T = Tb[blk], TF = TFb[blk];
+        // a TP row directly followed by a TP row cannot hold the maximum:
+        // (tp+1)/(n+1) >= tp/n, and on a tie the larger n wins (pr_better)
+        for (uint64_t m = T & ~(T >> 1); m != 0; m &= m - 1) {
+            const int q = __builtin_ctzll(m);
+            const uint64_t le = q == 63 ? ~0ull : ((2ull << q) - 1);   // rows <= q
+            const uint32_t tp = tp0 + (uint32_t)__popcll(T & le);
+            const uint32_t n = n0 + (uint32_t)__popcll(TF & le);
+            if (pr_better(tp, n, best)) best = pr_pack(tp, n);
+        }
+        tp0 += (uint32_t)__popcll(T);
+        n0 += (uint32_t)__popcll(TF);
+    }
+    a.cmax[o] = best;
+    if (INLINE) {
+        a.pre_tp[o] = pre_t;
+        a.pre_fp[o] = pre_f;
+    }
+    if (INLINE && ci.last) {                        // recall of the whole category
+        const int combo = ci.word * WAVE + lane;
+        if (combo < a.n_rng * N_THR) {
+            const int r = combo / N_THR, t = combo - r * N_THR;
+            const int64_t kr = (int64_t)ci.k * a.n_rng + r;
+            const int32_t ng = a.num_gt[kr];
+            if (ng > 0) a.rec[kr * N_THR + t] = (double)tp0 / (double)ng;
+        }
+    }
+    if (INLINE) {
+        // (last: stores, and nothing here is read back in this kernel)
         // the recall crossings (acc_prefix_kernel's table) depend on num_gt
         // only: every wavefront of the launch tabulates an equal slice of the
         // whole table, whatever category its chunk belongs to (tabulating a
@@ -336,50 +378,6 @@ __global__ __launch_bounds__(256) void acc_chunkmax_kernel(AccArgs a, RecThr rec
             const int64_t kr = i / N_REC;
             const int32_t ng = a.num_gt[kr];
             if (ng > 0) a.cj[i] = recall_crossing(rec.v[i - kr * N_REC], ng);
-        }
-    }
-    const int64_t o = ((int64_t)ci.c * a.n_words + ci.word) * WAVE + lane;
-    uint32_t tp0, n0;
-    if (INLINE) {
-        uint32_t fp0 = 0;
-        tp0 = 0;
-        for (int32_t c = a.cat_chunk_off[ci.k]; c < ci.c; c++) {
-            const int64_t oc = ((int64_t)c * a.n_words + ci.word) * WAVE + lane;
-            tp0 += a.cnt_tp[oc];
-            fp0 += a.cnt_fp[oc];
-        }
-        a.pre_tp[o] = tp0;
-        a.pre_fp[o] = fp0;
-        n0 = tp0 + fp0;
-    } else {
-        tp0 = a.pre_tp[o];
-        n0 = tp0 + a.pre_fp[o];
-    }
-    uint64_t best = PR_ZERO;
-    const int64_t tb = (((int64_t)ci.c * a.n_words + ci.word) * ACC_BLK) * WAVE + lane;
-    for (int blk = 0; blk * WAVE < ci.len; blk++) {
-        const uint64_t T = a.t_tp[tb + (int64_t)blk * WAVE];
-        const uint64_t TF = T | a.t_fp[tb + (int64_t)blk * WAVE];
-        // a TP row directly followed by a TP row cannot hold the maximum:
-        // (tp+1)/(n+1) >= tp/n, and on a tie the larger n wins (pr_better)
-        for (uint64_t m = T & ~(T >> 1); m != 0; m &= m - 1) {
-            const int q = __builtin_ctzll(m);
-            const uint64_t le = q == 63 ? ~0ull : ((2ull << q) - 1);   // rows <= q
-            const uint32_t tp = tp0 + (uint32_t)__popcll(T & le);
-            const uint32_t n = n0 + (uint32_t)__popcll(TF & le);
-            if (pr_better(tp, n, best)) best = pr_pack(tp, n);
-        }
-        tp0 += (uint32_t)__popcll(T);
-        n0 += (uint32_t)__popcll(TF);
-    }
-    a.cmax[o] = best;
-    if (INLINE && ci.last) {                        // recall of the whole category
-        const int combo = ci.word * WAVE + lane;
-        if (combo < a.n_rng * N_THR) {
-            const int r = combo / N_THR, t = combo - r * N_THR;
-            const int64_t kr = (int64_t)ci.k * a.n_rng + r;
-            const int32_t ng = a.num_gt[kr];
-            if (ng > 0) a.rec[kr * N_THR + t] = (double)tp0 / (double)ng;
         }
     }
 }
@@ -419,6 +417,54 @@ __global__ __launch_bounds__(256) void acc_sufmax_kernel(AccArgs a)
         }
 }
 
+// Emission burst: thresholds jcur-1, jcur-2, ... whose crossing count cj[.]
+// satisfies the condition (GT: cj > x, otherwise cj == x) take the value v.
+// cj is non-decreasing, so these are consecutive; the caller has checked the
+// first (cnext = cj[jcur-1]).  W = 4 (the fused sweep of short categories):
+// four candidates are fetched per step -- a track level category crosses ten
+// thresholds at one TP row, and a step per threshold is a chain of dependent
+// LDS reads (acc_fused_kernel at Config 2's track level: 100 -> 52 us with the
+// smaller workgroups).  The chunked sweep of long categories (bursts of one or
+// two) is faster with the plain loop, W = 1 (85 vs 99 us).
+template <bool GT, int W>
+__device__ __forceinline__ void emit_burst(uint64_t *__restrict__ out,
+                                           const int32_t *__restrict__ cj, int &jcur,
+                                           int32_t &cnext, int32_t x, uint64_t v)
+{
+    auto ok = [&](int32_t y) { return GT ? y > x : y == x; };
+    if (W == 1) {                     // long categories: a threshold or two per TP row
+        do {
+            out[--jcur] = v;
+            cnext = jcur > 0 ? cj[jcur - 1] : -1;
+        } while (ok(cnext));
+        return;
+    }
+    do {
+        int32_t c[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int idx = jcur - 2 - k;
+            c[k] = idx >= 0 ? cj[idx] : -1;
+        }
+        out[jcur - 1] = v;
+        int n = 1;
+        if (ok(c[0])) {
+            out[jcur - 2] = v;
+            n = 2;
+            if (ok(c[1])) {
+                out[jcur - 3] = v;
+                n = 3;
+                if (ok(c[2])) {
+                    out[jcur - 4] = v;
+                    n = 4;
+                }
+            }
+        }
+        cnext = c[n - 1];
+        jcur -= n;
+    } while (ok(cnext));
+}
+
 #define EMIT_RMAX 8   // ranges that can overlap one 64-combo word
 
 // INLINE (short categories): the envelope of the later chunks is gathered
@@ -451,6 +497,17 @@ __global__ __launch_bounds__(256) void acc_emit_kernel(AccArgs a)
     const int64_t o = ((int64_t)ci.c * a.n_words + ci.word) * WAVE + lane;
     uint32_t tp = a.pre_tp[o] + a.cnt_tp[o];
     uint32_t n = tp + a.pre_fp[o] + a.cnt_fp[o];
+    // every load ahead of the first store (see acc_count_kernel); blocks past
+    // the chunk's rows hold zero words
+    const int64_t tb = (((int64_t)ci.c * a.n_words + ci.word) * ACC_BLK) * WAVE + lane;
+    uint64_t Tb[ACC_BLK], TFb[ACC_BLK];
+#pragma unroll
+    for (int blk = 0; blk < ACC_BLK; blk++) {
+        const uint64_t t_ = a.t_tp[tb + (int64_t)blk * WAVE];
+        const uint64_t f_ = a.t_fp[tb + (int64_t)blk * WAVE];
+        Tb[blk] = live ? t_ : 0;
+        TFb[blk] = live ? (t_ | f_) : 0;
+    }
     uint64_t run;
     if (INLINE) {
         run = PR_ZERO;
@@ -461,7 +518,7 @@ __global__ __launch_bounds__(256) void acc_emit_kernel(AccArgs a)
     } else {
         run = a.cmax[o];
     }
-    double *__restrict__ out =
+    uint64_t *__restrict__ out =
         a.val + (((int64_t)ci.k * a.n_rng + r) * N_THR + t) * N_REC;
     // thresholds already reached by the TP count at the end of this chunk:
     // jcur = #{j : cj[j] <= tp} (cj is non-decreasing in j)
@@ -487,17 +544,17 @@ __global__ __launch_bounds__(256) void acc_emit_kernel(AccArgs a)
             if (jl >= N_REC) continue;
             const int cl = ci.word * WAVE + l;
             const int rl = cl / N_THR, tl = cl - rl * N_THR;
-            double *__restrict__ row =
+            uint64_t *__restrict__ row =
                 a.val + (((int64_t)ci.k * a.n_rng + rl) * N_THR + tl) * N_REC;
-            for (int j = jl + lane; j < N_REC; j += WAVE) row[j] = 0.0;
+            for (int j = jl + lane; j < N_REC; j += WAVE) row[j] = PR_ZERO;
         }
     }
-    const int64_t tb = (((int64_t)ci.c * a.n_words + ci.word) * ACC_BLK) * WAVE + lane;
     // next threshold to write, cached in a register: cj[jcur - 1], or -1
     int32_t cnext = jcur > 0 ? cj[jcur - 1] : -1;
-    for (int blk = (ci.len - 1) / WAVE; blk >= 0; blk--) {
-        const uint64_t T = live ? a.t_tp[tb + (int64_t)blk * WAVE] : 0;
-        const uint64_t TF = T | (live ? a.t_fp[tb + (int64_t)blk * WAVE] : 0);
+#pragma unroll
+    for (int blk = ACC_BLK - 1; blk >= 0; blk--) {
+        if (blk * WAVE >= ci.len) continue;
+        const uint64_t T = Tb[blk], TF = TFb[blk];
         // tp, n: counts at the END of this block.  Walk backwards over the TP
         // rows that can raise the envelope: a TP row directly followed by a
         // TP row never does ((tp+1)/(n+1) >= tp/n, ties go to the larger n),
@@ -510,19 +567,11 @@ __global__ __launch_bounds__(256) void acc_emit_kernel(AccArgs a)
             const uint32_t tpq = tp - (uint32_t)__popcll(T & gt);      // incl. row q
             const uint32_t nq = n - (uint32_t)__popcll(TF & gt);
             if (cnext > (int32_t)tpq) {        // reached above row q
-                const double v = pr_value(run);
-                do {
-                    out[--jcur] = v;
-                    cnext = jcur > 0 ? cj[jcur - 1] : -1;
-                } while (cnext > (int32_t)tpq);
+                emit_burst<true, 1>(out, cj, jcur, cnext, (int32_t)tpq, run);
             }
             if (pr_better(tpq, nq, run)) run = pr_pack(tpq, nq);
             if (cnext == (int32_t)tpq) {       // reached exactly at row q
-                const double v = pr_value(run);
-                do {
-                    out[--jcur] = v;
-                    cnext = jcur > 0 ? cj[jcur - 1] : -1;
-                } while (cnext == (int32_t)tpq);
+                emit_burst<false, 1>(out, cj, jcur, cnext, (int32_t)tpq, run);
             }
             m &= ~(1ull << q);
         }
@@ -531,15 +580,11 @@ __global__ __launch_bounds__(256) void acc_emit_kernel(AccArgs a)
         // rows of this block below its lowest visited row: thresholds between
         // the block's first TP count and that row see the current envelope
         if (cnext > (int32_t)tp) {
-            const double v = pr_value(run);
-            do {
-                out[--jcur] = v;
-                cnext = jcur > 0 ? cj[jcur - 1] : -1;
-            } while (cnext > (int32_t)tp);
+            emit_burst<true, 1>(out, cj, jcur, cnext, (int32_t)tp, run);
         }
     }
     if (live && ci.first && jcur > 0 && ci.len > 0) {
-        const double v = pr_value(run);
+        const uint64_t v = run;
         while (jcur > 0) {
             out[jcur - 1] = v;
             jcur--;
@@ -557,13 +602,13 @@ __global__ __launch_bounds__(256) void acc_emit_kernel(AccArgs a)
 // none of the intermediates of the general path (cnt, pre, cmax, t_tp, t_fp,
 // cj: ~100 MB of traffic and six more launches at Config 2) exists.
 // The arithmetic is the general path's, statement by statement.
-#define ACC_FUSED_WAVES 16
+#define ACC_FUSED_WAVES 16       // the largest workgroup; 4 and 8 serve shorter categories
 
-__global__ __launch_bounds__(ACC_FUSED_WAVES * WAVE) void acc_fused_kernel(AccArgs a,
-                                                                           RecThr rec)
+template <int FW>   // wavefronts of the workgroup
+__global__ __launch_bounds__(FW * WAVE) void acc_fused_kernel(AccArgs a, RecThr rec)
 {
-    __shared__ uint32_t s_tp[ACC_FUSED_WAVES][WAVE], s_fp[ACC_FUSED_WAVES][WAVE];
-    __shared__ uint64_t s_max[ACC_FUSED_WAVES][WAVE];
+    __shared__ uint32_t s_tp[FW][WAVE], s_fp[FW][WAVE];
+    __shared__ uint64_t s_max[FW][WAVE];
     __shared__ int32_t s_cj[32 * N_REC];            // [n_rng][N_REC]
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -577,7 +622,7 @@ __global__ __launch_bounds__(ACC_FUSED_WAVES * WAVE) void acc_fused_kernel(AccAr
     const int32_t start = sb + j * ACC_CH;
     const int len = mine ? min(ACC_CH, se - start) : 0;
     // ---- recall crossings of the category's ranges
-    for (int i = threadIdx.x; i < a.n_rng * N_REC; i += ACC_FUSED_WAVES * WAVE) {
+    for (int i = threadIdx.x; i < a.n_rng * N_REC; i += FW * WAVE) {
         const int q = i / N_REC;
         const int32_t ngq = a.num_gt[(int64_t)k * a.n_rng + q];
         s_cj[i] = ngq > 0 ? recall_crossing(rec.v[i - q * N_REC], ngq) : 0;
@@ -618,14 +663,14 @@ __global__ __launch_bounds__(ACC_FUSED_WAVES * WAVE) void acc_fused_kernel(AccAr
     const int32_t ng = active ? a.num_gt[(int64_t)k * a.n_rng + r] : 0;
     const bool live = active && ng > 0;
     const int64_t kr = (int64_t)k * a.n_rng + r;
-    double *__restrict__ out = a.val + (kr * N_THR + t) * N_REC;
+    uint64_t *__restrict__ out = a.val + (kr * N_THR + t) * N_REC;
     const bool last = mine && j == nch - 1, first = mine && j == 0;
     if (live && (last || (nch == 0 && j == 0 && wave < nw))) {
         a.rec[kr * N_THR + t] = (double)(tp0 + tp_own) / (double)ng;
         // a category without detections still has precision 0 / recall 0
         // where it has evaluated GT (reference lvis_amodal/eval.py:412-417)
         if (nch == 0)
-            for (int jj = 0; jj < N_REC; jj++) out[jj] = 0.0;
+            for (int jj = 0; jj < N_REC; jj++) out[jj] = PR_ZERO;
     }
     // ---- largest precision at a TP row of my chunk (see acc_chunkmax_kernel)
     uint64_t best = PR_ZERO;
@@ -673,9 +718,9 @@ __global__ __launch_bounds__(ACC_FUSED_WAVES * WAVE) void acc_fused_kernel(AccAr
             if (jl >= N_REC) continue;
             const int cl = word * WAVE + l;
             const int rl = cl / N_THR, tl = cl - rl * N_THR;
-            double *__restrict__ row =
+            uint64_t *__restrict__ row =
                 a.val + (((int64_t)k * a.n_rng + rl) * N_THR + tl) * N_REC;
-            for (int jj = jl + lane; jj < N_REC; jj += WAVE) row[jj] = 0.0;
+            for (int jj = jl + lane; jj < N_REC; jj += WAVE) row[jj] = PR_ZERO;
         }
     }
     int32_t cnext = jcur > 0 ? cj[jcur - 1] : -1;
@@ -689,34 +734,22 @@ __global__ __launch_bounds__(ACC_FUSED_WAVES * WAVE) void acc_fused_kernel(AccAr
             const uint32_t tpq = tp - (uint32_t)__popcll(Tb & gt);     // incl. row q
             const uint32_t nq = n - (uint32_t)__popcll(TFb & gt);
             if (cnext > (int32_t)tpq) {        // reached above row q
-                const double v = pr_value(run);
-                do {
-                    out[--jcur] = v;
-                    cnext = jcur > 0 ? cj[jcur - 1] : -1;
-                } while (cnext > (int32_t)tpq);
+                emit_burst<true, 4>(out, cj, jcur, cnext, (int32_t)tpq, run);
             }
             if (pr_better(tpq, nq, run)) run = pr_pack(tpq, nq);
             if (cnext == (int32_t)tpq) {       // reached exactly at row q
-                const double v = pr_value(run);
-                do {
-                    out[--jcur] = v;
-                    cnext = jcur > 0 ? cj[jcur - 1] : -1;
-                } while (cnext == (int32_t)tpq);
+                emit_burst<false, 4>(out, cj, jcur, cnext, (int32_t)tpq, run);
             }
             m &= ~(1ull << q);
         }
         tp -= (uint32_t)__popcll(Tb);
         n -= (uint32_t)__popcll(TFb);
         if (cnext > (int32_t)tp) {
-            const double v = pr_value(run);
-            do {
-                out[--jcur] = v;
-                cnext = jcur > 0 ? cj[jcur - 1] : -1;
-            } while (cnext > (int32_t)tp);
+            emit_burst<true, 4>(out, cj, jcur, cnext, (int32_t)tp, run);
         }
     }
     if (live && first && jcur > 0) {
-        const double v = pr_value(run);
+        const uint64_t v = run;
         while (jcur > 0) {
             out[jcur - 1] = v;
             jcur--;
@@ -728,7 +761,8 @@ __global__ __launch_bounds__(ACC_FUSED_WAVES * WAVE) void acc_fused_kernel(AccAr
 struct FinArgs {
     int32_t n_cat, n_rng;
     const int32_t *num_gt;
-    const double *val, *rec;
+    const uint64_t *val;
+    const double *rec;
     double *precision, *recall;
 };
 
@@ -765,7 +799,7 @@ __global__ __launch_bounds__(256) void acc_finalize_kernel(FinArgs a)
     if (live_rows != 0) {
         uint64_t m = live_rows & (0x1111111111111111ull << wave);
         const int64_t col = col0 + lane;
-        const double *__restrict__ src = a.val + row0 * COLS + (col < COLS ? col : 0);
+        const uint64_t *__restrict__ src = a.val + row0 * COLS + (col < COLS ? col : 0);
         while (m != 0) {
             int idx[4];
 #pragma unroll
@@ -773,13 +807,16 @@ __global__ __launch_bounds__(256) void acc_finalize_kernel(FinArgs a)
                 idx[q] = m != 0 ? __builtin_ctzll(m) : -1;
                 if (m != 0) m &= m - 1;
             }
-            double v[4];
+            uint64_t v[4];
 #pragma unroll
             for (int q = 0; q < 4; q++)
-                v[q] = idx[q] >= 0 ? src[(int64_t)idx[q] * COLS] : 0.0;
+                v[q] = idx[q] >= 0 ? src[(int64_t)idx[q] * COLS] : PR_ZERO;
+            // the sweeps leave (tp, n) records: the one fp64 division of a
+            // precision value, tp / (n + eps), happens here, on dense lanes,
+            // instead of inside their divergent emission branches
 #pragma unroll
             for (int q = 0; q < 4; q++)
-                if (idx[q] >= 0) tile[idx[q]][lane] = v[q];
+                if (idx[q] >= 0) tile[idx[q]][lane] = pr_value(v[q]);
         }
         __syncthreads();
     }
@@ -849,17 +886,30 @@ static int accumulate_compact(int64_t n_dt, int32_t n_cat, int32_t n_rng,
     a.n_words = (n_rng * N_THR + 63) / 64;
     a.n_chunks_max = max_chunks(n_dt, n_cat);
     a.cat_off = cat_off; a.matched = matched; a.ignored = ignored; a.order = order;
-    a.num_gt = num_gt; a.val = val; a.rec = rec;
+    a.num_gt = num_gt; a.val = (uint64_t *)val; a.rec = rec;
     a.k_begin = k_begin; a.k_end = k_end;
     a.inline_scans = 0;
     // every category fits one workgroup (the host says so): the fused
     // single-launch sweep.  Mixing the two paths per category was measured
     // slower than the chunked path alone when long categories exist (image
     // level, Config 2: 0.23 vs 0.18 ms), so it is all or nothing.
+    // The workgroup is as small as the longest category allows (4, 8 or 16
+    // wavefronts): a category of 30 tracks at four combo words keeps 4
+    // wavefronts busy, and with 16 the other 12 only held the CU's wave slots
+    // (2 workgroups per CU -> 2.4 rounds of 1203 categories; with 4
+    // wavefronts all categories are resident at once).
     a.fused_rows = ACC_FUSED_WAVES / a.n_words * ACC_CH;
     if (max_segment > 0 && max_segment <= a.fused_rows) {
-        TAO_TIMED("acc_fused_kernel", s, acc_fused_kernel<<<(unsigned)(k_end - k_begin), ACC_FUSED_WAVES * WAVE, 0, s>>>(
-            a, rec_thr()));
+        const unsigned grid = (unsigned)(k_end - k_begin);
+        if (max_segment <= 4 / a.n_words * ACC_CH) {
+            a.fused_rows = 4 / a.n_words * ACC_CH;
+            TAO_TIMED("acc_fused_kernel", s, acc_fused_kernel<4><<<grid, 4 * WAVE, 0, s>>>(a, rec_thr()));
+        } else if (max_segment <= 8 / a.n_words * ACC_CH) {
+            a.fused_rows = 8 / a.n_words * ACC_CH;
+            TAO_TIMED("acc_fused_kernel", s, acc_fused_kernel<8><<<grid, 8 * WAVE, 0, s>>>(a, rec_thr()));
+        } else {
+            TAO_TIMED("acc_fused_kernel", s, acc_fused_kernel<16><<<grid, 16 * WAVE, 0, s>>>(a, rec_thr()));
+        }
         TAO_LAUNCH_CHECK();
         return TAOAMD_OK;
     }
@@ -919,7 +969,7 @@ extern "C" int taoamd_finalize(int32_t n_cat, int32_t n_rng,
     if (n_cat <= 0 || n_rng < 1 || n_rng > 32) return TAOAMD_ERR_ARG;
     if (!num_gt || !val || !rec || !precision || !recall) return TAOAMD_ERR_ARG;
     FinArgs f;
-    f.n_cat = n_cat; f.n_rng = n_rng; f.num_gt = num_gt; f.val = val; f.rec = rec;
+    f.n_cat = n_cat; f.n_rng = n_rng; f.num_gt = num_gt; f.val = (const uint64_t *)val; f.rec = rec;
     f.precision = precision; f.recall = recall;
     const int64_t KR = (int64_t)n_cat * n_rng;
     dim3 grid((unsigned)((KR + FIN_RT - 1) / FIN_RT),

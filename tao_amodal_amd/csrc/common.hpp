@@ -96,6 +96,32 @@ __device__ __forceinline__ int32_t recall_crossing(double x, int32_t ng)
     return c;
 }
 
+// Precision records.  The sweeps track precision as the integer pair
+// (tp, n = tp + fp) packed as tp << 32 | n and leave such records in the
+// per-threshold table `val`; whoever writes the reference layout
+// (acc_finalize_kernel, ex_unpack_kernel) turns a record into
+// tp / (fp + tp + eps), the reference's expression (lvis_amodal/eval.py:384).
+// better(a, b): pair a gives a larger value than pair b: fl(tp / (n + eps)) is
+// monotone in the rational tp / n, and n + eps == n for n >= 2, so ties go to
+// the larger n, which ranks (1, 1) -> 1 / (1 + eps) below (k, k) -> 1.
+#define ACC_EPS 2.220446049250313e-16  // np.spacing(1)
+#define PR_ZERO 1ull                   // (0, 1): value 0
+__device__ __forceinline__ bool pr_better(uint32_t ta, uint32_t na, uint64_t b)
+{
+    const uint32_t tb = (uint32_t)(b >> 32), nb = (uint32_t)b;
+    const uint64_t l = (uint64_t)ta * nb, r = (uint64_t)tb * na;
+    return l > r || (l == r && na > nb);
+}
+__device__ __forceinline__ uint64_t pr_pack(uint32_t t, uint32_t n)
+{
+    return ((uint64_t)t << 32) | n;
+}
+__device__ __forceinline__ double pr_value(uint64_t p)
+{
+    const double t = (double)(uint32_t)(p >> 32), n = (double)(uint32_t)p;
+    return t / (n + ACC_EPS);   // fp + tp == n exactly
+}
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
 
 __device__ __forceinline__ double readlane_f64(double v, int lane)

@@ -22,7 +22,9 @@
 // (recall_crossing), expand, and write the reference layout
 // precision[T][R][K][A] / recall[T][K][A] directly (the transpose that
 // acc_finalize_kernel does on a single GPU), so expansion costs no extra pass.
-// Copying runs is exact by construction: no arithmetic touches the values.
+// Copying runs is exact by construction: no arithmetic touches the values --
+// they travel as the sweep's (tp, n) records (common.hpp) and become
+// tp / (n + eps) when the receiver writes the reference layout.
 //
 // One chunk per rank and equal chunk sizes make the whole exchange a single
 // in-place all_gather_into_tensor per evaluator.  The chunk capacity is fixed
@@ -144,9 +146,11 @@ struct PackArgs {
     int32_t block_rows;
     int64_t valid_rows;    // n_cat * n_rng
     const int32_t *num_gt; // local table [n_cat][n_rng]
-    const double *val, *rec;
+    const uint64_t *val;
+    const double *rec;
     int32_t *hdr;
-    double *rec_out, *levels;
+    double *rec_out;
+    uint64_t *levels;
     int64_t capacity;
     ExWs w;
 };
@@ -207,13 +211,13 @@ __global__ __launch_bounds__(256) void ex_unpack_kernel(UnpackArgs a)
             if (nd > 0) {
                 const int64_t b = row / a.block_rows, li = row - b * a.block_rows;
                 const unsigned char *ch = a.chunks + b * a.chunk_bytes;
-                const double *lv = (const double *)(ch + a.hdr_bytes + a.rec_bytes);
+                const uint64_t *lv = (const uint64_t *)(ch + a.hdr_bytes + a.rec_bytes);
                 const int32_t off = ((const int32_t *)ch)[a.block_rows + li];
                 const int t = (int)(col / N_REC), j = (int)(col - (int64_t)t * N_REC);
                 const int64_t slot = (int64_t)off + (int64_t)t * nd +
                                      a.w.dmap[row * N_REC + j];
                 v = 0.0;
-                if (slot < a.capacity) v = lv[slot];
+                if (slot < a.capacity) v = pr_value(lv[slot]);
                 else if (a.overflow) atomicOr(a.overflow, 1);
             }
         }
@@ -325,10 +329,10 @@ extern "C" int taoamd_exchange_pack(int32_t n_cat, int32_t n_rng,
     const Chunk c = chunk_layout(block_cats, n_rng, capacity);
     PackArgs a;
     a.row0 = r0; a.block_rows = BR; a.valid_rows = valid;
-    a.num_gt = num_gt; a.val = val; a.rec = rec;
+    a.num_gt = num_gt; a.val = (const uint64_t *)val; a.rec = rec;
     a.hdr = (int32_t *)chunk;
     a.rec_out = (double *)((unsigned char *)chunk + c.hdr_bytes);
-    a.levels = (double *)((unsigned char *)chunk + c.hdr_bytes + c.rec_bytes);
+    a.levels = (uint64_t *)((unsigned char *)chunk + c.hdr_bytes + c.rec_bytes);
     a.capacity = capacity; a.w = w;
     const int64_t threads = (int64_t)BR * N_THR * N_REC;
     TAO_TIMED("ex_pack_kernel", s, ex_pack_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>(a));

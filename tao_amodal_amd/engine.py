@@ -295,7 +295,9 @@ class DeviceProblem:
                     _ptr(self.t["padded"]), _ptr(inexact), _stream()),
                     "taoamd_track_pad")
         # integer boxes: frame sums are exact in any order, nothing to guard
-        self.exact_terms = not bool(inexact.item())
+        # (products < 2^40, tracks of at most 2^12 frames: every sum < 2^53)
+        longest = int((meta[:, 1] - meta[:, 0]).max()) + 1 if len(meta) else 0
+        self.exact_terms = not bool(inexact.item()) and longest <= 4096
 
     def input_bytes(self):
         return sum(v.numel() * v.element_size() for v in self.t.values()

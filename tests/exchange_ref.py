@@ -68,7 +68,17 @@ def pack(n_cat, n_rng, block_cats, rank, num_gt, val, rec, capacity):
     return chunk
 
 
-def unpack(n_cat, n_rng, block_cats, world, chunks, capacity):
+def decode_records(bits):
+    """(tp << 32 | n) records of the device sweeps -> tp / (n + eps), the
+    reference's precision expression (lvis_amodal/eval.py:384)."""
+    bits = np.asarray(bits).view(np.uint64)
+    tp = (bits >> np.uint64(32)).astype(np.float64)
+    n = (bits & np.uint64(0xffffffff)).astype(np.float64)
+    return tp / (n + np.spacing(1))
+
+
+def unpack(n_cat, n_rng, block_cats, world, chunks, capacity, records=False):
+    """records=True: the levels are the device sweeps' (tp, n) records."""
     hdr, recb, total = layout(block_cats, n_rng, capacity)
     rows = block_cats * n_rng
     chunks = np.asarray(chunks).view(np.uint8)
@@ -82,6 +92,8 @@ def unpack(n_cat, n_rng, block_cats, world, chunks, capacity):
         ho = c[rows * 4:rows * 8].view(np.int32)
         r = c[hdr:hdr + rows * N_THR * 8].view(np.float64).reshape(rows, N_THR)
         lv = c[hdr + recb:hdr + recb + capacity * 8].view(np.float64)
+        if records:
+            lv = decode_records(lv)
         for i in range(rows):
             row = b * rows + i
             if row >= KR:
