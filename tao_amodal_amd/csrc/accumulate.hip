@@ -50,7 +50,9 @@
 
 using namespace taoamd;
 
+#ifndef ACC_CH
 #define ACC_CH 256
+#endif
 #ifndef ACC_INLINE_CHUNKS
 #define ACC_INLINE_CHUNKS 64    // categories up to 16384 rows scan their chunks inline
 #endif
@@ -73,6 +75,7 @@ struct AccArgs {
     double *rec;                 // [n_cat][n_rng][N_THR]
     int32_t k_begin, k_end;      // categories swept by this call
     int32_t fused_rows;          // categories up to this many rows take acc_fused_kernel
+    int32_t fused_lo;            // ... and more than this many (size class of the launch)
     int32_t inline_scans;        // short categories: no acc_prefix / acc_sufmax launches
 };
 
@@ -614,7 +617,8 @@ __global__ __launch_bounds__(FW * WAVE) void acc_fused_kernel(AccArgs a, RecThr 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int32_t k = a.k_begin + (int32_t)blockIdx.x;
     const int32_t sb = a.cat_off[k], se = a.cat_off[k + 1];
-    if (se - sb > a.fused_rows) return;     // long category: the chunked kernels' job
+    // another size class, or a long category (the chunked kernels' job)
+    if (se - sb > a.fused_rows || se - sb <= a.fused_lo) return;
     const int nw = a.n_words;
     const int nch = (se - sb + ACC_CH - 1) / ACC_CH;
     const int j = wave / nw, word = wave - j * nw;   // my chunk, my combo word
@@ -889,31 +893,41 @@ static int accumulate_compact(int64_t n_dt, int32_t n_cat, int32_t n_rng,
     a.num_gt = num_gt; a.val = (uint64_t *)val; a.rec = rec;
     a.k_begin = k_begin; a.k_end = k_end;
     a.inline_scans = 0;
-    // every category fits one workgroup (the host says so): the fused
-    // single-launch sweep.  Mixing the two paths per category was measured
-    // slower than the chunked path alone when long categories exist (image
-    // level, Config 2: 0.23 vs 0.18 ms), so it is all or nothing.
-    // The workgroup is as small as the longest category allows (4, 8 or 16
-    // wavefronts): a category of 30 tracks at four combo words keeps 4
-    // wavefronts busy, and with 16 the other 12 only held the CU's wave slots
-    // (2 workgroups per CU -> 2.4 rounds of 1203 categories; with 4
-    // wavefronts all categories are resident at once).
-    a.fused_rows = ACC_FUSED_WAVES / a.n_words * ACC_CH;
-    if (max_segment > 0 && max_segment <= a.fused_rows) {
+    // every category fits one workgroup (the host says so): the fused sweep.
+    // Mixing the two paths per category was measured slower than the chunked
+    // path alone when long categories exist (image level, Config 2: 162 vs
+    // 126 us of kernel time), so it is all or nothing.
+    // One launch per size class: categories of up to 4, 8 and 16 wavefronts'
+    // worth of (chunk, word) pairs get a workgroup of that size -- a category
+    // of 30 tracks at four combo words keeps 4 wavefronts busy, and in a
+    // 16-wave workgroup the other 12 only hold the CU's wave slots (2
+    // workgroups per CU).  Track level, 2000 videos: 305 -> 104 us.
+    // Workgroups of the other classes leave at once.
+    const int32_t fused_cap = ACC_FUSED_WAVES / a.n_words * ACC_CH;
+    const bool all_fused = max_segment > 0 && max_segment <= fused_cap;
+    a.fused_rows = 0;
+    a.fused_lo = -1;
+    if (all_fused) {
         const unsigned grid = (unsigned)(k_end - k_begin);
-        if (max_segment <= 4 / a.n_words * ACC_CH) {
-            a.fused_rows = 4 / a.n_words * ACC_CH;
-            TAO_TIMED("acc_fused_kernel", s, acc_fused_kernel<4><<<grid, 4 * WAVE, 0, s>>>(a, rec_thr()));
-        } else if (max_segment <= 8 / a.n_words * ACC_CH) {
-            a.fused_rows = 8 / a.n_words * ACC_CH;
-            TAO_TIMED("acc_fused_kernel", s, acc_fused_kernel<8><<<grid, 8 * WAVE, 0, s>>>(a, rec_thr()));
-        } else {
-            TAO_TIMED("acc_fused_kernel", s, acc_fused_kernel<16><<<grid, 16 * WAVE, 0, s>>>(a, rec_thr()));
+        int32_t lo = -1;
+        for (int fw = 4; fw <= ACC_FUSED_WAVES; fw *= 2) {
+            const int32_t hi = fw / a.n_words * ACC_CH;
+            if (hi <= lo || hi == 0) continue;
+            a.fused_lo = lo;
+            a.fused_rows = hi;
+            if (fw == 4) {
+                TAO_TIMED("acc_fused_kernel", s, acc_fused_kernel<4><<<grid, 4 * WAVE, 0, s>>>(a, rec_thr()));
+            } else if (fw == 8) {
+                TAO_TIMED("acc_fused_kernel", s, acc_fused_kernel<8><<<grid, 8 * WAVE, 0, s>>>(a, rec_thr()));
+            } else {
+                TAO_TIMED("acc_fused_kernel", s, acc_fused_kernel<16><<<grid, 16 * WAVE, 0, s>>>(a, rec_thr()));
+            }
+            lo = hi;
+            if (max_segment > 0 && max_segment <= hi) break;
         }
         TAO_LAUNCH_CHECK();
         return TAOAMD_OK;
     }
-    a.fused_rows = 0;
     // categories of at most ACC_INLINE_CHUNKS chunks: the two per-category
     // scan kernels are folded into their consumers (four launches on the
     // chain instead of six; all or nothing, like the fused sweep)
