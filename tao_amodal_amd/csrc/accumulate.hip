@@ -300,6 +300,38 @@ __global__ __launch_bounds__(256) void acc_prefix_kernel(AccArgs a, RecThr rec)
     }
 }
 
+// ---------------------------------------------------------------------------
+// The two walks over the TP rows of a 64-row block.  A TP row directly followed
+// by a TP row cannot hold the maximum precision ((tp+1)/(n+1) >= tp/n, and on
+// a tie the larger n wins, pr_better), so only the LAST row of each run of
+// consecutive TP rows is visited: the bits of m = T & ~(T >> 1).  The block's
+// 64-bit words are walked as two 32-bit halves: q, the "rows above / below q"
+// mask and the two popcounts are then one instruction each instead of a
+// 64-bit pair (32 -> 18 VALU instructions per visited row).
+// ---------------------------------------------------------------------------
+
+// forward: best (tp, n) at a TP row of the block; tp0 / n0 = counts before it
+__device__ __forceinline__ void best_of_block(uint64_t T, uint64_t TF, uint32_t &tp0,
+                                              uint32_t &n0, uint64_t &best)
+{
+    const uint32_t Th[2] = {(uint32_t)T, (uint32_t)(T >> 32)};
+    const uint32_t TFh[2] = {(uint32_t)TF, (uint32_t)(TF >> 32)};
+    // run ends; row 31's successor is row 32 (bit 0 of the high half)
+    const uint32_t mh[2] = {Th[0] & ~((Th[0] >> 1) | (Th[1] << 31)), Th[1] & ~(Th[1] >> 1)};
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        for (uint32_t m = mh[h]; m != 0; m &= m - 1) {
+            const int q = __builtin_ctz(m);
+            const uint32_t le = (2u << q) - 1;                 // rows <= q (q = 31: all)
+            const uint32_t tp = tp0 + (uint32_t)__popc(Th[h] & le);
+            const uint32_t n = n0 + (uint32_t)__popc(TFh[h] & le);
+            if (pr_better(tp, n, best)) best = pr_pack(tp, n);
+        }
+        tp0 += (uint32_t)__popc(Th[h]);
+        n0 += (uint32_t)__popc(TFh[h]);
+    }
+}
+
 // INLINE: the category is short (the host says so): the chunk adds up the
 // counts of the chunks before it by itself -- at most ACC_INLINE_CHUNKS - 1
 // loads per lane, which is cheaper than a launch between two dependent
@@ -338,18 +370,7 @@ __global__ __launch_bounds__(256) void acc_chunkmax_kernel(AccArgs a, RecThr rec
     }
 #pragma unroll
     for (int blk = 0; blk < ACC_BLK; blk++) {
-        const uint64_t T = Tb[blk], TF = TFb[blk];
-        // a TP row directly followed by a TP row cannot hold the maximum:
-        // (tp+1)/(n+1) >= tp/n, and on a tie the larger n wins (pr_better)
-        for (uint64_t m = T & ~(T >> 1); m != 0; m &= m - 1) {
-            const int q = __builtin_ctzll(m);
-            const uint64_t le = q == 63 ? ~0ull : ((2ull << q) - 1);   // rows <= q
-            const uint32_t tp = tp0 + (uint32_t)__popcll(T & le);
-            const uint32_t n = n0 + (uint32_t)__popcll(TF & le);
-            if (pr_better(tp, n, best)) best = pr_pack(tp, n);
-        }
-        tp0 += (uint32_t)__popcll(T);
-        n0 += (uint32_t)__popcll(TF);
+        best_of_block(Tb[blk], TFb[blk], tp0, n0, best);
     }
     a.cmax[o] = best;
     if (INLINE) {
@@ -468,6 +489,41 @@ __device__ __forceinline__ void emit_burst(uint64_t *__restrict__ out,
     } while (ok(cnext));
 }
 
+// backward: the emission sweep of one block.  tp / n = counts at the END of
+// the block on entry, at its start on return; run = envelope of everything
+// behind.  Thresholds reached at a skipped row (inside a run) take the
+// envelope of the rows above it, i.e. the running value BEFORE the next
+// visited row; thresholds reached below the lowest visited row of the block
+// see the envelope after it.
+template <int W>
+__device__ __forceinline__ void emit_block(uint64_t T, uint64_t TF, uint32_t &tp,
+                                           uint32_t &n, uint64_t &run, int &jcur,
+                                           int32_t &cnext, uint64_t *__restrict__ out,
+                                           const int32_t *__restrict__ cj)
+{
+    const uint32_t Th[2] = {(uint32_t)T, (uint32_t)(T >> 32)};
+    const uint32_t TFh[2] = {(uint32_t)TF, (uint32_t)(TF >> 32)};
+    const uint32_t mh[2] = {Th[0] & ~((Th[0] >> 1) | (Th[1] << 31)), Th[1] & ~(Th[1] >> 1)};
+#pragma unroll
+    for (int h = 1; h >= 0; h--) {
+        for (uint32_t m = mh[h]; m != 0;) {
+            const int q = 31 - __builtin_clz(m);
+            const uint32_t gt = 0xfffffffeu << q;              // rows > q (q = 31: none)
+            const uint32_t tpq = tp - (uint32_t)__popc(Th[h] & gt);    // incl. row q
+            const uint32_t nq = n - (uint32_t)__popc(TFh[h] & gt);
+            if (cnext > (int32_t)tpq)          // reached above row q
+                emit_burst<true, W>(out, cj, jcur, cnext, (int32_t)tpq, run);
+            if (pr_better(tpq, nq, run)) run = pr_pack(tpq, nq);
+            if (cnext == (int32_t)tpq)         // reached exactly at row q
+                emit_burst<false, W>(out, cj, jcur, cnext, (int32_t)tpq, run);
+            m &= ~(1u << q);
+        }
+        tp -= (uint32_t)__popc(Th[h]);
+        n -= (uint32_t)__popc(TFh[h]);
+    }
+    if (cnext > (int32_t)tp) emit_burst<true, W>(out, cj, jcur, cnext, (int32_t)tp, run);
+}
+
 #define EMIT_RMAX 8   // ranges that can overlap one 64-combo word
 
 // INLINE (short categories): the envelope of the later chunks is gathered
@@ -557,34 +613,7 @@ __global__ __launch_bounds__(256) void acc_emit_kernel(AccArgs a)
 #pragma unroll
     for (int blk = ACC_BLK - 1; blk >= 0; blk--) {
         if (blk * WAVE >= ci.len) continue;
-        const uint64_t T = Tb[blk], TF = TFb[blk];
-        // tp, n: counts at the END of this block.  Walk backwards over the TP
-        // rows that can raise the envelope: a TP row directly followed by a
-        // TP row never does ((tp+1)/(n+1) >= tp/n, ties go to the larger n),
-        // so only the last row of each run of consecutive TP rows is visited.
-        // Thresholds reached at a skipped row take the envelope of the rows
-        // above it, i.e. the running value BEFORE the next visited row.
-        for (uint64_t m = T & ~(T >> 1); m != 0;) {
-            const int q = 63 - __builtin_clzll(m);
-            const uint64_t gt = q == 63 ? 0ull : ~((2ull << q) - 1);   // rows > q
-            const uint32_t tpq = tp - (uint32_t)__popcll(T & gt);      // incl. row q
-            const uint32_t nq = n - (uint32_t)__popcll(TF & gt);
-            if (cnext > (int32_t)tpq) {        // reached above row q
-                emit_burst<true, 1>(out, cj, jcur, cnext, (int32_t)tpq, run);
-            }
-            if (pr_better(tpq, nq, run)) run = pr_pack(tpq, nq);
-            if (cnext == (int32_t)tpq) {       // reached exactly at row q
-                emit_burst<false, 1>(out, cj, jcur, cnext, (int32_t)tpq, run);
-            }
-            m &= ~(1ull << q);
-        }
-        tp -= (uint32_t)__popcll(T);
-        n -= (uint32_t)__popcll(TF);
-        // rows of this block below its lowest visited row: thresholds between
-        // the block's first TP count and that row see the current envelope
-        if (cnext > (int32_t)tp) {
-            emit_burst<true, 1>(out, cj, jcur, cnext, (int32_t)tp, run);
-        }
+        emit_block<1>(Tb[blk], TFb[blk], tp, n, run, jcur, cnext, out, cj);
     }
     if (live && ci.first && jcur > 0 && ci.len > 0) {
         const uint64_t v = run;
@@ -682,15 +711,7 @@ __global__ __launch_bounds__(FW * WAVE) void acc_fused_kernel(AccArgs a, RecThr 
         uint32_t tpb = tp0, nb = tp0 + fp0;
 #pragma unroll
         for (int blk = 0; blk < ACC_BLK; blk++) {
-            for (uint64_t m = T[blk] & ~(T[blk] >> 1); m != 0; m &= m - 1) {
-                const int q = __builtin_ctzll(m);
-                const uint64_t le = q == 63 ? ~0ull : ((2ull << q) - 1);   // rows <= q
-                const uint32_t tpq = tpb + (uint32_t)__popcll(T[blk] & le);
-                const uint32_t nq = nb + (uint32_t)__popcll(TF[blk] & le);
-                if (pr_better(tpq, nq, best)) best = pr_pack(tpq, nq);
-            }
-            tpb += (uint32_t)__popcll(T[blk]);
-            nb += (uint32_t)__popcll(TF[blk]);
+            best_of_block(T[blk], TF[blk], tpb, nb, best);
         }
     }
     s_max[wave][lane] = best;
@@ -731,26 +752,7 @@ __global__ __launch_bounds__(FW * WAVE) void acc_fused_kernel(AccArgs a, RecThr 
 #pragma unroll
     for (int blk = ACC_BLK - 1; blk >= 0; blk--) {
         if (blk * WAVE >= len) continue;
-        const uint64_t Tb = live ? T[blk] : 0, TFb = live ? TF[blk] : 0;
-        for (uint64_t m = Tb & ~(Tb >> 1); m != 0;) {
-            const int q = 63 - __builtin_clzll(m);
-            const uint64_t gt = q == 63 ? 0ull : ~((2ull << q) - 1);   // rows > q
-            const uint32_t tpq = tp - (uint32_t)__popcll(Tb & gt);     // incl. row q
-            const uint32_t nq = n - (uint32_t)__popcll(TFb & gt);
-            if (cnext > (int32_t)tpq) {        // reached above row q
-                emit_burst<true, 4>(out, cj, jcur, cnext, (int32_t)tpq, run);
-            }
-            if (pr_better(tpq, nq, run)) run = pr_pack(tpq, nq);
-            if (cnext == (int32_t)tpq) {       // reached exactly at row q
-                emit_burst<false, 4>(out, cj, jcur, cnext, (int32_t)tpq, run);
-            }
-            m &= ~(1ull << q);
-        }
-        tp -= (uint32_t)__popcll(Tb);
-        n -= (uint32_t)__popcll(TFb);
-        if (cnext > (int32_t)tp) {
-            emit_burst<true, 4>(out, cj, jcur, cnext, (int32_t)tp, run);
-        }
+        emit_block<4>(live ? T[blk] : 0, live ? TF[blk] : 0, tp, n, run, jcur, cnext, out, cj);
     }
     if (live && first && jcur > 0) {
         const uint64_t v = run;
