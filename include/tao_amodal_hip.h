@@ -515,6 +515,21 @@ int taoamd_accumulate(int64_t n_dt, int32_t n_cat, int32_t n_rng,
                       const int32_t *num_gt, int32_t max_segment, double *precision,
                       double *recall, void *workspace, size_t workspace_bytes,
                       void *stream);
+/* The same in two steps, for a caller that sweeps the same categories again and
+ * again (an evaluation plan replayed per pass): _prepare builds the table that
+ * cuts the categories into chunks -- it depends on cat_off alone -- in the
+ * workspace, _prepared is taoamd_accumulate without that launch.  Same
+ * workspace, n_dt, n_cat, n_rng, cat_off and max_segment in both; nothing else
+ * may use the workspace in between. */
+int taoamd_accumulate_prepare(int64_t n_dt, int32_t n_cat, int32_t n_rng,
+                              const int32_t *cat_off, int32_t max_segment,
+                              void *workspace, size_t workspace_bytes, void *stream);
+int taoamd_accumulate_prepared(int64_t n_dt, int32_t n_cat, int32_t n_rng,
+                      const int32_t *cat_off, const uint64_t *matched,
+                      const uint64_t *ignored,
+                      const int32_t *num_gt, int32_t max_segment, double *precision,
+                      double *recall, void *workspace, size_t workspace_bytes,
+                      void *stream);
 /* The same with the rows where the match kernel left them when it ran WITHOUT
  * `dst` (row = detection, cell order): order[p] = detection at sorted position
  * p (taoamd_sort_segments).  The first sweep gathers the rows through it -- the

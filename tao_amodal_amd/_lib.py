@@ -117,6 +117,9 @@ SIGNATURES = {
     "taoamd_accumulate_workspace": (_sz, [_i64, _i32, _i32]),
     "taoamd_accumulate": (C.c_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _i32,
                                     _vp, _vp, _vp, _sz, _vp]),
+    "taoamd_accumulate_prepare": (C.c_int, [_i64, _i32, _i32, _vp, _i32, _vp, _sz, _vp]),
+    "taoamd_accumulate_prepared": (C.c_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _i32,
+                                    _vp, _vp, _vp, _sz, _vp]),
     "taoamd_accumulate_by_order": (C.c_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp,
                                              _vp, _i32, _vp, _vp, _vp, _sz, _vp]),
 }

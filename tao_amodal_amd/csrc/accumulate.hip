@@ -871,16 +871,23 @@ extern "C" size_t taoamd_accumulate_workspace(int64_t n_dt, int32_t n_cat,
            align256((size_t)n_cat * n_rng * N_THR * 8);
 }
 
+// phases of accumulate_compact: the chunk table depends on cat_off alone, so a
+// caller that sweeps the same categories again and again builds it once
+// (taoamd_accumulate_prepare) and keeps one launch off its critical chain
+enum { ACC_ALL = 0, ACC_PLAN = 1, ACC_SWEEP = 2 };
+
 static int accumulate_compact(int64_t n_dt, int32_t n_cat, int32_t n_rng,
                               const int32_t *cat_off, const int32_t *order,
                               const uint64_t *matched, const uint64_t *ignored,
                               const int32_t *num_gt, int32_t k_begin, int32_t k_end,
                               int32_t max_segment, double *val, double *rec,
-                              void *workspace, size_t workspace_bytes, void *stream)
+                              void *workspace, size_t workspace_bytes, void *stream,
+                              int phase = ACC_ALL)
 {
     if (n_cat <= 0 || n_rng < 1 || n_rng > 32) return TAOAMD_ERR_ARG;
     if (k_begin < 0 || k_end > n_cat || k_begin > k_end) return TAOAMD_ERR_ARG;
-    if (!cat_off || !num_gt || !val || !rec || !workspace) return TAOAMD_ERR_ARG;
+    if (!cat_off || !workspace) return TAOAMD_ERR_ARG;
+    if (phase != ACC_PLAN && (!num_gt || !val || !rec)) return TAOAMD_ERR_ARG;
     if (workspace_bytes < base_workspace(n_dt, n_cat, n_rng))
         return TAOAMD_ERR_WORKSPACE;
     if (k_begin == k_end) return TAOAMD_OK;
@@ -909,6 +916,7 @@ static int accumulate_compact(int64_t n_dt, int32_t n_cat, int32_t n_rng,
     const bool all_fused = max_segment > 0 && max_segment <= fused_cap;
     a.fused_rows = 0;
     a.fused_lo = -1;
+    if (all_fused && phase == ACC_PLAN) return TAOAMD_OK;     // no chunk table
     if (all_fused) {
         const unsigned grid = (unsigned)(k_end - k_begin);
         int32_t lo = -1;
@@ -947,7 +955,12 @@ static int accumulate_compact(int64_t n_dt, int32_t n_cat, int32_t n_rng,
     a.cj = (int32_t *)w;
     const unsigned chunk_blocks = (unsigned)((nc * nw + 3) / 4);
     const unsigned cat_blocks = (unsigned)((size_t)(k_end - k_begin) * nw);
-    TAO_TIMED("acc_chunks_kernel", s, acc_chunks_kernel<<<1, 256, 0, s>>>(a));
+    if (phase != ACC_SWEEP)
+        TAO_TIMED("acc_chunks_kernel", s, acc_chunks_kernel<<<1, 256, 0, s>>>(a));
+    if (phase == ACC_PLAN) {
+        TAO_LAUNCH_CHECK();
+        return TAOAMD_OK;
+    }
     TAO_TIMED("acc_count_kernel", s, acc_count_kernel<<<chunk_blocks, 256, 0, s>>>(a));
     if (a.inline_scans) {
         TAO_TIMED("acc_chunkmax_kernel", s, acc_chunkmax_kernel<true><<<chunk_blocks, 256, 0, s>>>(a, rec_thr()));
@@ -1000,7 +1013,7 @@ static int accumulate_all(int64_t n_dt, int32_t n_cat, int32_t n_rng,
                           const uint64_t *matched, const uint64_t *ignored,
                           const int32_t *num_gt, int32_t max_segment,
                           double *precision, double *recall, void *workspace,
-                          size_t workspace_bytes, void *stream)
+                          size_t workspace_bytes, void *stream, int phase = ACC_ALL)
 {
     if (n_cat <= 0 || n_rng < 1 || n_rng > 32) return TAOAMD_ERR_ARG;
     if (!workspace) return TAOAMD_ERR_ARG;
@@ -1012,8 +1025,8 @@ static int accumulate_all(int64_t n_dt, int32_t n_cat, int32_t n_rng,
     double *rec = val + (align256(taoamd_compact_elems(n_cat, n_rng) * 8) / 8);
     int st = accumulate_compact(n_dt, n_cat, n_rng, cat_off, order, matched, ignored,
                                 num_gt, 0, n_cat, max_segment, val, rec, w, base,
-                                stream);
-    if (st != TAOAMD_OK) return st;
+                                stream, phase);
+    if (st != TAOAMD_OK || phase == ACC_PLAN) return st;
     return taoamd_finalize(n_cat, n_rng, num_gt, val, rec, precision, recall, stream);
 }
 
@@ -1044,4 +1057,28 @@ extern "C" int taoamd_accumulate_by_order(int64_t n_dt, int32_t n_cat, int32_t n
     return accumulate_all(n_dt, n_cat, n_rng, cat_off, order, matched, ignored,
                           num_gt, max_segment, precision, recall, workspace,
                           workspace_bytes, stream);
+}
+
+extern "C" int taoamd_accumulate_prepare(int64_t n_dt, int32_t n_cat, int32_t n_rng,
+                                         const int32_t *cat_off, int32_t max_segment,
+                                         void *workspace, size_t workspace_bytes,
+                                         void *stream)
+{
+    return accumulate_all(n_dt, n_cat, n_rng, cat_off, nullptr, nullptr, nullptr,
+                          nullptr, max_segment, nullptr, nullptr, workspace,
+                          workspace_bytes, stream, ACC_PLAN);
+}
+
+extern "C" int taoamd_accumulate_prepared(int64_t n_dt, int32_t n_cat, int32_t n_rng,
+                                          const int32_t *cat_off,
+                                          const uint64_t *matched,
+                                          const uint64_t *ignored,
+                                          const int32_t *num_gt, int32_t max_segment,
+                                          double *precision, double *recall,
+                                          void *workspace, size_t workspace_bytes,
+                                          void *stream)
+{
+    return accumulate_all(n_dt, n_cat, n_rng, cat_off, nullptr, matched, ignored,
+                          num_gt, max_segment, precision, recall, workspace,
+                          workspace_bytes, stream, ACC_SWEEP);
 }

@@ -329,6 +329,16 @@ class Workspace:
         self.acc_bytes = lib.taoamd_accumulate_workspace(dp.n_dt, dp.n_cat,
                                                          dp.n_rng)
         self.acc_ws = buf(self.acc_bytes)
+        # the chunk table of the sweep depends on cat_off alone: built once here,
+        # one launch less on the chain of every pass
+        self.acc_prepared = None          # the max_segment hint it was built for
+        if torch.device(dev).type == "cuda":
+            with torch.cuda.device(dev):
+                _lib.check(lib.taoamd_accumulate_prepare(
+                    dp.n_dt, dp.n_cat, dp.n_rng, _ptr(dp.t["cat_off"]), dp.acc_hint,
+                    _ptr(self.acc_ws), self.acc_bytes, _stream()),
+                    "taoamd_accumulate_prepare")
+            self.acc_prepared = dp.acc_hint
         self.precision = torch.empty((N_THR, N_REC, dp.n_cat, dp.n_rng),
                                      dtype=torch.float64, device=dev)
         self.recall = torch.empty((N_THR, dp.n_cat, dp.n_rng),
@@ -553,7 +563,9 @@ def stage_accumulate_by_order(dp, ws):
 
 def stage_accumulate(dp, ws):
     lib, t, s = _lib.load(), dp.t, _stream()
-    _lib.check(lib.taoamd_accumulate(
+    fn = lib.taoamd_accumulate_prepared if ws.acc_prepared == dp.acc_hint \
+        else lib.taoamd_accumulate
+    _lib.check(fn(
         dp.n_dt, dp.n_cat, dp.n_rng, _ptr(t["cat_off"]), _ptr(ws.matched),
         _ptr(ws.ignored), _ptr(ws.num_gt), dp.acc_hint, _ptr(ws.precision),
         _ptr(ws.recall), _ptr(ws.acc_ws), ws.acc_bytes, s),
