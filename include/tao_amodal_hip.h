@@ -487,10 +487,14 @@ size_t taoamd_accumulate_workspace(int64_t n_dt, int32_t n_cat, int32_t n_rng);
 /* The two halves of taoamd_accumulate, used separately by the multi-GPU path:
  *  _compact  sweeps the categories [k_begin, k_end) (rows of other categories
  *            must be absent) and writes the category-major tables
- *              val[n_cat][n_rng][T][R]   precision at the recall thresholds
+ *              val[n_cat][n_rng][T][R]   precision at the recall thresholds,
+ *                                        as opaque 8-byte records (tp << 32 |
+ *                                        tp + fp of the row that sets the
+ *                                        value; declared double for size)
  *              rec[n_cat][n_rng][T]      recall
  *            for every (k, range) with num_gt > 0 in that category range;
- *  _finalize turns complete tables into the reference layout (-1 fill).
+ *  _finalize turns complete tables into the reference layout (-1 fill) and a
+ *            record into tp / (fp + tp + eps), L/eval.py:384.
  * Category-major tables make a rank's share one contiguous block, so ranks
  * exchange them with a single all-gather.
  * max_segment: rows of the longest category among those swept (the host
@@ -499,7 +503,7 @@ size_t taoamd_accumulate_workspace(int64_t n_dt, int32_t n_cat, int32_t n_rng);
  * is a single fused launch with all intermediates in LDS / registers;
  * otherwise (or with 0) categories are cut into chunks spread over the chip.
  * Workspace of _compact: taoamd_accumulate_workspace (val/rec excluded). */
-size_t taoamd_compact_elems(int32_t n_cat, int32_t n_rng); /* doubles in val */
+size_t taoamd_compact_elems(int32_t n_cat, int32_t n_rng); /* 8-byte elements in val */
 int taoamd_accumulate_compact(int64_t n_dt, int32_t n_cat, int32_t n_rng,
                               const int32_t *cat_off, const uint64_t *matched,
                               const uint64_t *ignored, const int32_t *num_gt,
