@@ -232,6 +232,11 @@ class DeviceProblem:
         self.t["groups"] = torch.from_numpy(runs).to(self.device)
         self.n_tasks = 0
         self.exact_terms = False
+        # decimal boxes: the host tables the frame-order guard recomputes the
+        # listed pairs from (apply_iou_guard); dropped again if the boxes turn
+        # out to be integers
+        self.guard_flat = flat if (self.kind == "tao" and
+                                   self.device.type == "cuda") else None
         if self.kind == "tao":
             self._plan_track_iou(flat)
         # per detection {first GT of its cell, GT count, position in the cell,
@@ -298,6 +303,8 @@ class DeviceProblem:
         # (products < 2^40, tracks of at most 2^12 frames: every sum < 2^53)
         longest = int((meta[:, 1] - meta[:, 0]).max()) + 1 if len(meta) else 0
         self.exact_terms = not bool(inexact.item()) and longest <= 4096
+        if self.exact_terms:
+            self.guard_flat = None
 
     def input_bytes(self):
         return sum(v.numel() * v.element_size() for v in self.t.values()
@@ -754,6 +761,10 @@ def run_forked(dp, ws, aux, head_only=False, sort_aside=False):
             stage_ranges(dp, ws)
             stage_sort(dp, ws)
         _probed("track_iou", stage_track_iou_guarded, dp, ws)
+        if dp.guard_flat is not None:
+            # decimal boxes: one host synchronisation, the listed pairs are
+            # patched in the reference's frame order before the match
+            ws.guarded_pairs = apply_iou_guard(dp, ws, dp.guard_flat)
     cur.wait_stream(aux)
     _probed("match", stage_match, dp, ws)
     if not head_only:

@@ -83,3 +83,45 @@ def test_class_api_reports_the_guarded_pairs(tmp_path):
     want = load_json_gz("f7", "tao.json.gz")
     res = [[k if isinstance(k, str) else list(k), float(v)] for k, v in ev.results.items()]
     assert res == want["results"]
+
+
+@pytest.mark.parametrize("mode", ["category", "unit"])
+def test_multi_gpu_plans_apply_the_guard(mode):
+    """The plans of dist.py (one rank here: RCCL group of one) patch the
+    listed pairs between the 3D IoU and the match like the single-GPU path:
+    the adversarial fixture comes out as the reference computed it."""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    from tao_amodal_amd import dist as tdist, engine, flatten_dev
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        gtj, predj = load_inputs("f7")
+        gt, dt = GTColumns.from_json(gtj), DTColumns.from_json(predj)
+        f_l = flatten_dev.flatten_lvis(gt, dt, device=dev)
+        dt.track_id, _ = fl.make_track_ids_unique(dt)
+        f_t = flatten_dev.flatten_tao(gt, dt, device=dev)
+        dpl, dpt = engine.DeviceProblem(f_l, dev), engine.DeviceProblem(f_t, dev)
+        assert not dpt.exact_terms and dpt.guard_flat is not None
+        cls = tdist.CategoryPlan if mode == "category" else tdist.ExchangePlan
+        plan = cls(dpl, dpt, 0, 1, dev)
+        plan.step()
+        plan.step()
+        torch.cuda.synchronize()
+        assert plan.tao.ws.guarded_pairs > 0
+        p, r = load_eval("f7")["tao"]
+        assert np.array_equal(plan.tao.precision.cpu().numpy().reshape(p.shape), p)
+        assert np.array_equal(plan.tao.recall.cpu().numpy().reshape(r.shape), r)
+        p, r = load_eval("f7")["lvis"]
+        assert np.array_equal(plan.lvis.precision.cpu().numpy().reshape(p.shape), p)
+        assert np.array_equal(plan.lvis.recall.cpu().numpy().reshape(r.shape), r)
+    finally:
+        dist.destroy_process_group()
