@@ -304,6 +304,7 @@ struct SegArgs {
     uint64_t *key[2];
     int32_t *idx[2];
     int32_t *order, *dst;
+    int32_t *bnd;              // splitter ranks per (bucket, tile) of the long categories
     int64_t n;
     int32_t n_cat, n_tiles;
 };
@@ -452,52 +453,17 @@ __device__ __forceinline__ void seg_passes(SegLds &L, int base, int n, int p0, i
     }
 }
 
-__global__ __launch_bounds__(SEG_THREADS, 5) void seg_tile_kernel(SegArgs a)
+// Stable sort of L.key[0 .. n) (with L.pos) in LDS: high-word passes, then the
+// repair of runs of equal high words (see above).  `load` fills L.key[i] and
+// L.pos[i] = i for all i (it is called again if the tile starts over with all
+// eight passes).  Returns whether elements carry run marks (seg_final_slot).
+template <class Load>
+__device__ __forceinline__ bool seg_sort_lds(SegLds &L, int n, Load load)
 {
-    __shared__ SegLds L;
-    // category owning this tile: last k with tile_off[k] <= blockIdx.x
-    int32_t lo = 0, hi = a.n_cat;
-    while (hi - lo > 1) {
-        const int32_t mid = (lo + hi) >> 1;
-        if (a.tile_off[mid] <= (int32_t)blockIdx.x) lo = mid; else hi = mid;
-    }
-    const int32_t k = lo, t = blockIdx.x - a.tile_off[k];
-    const int32_t sb = a.cat_off[k], se = a.cat_off[k + 1];
-    const int32_t b = sb + t * SEG_TILE;
-    const int32_t n = min(SEG_TILE, se - b);
-    if (n <= 0) return;
-    const int lane = lane_id(), wave = threadIdx.x >> 6;
-    if (n <= WAVE) {
-        // tiny category: one wavefront, rank by counting -- element i goes to
-        // the number of elements that precede it in (key, position) order
-        if (wave != 0) return;
-        const uint64_t mine = lane < n ? desc_key(a.score[b + lane]) : ~0ull;
-        int rank = 0;
-        for (int j = 0; j < n; j++) {
-            const uint32_t lo_ = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine, j);
-            const uint32_t hi_ = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mine >> 32), j);
-            const uint64_t other = ((uint64_t)hi_ << 32) | lo_;
-            rank += (other < mine || (other == mine && j < lane)) ? 1 : 0;
-        }
-        if (lane < n) {
-            if (se - sb <= SEG_TILE) {
-                if (a.order) a.order[b + rank] = b + lane;
-                if (a.dst) a.dst[b + lane] = b + rank;
-            } else {    // short last tile of a long category: goes on to merge
-                a.key[0][b + rank] = mine;
-                a.idx[0][b + rank] = b + lane;
-            }
-        }
-        return;
-    }
     bool repaired = false;
 #pragma nounroll
     for (int attempt = 0; attempt < 2; attempt++) {
-#pragma nounroll
-        for (int i = threadIdx.x; i < n; i += SEG_THREADS) {
-            L.key[i] = desc_key(a.score[b + i]);
-            L.pos[i] = (uint16_t)i;
-        }
+        load();
         if (threadIdx.x == 0) L.n_long = 0;
         __syncthreads();
         seg_passes(L, 0, n, attempt == 0 ? 4 : 0, 8);
@@ -562,27 +528,80 @@ __global__ __launch_bounds__(SEG_THREADS, 5) void seg_tile_kernel(SegArgs a)
             seg_passes(L, L.long_s[q], L.long_e[q] - L.long_s[q], 0, 4);
         break;
     }
+    return repaired;
+}
+
+// final place of the element at LDS position i: itself, or -- a marked member
+// of a short run of equal high words -- its rank in the run by (key, position)
+__device__ __forceinline__ int seg_final_slot(const SegLds &L, int i, int n, bool repaired)
+{
+    if (!(repaired && (L.pos[i] & 0x8000u))) return i;
+    const uint64_t mine = L.key[i];
+    const uint32_t h = (uint32_t)(mine >> 32);
+    int s0 = i, e0 = i + 1;
+    while (s0 > 0 && (uint32_t)(L.key[s0 - 1] >> 32) == h) s0--;
+    while (e0 < n && (uint32_t)(L.key[e0] >> 32) == h) e0++;
+    int rk = 0;
+    for (int j = s0; j < e0; j++) {
+        const uint64_t o = L.key[j];
+        rk += (o < mine || (o == mine && j < i)) ? 1 : 0;
+    }
+    return s0 + rk;
+}
+
+__global__ __launch_bounds__(SEG_THREADS, 5) void seg_tile_kernel(SegArgs a)
+{
+    __shared__ SegLds L;
+    // category owning this tile: last k with tile_off[k] <= blockIdx.x
+    int32_t lo = 0, hi = a.n_cat;
+    while (hi - lo > 1) {
+        const int32_t mid = (lo + hi) >> 1;
+        if (a.tile_off[mid] <= (int32_t)blockIdx.x) lo = mid; else hi = mid;
+    }
+    const int32_t k = lo, t = blockIdx.x - a.tile_off[k];
+    const int32_t sb = a.cat_off[k], se = a.cat_off[k + 1];
+    const int32_t b = sb + t * SEG_TILE;
+    const int32_t n = min(SEG_TILE, se - b);
+    if (n <= 0) return;
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    if (n <= WAVE) {
+        // tiny category: one wavefront, rank by counting -- element i goes to
+        // the number of elements that precede it in (key, position) order
+        if (wave != 0) return;
+        const uint64_t mine = lane < n ? desc_key(a.score[b + lane]) : ~0ull;
+        int rank = 0;
+        for (int j = 0; j < n; j++) {
+            const uint32_t lo_ = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine, j);
+            const uint32_t hi_ = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mine >> 32), j);
+            const uint64_t other = ((uint64_t)hi_ << 32) | lo_;
+            rank += (other < mine || (other == mine && j < lane)) ? 1 : 0;
+        }
+        if (lane < n) {
+            if (se - sb <= SEG_TILE) {
+                if (a.order) a.order[b + rank] = b + lane;
+                if (a.dst) a.dst[b + lane] = b + rank;
+            } else {    // short last tile of a long category: goes on to merge
+                a.key[0][b + rank] = mine;
+                a.idx[0][b + rank] = b + lane;
+            }
+        }
+        return;
+    }
+    const bool repaired = seg_sort_lds(L, n, [&]() {
+#pragma nounroll
+        for (int i = threadIdx.x; i < n; i += SEG_THREADS) {
+            L.key[i] = desc_key(a.score[b + i]);
+            L.pos[i] = (uint16_t)i;
+        }
+    });
     // ---- output from LDS; a marked element goes to its rank in its run by
     // (key, position in the run)
     const bool single = se - sb <= SEG_TILE;
 #pragma nounroll
     for (int i = threadIdx.x; i < n; i += SEG_THREADS) {
         const uint64_t mine = L.key[i];
-        const uint32_t pw = L.pos[i];
-        int to = i;
-        if (repaired && (pw & 0x8000u)) {
-            const uint32_t h = (uint32_t)(mine >> 32);
-            int s0 = i, e0 = i + 1;
-            while (s0 > 0 && (uint32_t)(L.key[s0 - 1] >> 32) == h) s0--;
-            while (e0 < n && (uint32_t)(L.key[e0] >> 32) == h) e0++;
-            int rk = 0;
-            for (int j = s0; j < e0; j++) {
-                const uint64_t o = L.key[j];
-                rk += (o < mine || (o == mine && j < i)) ? 1 : 0;
-            }
-            to = s0 + rk;
-        }
-        const int32_t d = b + (int32_t)(pw & 0x0fffu);
+        const int to = seg_final_slot(L, i, n, repaired);
+        const int32_t d = b + (int32_t)(L.pos[i] & 0x0fffu);
         if (single) {
             if (a.order) a.order[b + to] = d;
             if (a.dst) a.dst[d] = b + to;
@@ -640,6 +659,173 @@ __global__ __launch_bounds__(256) void seg_kmerge_kernel(SegArgs a)
 }
 
 // ---------------------------------------------------------------------------
+// Long categories by SPLITTERS: a sample sort over the already sorted tiles,
+// ONE more pass over the data whatever the number of tiles (the pairwise
+// merge-path passes need log2(tiles) of them: 4 x 0.23 ms of a 2.9 ms step at
+// 2000 videos).
+//   seg_split_kernel   one workgroup per category of 2..SEG_SPLIT_TILES tiles:
+//                      every s-th element of every sorted tile is a sample; the
+//                      samples are sorted in LDS and every q-th of them is a
+//                      splitter; the rank of every splitter in every tile (one
+//                      binary search, unique (key, input position) order) cuts
+//                      the tiles into B buckets;
+//   seg_bucket_kernel  one workgroup per bucket: its pieces of the tiles are
+//                      gathered in tile order (= input order among equal keys),
+//                      sorted in LDS like a tile and written to their final
+//                      places (the elements before the bucket are the sum of
+//                      the ranks of its lower splitter).
+// A bucket cannot overflow the LDS tile: between two consecutive splitters lie
+// q samples, and a tile holds at most s elements between two of ITS samples, so
+// the bucket has at most s * (q + tiles) elements; q = SEG_TILE / s - tiles
+// makes that SEG_TILE.  s = 16 up to 16 tiles (buckets ~91-98 % full), 32 up to
+// 32 tiles (64-80 %); longer categories take the merge-path passes.
+#define SEG_SPLIT_TILES 32
+#define SEG_BND_PER_SLOT 256    // ints of the rank table per SEG_TILE elements of input
+
+struct SegLdsX {                // seg_split_kernel
+    SegLds L;
+    int32_t idx[SEG_TILE];
+    uint64_t spl_key[2 * SEG_SPLIT_TILES];
+    int32_t spl_idx[2 * SEG_SPLIT_TILES];
+};
+struct SegLdsB {                // seg_bucket_kernel: under 32 KB, five workgroups per CU
+    SegLds L;
+    int32_t piece_lo[SEG_SPLIT_TILES], piece_at[SEG_SPLIT_TILES + 1];
+    int32_t out_base;
+};
+
+struct SplitGeom {
+    int32_t sb, n, m, s, S, q, ns, B;
+    bool on;
+};
+
+__device__ __forceinline__ SplitGeom split_geom(const SegArgs &a, int32_t k)
+{
+    SplitGeom g;
+    g.sb = a.cat_off[k];
+    g.n = a.cat_off[k + 1] - g.sb;
+    g.m = (g.n + SEG_TILE - 1) / SEG_TILE;
+    g.on = g.m >= 2 && g.m <= SEG_SPLIT_TILES;
+    g.s = g.m <= 16 ? 16 : 32;
+    g.S = SEG_TILE / g.s;
+    g.q = g.S - g.m;
+    const int32_t last_len = g.n - (g.m - 1) * SEG_TILE;
+    g.ns = (g.m - 1) * g.S + last_len / g.s;
+    g.B = (g.ns + g.q - 1) / g.q;
+    return g;
+}
+
+__global__ __launch_bounds__(SEG_THREADS, 3) void seg_split_kernel(SegArgs a)
+{
+    __shared__ SegLdsX X;
+    SegLds &L = X.L;
+    const SplitGeom g = split_geom(a, (int32_t)blockIdx.x);
+    if (!g.on) return;
+    const uint64_t *__restrict__ kin = a.key[0];
+    const int32_t *__restrict__ iin = a.idx[0];
+    // sample i, tile-major: the last element of a group of s elements
+    auto src_of = [&](int i) {
+        const int t = i / g.S, j = i - t * g.S;
+        return g.sb + t * SEG_TILE + (j + 1) * g.s - 1;
+    };
+    for (int i = threadIdx.x; i < g.ns; i += SEG_THREADS) X.idx[i] = iin[src_of(i)];
+    const bool repaired = seg_sort_lds(L, g.ns, [&]() {
+#pragma nounroll
+        for (int i = threadIdx.x; i < g.ns; i += SEG_THREADS) {
+            L.key[i] = kin[src_of(i)];
+            L.pos[i] = (uint16_t)i;
+        }
+    });
+    // splitter b = the sample at sorted place b * q - 1, b = 1 .. B - 1
+#pragma nounroll
+    for (int i = threadIdx.x; i < g.ns; i += SEG_THREADS) {
+        const int to = seg_final_slot(L, i, g.ns, repaired) + 1;
+        if (to % g.q == 0 && to / g.q < g.B) {
+            X.spl_key[to / g.q] = L.key[i];
+            X.spl_idx[to / g.q] = X.idx[L.pos[i] & 0x0fffu];
+        }
+    }
+    __syncthreads();
+    int32_t *__restrict__ bnd = a.bnd + (int64_t)(g.sb / SEG_TILE) * SEG_BND_PER_SLOT;
+    for (int i = threadIdx.x; i < (g.B - 1) * g.m; i += SEG_THREADS) {
+        const int b = 1 + i / g.m, t = i - (b - 1) * g.m;
+        const int32_t tb = g.sb + t * SEG_TILE, te = min(tb + SEG_TILE, g.sb + g.n);
+        // elements of tile t at or before the splitter in (key, position) order
+        bnd[b * SEG_SPLIT_TILES + t] = rank_in(kin, iin, tb, te, X.spl_key[b], X.spl_idx[b] + 1);
+    }
+}
+
+__global__ __launch_bounds__(SEG_THREADS, 5) void seg_bucket_kernel(SegArgs a)
+{
+    __shared__ SegLdsB X;
+    SegLds &L = X.L;
+    int32_t lo = 0, hi = a.n_cat;
+    const int32_t tile = (int32_t)(blockIdx.x >> 1);
+    while (hi - lo > 1) {
+        const int32_t mid = (lo + hi) >> 1;
+        if (a.tile_off[mid] <= tile) lo = mid; else hi = mid;
+    }
+    const int32_t k = lo;
+    const SplitGeom g = split_geom(a, k);
+    const int32_t b = (int32_t)blockIdx.x - 2 * a.tile_off[k];
+    if (!g.on || b >= g.B) return;
+    const uint64_t *__restrict__ kin = a.key[0];
+    const int32_t *__restrict__ iin = a.idx[0];
+    const int32_t *__restrict__ bnd = a.bnd + (int64_t)(g.sb / SEG_TILE) * SEG_BND_PER_SLOT;
+    // ---- my piece of every tile (first wavefront: tiles <= 32)
+    if (threadIdx.x < WAVE) {
+        const int t = threadIdx.x;
+        int32_t plo = 0, cnt = 0;
+        if (t < g.m) {
+            const int32_t len_t = min(SEG_TILE, g.n - t * SEG_TILE);
+            plo = b > 0 ? bnd[b * SEG_SPLIT_TILES + t] : 0;
+            const int32_t phi = b + 1 < g.B ? bnd[(b + 1) * SEG_SPLIT_TILES + t] : len_t;
+            cnt = phi - plo;
+        }
+        int32_t inc = cnt, before = plo;
+#pragma unroll
+        for (int off = 1; off < WAVE; off <<= 1) {
+            const int32_t v = __shfl_up(inc, off, WAVE), w = __shfl_xor(before, off, WAVE);
+            if ((int)threadIdx.x >= off) inc += v;
+            before += w;
+        }
+        if (t < g.m) {
+            X.piece_lo[t] = plo;
+            X.piece_at[t] = inc - cnt;
+        }
+        if (t == g.m - 1) X.piece_at[g.m] = inc;
+        if (t == 0) X.out_base = g.sb + before;     // everything before the bucket
+    }
+    __syncthreads();
+    const int32_t total = min(X.piece_at[g.m], (int32_t)SEG_TILE);   // (<= SEG_TILE by construction)
+    if (total <= 0) return;
+    auto src_of = [&](int i) {
+        int t0 = 0, t1 = g.m;                  // piece holding gathered element i
+        while (t1 - t0 > 1) {
+            const int mid = (t0 + t1) >> 1;
+            if (X.piece_at[mid] <= i) t0 = mid; else t1 = mid;
+        }
+        return g.sb + t0 * SEG_TILE + X.piece_lo[t0] + (i - X.piece_at[t0]);
+    };
+    const bool repaired = seg_sort_lds(L, total, [&]() {
+#pragma nounroll
+        for (int i = threadIdx.x; i < total; i += SEG_THREADS) {
+            L.key[i] = kin[src_of(i)];
+            L.pos[i] = (uint16_t)i;
+        }
+    });
+    const int32_t out = X.out_base;
+#pragma nounroll
+    for (int i = threadIdx.x; i < total; i += SEG_THREADS) {
+        const int32_t p = out + seg_final_slot(L, i, total, repaired);
+        // (the input position is fetched now rather than carried through LDS)
+        const int32_t d = iin[src_of((int)(L.pos[i] & 0x0fffu))];
+        if (a.order) a.order[p] = d;
+        if (a.dst) a.dst[d] = p;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Pairwise merge passes by MERGE PATH for categories of many tiles: a workgroup
 // produces one tile-sized slice of a merged pair of runs.  Two searches along
 // the slice's diagonals tell which pieces of the two runs feed it; the pieces
@@ -662,7 +848,8 @@ __device__ __forceinline__ int32_t merge_split(KA A, int32_t na, KB B, int32_t n
     return lo;
 }
 
-__global__ __launch_bounds__(256) void seg_mpass_kernel(SegArgs a, int pass, int last)
+__global__ __launch_bounds__(256) void seg_mpass_kernel(SegArgs a, int pass, int last,
+                                                        int32_t longer_than)
 {
     __shared__ uint64_t m_key[SEG_TILE];
     __shared__ int32_t m_idx[SEG_TILE];
@@ -675,7 +862,7 @@ __global__ __launch_bounds__(256) void seg_mpass_kernel(SegArgs a, int pass, int
     }
     const int32_t k = lo;
     const int32_t sb = a.cat_off[k], se = a.cat_off[k + 1];
-    if (se - sb <= SEG_TILE) return;
+    if (se - sb <= longer_than) return;     // one tile, or the splitter kernels' category
     const int32_t tb = sb + ((int32_t)blockIdx.x - a.tile_off[k]) * SEG_TILE;
     const int32_t len = min(SEG_TILE, se - tb);
     if (len <= 0) return;
@@ -733,7 +920,8 @@ __global__ __launch_bounds__(256) void seg_mpass_kernel(SegArgs a, int pass, int
 extern "C" size_t taoamd_sort_segments_workspace(int64_t n)
 {
     if (n < 1) n = 1;
-    return 2 * align256((size_t)n * 8) + 2 * align256((size_t)n * 4) + 4096;
+    return 2 * align256((size_t)n * 8) + 2 * align256((size_t)n * 4) +
+           align256(((size_t)n / SEG_TILE + 2) * SEG_BND_PER_SLOT * 4) + 4096;
 }
 
 extern "C" int taoamd_sort_segments(int64_t n, int32_t n_cat,
@@ -756,15 +944,25 @@ extern "C" int taoamd_sort_segments(int64_t n, int32_t n_cat,
     a.key[0] = (uint64_t *)w; w += align256((size_t)n * 8);
     a.key[1] = (uint64_t *)w; w += align256((size_t)n * 8);
     a.idx[0] = (int32_t *)w;  w += align256((size_t)n * 4);
-    a.idx[1] = (int32_t *)w;
+    a.idx[1] = (int32_t *)w;  w += align256((size_t)n * 4);
+    a.bnd = (int32_t *)w;
     TAO_TIMED("seg_tile_kernel", s, seg_tile_kernel<<<(unsigned)n_tiles, SEG_THREADS, 0, s>>>(a));
-    if (max_segment > SEG_TILE && max_segment <= (int64_t)SEG_KMERGE_TILES * SEG_TILE) {
+    static const int split_min = getenv("TAOAMD_SPLIT_MIN") ? atoi(getenv("TAOAMD_SPLIT_MIN"))
+                                                            : SEG_KMERGE_TILES + 1;
+    if (max_segment > SEG_TILE && max_segment <= (int64_t)(split_min - 1) * SEG_TILE) {
         TAO_TIMED("seg_kmerge_kernel", s, seg_kmerge_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(a));
     } else if (max_segment > SEG_TILE) {
-        int passes = 0;
-        for (int64_t L = SEG_TILE; L < max_segment; L <<= 1) passes++;
-        for (int p = 0; p < passes; p++)
-            TAO_TIMED("seg_mpass_kernel", s, seg_mpass_kernel<<<(unsigned)n_tiles, 256, 0, s>>>(a, p, p == passes - 1));
+        // categories of up to SEG_SPLIT_TILES tiles: splitter buckets; longer
+        // ones (if any): pairwise merge-path passes, their last one final
+        TAO_TIMED("seg_split_kernel", s, seg_split_kernel<<<(unsigned)n_cat, SEG_THREADS, 0, s>>>(a));
+        TAO_TIMED("seg_bucket_kernel", s, seg_bucket_kernel<<<2u * (unsigned)n_tiles, SEG_THREADS, 0, s>>>(a));
+        const int32_t longer_than = SEG_SPLIT_TILES * SEG_TILE;
+        if (max_segment > longer_than) {
+            int passes = 0;
+            for (int64_t L = SEG_TILE; L < max_segment; L <<= 1) passes++;
+            for (int p = 0; p < passes; p++)
+                TAO_TIMED("seg_mpass_kernel", s, seg_mpass_kernel<<<(unsigned)n_tiles, 256, 0, s>>>(a, p, p == passes - 1, longer_than));
+        }
     }
     TAO_LAUNCH_CHECK();
     return TAOAMD_OK;

@@ -258,7 +258,12 @@ def test_sharded_path_on_one_gpu_equals_plain_path():
 @pytest.mark.parametrize("n,n_cat,quant", [(50000, 7, 50), (200000, 3, 0), (3000, 500, 5),
                                             (70000, 1, 3), (60000, 40, -1), (60000, 40, -2),
                                             (20000, 300, -1), (9000, 2, -2), (30000, 20, -3),
-                                            (5000, 1, -3), (100000, 60, -4)])
+                                            (5000, 1, -3), (100000, 60, -4),
+                                            # categories of 6..32 tiles (splitter buckets),
+                                            # of more (merge-path passes)
+                                            (30000, 1, 0), (60000, 1, 5), (90000, 2, -2),
+                                            (45000, 1, -4), (130000, 1, -4), (95000, 1, 2),
+                                            (250000, 12, -1)])
 def test_both_sorts_are_the_stable_mergesort_order(n, n_cat, quant):
     """Radix sort and tile+merge sort against numpy's stable argsort, with
     heavy score ties and categories far longer than one LDS tile."""
@@ -593,3 +598,39 @@ def test_sort_beside_the_match_gives_the_same_tables():
         torch.cuda.synchronize()
         assert np.array_equal(ws.precision.cpu().numpy(), want["precision"]), aside
         assert np.array_equal(ws.recall.cpu().numpy(), want["recall"]), aside
+
+
+def test_segment_sort_mixes_the_three_ways_of_finishing_a_category():
+    """One launch sequence, four kinds of category: one tile (final from the
+    tile sort), 4 tiles and 11 tiles (splitter buckets), 47 tiles (merge-path
+    passes beside the buckets).  Scores with many exact ties."""
+    import torch
+    from tao_amodal_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(77)
+    sizes = [500, 130000, 9000, 30000, 0, 2816, 2817]
+    cat = np.repeat(np.arange(len(sizes)), sizes).astype(np.int32)
+    n, n_cat = len(cat), len(sizes)
+    score = rng.random(n)
+    score[rng.random(n) < 0.3] = 0.5
+    score[rng.random(n) < 0.2] = np.round(score[rng.random(n) < 0.2][:1], 2)
+    want = np.lexsort((np.arange(n), -score, cat))
+    cat_off = np.zeros(n_cat + 1, np.int32)
+    np.cumsum(sizes, out=cat_off[1:])
+    tiles = (np.diff(cat_off) + _lib.SEGMENT_TILE - 1) // _lib.SEGMENT_TILE
+    tile_off = np.zeros(n_cat + 1, np.int32)
+    np.cumsum(tiles, out=tile_off[1:])
+    d_cat, d_score = torch.from_numpy(cat).cuda(), torch.from_numpy(score).cuda()
+    d_co, d_to = torch.from_numpy(cat_off).cuda(), torch.from_numpy(tile_off).cuda()
+    order = torch.zeros(n, dtype=torch.int32, device="cuda")
+    dst = torch.zeros(n, dtype=torch.int32, device="cuda")
+    nb = lib.taoamd_sort_segments_workspace(n)
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    for _ in range(2):
+        _lib.check(lib.taoamd_sort_segments(
+            n, n_cat, d_co.data_ptr(), d_to.data_ptr(), int(tile_off[-1]), max(sizes),
+            d_cat.data_ptr(), d_score.data_ptr(), order.data_ptr(), dst.data_ptr(),
+            ws.data_ptr(), nb, None), "segments")
+    torch.cuda.synchronize()
+    assert np.array_equal(order.cpu().numpy(), want)
+    assert np.array_equal(dst.cpu().numpy()[want], np.arange(n))
