@@ -167,6 +167,8 @@ def kernel_models(dp, ws):
     m["seg_tile_kernel"] = n_dt * (8 + 8)           # score in; order + dst (or key + index) out
     m["seg_kmerge_kernel"] = n_multi * (12 + 8)     # key + index in; order + dst out
     m["seg_mpass_kernel"] = n_multi * 24
+    m["seg_bucket_kernel"] = n_multi * (12 + 8)     # key + index in; order + dst out
+    m["seg_split_kernel"] = n_multi // 16 * 12      # every 16th (key, index) as a sample
     m["acc_count_kernel"] = rows
     m["acc_chunkmax_kernel"] = rows
     m["acc_emit_kernel"] = rows + live * table
@@ -174,6 +176,8 @@ def kernel_models(dp, ws):
     m["acc_finalize_kernel"] = live * table + K * A * (table + 8 * T)
     grids = {"seg_tile_kernel": dp.n_tiles * 256,
              "seg_mpass_kernel": dp.n_tiles * 256,
+             "seg_bucket_kernel": dp.n_tiles * 2 * 256,
+             "seg_split_kernel": K * 256,
              "seg_kmerge_kernel": (n_dt + 255) // 256 * 256,
              "acc_finalize_kernel": ((K * A + 63) // 64) * ((T * R + 63) // 64) * 256}
     return m, grids
