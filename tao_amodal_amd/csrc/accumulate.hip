@@ -66,6 +66,7 @@ struct AccArgs {
     const int32_t *order;    // optional: sorted position -> row of matched / ignored
     const int32_t *num_gt;
     int32_t *cat_chunk_off;  // [n_cat + 1]
+    const int32_t *chunk_tab;  // [chunk] category of the chunk; null: searched per wavefront
     uint32_t *cnt_tp, *cnt_fp;   // [chunk][word][64] counts inside the chunk
     uint32_t *pre_tp, *pre_fp;   // exclusive prefix inside the category
     uint64_t *t_tp, *t_fp;       // [chunk][word][4 blocks][64] transposed TP / FP words
@@ -121,6 +122,13 @@ __device__ __forceinline__ int32_t chunk_cat(const int32_t *__restrict__ off,
         if (off[mid] <= c) lo = mid; else hi = mid;
     }
     return lo;
+}
+
+// chunk -> category table of a prepared plan (taoamd_accumulate_prepare)
+__global__ void acc_chunktab_kernel(AccArgs a, int32_t *__restrict__ tab)
+{
+    const int32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < a.cat_chunk_off[a.n_cat]) tab[c] = chunk_cat(a.cat_chunk_off, a.n_cat, c);
 }
 
 __device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int lane)
@@ -191,7 +199,9 @@ __device__ __forceinline__ ChunkInfo chunk_info(const AccArgs &a)
     const int32_t total = a.cat_chunk_off[a.n_cat];
     ci.valid = ci.c < total;
     if (!ci.valid) return ci;
-    ci.k = chunk_cat(a.cat_chunk_off, a.n_cat, ci.c);
+    // (a wave-lifetime trace of the emission kernel: the eleven dependent
+    // scalar loads of the search were 3.8 us of a 23 us wavefront)
+    ci.k = a.chunk_tab ? a.chunk_tab[ci.c] : chunk_cat(a.cat_chunk_off, a.n_cat, ci.c);
     const int32_t j = ci.c - a.cat_chunk_off[ci.k];
     ci.start = (int64_t)a.cat_off[ci.k] + (int64_t)j * ACC_CH;
     const int64_t end = a.cat_off[ci.k + 1];
@@ -511,11 +521,27 @@ __device__ __forceinline__ void emit_block(uint64_t T, uint64_t TF, uint32_t &tp
             const uint32_t gt = 0xfffffffeu << q;              // rows > q (q = 31: none)
             const uint32_t tpq = tp - (uint32_t)__popc(Th[h] & gt);    // incl. row q
             const uint32_t nq = n - (uint32_t)__popc(TFh[h] & gt);
-            if (cnext > (int32_t)tpq)          // reached above row q
-                emit_burst<true, W>(out, cj, jcur, cnext, (int32_t)tpq, run);
-            if (pr_better(tpq, nq, run)) run = pr_pack(tpq, nq);
-            if (cnext == (int32_t)tpq)         // reached exactly at row q
-                emit_burst<false, W>(out, cj, jcur, cnext, (int32_t)tpq, run);
+            if (W == 1) {
+                // one loop for both kinds of threshold reached here: above row
+                // q (crossing count > tpq: the envelope before this row) and
+                // exactly at it (== tpq: the envelope including it) -- the
+                // heaviest wavefronts of the chunked sweep, the first chunks of
+                // their categories, take this branch at nearly every row
+                const uint64_t above = run;
+                if (pr_better(tpq, nq, run)) run = pr_pack(tpq, nq);
+                if (cnext >= (int32_t)tpq) {
+                    do {
+                        out[--jcur] = cnext > (int32_t)tpq ? above : run;
+                        cnext = jcur > 0 ? cj[jcur - 1] : -1;
+                    } while (cnext >= (int32_t)tpq);
+                }
+            } else {
+                if (cnext > (int32_t)tpq)          // reached above row q
+                    emit_burst<true, W>(out, cj, jcur, cnext, (int32_t)tpq, run);
+                if (pr_better(tpq, nq, run)) run = pr_pack(tpq, nq);
+                if (cnext == (int32_t)tpq)         // reached exactly at row q
+                    emit_burst<false, W>(out, cj, jcur, cnext, (int32_t)tpq, run);
+            }
             m &= ~(1u << q);
         }
         tp -= (uint32_t)__popc(Th[h]);
@@ -542,22 +568,27 @@ __global__ __launch_bounds__(256) void acc_emit_kernel(AccArgs a)
     const int t = active ? combo - r * N_THR : 0;
     const int r_lo = (ci.word * WAVE) / N_THR;
     const int r_hi = min(a.n_rng - 1, (ci.word * WAVE + WAVE - 1) / N_THR);
-    for (int q = r_lo; q <= r_hi; q++) {
-        const bool has = a.num_gt[(int64_t)ci.k * a.n_rng + q] > 0;
-        for (int j = lane; j < N_REC; j += WAVE)
-            s_cj[wave][q - r_lo][j] =
-                has ? a.cj[((int64_t)ci.k * a.n_rng + q) * N_REC + j] : 0;
+    // Every global load of the set-up in one batch, ahead of the first wait
+    // (the trace of this kernel showed the set-up as five memory round trips in
+    // a row -- crossings to LDS, counts, transposed words, the later chunks'
+    // maxima -- 11 us of a 23 us wavefront; the crossings of a row without
+    // evaluated ground truth were never written: loaded anyway, not used).
+    int32_t cjv[EMIT_RMAX][2];
+    int32_t ngq[EMIT_RMAX];
+#pragma unroll
+    for (int q = 0; q < EMIT_RMAX; q++) {
+        const int rq = min(r_lo + q, r_hi);
+        const int64_t base = ((int64_t)ci.k * a.n_rng + rq) * N_REC;
+        ngq[q] = a.num_gt[(int64_t)ci.k * a.n_rng + rq];
+        cjv[q][0] = a.cj[base + lane];
+        cjv[q][1] = a.cj[base + min(lane + WAVE, N_REC - 1)];
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    const int32_t *__restrict__ cj = s_cj[wave][active ? r - r_lo : 0];
     const int32_t ng = active ? a.num_gt[(int64_t)ci.k * a.n_rng + r] : 0;
     const bool live = active && ng > 0;
     const int64_t o = ((int64_t)ci.c * a.n_words + ci.word) * WAVE + lane;
     uint32_t tp = a.pre_tp[o] + a.cnt_tp[o];
     uint32_t n = tp + a.pre_fp[o] + a.cnt_fp[o];
-    // every load ahead of the first store (see acc_count_kernel); blocks past
-    // the chunk's rows hold zero words
+    // (blocks past the chunk's rows hold zero words)
     const int64_t tb = (((int64_t)ci.c * a.n_words + ci.word) * ACC_BLK) * WAVE + lane;
     uint64_t Tb[ACC_BLK], TFb[ACC_BLK];
 #pragma unroll
@@ -569,14 +600,32 @@ __global__ __launch_bounds__(256) void acc_emit_kernel(AccArgs a)
     }
     uint64_t run;
     if (INLINE) {
+        // four later chunks per step: their loads are in flight together
         run = PR_ZERO;
-        for (int32_t c = a.cat_chunk_off[ci.k + 1] - 1; c > ci.c; c--) {
-            const uint64_t v = a.cmax[((int64_t)c * a.n_words + ci.word) * WAVE + lane];
-            if (pr_better((uint32_t)(v >> 32), (uint32_t)v, run)) run = v;
+        const int32_t c_end = a.cat_chunk_off[ci.k + 1];
+        for (int32_t c = ci.c + 1; c < c_end; c += 4) {
+            uint64_t v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                v[u] = a.cmax[((int64_t)min(c + u, c_end - 1) * a.n_words + ci.word) * WAVE + lane];
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (pr_better((uint32_t)(v[u] >> 32), (uint32_t)v[u], run)) run = v[u];
         }
     } else {
         run = a.cmax[o];
     }
+#pragma unroll
+    for (int q = 0; q < EMIT_RMAX; q++) {
+        if (r_lo + q <= r_hi) {
+            const bool has = ngq[q] > 0;
+            s_cj[wave][q][lane] = has ? cjv[q][0] : 0;
+            if (lane + WAVE < N_REC) s_cj[wave][q][lane + WAVE] = has ? cjv[q][1] : 0;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    const int32_t *__restrict__ cj = s_cj[wave][active ? r - r_lo : 0];
     uint64_t *__restrict__ out =
         a.val + (((int64_t)ci.k * a.n_rng + r) * N_THR + t) * N_REC;
     // thresholds already reached by the TP count at the end of this chunk:
@@ -598,13 +647,10 @@ __global__ __launch_bounds__(256) void acc_emit_kernel(AccArgs a)
         // (a category without detections: precision 0 everywhere it has
         // evaluated GT, reference lvis_amodal/eval.py:412-417)
         const int jz = live ? (ci.len == 0 ? 0 : jcur) : N_REC;
-        for (int l = 0; l < WAVE; l++) {
+        for (uint64_t need = __ballot(jz < N_REC); need != 0; need &= need - 1) {
+            const int l = __builtin_ctzll(need);
             const int jl = __builtin_amdgcn_readlane(jz, l);
-            if (jl >= N_REC) continue;
-            const int cl = ci.word * WAVE + l;
-            const int rl = cl / N_THR, tl = cl - rl * N_THR;
-            uint64_t *__restrict__ row =
-                a.val + (((int64_t)ci.k * a.n_rng + rl) * N_THR + tl) * N_REC;
+            uint64_t *__restrict__ row = (uint64_t *)readlane_u64((uint64_t)out, l);
             for (int j = jl + lane; j < N_REC; j += WAVE) row[j] = PR_ZERO;
         }
     }
@@ -852,7 +898,8 @@ static size_t base_workspace(int64_t n_dt, int32_t n_cat, int32_t n_rng)
 {
     const size_t nw = (size_t)(n_rng * N_THR + 63) / 64;
     const size_t nc = (size_t)max_chunks(n_dt, n_cat);
-    return align256(((size_t)n_cat + 1) * 4) + 4 * align256(nc * nw * WAVE * 4) +
+    return align256(((size_t)n_cat + 1) * 4) + align256(nc * 4) +
+           4 * align256(nc * nw * WAVE * 4) +
            align256(nc * nw * WAVE * 8) +
            2 * align256(nc * nw * ACC_BLK * WAVE * 8) +
            align256((size_t)n_cat * n_rng * N_REC * 4) + 4096;
@@ -893,7 +940,7 @@ static int accumulate_compact(int64_t n_dt, int32_t n_cat, int32_t n_rng,
     if (k_begin == k_end) return TAOAMD_OK;
     hipStream_t s = (hipStream_t)stream;
     AccArgs a;
-    a.cat_chunk_off = nullptr; a.cnt_tp = a.cnt_fp = a.pre_tp = a.pre_fp = nullptr;
+    a.cat_chunk_off = nullptr; a.chunk_tab = nullptr; a.cnt_tp = a.cnt_fp = a.pre_tp = a.pre_fp = nullptr;
     a.cmax = a.t_tp = a.t_fp = nullptr; a.cj = nullptr;
     a.n_dt = n_dt; a.n_cat = n_cat; a.n_rng = n_rng;
     a.n_words = (n_rng * N_THR + 63) / 64;
@@ -945,6 +992,8 @@ static int accumulate_compact(int64_t n_dt, int32_t n_cat, int32_t n_rng,
     unsigned char *w = (unsigned char *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     const size_t nc = (size_t)a.n_chunks_max, nw = (size_t)a.n_words;
     a.cat_chunk_off = (int32_t *)w; w += align256(((size_t)n_cat + 1) * 4);
+    int32_t *chunk_tab = (int32_t *)w; w += align256(nc * 4);
+    a.chunk_tab = phase == ACC_SWEEP ? chunk_tab : nullptr;
     a.cnt_tp = (uint32_t *)w; w += align256(nc * nw * WAVE * 4);
     a.cnt_fp = (uint32_t *)w; w += align256(nc * nw * WAVE * 4);
     a.pre_tp = (uint32_t *)w; w += align256(nc * nw * WAVE * 4);
@@ -958,6 +1007,7 @@ static int accumulate_compact(int64_t n_dt, int32_t n_cat, int32_t n_rng,
     if (phase != ACC_SWEEP)
         TAO_TIMED("acc_chunks_kernel", s, acc_chunks_kernel<<<1, 256, 0, s>>>(a));
     if (phase == ACC_PLAN) {
+        TAO_TIMED("acc_chunktab_kernel", s, acc_chunktab_kernel<<<(unsigned)((nc + 255) / 256), 256, 0, s>>>(a, chunk_tab));
         TAO_LAUNCH_CHECK();
         return TAOAMD_OK;
     }
