@@ -426,18 +426,33 @@ __global__ __launch_bounds__(256) void match_group_kernel(MatchArgs a, IouThr th
             myghid = (HID >> (gb + cand)) & 1ull;
         }
         const bool consumes = !(t_flags & TAOAMD_DT_NO_CONSUME);
-        uint32_t m10 = 0;
-        for (int q = 0; q < N_THR; q++) {
-            const double tq = fmin(thr.v[q], 1 - 1e-10);
-            const bool pass = simple && cand >= 0 && !(vc < tq);
-            bool taken_before = false;
-            for (int c = 0; c < GRP_GCAP; c++) {
-                const uint64_t cons = __ballot(pass && consumes && cand == c);
-                if (__ballot(simple && cand > c) == 0 && cons == 0) break;   // wave-uniform
-                if (cand == c) taken_before = (cons & cellmask) != 0;
-            }
-            if (pass && !taken_before) m10 |= 1u << q;
+        // The thresholds ascend, so a detection passes the first `qpass` of
+        // them, and its candidate is taken at threshold q by an EARLIER
+        // consuming detection of the cell with the same candidate iff one of
+        // those passes q, i.e. iff q < M, the largest qpass among them: the
+        // detection matches at the thresholds M <= q < qpass.  M is a
+        // segmented exclusive prefix maximum over the cell's lanes, one scan
+        // per candidate index in use (before: two ballots per threshold and
+        // candidate index -- 45 % of the kernel's time in a wave-lifetime trace).
+        int qpass = 0;
+        if (simple && cand >= 0) {
+#pragma unroll
+            for (int q = 0; q < N_THR; q++) qpass += !(vc < fmin(thr.v[q], 1 - 1e-10)) ? 1 : 0;
         }
+        const int val = consumes ? qpass : 0;
+        int M = 0;
+        for (int c = 0; c < GRP_GCAP; c++) {
+            if (__ballot(simple && cand >= c) == 0) break;          // wave-uniform
+            int x = cand == c ? val : 0;
+#pragma unroll
+            for (int d = 1; d < WAVE; d <<= 1) {
+                const int y = __shfl_up(x, d, WAVE);
+                if (lane - d >= ca) x = max(x, y);
+            }
+            const int before = __shfl_up(x, 1, WAVE);
+            if (cand == c) M = lane - 1 >= ca ? before : 0;
+        }
+        const uint32_t m10 = qpass > M ? ((1u << qpass) - 1) & ~((1u << M) - 1) : 0u;
         if (simple) {
             const uint32_t all10 = (1u << N_THR) - 1;
             const int r_lo = (word * WAVE) / N_THR;
