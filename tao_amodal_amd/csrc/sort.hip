@@ -947,9 +947,7 @@ extern "C" int taoamd_sort_segments(int64_t n, int32_t n_cat,
     a.idx[1] = (int32_t *)w;  w += align256((size_t)n * 4);
     a.bnd = (int32_t *)w;
     TAO_TIMED("seg_tile_kernel", s, seg_tile_kernel<<<(unsigned)n_tiles, SEG_THREADS, 0, s>>>(a));
-    static const int split_min = getenv("TAOAMD_SPLIT_MIN") ? atoi(getenv("TAOAMD_SPLIT_MIN"))
-                                                            : SEG_KMERGE_TILES + 1;
-    if (max_segment > SEG_TILE && max_segment <= (int64_t)(split_min - 1) * SEG_TILE) {
+    if (max_segment > SEG_TILE && max_segment <= (int64_t)SEG_KMERGE_TILES * SEG_TILE) {
         TAO_TIMED("seg_kmerge_kernel", s, seg_kmerge_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(a));
     } else if (max_segment > SEG_TILE) {
         // categories of up to SEG_SPLIT_TILES tiles: splitter buckets; longer
