@@ -160,23 +160,50 @@ __device__ __forceinline__ void load_rows(const AccArgs &a, int64_t first, int w
     fpw = ~m & ~i;
 }
 
+// value of lane (i ^ S): CDNA4 lane permutes that need neither an address VGPR
+// nor a round trip through the LDS crossbar queue (what __shfl_xor compiles to,
+// ds_bpermute_b32): v_permlane32_swap / v_permlane16_swap for the two widest
+// strides, DPP row_ror:8 and quad_perm for 8 / 2 / 1, ds_swizzle for 4
+template <int S>
+__device__ __forceinline__ uint32_t xor_lane(uint32_t x, int lane)
+{
+    if constexpr (S == 32) {
+        auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+        return (lane & 32) ? r[0] : r[1];
+    } else if constexpr (S == 16) {
+        auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+        return (lane & 16) ? r[0] : r[1];
+    } else if constexpr (S == 8) {
+        return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x128, 0xf, 0xf, false);   // row_ror:8
+    } else if constexpr (S == 4) {
+        return (uint32_t)__builtin_amdgcn_ds_swizzle((int)x, 0x101f);                // xor 4
+    } else if constexpr (S == 2) {
+        return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x4e, 0xf, 0xf, false);    // [2,3,0,1]
+    } else {
+        return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xb1, 0xf, 0xf, false);    // [1,0,3,2]
+    }
+}
+
 // 64 x 64 bit-matrix transpose across the wavefront: in: lane i holds row i
 // (bit j = element (i, j)); out: lane j holds column j (bit i = element (i, j)).
 // Stage s swaps the off-diagonal s x s blocks between lanes i and i ^ s.
+template <int S>
+__device__ __forceinline__ uint64_t transpose_stage(uint64_t x, int lane, uint64_t lo_mask)
+{
+    const uint32_t ylo = xor_lane<S>((uint32_t)x, lane);
+    const uint32_t yhi = xor_lane<S>((uint32_t)(x >> 32), lane);
+    const uint64_t y = ((uint64_t)yhi << 32) | ylo;
+    return (lane & S) ? ((x & ~lo_mask) | ((y & ~lo_mask) >> S))
+                      : ((x & lo_mask) | ((y & lo_mask) << S));
+}
 __device__ __forceinline__ uint64_t transpose64(uint64_t x, int lane)
 {
-    const uint64_t LO[6] = {0x00000000ffffffffull, 0x0000ffff0000ffffull,
-                            0x00ff00ff00ff00ffull, 0x0f0f0f0f0f0f0f0full,
-                            0x3333333333333333ull, 0x5555555555555555ull};
-#pragma unroll
-    for (int k = 0; k < 6; k++) {
-        const int s = 32 >> k;
-        const uint32_t ylo = (uint32_t)__shfl_xor((int)(uint32_t)x, s, WAVE);
-        const uint32_t yhi = (uint32_t)__shfl_xor((int)(uint32_t)(x >> 32), s, WAVE);
-        const uint64_t y = ((uint64_t)yhi << 32) | ylo;
-        x = (lane & s) ? ((x & ~LO[k]) | ((y & ~LO[k]) >> s))
-                       : ((x & LO[k]) | ((y & LO[k]) << s));
-    }
+    x = transpose_stage<32>(x, lane, 0x00000000ffffffffull);
+    x = transpose_stage<16>(x, lane, 0x0000ffff0000ffffull);
+    x = transpose_stage<8>(x, lane, 0x00ff00ff00ff00ffull);
+    x = transpose_stage<4>(x, lane, 0x0f0f0f0f0f0f0f0full);
+    x = transpose_stage<2>(x, lane, 0x3333333333333333ull);
+    x = transpose_stage<1>(x, lane, 0x5555555555555555ull);
     return x;
 }
 
