@@ -568,6 +568,10 @@ int taoamd_accumulate_by_order(int64_t n_dt, int32_t n_cat, int32_t n_rng,
  *           (-1 fill) and optionally the assembled num_gt[n_cat][n_rng]
  * *overflow (device int32, may be NULL) is OR-ed with 1 if a block needs more
  * than `capacity` levels (the excess is dropped, results are then invalid).
+ * maps_ready != 0: the run maps and level offsets of ALL rows are already in
+ * the workspace -- a _sizes call on the num_gt of all rows earlier in the
+ * pass (a rank of the by-video partition knows them from its all-reduce, long
+ * before the sweep ends) -- so _pack / _unpack start their copy at once.
  * Workspace: taoamd_exchange_workspace(block_cats, n_rng, world). */
 size_t taoamd_exchange_chunk_bytes(int32_t block_cats, int32_t n_rng, int64_t capacity);
 size_t taoamd_exchange_workspace(int32_t block_cats, int32_t n_rng, int32_t world);
@@ -578,12 +582,12 @@ int taoamd_exchange_pack(int32_t n_cat, int32_t n_rng, int32_t block_cats,
                          int32_t world, int32_t rank, const int32_t *num_gt,
                          const double *val, const double *rec, void *chunk,
                          int64_t capacity, int32_t *overflow, void *workspace,
-                         size_t workspace_bytes, void *stream);
+                         size_t workspace_bytes, int32_t maps_ready, void *stream);
 int taoamd_exchange_unpack(int32_t n_cat, int32_t n_rng, int32_t block_cats,
                            int32_t world, const void *chunks, int64_t capacity,
                            int32_t *num_gt_out, double *precision, double *recall,
                            int32_t *overflow, void *workspace,
-                           size_t workspace_bytes, void *stream);
+                           size_t workspace_bytes, int32_t maps_ready, void *stream);
 
 /* By-video partition, owner side.  `records` = what one all_to_all delivered:
  * for source s the rows [src_base[s], src_base[s + 1]), each `width` int64

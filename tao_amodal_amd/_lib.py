@@ -106,9 +106,9 @@ SIGNATURES = {
     "taoamd_exchange_workspace": (_sz, [_i32, _i32, _i32]),
     "taoamd_exchange_sizes": (C.c_int, [_i32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
     "taoamd_exchange_pack": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _vp, _vp,
-                                       _vp, _vp, _i64, _vp, _vp, _sz, _vp]),
+                                       _vp, _vp, _i64, _vp, _vp, _sz, _i32, _vp]),
     "taoamd_exchange_unpack": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _i64, _vp,
-                                         _vp, _vp, _vp, _vp, _sz, _vp]),
+                                         _vp, _vp, _vp, _vp, _sz, _i32, _vp]),
     "taoamd_exchange_merge": (C.c_int, [_i64, _i32, _i32, _i32, _vp, _i64, _i32,
                                         _vp, _vp, _vp, _vp, _vp, _vp]),
     "taoamd_sort_workspace": (_sz, [_i64]),

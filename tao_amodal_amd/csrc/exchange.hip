@@ -155,29 +155,36 @@ struct PackArgs {
     ExWs w;
 };
 
-// thread = (row of the block, column (t, j)): the first column of each run is
-// copied to its level slot
+// thread = (row of the block, recall column j): if j starts a run, its value
+// at every IoU threshold is copied to the run's level slot (lanes = consecutive
+// columns: the reads of a threshold's row and the writes of its levels are
+// contiguous).  Before (round 1): a thread per (row, threshold, column), ten
+// times the threads for the same copies (52 us in the by-video step).
 __global__ __launch_bounds__(256) void ex_pack_kernel(PackArgs a)
 {
     const int64_t COLS = (int64_t)N_THR * N_REC;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t i = idx / COLS;
+    const int64_t i = idx / 128;                   // 128 threads per row: 101 columns
     if (i >= a.block_rows) return;
-    const int col = (int)(idx - i * COLS);
+    const int j = (int)(idx - i * 128);
     const int64_t row = a.row0 + i;
     const int32_t ng = row < a.valid_rows ? a.num_gt[row] : 0;
-    if (col == 0) {
+    if (j == 0) {
         a.hdr[i] = ng;
         a.hdr[a.block_rows + i] = ng > 0 ? a.w.off[row] : 0;
     }
-    if (col < N_THR) a.rec_out[i * N_THR + col] = ng > 0 ? a.rec[row * N_THR + col] : -1.0;
-    if (ng <= 0) return;
-    const int t = col / N_REC, j = col - t * N_REC;
+    if (j < N_THR) a.rec_out[i * N_THR + j] = ng > 0 ? a.rec[row * N_THR + j] : -1.0;
+    if (ng <= 0 || j >= N_REC) return;
     const uint8_t *dm = a.w.dmap + row * N_REC;
     const int d = dm[j];
     if (j > 0 && dm[j - 1] == d) return;
-    const int64_t slot = (int64_t)a.w.off[row] + (int64_t)t * a.w.nd[row] + d;
-    if (slot < a.capacity) a.levels[slot] = a.val[row * COLS + col];
+    const int32_t nd = a.w.nd[row];
+    const int64_t slot0 = (int64_t)a.w.off[row] + d;
+#pragma unroll
+    for (int t = 0; t < N_THR; t++) {
+        const int64_t slot = slot0 + (int64_t)t * nd;
+        if (slot < a.capacity) a.levels[slot] = a.val[row * COLS + (int64_t)t * N_REC + j];
+    }
 }
 
 struct UnpackArgs {
@@ -191,45 +198,50 @@ struct UnpackArgs {
     ExWs w;
 };
 
-// levels -> precision[T][R][K][A], rec -> recall[T][K][A]; same 32 x 32 LDS
-// transpose as acc_finalize_kernel, the load side expands the runs.  The run
-// maps come from ex_levels_kernel on the received headers, the row offsets
-// from the headers themselves (no scan on the receiving side).
+// levels -> precision[T][R][K][A], rec -> recall[T][K][A]: the layout pass of
+// acc_finalize_kernel (64 rows x 64 columns per workgroup, rows without
+// evaluated ground truth never read, every column stored as full-wavefront
+// 512-byte runs) with the run expansion on its load side.  The run maps come
+// from ex_levels_kernel on the received headers, the row offsets from the
+// headers themselves (no scan on the receiving side).  (Round 2; the 32 x 32
+// tiling it replaces took 56 us where acc_finalize_kernel takes 21.)
 __global__ __launch_bounds__(256) void ex_unpack_kernel(UnpackArgs a)
 {
-    __shared__ double tile[32][33];
+    __shared__ double tile[64][65];
     const int64_t KR = (int64_t)a.n_cat * a.n_rng;
     const int64_t COLS = (int64_t)N_THR * N_REC;
-    const int64_t row0 = (int64_t)blockIdx.x * 32;
-    const int64_t col0 = (int64_t)blockIdx.y * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    for (int i = ty; i < 32; i += 8) {
-        const int64_t row = row0 + i, col = col0 + tx;
-        double v = -1.0;
-        if (row < KR && col < COLS) {
+    const int64_t row0 = (int64_t)blockIdx.x * 64;
+    const int64_t col0 = (int64_t)blockIdx.y * 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ncol = (int)min((int64_t)64, COLS - col0);
+    const int64_t orow = row0 + lane;                    // lane = row of the tile
+    const bool olive = orow < KR && a.w.nd[orow] > 0;
+    const uint64_t live_rows = __ballot(olive);          // same in every wavefront
+    if (live_rows != 0) {
+        const int64_t col = min(col0 + lane, COLS - 1);
+        const int t = (int)(col / N_REC), j = (int)(col - (int64_t)t * N_REC);
+        // rows i = wave (mod 4) are mine to fetch
+        for (uint64_t m = live_rows & (0x1111111111111111ull << wave); m != 0; m &= m - 1) {
+            const int idx = __builtin_ctzll(m);
+            const int64_t row = row0 + idx;
             const int32_t nd = a.w.nd[row];
-            if (nd > 0) {
-                const int64_t b = row / a.block_rows, li = row - b * a.block_rows;
-                const unsigned char *ch = a.chunks + b * a.chunk_bytes;
-                const uint64_t *lv = (const uint64_t *)(ch + a.hdr_bytes + a.rec_bytes);
-                const int32_t off = ((const int32_t *)ch)[a.block_rows + li];
-                const int t = (int)(col / N_REC), j = (int)(col - (int64_t)t * N_REC);
-                const int64_t slot = (int64_t)off + (int64_t)t * nd +
-                                     a.w.dmap[row * N_REC + j];
-                v = 0.0;
-                if (slot < a.capacity) v = pr_value(lv[slot]);
-                else if (a.overflow) atomicOr(a.overflow, 1);
-            }
+            const int64_t b = row / a.block_rows, li = row - b * a.block_rows;
+            const unsigned char *ch = a.chunks + b * a.chunk_bytes;
+            const uint64_t *lv = (const uint64_t *)(ch + a.hdr_bytes + a.rec_bytes);
+            const int32_t off = ((const int32_t *)ch)[a.block_rows + li];
+            const int64_t slot = (int64_t)off + (int64_t)t * nd + a.w.dmap[row * N_REC + j];
+            double v = 0.0;
+            if (slot < a.capacity) v = pr_value(lv[slot]);
+            else if (a.overflow) atomicOr(a.overflow, 1);
+            tile[idx][lane] = v;
         }
-        tile[i][tx] = v;
+        __syncthreads();
     }
-    __syncthreads();
-    for (int i = ty; i < 32; i += 8) {
-        const int64_t col = col0 + i, row = row0 + tx;
-        if (row < KR && col < COLS) a.precision[col * KR + row] = tile[tx][i];
-    }
+    if (orow < KR)
+        for (int c = wave; c < ncol; c += 4)
+            a.precision[(col0 + c) * KR + orow] = olive ? tile[lane][c] : -1.0;
     if (blockIdx.y == 0) {
-        for (int i = threadIdx.x; i < 32 * N_THR; i += 256) {
+        for (int i = threadIdx.x; i < 64 * N_THR; i += 256) {
             const int64_t row = row0 + i / N_THR;
             const int t = i % N_THR;
             if (row >= KR) continue;
@@ -308,7 +320,8 @@ extern "C" int taoamd_exchange_pack(int32_t n_cat, int32_t n_rng,
                                     const double *val, const double *rec,
                                     void *chunk, int64_t capacity,
                                     int32_t *overflow, void *workspace,
-                                    size_t workspace_bytes, void *stream)
+                                    size_t workspace_bytes, int32_t maps_ready,
+                                    void *stream)
 {
     if (bad_shape(block_cats, n_rng, world) || n_cat <= 0 || rank < 0 ||
         rank >= world || (int64_t)block_cats * world < n_cat || capacity < 0)
@@ -323,9 +336,11 @@ extern "C" int taoamd_exchange_pack(int32_t n_cat, int32_t n_rng,
     const int64_t r0 = (int64_t)rank * BR;
     // the local table is addressed by global row: one "block" spanning it all
     NumSrc src{(const unsigned char *)num_gt, 0, valid, (int32_t)0x7fffffff};
-    TAO_TIMED("ex_levels_kernel", s, ex_levels_kernel<<<(unsigned)((BR + 3) / 4), 256, 0, s>>>(src, r0, r0 + BR, w,
-                                                              rec_thr()));
-    TAO_TIMED("ex_offsets_kernel", s, ex_offsets_kernel<<<1, 1024, 0, s>>>(rank, BR, capacity, w, overflow));
+    if (!maps_ready) {
+        TAO_TIMED("ex_levels_kernel", s, ex_levels_kernel<<<(unsigned)((BR + 3) / 4), 256, 0, s>>>(src, r0, r0 + BR, w,
+                                                                  rec_thr()));
+        TAO_TIMED("ex_offsets_kernel", s, ex_offsets_kernel<<<1, 1024, 0, s>>>(rank, BR, capacity, w, overflow));
+    }
     const Chunk c = chunk_layout(block_cats, n_rng, capacity);
     PackArgs a;
     a.row0 = r0; a.block_rows = BR; a.valid_rows = valid;
@@ -334,7 +349,7 @@ extern "C" int taoamd_exchange_pack(int32_t n_cat, int32_t n_rng,
     a.rec_out = (double *)((unsigned char *)chunk + c.hdr_bytes);
     a.levels = (uint64_t *)((unsigned char *)chunk + c.hdr_bytes + c.rec_bytes);
     a.capacity = capacity; a.w = w;
-    const int64_t threads = (int64_t)BR * N_THR * N_REC;
+    const int64_t threads = (int64_t)BR * 128;
     TAO_TIMED("ex_pack_kernel", s, ex_pack_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>(a));
     TAO_LAUNCH_CHECK();
     return TAOAMD_OK;
@@ -346,7 +361,7 @@ extern "C" int taoamd_exchange_unpack(int32_t n_cat, int32_t n_rng,
                                       int32_t *num_gt_out, double *precision,
                                       double *recall, int32_t *overflow,
                                       void *workspace, size_t workspace_bytes,
-                                      void *stream)
+                                      int32_t maps_ready, void *stream)
 {
     if (bad_shape(block_cats, n_rng, world) || n_cat <= 0 ||
         (int64_t)block_cats * world < n_cat || capacity < 0)
@@ -360,15 +375,16 @@ extern "C" int taoamd_exchange_unpack(int32_t n_cat, int32_t n_rng,
     UnpackArgs a;
     a.w = carve(workspace, rows, world);
     NumSrc src{(const unsigned char *)chunks, (int64_t)c.bytes, rows, BR};
-    TAO_TIMED("ex_levels_kernel", s, ex_levels_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, s>>>(src, 0, rows, a.w,
-                                                                rec_thr()));
+    if (!maps_ready)
+        TAO_TIMED("ex_levels_kernel", s, ex_levels_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, s>>>(src, 0, rows, a.w,
+                                                                    rec_thr()));
     a.n_cat = n_cat; a.n_rng = n_rng; a.block_rows = BR;
     a.chunks = (const unsigned char *)chunks;
     a.chunk_bytes = c.bytes; a.hdr_bytes = c.hdr_bytes; a.rec_bytes = c.rec_bytes;
     a.capacity = capacity; a.num_gt_out = num_gt_out;
     a.precision = precision; a.recall = recall; a.overflow = overflow;
     const int64_t KR = (int64_t)n_cat * n_rng;
-    dim3 grid((unsigned)((KR + 31) / 32), (unsigned)((N_THR * N_REC + 31) / 32));
+    dim3 grid((unsigned)((KR + 63) / 64), (unsigned)((N_THR * N_REC + 63) / 64));
     TAO_TIMED("ex_unpack_kernel", s, ex_unpack_kernel<<<grid, 256, 0, s>>>(a));
     TAO_LAUNCH_CHECK();
     return TAOAMD_OK;

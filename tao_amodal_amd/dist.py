@@ -155,18 +155,19 @@ class HipBackend:
             xws.numel(), self._s()), "taoamd_exchange_sizes")
 
     def exchange_pack(self, n_cat, n_rng, block_cats, world, rank, num_gt, val,
-                      rec, chunk, capacity, overflow, xws):
+                      rec, chunk, capacity, overflow, xws, maps_ready=False):
         _lib.check(self.lib.taoamd_exchange_pack(
             n_cat, n_rng, block_cats, world, rank, _ptr(num_gt), _ptr(val),
             _ptr(rec), _ptr(chunk), capacity, _ptr(overflow), _ptr(xws),
-            xws.numel(), self._s()), "taoamd_exchange_pack")
+            xws.numel(), int(maps_ready), self._s()), "taoamd_exchange_pack")
 
     def exchange_unpack(self, n_cat, n_rng, block_cats, world, chunks, capacity,
-                        num_gt, precision, recall, overflow, xws):
+                        num_gt, precision, recall, overflow, xws, maps_ready=False):
         _lib.check(self.lib.taoamd_exchange_unpack(
             n_cat, n_rng, block_cats, world, _ptr(chunks), capacity,
             _ptr(num_gt), _ptr(precision), _ptr(recall), _ptr(overflow),
-            _ptr(xws), xws.numel(), self._s()), "taoamd_exchange_unpack")
+            _ptr(xws), xws.numel(), int(maps_ready), self._s()),
+            "taoamd_exchange_unpack")
 
 
 class ShardedEval:
@@ -235,14 +236,24 @@ class ShardedEval:
         backend.ranges(dp, ws)
         self.num_gt.copy_(ws.num_gt)
         dist.all_reduce(self.num_gt, group=group)
-        table = torch.zeros((Kb * world, R), dtype=torch.int32, device=dev)
-        table[:K].copy_(self.num_gt)
-        totals = torch.zeros(world, dtype=torch.int64, device=dev)
-        backend.exchange_sizes(Kb, R, world, table, totals, self.xws)
-        self.capacity = int(totals.max().item())
+        self.table = torch.zeros((Kb * world, R), dtype=torch.int32, device=dev)
+        self.table[:K].copy_(self.num_gt)
+        self.totals = torch.zeros(world, dtype=torch.int64, device=dev)
+        backend.exchange_sizes(Kb, R, world, self.table, self.totals, self.xws)
+        self.capacity = int(self.totals.max().item())
         self.chunk_bytes = backend.exchange_chunk_bytes(Kb, R, self.capacity)
         self.chunks = torch.zeros(world * self.chunk_bytes, dtype=torch.uint8,
                                   device=dev)
+
+    def _global_num_gt(self):
+        """num_gt of all rows (one all-reduce) and, from it, the run maps and
+        level offsets the result exchange needs -- known at the head of the
+        pass, beside the sort and the match, not after the sweep."""
+        self.num_gt.copy_(self.ws.num_gt)
+        dist.all_reduce(self.num_gt, group=self.group)
+        self.table[:self.dp.n_cat].copy_(self.num_gt)
+        self.be.exchange_sizes(self.Kb, self.dp.n_rng, self.world, self.table,
+                               self.totals, self.xws)
 
     def _exchange(self):
         dist.all_to_all_single(
@@ -261,12 +272,10 @@ class ShardedEval:
             aux.wait_stream(cur)
             with torch.cuda.stream(aux):
                 be.ranges(dp, ws)
-                self.num_gt.copy_(ws.num_gt)
-                dist.all_reduce(self.num_gt, group=self.group)
+                self._global_num_gt()
         else:
             be.ranges(dp, ws)
-            self.num_gt.copy_(ws.num_gt)
-            dist.all_reduce(self.num_gt, group=self.group)
+            self._global_num_gt()
         be.sort_local(dp, ws)
         if not self._static and dp.n_dt:
             # the inputs of the exchange that no pass changes: a record's
@@ -290,12 +299,12 @@ class ShardedEval:
         lo, hi = self.rank * self.chunk_bytes, (self.rank + 1) * self.chunk_bytes
         be.exchange_pack(dp.n_cat, dp.n_rng, self.Kb, self.world, self.rank,
                          self.num_gt, self.val, self.rec, self.chunks[lo:hi],
-                         self.capacity, self.overflow, self.xws)
+                         self.capacity, self.overflow, self.xws, maps_ready=True)
         dist.all_gather_into_tensor(self.chunks, self.chunks[lo:hi],
                                     group=self.group)
         be.exchange_unpack(dp.n_cat, dp.n_rng, self.Kb, self.world, self.chunks,
                            self.capacity, self.num_gt_out, self.precision,
-                           self.recall, self.overflow, self.xws)
+                           self.recall, self.overflow, self.xws, maps_ready=True)
 
     def check(self):
         """Host-side guard (synchronises): the capacity held."""

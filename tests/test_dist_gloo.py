@@ -258,13 +258,13 @@ class OracleCategoryBackend(OracleBackend):
             exchange_ref.sizes(block_cats, n_rng, world, num_gt.numpy())))
 
     def exchange_pack(self, n_cat, n_rng, block_cats, world, rank, num_gt, val,
-                      rec, chunk, capacity, overflow, xws):
+                      rec, chunk, capacity, overflow, xws, maps_ready=False):
         chunk.copy_(torch.from_numpy(exchange_ref.pack(
             n_cat, n_rng, block_cats, rank, num_gt.numpy(), val.numpy(),
             rec.numpy(), capacity)))
 
     def exchange_unpack(self, n_cat, n_rng, block_cats, world, chunks, capacity,
-                        num_gt, precision, recall, overflow, xws):
+                        num_gt, precision, recall, overflow, xws, maps_ready=False):
         ng, p, r = exchange_ref.unpack(n_cat, n_rng, block_cats, world,
                                        chunks.numpy(), capacity)
         num_gt.copy_(torch.from_numpy(ng))
