@@ -299,13 +299,27 @@ __global__ __launch_bounds__(256) void acc_prefix_kernel(AccArgs a, RecThr rec)
     const int32_t q = (c1 - c0 + 3) / 4;
     const int32_t lo = min(c1, c0 + wave * q), hi = min(c1, lo + q);
     uint32_t tp = 0, fp = 0;
-    for (int32_t c = lo; c < hi; c++) {
-        const int64_t o = ((int64_t)c * a.n_words + word) * WAVE + lane;
-        const uint32_t t_ = a.cnt_tp[o], f_ = a.cnt_fp[o];
-        a.pre_tp[o] = tp;
-        a.pre_fp[o] = fp;
-        tp += t_;
-        fp += f_;
+    // eight chunks per step: their sixteen loads are in flight together, then
+    // the sixteen stores (one by one every load waited for the stores before
+    // it: loads and stores share vmcnt)
+    for (int32_t c = lo; c < hi; c += 8) {
+        uint32_t t_[8], f_[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int64_t o = ((int64_t)min(c + u, hi - 1) * a.n_words + word) * WAVE + lane;
+            t_[u] = a.cnt_tp[o];
+            f_[u] = a.cnt_fp[o];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            if (c + u < hi) {
+                const int64_t o = ((int64_t)(c + u) * a.n_words + word) * WAVE + lane;
+                a.pre_tp[o] = tp;
+                a.pre_fp[o] = fp;
+                tp += t_[u];
+                fp += f_[u];
+            }
+        }
     }
     s_tp[wave][lane] = tp;
     s_fp[wave][lane] = fp;
@@ -457,11 +471,18 @@ __global__ __launch_bounds__(256) void acc_sufmax_kernel(AccArgs a)
     const int32_t q = (c1 - c0 + 3) / 4;
     const int32_t lo = min(c1, c0 + wave * q), hi = min(c1, lo + q);
     uint64_t run = PR_ZERO;
-    for (int32_t c = hi - 1; c >= lo; c--) {
-        const int64_t o = ((int64_t)c * a.n_words + word) * WAVE + lane;
-        const uint64_t v = a.cmax[o];
-        a.cmax[o] = run;
-        if (pr_better((uint32_t)(v >> 32), (uint32_t)v, run)) run = v;
+    for (int32_t c = hi - 1; c >= lo; c -= 8) {           // (eight at a time, as above)
+        uint64_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            v[u] = a.cmax[((int64_t)max(c - u, lo) * a.n_words + word) * WAVE + lane];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            if (c - u >= lo) {
+                a.cmax[((int64_t)(c - u) * a.n_words + word) * WAVE + lane] = run;
+                if (pr_better((uint32_t)(v[u] >> 32), (uint32_t)v[u], run)) run = v[u];
+            }
+        }
     }
     s_max[wave][lane] = run;
     __syncthreads();
