@@ -126,10 +126,11 @@ __global__ __launch_bounds__(256) void track_iou_kernel(
 
 // Task variant (the path every planned call takes).  A task = up to TT_ROWS
 // tracks (of one or several cells) and up to 64 (detection track, GT track)
-// pairs among them, run by a workgroup of TWO wavefronts with separate jobs:
+// pairs among them, run by a workgroup of THREE wavefronts with separate jobs:
 //
-//   stager  (wave 0) fetches the tracks' frames and parks them in LDS,
-//   adder   (wave 1) lane = track pair, adds the per-frame terms in order.
+//   stagers (waves 0, 1) fetch the tracks' frames and park them in LDS, each
+//           the rows of every other round (tt_stager<0 / 1>),
+//   adder   (wave 2) lane = track pair, adds the per-frame terms in order.
 //
 // They meet at one barrier per chunk of TT_P timeline positions; the frames
 // live in two LDS buffers, so the stager fills chunk k + 1 while the adder
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(256) void track_iou_kernel(
 // meanwhile (two register sets).  The adder's instruction stream -- the one that bounds the
 // kernel: 13 fp64 operations per pair and position, a chain of dependent adds
 // -- therefore never waits for global memory or for the staging arithmetic.
-// 24 KB of LDS per task: 6 tasks = 12 wavefronts per CU.
+// 24 KB of LDS per task: 6 tasks = 18 wavefronts per CU.
 //
 // Tracks are read from the PADDED frame table (taoamd_track_pad): the frames
 // of a track occupy consecutive slots first .. last of the timeline, a
@@ -202,8 +203,99 @@ __device__ __forceinline__ void tt_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// The stager's work of one chunk -- own rounds of rows only -- for stager S of
+// two: rounds S, S + 2, ... (a phase trace of the kernel with ONE stager: a
+// chunk took 2250 cycles for ~200 stager and ~160 adder instructions, two
+// wavefronts per SIMD, i.e. one dependent instruction every ~10 cycles: the
+// stager was the longer of the two chains).
+template <int S>
+__device__ __forceinline__ void tt_stager(
+    const double4 *__restrict__ padded, double (*rows)[TT_ROWS * TT_RS],
+    const int4 *meta, uint32_t (*rmask)[TT_SLOTS], uint32_t (*flags)[2][2],
+    int32_t p_first, int n_chunks, int lane)
+{
+    constexpr int NR = (TT_ROUNDS - S + 1) / 2;      // my rounds
+    const int grp = lane / TT_P, j = lane % TT_P;
+    // lane (grp, j) serves position j of the rows grp, TT_GROUPS + grp, ...
+    int32_t F[NR], L[NR], M[NR];
+    uint32_t isdt = 0;
+#pragma unroll
+    for (int i = 0; i < NR; i++) {
+        const int4 m = meta[TT_GROUPS * (S + 2 * i) + grp];
+        F[i] = m.x;
+        L[i] = m.y;
+        M[i] = m.z;
+        isdt |= (uint32_t)(m.w & 1) << i;
+    }
+    // TT_SETS register sets: the loads of chunk k + TT_SETS are issued when
+    // chunk k has been staged.  Every round loads (lanes out of range read
+    // slot 0), so the number of loads in flight is known at compile time
+    // and a chunk waits for ITS loads only (s_waitcnt vmcnt(n > 0)).
+    double4 B[TT_SETS][NR];
+    uint32_t wiped[2] = {~0u, ~0u};   // bit i: my round i's row holds far boxes in buffer b
+
+    auto issue = [&](double4 *Bx, int32_t pc) {
+        const int32_t p = pc + j;
+#pragma unroll
+        for (int i = 0; i < NR; i++) {
+            const bool in = p >= F[i] && p <= L[i];
+            Bx[i] = padded[in ? M[i] + p : 0];      // slot 0: the far box
+        }
+    };
+    auto stage = [&](const double4 *Bx, int32_t pc, int b) {
+        uint64_t any = 0, anydt = 0;
+        uint32_t wp = wiped[b];
+#pragma unroll
+        for (int i = 0; i < NR; i++) {
+            const int r = TT_GROUPS * (S + 2 * i) + grp;
+            const bool ov = F[i] < pc + TT_P && L[i] >= pc;   // same for the row's lanes
+            const bool act = ov || !((wp >> i) & 1u);
+            if (__ballot(act) == 0) continue;
+            const double4 bx = Bx[i];
+            const bool present = bx.x != TT_FAR;
+            const uint64_t ball = __ballot(present);
+            any |= ball;
+            anydt |= __ballot(present && ((isdt >> i) & 1u));
+            if (act) {
+                double *rb = rows[b] + r * TT_RS + j;
+                rb[0] = bx.x;
+                rb[TT_P] = bx.y;
+                rb[2 * TT_P] = bx.x + bx.z;
+                rb[3 * TT_P] = bx.y + bx.w;
+                rb[4 * TT_P] = bx.z * bx.w;
+                if (j == 0)
+                    rmask[b][r] = (uint32_t)(ball >> (TT_P * grp)) & ((1u << TT_P) - 1);
+            }
+            wp = ov ? wp & ~(1u << i) : wp | (1u << i);
+        }
+        wiped[b] = wp;
+        if (lane == 0) {
+            flags[b][S][0] = any != 0;
+            flags[b][S][1] = anydt != 0;
+        }
+    };
+    // chunk c lives in register set c % TT_SETS and in LDS buffer c & 1
+#pragma unroll
+    for (int c = 0; c < TT_SETS; c++) issue(B[c], p_first + c * TT_P);
+    if (n_chunks > 0) stage(B[0], p_first, 0);
+    issue(B[0], p_first + TT_SETS * TT_P);
+    tt_barrier();
+    for (int k = 0; k < n_chunks; k += TT_SETS) {
+#pragma unroll
+        for (int a = 1; a <= TT_SETS; a++) {
+            // the adder is on chunk k + a - 1: fill the other buffer with
+            // chunk k + a
+            const int c = k + a;
+            if (c - 1 >= n_chunks) break;
+            if (c < n_chunks) stage(B[a % TT_SETS], p_first + c * TT_P, a & 1);
+            issue(B[a % TT_SETS], p_first + (c + TT_SETS) * TT_P);
+            tt_barrier();
+        }
+    }
+}
+
 template <int MODE>
-__global__ __launch_bounds__(128) void track_iou_task_kernel(
+__global__ __launch_bounds__(192) void track_iou_task_kernel(
     const int4 *__restrict__ tasks, const int32_t *__restrict__ task_rows,
     const int32_t *__restrict__ task_pairs, const int64_t *__restrict__ task_out,
     const double4 *__restrict__ padded, const int4 *__restrict__ trk_meta,
@@ -212,15 +304,16 @@ __global__ __launch_bounds__(128) void track_iou_task_kernel(
     __shared__ __align__(16) double rows[2][TT_ROWS * TT_RS];
     __shared__ int4 meta[TT_SLOTS];
     __shared__ uint32_t rmask[2][TT_SLOTS];   // positions of the chunk that hold a frame
-    __shared__ uint32_t flags[2][2];          // {any frame, any detection frame} of the chunk
+    __shared__ uint32_t flags[2][2][2];       // per stager {any frame, any detection frame} of the chunk
     __shared__ int32_t span[2];               // first chunk start, last position
 
     const int lane = threadIdx.x & 63;
-    const bool stager = threadIdx.x < 64;     // wave-uniform
+    const int wave = threadIdx.x >> 6;        // 0, 1: stagers; 2: adder
+    const bool stager = wave < 2;             // wave-uniform
     const int4 tk = tasks[blockIdx.x];        // {first row, rows, first pair, pairs}
     const int n_rows = tk.y, n_pairs = tk.w;
 
-    if (stager) {
+    if (wave == 0) {
         // ---- {first, last, base - first, is detection} of the task's tracks
         int32_t p_lo = INT32_MAX, p_hi = -1;
         if (lane < TT_SLOTS) {
@@ -233,12 +326,6 @@ __global__ __launch_bounds__(128) void track_iou_task_kernel(
             meta[lane] = m;
             rmask[0][lane] = rmask[1][lane] = 0;
         }
-        for (int s = lane; s < 2 * TT_ROWS * TT_P; s += 64) {
-            const int b = s / (TT_ROWS * TT_P), t = s % (TT_ROWS * TT_P);
-            double *rb = rows[b] + (t / TT_P) * TT_RS + (t % TT_P);
-            rb[0] = rb[TT_P] = rb[2 * TT_P] = rb[3 * TT_P] = TT_FAR;
-            rb[4 * TT_P] = 0.0;
-        }
 #pragma unroll
         for (int s = 32; s > 0; s >>= 1) {
             p_lo = min(p_lo, __shfl_xor(p_lo, s));
@@ -248,89 +335,24 @@ __global__ __launch_bounds__(128) void track_iou_task_kernel(
             span[0] = p_lo & ~(TT_P - 1);
             span[1] = p_hi;
         }
+    } else {
+        // the other two wavefronts put far boxes into both buffers meanwhile
+        for (int s = (wave - 1) * 64 + lane; s < 2 * TT_ROWS * TT_P; s += 128) {
+            const int b = s / (TT_ROWS * TT_P), t = s % (TT_ROWS * TT_P);
+            double *rb = rows[b] + (t / TT_P) * TT_RS + (t % TT_P);
+            rb[0] = rb[TT_P] = rb[2 * TT_P] = rb[3 * TT_P] = TT_FAR;
+            rb[4 * TT_P] = 0.0;
+        }
     }
     __syncthreads();
     const int32_t p_first = span[0], p_hi = span[1];
     const int n_chunks = p_hi < 0 ? 0 : (p_hi - p_first) / TT_P + 1;
 
     if (stager) {
-        const int grp = lane / TT_P, j = lane % TT_P;
-        // lane (grp, j) serves position j of the rows grp, TT_GROUPS + grp, ...
-        int32_t F[TT_ROUNDS], L[TT_ROUNDS], M[TT_ROUNDS];
-        uint32_t isdt = 0;
-#pragma unroll
-        for (int q = 0; q < TT_ROUNDS; q++) {
-            const int4 m = meta[TT_GROUPS * q + grp];
-            F[q] = m.x;
-            L[q] = m.y;
-            M[q] = m.z;
-            isdt |= (uint32_t)(m.w & 1) << q;
-        }
-        // TT_SETS register sets: the loads of chunk k + TT_SETS are issued when
-        // chunk k has been staged.  Every round loads (lanes out of range read
-        // slot 0), so the number of loads in flight is known at compile time
-        // and a chunk waits for ITS loads only (s_waitcnt vmcnt(n > 0)).
-        double4 B[TT_SETS][TT_ROUNDS];
-        uint32_t wiped[2] = {~0u, ~0u};   // bit q: round q's row holds far boxes in buffer b
-
-        auto issue = [&](double4 *Bx, int32_t pc) {
-            const int32_t p = pc + j;
-#pragma unroll
-            for (int q = 0; q < TT_ROUNDS; q++) {
-                const bool in = p >= F[q] && p <= L[q];
-                Bx[q] = padded[in ? M[q] + p : 0];      // slot 0: the far box
-            }
-        };
-        auto stage = [&](const double4 *Bx, int32_t pc, int b) {
-            uint64_t any = 0, anydt = 0;
-            uint32_t wp = wiped[b];
-#pragma unroll
-            for (int q = 0; q < TT_ROUNDS; q++) {
-                const int r = TT_GROUPS * q + grp;
-                const bool ov = F[q] < pc + TT_P && L[q] >= pc;   // same for the row's lanes
-                const bool act = ov || !((wp >> q) & 1u);
-                if (__ballot(act) == 0) continue;
-                const double4 bx = Bx[q];
-                const bool present = bx.x != TT_FAR;
-                const uint64_t ball = __ballot(present);
-                any |= ball;
-                anydt |= __ballot(present && ((isdt >> q) & 1u));
-                if (act) {
-                    double *rb = rows[b] + r * TT_RS + j;
-                    rb[0] = bx.x;
-                    rb[TT_P] = bx.y;
-                    rb[2 * TT_P] = bx.x + bx.z;
-                    rb[3 * TT_P] = bx.y + bx.w;
-                    rb[4 * TT_P] = bx.z * bx.w;
-                    if (j == 0)
-                        rmask[b][r] = (uint32_t)(ball >> (TT_P * grp)) & ((1u << TT_P) - 1);
-                }
-                wp = ov ? wp & ~(1u << q) : wp | (1u << q);
-            }
-            wiped[b] = wp;
-            if (lane == 0) {
-                flags[b][0] = any != 0;
-                flags[b][1] = anydt != 0;
-            }
-        };
-        // chunk c lives in register set c % TT_SETS and in LDS buffer c & 1
-#pragma unroll
-        for (int c = 0; c < TT_SETS; c++) issue(B[c], p_first + c * TT_P);
-        if (n_chunks > 0) stage(B[0], p_first, 0);
-        issue(B[0], p_first + TT_SETS * TT_P);
-        tt_barrier();
-        for (int k = 0; k < n_chunks; k += TT_SETS) {
-#pragma unroll
-            for (int a = 1; a <= TT_SETS; a++) {
-                // the adder is on chunk k + a - 1: fill the other buffer with
-                // chunk k + a
-                const int c = k + a;
-                if (c - 1 >= n_chunks) break;
-                if (c < n_chunks) stage(B[a % TT_SETS], p_first + c * TT_P, a & 1);
-                issue(B[a % TT_SETS], p_first + (c + TT_SETS) * TT_P);
-                tt_barrier();
-            }
-        }
+        if (wave == 0)
+            tt_stager<0>(padded, rows, meta, rmask, flags, p_first, n_chunks, lane);
+        else
+            tt_stager<1>(padded, rows, meta, rmask, flags, p_first, n_chunks, lane);
         return;
     }
 
@@ -345,12 +367,14 @@ __global__ __launch_bounds__(128) void track_iou_task_kernel(
     double u = 0.0, i = 0.0;
     unsigned long long common = 0;
     auto add = [&](int b) {
-        if (!flags[b][0] || lane >= n_pairs) return;
+        const bool any = flags[b][0][0] | flags[b][1][0];
+        const bool anydt = flags[b][0][1] | flags[b][1][1];
+        if (!any || lane >= n_pairs) return;
         const double *__restrict__ dr = rows[b] + rowd * TT_RS;
         const double *__restrict__ gr = rows[b] + rowg * TT_RS;
         const uint32_t dm = rmask[b][rowd], gm = rmask[b][rowg];
         if (MODE == 0) {
-            if (flags[b][1]) {
+            if (anydt) {
                 // two positions per 16-byte LDS read of every field
                 const double2 *__restrict__ d2 = reinterpret_cast<const double2 *>(dr);
                 const double2 *__restrict__ g2 = reinterpret_cast<const double2 *>(gr);
@@ -538,7 +562,7 @@ extern "C" int taoamd_track_iou_planned(int64_t n_tasks, const int32_t *tasks,
     unsigned long long *pf = (unsigned long long *)pair_frames;
 #define TT_LAUNCH(M)                                                           \
     TAO_TIMED("track_iou_task_kernel", s,                                      \
-              track_iou_task_kernel<M><<<(unsigned)n_tasks, 128, 0, s>>>(       \
+              track_iou_task_kernel<M><<<(unsigned)n_tasks, 192, 0, s>>>(       \
                   (const int4 *)tasks, task_rows, task_pairs, task_out,        \
                   (const double4 *)padded, (const int4 *)trk_meta, iou, pf))
     if (mode == 0) TT_LAUNCH(0);
