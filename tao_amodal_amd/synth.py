@@ -1,12 +1,14 @@
 """Seeded synthetic TAO-Amodal-shaped inputs (``SYNTH``).
 
 There is no dataset in the container, so every config of BASELINE.json other
-than the first is driven by this generator.  All box coordinates are integers:
-every per-frame product and every sum of products is then exact in fp64, so the
-3D-IoU of a track pair does not depend on the order frames are summed in and
-the results are bit-comparable with the reference evaluator (which sums in
-CPython set-iteration order, reference tao_amodal/evaluation/tao_amodal/
-eval.py:83-94).
+than the first is driven by this generator.  By default all box coordinates are
+integers: every per-frame product and every sum of products is then exact in
+fp64, so the 3D-IoU of a track pair does not depend on the order frames are
+summed in (the reference sums in CPython set-iteration order, reference
+tao_amodal/evaluation/tao_amodal/eval.py:83-94).  ``decimal=True`` gives
+coordinates like the real files have (ground truth to 2 decimals, predictions
+to 3): per-frame terms are then inexact, the sums depend on the order, and the
+evaluation goes through the frame-order guard (engine.stage_iou_guard).
 
 Output is columnar (``GTColumns`` / ``DTColumns``); call ``.to_json()`` on the
 pair to obtain the ``validation_lvis_v1.json`` / ``prediction.json`` shaped
@@ -48,7 +50,7 @@ def _walk(rng, n_trk, lens, W, H):
 def synth(seed=20240807, V=200, F=300, C=1203, dets_per_frame=50,
           gt_tracks_per_video=10, n_present=5, n_neg=2, W=1280, H=720,
           shuffle_image_ids=False, collide_track_ids=False, n_merged=0,
-          video_id_base=0):
+          video_id_base=0, decimal=False):
     """Generate one synthetic (ground truth, predictions) pair.
 
     ``video_id_base`` offsets every id so that independently generated shards
@@ -165,6 +167,12 @@ def synth(seed=20240807, V=200, F=300, C=1203, dets_per_frame=50,
     ineg = _csr([x for x in vid_neg for _ in range(F)])
     inel = _csr([x for x in vid_nel for _ in range(F)])
     bbox = np.concatenate(gt_parts["bbox"])
+    dt_bbox = np.concatenate(dt_parts["bbox"])
+    if decimal:
+        # (its own stream: the integer sets of a seed stay what they were)
+        drng = np.random.default_rng([seed, 0xdec])
+        bbox = bbox + np.round(drng.random(bbox.shape), 2)
+        dt_bbox = dt_bbox + np.round(drng.random(dt_bbox.shape), 3)
     x, y, w, h = bbox.T
     oof = ((x < 0) | (y < 0) | (x + w > W) | (y + h > H)).astype(np.uint8)
     n_ann = len(bbox)
@@ -190,7 +198,7 @@ def synth(seed=20240807, V=200, F=300, C=1203, dets_per_frame=50,
     dt = DTColumns(
         image_id=np.concatenate(dt_parts["img"]),
         category_id=np.concatenate(dt_parts["cat"]).astype(np.int64),
-        bbox=np.concatenate(dt_parts["bbox"]),
+        bbox=dt_bbox,
         score=np.concatenate(dt_parts["score"]),
         track_id=np.concatenate(dt_parts["trk"]).astype(np.int64),
         video_id=np.concatenate(dt_parts["vid"]).astype(np.int64),

@@ -15,6 +15,10 @@ F7  adversarial decimal coordinates: every (detection track, GT track) pair
     arithmetic, so its fp64 value lands within a few ulp of the threshold and
     the side it falls on depends on the order the frames are added in -- the
     reference's CPython set order (T/eval.py:83-94) against timeline order
+F8  a down-scaled Config 2 with DECIMAL coordinates (16 videos x 300 frames
+    x 10 boxes, 100 categories): tracks of hundreds of frames whose per-frame
+    terms are inexact in fp64, i.e. the shape real prediction files have.  Its
+    golden 3D IoUs are the reference's set-order sums over up to 600 frames
 """
 import os
 import sys
@@ -286,4 +290,13 @@ def f7():
     return gt, preds
 
 
-ALL = {"f1": f1, "f2": f2, "f3": f3, "f4": f4, "f5": f5, "f7": f7}
+def f8():
+    gt, dt = synth(seed=88, V=16, F=300, C=100, dets_per_frame=10,
+                   decimal=True, shuffle_image_ids=True)
+    return gt.to_json(), dt.to_json()
+
+
+ALL = {"f1": f1, "f2": f2, "f3": f3, "f4": f4, "f5": f5, "f7": f7, "f8": f8}
+# big fixtures: inputs stored gzipped, image level reduced to the integer
+# match counts + precision / recall + results + text (make_golden.py)
+LITE = {"f8"}

@@ -109,8 +109,13 @@ def run_fixture(name):
     out = os.path.join(HERE, name)
     os.makedirs(out, exist_ok=True)
     gt, pred = fixtures.ALL[name]()
-    gt_path = os.path.join(out, "gt.json")
-    pred_path = os.path.join(out, "pred.json")
+    lite = name in fixtures.LITE
+    # (big fixtures: the reference reads plain JSON from a scratch directory,
+    # the committed copies are gzipped)
+    work = os.path.join("/tmp", "golden_" + name) if lite else out
+    os.makedirs(work, exist_ok=True)
+    gt_path = os.path.join(work, "gt.json")
+    pred_path = os.path.join(work, "pred.json")
     with open(gt_path, "w") as f:
         json.dump(gt, f, separators=(",", ":"))
     with open(pred_path, "w") as f:
@@ -136,10 +141,16 @@ def run_fixture(name):
     lvis = {
         "img_ids": [int(x) for x in P.img_ids],
         "cat_ids": [int(x) for x in P.cat_ids],
-        "cells": dump_cells(le.ious, evals,
-                            lambda e: (e["image_id"], e["category_id"],
+        "cells": None if lite else dump_cells(
+            le.ious, evals, lambda e: (e["image_id"], e["category_id"],
                                        e["_a"]), n_rng),
-        "dt_pointers": pointers(le.eval["dt_pointers"], 2),
+        "dt_pointers": None if lite else pointers(le.eval["dt_pointers"], 2),
+        # the integer match counts: [category index, range, detections,
+        # TPs per threshold, FPs per threshold]
+        "counts": [[p["idx"][0], p["idx"][1], len(p["dt_ids"]),
+                    [int(np.sum(t)) for t in p["tps"]],
+                    [int(np.sum(t)) for t in p["fps"]]]
+                   for p in pointers(le.eval["dt_pointers"], 2)],
         "results": results_dict(le.results),
         "printed": buf.getvalue().splitlines(),
         "freq_groups": le.freq_groups,
@@ -214,9 +225,14 @@ def run_fixture(name):
         f.write(r.stdout)
     # the two "Evaluating <path>" / "Loading gt <path>" lines carry the
     # absolute path of this checkout: make them location independent
-    txt = open(log).read().replace(out + os.sep, "<DIR>/")
+    txt = open(log).read().replace(work + os.sep, "<DIR>/")
     with open(log, "w") as f:
         f.write(txt)
+    if lite:
+        for fn in ("gt.json", "pred.json"):
+            with open(os.path.join(work, fn), "rb") as src, gzip.GzipFile(
+                    os.path.join(out, fn + ".gz"), "wb", mtime=0) as dst:
+                dst.write(src.read())
     sizes = {f: os.path.getsize(os.path.join(out, f))
              for f in sorted(os.listdir(out))}
     print(name, "LVIS AP", le.results["AP"], "TAO AP", te.results["AP"],

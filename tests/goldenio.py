@@ -12,6 +12,10 @@ INTEGER_FIXTURES = ["f1", "f2", "f3", "f5"]
 # pair's frames in the reference's CPython set order (the Python oracle with
 # frame_order="set", the HIP path behind its frame-order guard) reproduces it
 ADVERSARIAL_FIXTURES = ["f7"]
+# a down-scaled Config 2 with decimal coordinates: tracks of hundreds of
+# frames, golden 3D IoUs = the reference's set-order sums.  Inputs gzipped, the
+# image level reduced to the integer match counts (fixtures.LITE)
+DECIMAL_SCALE_FIXTURES = ["f8"]
 
 
 def path(name, fn):
@@ -19,11 +23,28 @@ def path(name, fn):
 
 
 def load_inputs(name):
+    if not os.path.exists(path(name, "gt.json")):
+        return (load_json_gz(name, "gt.json.gz"),
+                load_json_gz(name, "pred.json.gz"))
     with open(path(name, "gt.json")) as f:
         gt = json.load(f)
     with open(path(name, "pred.json")) as f:
         pred = json.load(f)
     return gt, pred
+
+
+def input_paths(name, tmp_dir):
+    """Paths of plain-JSON inputs (gunzipped into tmp_dir when the fixture
+    stores them compressed)."""
+    out = []
+    for fn in ("gt.json", "pred.json"):
+        p = path(name, fn)
+        if not os.path.exists(p):
+            p = os.path.join(str(tmp_dir), fn)
+            with gzip.open(path(name, fn + ".gz"), "rb") as src, open(p, "wb") as dst:
+                dst.write(src.read())
+        out.append(p)
+    return out
 
 
 def load_json_gz(name, fn):

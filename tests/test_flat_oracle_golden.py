@@ -111,6 +111,58 @@ def test_tao_flatten_and_c_oracle(name):
     assert np.array_equal(out["recall"].reshape(r.shape), r)
 
 
+def check_lvis_counts(f, out, want):
+    """Integer match counts of a LITE fixture: detections, TPs and FPs per
+    (category, range, threshold)."""
+    got = {}
+    cat = f.dt_cat[out["order"]]
+    for k in np.unique(cat):
+        sel = out["order"][cat == k]
+        for r in range(6):
+            if out["num_gt"][k, r] == 0:
+                continue
+            tps, fps = [], []
+            for t in range(N_THR):
+                mt = _bits(out["matched"][sel], r * N_THR + t)
+                ig = _bits(out["ignored"][sel], r * N_THR + t)
+                tps.append(int((mt & (1 - ig)).sum()))
+                fps.append(int(((1 - mt) & (1 - ig)).sum()))
+            got[int(k), r] = [len(sel), tps, fps]
+    for k, r in zip(*np.nonzero(out["num_gt"])):
+        got.setdefault((int(k), int(r)), [0, [0] * N_THR, [0] * N_THR])
+    assert got == {(c[0], c[1]): c[2:] for c in want["counts"]}
+
+
+from goldenio import DECIMAL_SCALE_FIXTURES
+
+
+@pytest.mark.parametrize("name", DECIMAL_SCALE_FIXTURES)
+def test_decimal_scale_fixture_flatten_and_c_oracle(name):
+    """F8 (down-scaled decimal Config 2, golden from the reference): the C
+    oracle adds a pair's frames in timeline order, so its IoUs carry other last
+    bits (1e-12) -- no comparison of the match sits that close on this set, and
+    every decision, count and table is the reference's."""
+    gtj, predj = load_inputs(name)
+    gt, dt = GTColumns.from_json(gtj), DTColumns.from_json(predj)
+    want = load_json_gz(name, "lvis.json.gz")
+    f = fl.flatten_lvis(gt, dt)
+    assert f.img_ids.tolist() == want["img_ids"] and f.cat_ids.tolist() == want["cat_ids"]
+    out = orclib.run_flat(f)
+    check_lvis_counts(f, out, want)
+    ev = load_eval(name)
+    assert np.array_equal(out["precision"], ev["lvis"][0])
+    assert np.array_equal(out["recall"], ev["lvis"][1])
+    want = load_json_gz(name, "tao.json.gz")
+    dt.track_id, n = fl.make_track_ids_unique(dt)
+    assert n == want["n_track_ids_changed"]
+    f = fl.flatten_tao(gt, dt)
+    out = orclib.run_flat(f)
+    _check_side(f, out, want, f.vid_ids, -1, exact_iou=False)
+    p, r = ev["tao"]
+    assert np.array_equal(out["precision"].reshape(p.shape), p)
+    assert np.array_equal(out["recall"].reshape(r.shape), r)
+
+
 def test_thresholds_are_numpy_linspace_bit_for_bit():
     a, b = orclib.thresholds()
     assert np.array_equal(a, np.linspace(0.5, 0.95, 10))

@@ -2,8 +2,8 @@
 import numpy as np
 import pytest
 
-from goldenio import (ADVERSARIAL_FIXTURES, FIXTURES, INTEGER_FIXTURES, load_eval,
-                      load_inputs, load_json_gz)
+from goldenio import (ADVERSARIAL_FIXTURES, DECIMAL_SCALE_FIXTURES, FIXTURES,
+                      INTEGER_FIXTURES, load_eval, load_inputs, load_json_gz)
 from oracle import pyoracle
 
 
@@ -78,6 +78,23 @@ def test_tao_oracle_matches_reference(name):
     assert np.array_equal(got["precision"], p)
     assert np.array_equal(got["recall"], r)
     _check_pointers(got["pointers"], want["dt_pointers"])
+    _check_results(got["results"], want["results"])
+    assert got["printed"] == want["printed"]
+
+
+@pytest.mark.parametrize("name", DECIMAL_SCALE_FIXTURES)
+def test_tao_oracle_matches_reference_on_long_decimal_tracks(name):
+    """F8: tracks of hundreds of frames with decimal boxes -- the oracle's
+    set-order sums equal the reference's bit for bit (the image level of this
+    fixture is held by the flatten + C oracle test)."""
+    gt, pred = load_inputs(name)
+    want = load_json_gz(name, "tao.json.gz")
+    pyoracle.make_track_ids_unique(pred)
+    got = pyoracle.tao_eval(gt, pred, frame_order="set")
+    _check_cells(got["cells"], want["cells"])
+    p, r = load_eval(name)["tao"]
+    assert np.array_equal(got["precision"], p)
+    assert np.array_equal(got["recall"], r)
     _check_results(got["results"], want["results"])
     assert got["printed"] == want["printed"]
 
