@@ -73,6 +73,9 @@ def parse():
     p.add_argument("--cpu-sample-videos", type=int, default=200,
                    help="videos of the same workload timed through the C "
                         "oracle for cpu_baseline (rank 0, N=1 only)")
+    p.add_argument("--decimal", action="store_true",
+                   help="decimal box coordinates, as real prediction files have: "
+                        "the track level runs with the frame-order guard active")
     p.add_argument("--no-cpu", action="store_true")
     p.add_argument("--no-verify", action="store_true")
     p.add_argument("--serial", action="store_true",
@@ -281,7 +284,7 @@ def main():
         from tao_amodal_amd.columns import DTColumns, GTColumns
         parts = [synth(seed=args.seed + r, V=args.videos, F=args.frames,
                        C=args.cats, dets_per_frame=args.dets,
-                       video_id_base=r * args.videos)
+                       video_id_base=r * args.videos, decimal=args.decimal)
                  for r in range(data_world)]
         gt = GTColumns.concat([p[0] for p in parts])
         dt = DTColumns.concat([p[1] for p in parts])
@@ -289,7 +292,7 @@ def main():
     else:
         gt, dt = synth(seed=args.seed + rank, V=args.videos, F=args.frames,
                        C=args.cats, dets_per_frame=args.dets,
-                       video_id_base=rank * args.videos)
+                       video_id_base=rank * args.videos, decimal=args.decimal)
     t_gen = time.time() - t0
     n_boxes_in = len(dt)
     t0 = time.time()
@@ -399,11 +402,11 @@ def main():
     value = total_pairs * timed_steps / elapsed / 1e6
 
     workload = ("%s: %d videos x %d frames x %d dets/frame, %d categories per "
-                "GPU; LVISEval + TaoEval passes"
+                "GPU%s; LVISEval + TaoEval passes"
                 % (CONFIGS[args.config]["name"] if (args.videos, args.frames, args.dets)
                    == tuple(CONFIGS[args.config][k] for k in ("videos", "frames", "dets"))
                    else "SYNTH custom", args.videos, args.frames, args.dets,
-                   args.cats))
+                   args.cats, ", decimal coordinates" if args.decimal else ""))
 
     # ---- per-kernel durations inside the timed steps -> dominant kernel
     stages, roof, roof_other, kernels_ms, step_roof = None, None, None, None, None
@@ -497,7 +500,7 @@ def main():
         if args.frames * args.dets < 3000:        # stress shape: many tiny videos
             nv = min(args.videos, max(nv, 3000000 // max(args.frames * args.dets, 1)))
         sgt, sdt = synth(seed=args.seed, V=nv, F=args.frames, C=args.cats,
-                         dets_per_frame=args.dets)
+                         dets_per_frame=args.dets, decimal=args.decimal)
         sfl = flatten.flatten_lvis(sgt, sdt)
         sdt.track_id, _ = flatten.make_track_ids_unique(sdt)
         sft = flatten.flatten_tao(sgt, sdt)
@@ -545,6 +548,30 @@ def main():
                     and np.array_equal(wst.precision.cpu().numpy(), ot["precision"])
                     and np.array_equal(wst.recall.cpu().numpy(), ot["recall"]))
 
+    # ---- decimal coordinates: a sample of the same workload through the Python
+    # oracle in the reference's own frame order (CPython sets), against the HIP
+    # path with its guard -- the C oracle above adds frames in timeline order
+    set_order_check = None
+    if args.decimal and not use_dist and rank == 0 and not args.no_cpu \
+            and not args.no_verify:
+        from oracle import pyoracle
+        nv = min(6, args.videos)
+        sgt, sdt = synth(seed=args.seed, V=nv, F=args.frames, C=args.cats,
+                         dets_per_frame=args.dets, decimal=True)
+        t0 = time.perf_counter()
+        gj, pj = sgt.to_json(), sdt.to_json()
+        pyoracle.make_track_ids_unique(pj)
+        po = pyoracle.tao_eval(gj, pj, frame_order="set")
+        t_py = time.perf_counter() - t0
+        sdt.track_id, _ = flatten.make_track_ids_unique(sdt)
+        gg = engine.evaluate_flat(flatten.flatten_tao(sgt, sdt), dev)
+        set_order_check = {
+            "videos": nv, "python_oracle_s": round(t_py, 2),
+            "precision_equal": bool(np.array_equal(
+                gg["precision"].reshape(po["precision"].shape), po["precision"])),
+            "recall_equal": bool(np.array_equal(
+                gg["recall"].reshape(po["recall"].shape), po["recall"]))}
+
     if rank == 0:
         out = {
             "metric": "box-pair IoU+match throughput", "value": round(value, 3),
@@ -573,8 +600,17 @@ def main():
             "bit_exact_vs_oracle": verified,
             "frame_order_guard": {
                 "exact_terms": bool(dpt.exact_terms),
-                "near_threshold_pairs": 0 if dpt.exact_terms or not hasattr(wst, "near_count")
-                else int(wst.near_count.item())},
+                "active": bool(dpt.guard_active()),
+                "where": ("device (taoamd_track_iou_near + taoamd_track_iou_setorder, "
+                          "no host round trip)" if dpt.guard_on_device else
+                          "host" if dpt.guard_active() else None),
+                "near_ulp": dpt.near_ulp,
+                "near_threshold_pairs": engine.guarded_pairs(dpt, wst),
+                "ms_per_step": (round(sum(kernels_ms.get("tao:" + k, 0.0) for k in
+                                          ("track_iou_near_kernel",
+                                           "track_iou_setorder_kernel")), 4)
+                                if kernels_ms else None),
+                "set_order_sample": set_order_check},
             "ranks_verified": ranks_verified,
             "exchange_verified": exchange_ok,
             "exchange_chunk_bytes": ([plan.lvis.chunk_bytes, plan.tao.chunk_bytes]

@@ -225,13 +225,57 @@ int taoamd_track_pad(int64_t n_trk, int64_t n_frames, const int32_t *frame_off,
  * ten IoU thresholds or of another ground truth's IoU in the same row -- the
  * comparisons of the greedy match that a last-bit difference could flip.
  * *count = number of such pairs (zeroed by the call), list[0 .. min(count,
- * capacity)) = their indices into `iou`.  The host recomputes those pairs in
- * the reference's order and patches `iou` before the match
- * (tao_amodal_amd/engine.py: apply_iou_guard). */
+ * capacity)) = their indices into `iou`.  max_ulp must bound the reordering
+ * error: adding n non-negative fp64 terms in two different orders moves a sum
+ * by at most 2 (n - 1) units of roundoff, a quotient of two such sums by at
+ * most 4 n - 2 units in the last place; callers pass 8 (n_dt + n_gt) + 8 for
+ * the longest tracks (two rivals move independently).  The listed pairs are
+ * recomputed in the reference's order by taoamd_track_iou_setorder. */
 int taoamd_track_iou_near(int64_t n_cells, const int32_t *cell_gt_off,
                           const int64_t *cell_iou_off, int64_t n_pairs,
                           const double *iou, int32_t max_ulp, int32_t capacity,
                           int32_t *count, int64_t *list, void *stream);
+
+/* The listed pairs recomputed on the device in the reference's order
+ * (replaces compute_track_box_iou / compute_avg_track_iou, T/eval.py:73-117,
+ * for exactly those pairs).  A thread per pair restates CPython's
+ * ``set(gt_track.keys()) | set(dt_track.keys())`` (Objects/setobject.c of
+ * 3.7 - 3.12, csrc/pyset.hpp), visits the union in slot order and adds the
+ * per-frame terms of bb_intersect_union (T/eval.py:32-48) as the reference
+ * does: mode 0 sums intersections and unions left to right, mode 1 takes
+ * np.mean (numpy's pairwise summation) of the per-frame ratios.
+ *   cell_unit      int32  video index of a cell
+ *   tl_vid_start   int64  first timeline slot of a video in tl_image_id
+ *   tl_image_id    int64  image id at (video, timeline position): the dict key
+ *                         (all ids in [0, 2^61 - 1): hash(id) == id)
+ *   count, list    device: the output of taoamd_track_iou_near (count read on
+ *                  the device: no host round trip); `capacity` = entries of list
+ *   scratch        int32[scratch_slots], 3 * table_cap slots per worker thread;
+ *                  table_cap >= taoamd_track_iou_setorder_table(longest
+ *                  detection track, longest GT track) in frames
+ *   status         int32[1], bit 0 set if a pair needed a larger table (skipped)
+ * Patches iou[list[k]] in place; asynchronous on `stream`. */
+int64_t taoamd_track_iou_setorder_table(int64_t max_dt_frames, int64_t max_gt_frames);
+int taoamd_track_iou_setorder(
+    int64_t n_cells, const int32_t *cell_dt_off, const int32_t *cell_gt_off,
+    const int64_t *cell_iou_off, const int32_t *cell_unit, const int64_t *tl_vid_start,
+    const int64_t *tl_image_id, const int32_t *dt_frame_off, const int32_t *dt_frame_pos,
+    const double *dt_frame_box, const int32_t *gt_frame_off, const int32_t *gt_frame_pos,
+    const double *gt_frame_box, int32_t mode, const int32_t *count, int32_t capacity,
+    const int64_t *list, double *iou, int32_t *scratch, int64_t scratch_slots,
+    int64_t table_cap, int32_t *status, void *stream);
+
+/* Host statements of the same text (test seams; synchronous, no GPU):
+ * one pair's set-order IoU from host arrays (positions ascending, boxes x, y,
+ * w, h; tl_image_id indexed by position), and the iteration order of
+ * ``set(a) | set(b)`` for two lists of non-negative ints (out: n_a + n_b
+ * entries). */
+int taoamd_set_order_iou_host(const int64_t *tl_image_id, int32_t n_dt,
+                              const int32_t *dt_pos, const double *dt_box, int32_t n_gt,
+                              const int32_t *gt_pos, const double *gt_box, int32_t mode,
+                              double *out);
+int taoamd_pyset_union_order_host(int64_t n_a, const int64_t *a, int64_t n_b,
+                                  const int64_t *b, int64_t *out, int64_t *n_out);
 
 /* Launch plan of taoamd_track_iou_planned from HOST copies of the cell offsets
  * and of trk_meta (detection tracks first, then GT tracks).  Call with

@@ -46,6 +46,13 @@ SIGNATURES = {
                                    _vp, _vp, _vp]),
     "taoamd_track_iou_near": (C.c_int, [_i64, _vp, _vp, _i64, _vp, _i32, _i32,
                                         _vp, _vp, _vp]),
+    "taoamd_track_iou_setorder_table": (_i64, [_i64, _i64]),
+    "taoamd_track_iou_setorder": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                            _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32,
+                                            _vp, _vp, _vp, _i64, _i64, _vp, _vp]),
+    "taoamd_set_order_iou_host": (C.c_int, [_vp, _i32, _vp, _vp, _i32, _vp, _vp,
+                                            _i32, _vp]),
+    "taoamd_pyset_union_order_host": (C.c_int, [_i64, _vp, _i64, _vp, _vp, _vp]),
     "taoamd_track_iou_plan_host": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp,
                                              _vp, _vp, _vp, _vp]),
     "taoamd_flat_map": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp,

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "pyset.hpp"
 
 using namespace taoamd;
 
@@ -515,6 +516,49 @@ __global__ void track_iou_near_kernel(int64_t n_cells,
     }
 }
 
+// The listed pairs recomputed ON THE DEVICE in the reference's order: a thread
+// per pair restates CPython's ``set(gt.keys()) | set(dt.keys())`` (pyset.hpp)
+// in its own scratch tables, walks the union's slots and adds the per-frame
+// terms as the reference does -- no host round trip between the 3D IoU and the
+// match.  Listed pairs are rare (an IoU within the reordering bound of a
+// threshold or of a rival), so this is a handful of serial threads; a grid-
+// stride loop over the list whose length is read from device memory.
+__global__ __launch_bounds__(64) void track_iou_setorder_kernel(
+    int64_t n_cells, const int32_t *__restrict__ cell_dt_off,
+    const int32_t *__restrict__ cell_gt_off, const int64_t *__restrict__ cell_iou_off,
+    const int32_t *__restrict__ cell_unit, const int64_t *__restrict__ tl_vid_start,
+    const int64_t *__restrict__ tl_image_id, const int32_t *__restrict__ dfoff,
+    const int32_t *__restrict__ dfpos, const double *__restrict__ dfbox,
+    const int32_t *__restrict__ gfoff, const int32_t *__restrict__ gfpos,
+    const double *__restrict__ gfbox, int mode, const int32_t *__restrict__ count,
+    int32_t list_cap, const int64_t *__restrict__ list, int32_t *__restrict__ scratch,
+    uint32_t table_cap, double *__restrict__ iou, int32_t *__restrict__ status)
+{
+    const int64_t w = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t W = gridDim.x * (int64_t)blockDim.x;
+    int64_t n = *count;
+    if (n > list_cap) n = list_cap;
+    int32_t *buf = scratch + 3 * w * (int64_t)table_cap;
+    for (int64_t k = w; k < n; k += W) {
+        const int64_t p = list[k];
+        const int64_t c = find_cell(cell_iou_off, n_cells, p);
+        const int32_t G = cell_gt_off[c + 1] - cell_gt_off[c];
+        const int64_t local = p - cell_iou_off[c];
+        const int32_t td = cell_dt_off[c] + (int32_t)(local / G);
+        const int32_t tg = cell_gt_off[c] + (int32_t)(local % G);
+        const pyset::Frames D{dfpos + dfoff[td], dfbox + 4 * (int64_t)dfoff[td],
+                              dfoff[td + 1] - dfoff[td]};
+        const pyset::Frames Gf{gfpos + gfoff[tg], gfbox + 4 * (int64_t)gfoff[tg],
+                               gfoff[tg + 1] - gfoff[tg]};
+        if (pyset::table_size(4ull * ((uint64_t)D.n + Gf.n)) > table_cap) {
+            atomicOr(status, 1);            // scratch too small for this pair
+            continue;
+        }
+        iou[p] = pyset::set_order_iou(tl_image_id + tl_vid_start[cell_unit[c]], D, Gf,
+                                      mode, buf, table_cap);
+    }
+}
+
 __global__ void track_pad_fill_kernel(int64_t n, double4 *__restrict__ padded)
 {
     const int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -616,6 +660,99 @@ extern "C" int taoamd_track_iou_near(int64_t n_cells, const int32_t *cell_gt_off
         n_cells, cell_gt_off, cell_iou_off, n_pairs, iou, iou_thr(), max_ulp, capacity,
         count, list));
     TAO_LAUNCH_CHECK();
+    return TAOAMD_OK;
+}
+
+extern "C" int64_t taoamd_track_iou_setorder_table(int64_t max_dt_frames,
+                                                  int64_t max_gt_frames)
+{
+    if (max_dt_frames < 0 || max_gt_frames < 0) return -1;
+    return pyset::table_size(4ull * (uint64_t)(max_dt_frames + max_gt_frames));
+}
+
+extern "C" int taoamd_track_iou_setorder(
+    int64_t n_cells, const int32_t *cell_dt_off, const int32_t *cell_gt_off,
+    const int64_t *cell_iou_off, const int32_t *cell_unit, const int64_t *tl_vid_start,
+    const int64_t *tl_image_id, const int32_t *dt_frame_off, const int32_t *dt_frame_pos,
+    const double *dt_frame_box, const int32_t *gt_frame_off, const int32_t *gt_frame_pos,
+    const double *gt_frame_box, int32_t mode, const int32_t *count, int32_t capacity,
+    const int64_t *list, double *iou, int32_t *scratch, int64_t scratch_slots,
+    int64_t table_cap, int32_t *status, void *stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (mode < 0 || mode > 1 || n_cells < 0 || capacity < 0 || table_cap < 8 ||
+        table_cap > (1ll << 30) || !count || !status)
+        return TAOAMD_ERR_ARG;
+    if (n_cells == 0 || capacity == 0) return TAOAMD_OK;
+    if (!cell_dt_off || !cell_gt_off || !cell_iou_off || !cell_unit || !tl_vid_start ||
+        !tl_image_id || !dt_frame_off || !dt_frame_pos || !dt_frame_box || !gt_frame_off ||
+        !gt_frame_pos || !gt_frame_box || !list || !iou || !scratch)
+        return TAOAMD_ERR_ARG;
+    const int64_t workers = scratch_slots / (3 * table_cap);
+    if (workers < 1) return TAOAMD_ERR_ARG;
+    int64_t blocks = workers / 64;
+    unsigned threads = 64;
+    if (blocks == 0) { blocks = 1; threads = (unsigned)workers; }
+    if (blocks > 4096) blocks = 4096;
+    TAO_TIMED("track_iou_setorder_kernel", s,
+              track_iou_setorder_kernel<<<(unsigned)blocks, threads, 0, s>>>(
+                  n_cells, cell_dt_off, cell_gt_off, cell_iou_off, cell_unit, tl_vid_start,
+                  tl_image_id, dt_frame_off, dt_frame_pos, dt_frame_box, gt_frame_off,
+                  gt_frame_pos, gt_frame_box, mode, count, capacity, list, scratch,
+                  (uint32_t)table_cap, iou, status));
+    TAO_LAUNCH_CHECK();
+    return TAOAMD_OK;
+}
+
+// ---- host statements of the same text, for the CPU tests (tests/test_pyset.py)
+extern "C" int taoamd_set_order_iou_host(const int64_t *tl_image_id, int32_t n_dt,
+                                         const int32_t *dt_pos, const double *dt_box,
+                                         int32_t n_gt, const int32_t *gt_pos,
+                                         const double *gt_box, int32_t mode, double *out)
+{
+    if (!tl_image_id || n_dt < 0 || n_gt < 0 || (n_dt && (!dt_pos || !dt_box)) ||
+        (n_gt && (!gt_pos || !gt_box)) || mode < 0 || mode > 1 || !out || n_dt + n_gt == 0)
+        return TAOAMD_ERR_ARG;
+    const uint32_t cap = pyset::table_size(4ull * ((uint64_t)n_dt + n_gt));
+    std::vector<int32_t> buf(3 * (size_t)cap);
+    const pyset::Frames D{dt_pos, dt_box, n_dt}, G{gt_pos, gt_box, n_gt};
+    *out = pyset::set_order_iou(tl_image_id, D, G, mode, buf.data(), cap);
+    return TAOAMD_OK;
+}
+
+extern "C" int taoamd_pyset_union_order_host(int64_t n_a, const int64_t *a, int64_t n_b,
+                                             const int64_t *b, int64_t *out, int64_t *n_out)
+{
+    if (n_a < 0 || n_b < 0 || (n_a && !a) || (n_b && !b) || !out || !n_out ||
+        n_a + n_b > (1 << 27))
+        return TAOAMD_ERR_ARG;
+    // codes: 1 + index into the list of keys (a then b); equal keys share the
+    // code of their first occurrence
+    std::vector<int64_t> keys(a, a + n_a);
+    keys.insert(keys.end(), b, b + n_b);
+    std::vector<int32_t> code(keys.size());
+    {
+        std::vector<int64_t> idx(keys.size());
+        for (size_t i = 0; i < idx.size(); i++) idx[i] = (int64_t)i;
+        std::stable_sort(idx.begin(), idx.end(),
+                         [&](int64_t x, int64_t y) { return keys[x] < keys[y]; });
+        for (size_t i = 0; i < idx.size(); i++) {
+            if (keys[idx[i]] < 0 || keys[idx[i]] >= (1ll << 61) - 1) return TAOAMD_ERR_ARG;
+            code[idx[i]] = (i && keys[idx[i - 1]] == keys[idx[i]]) ? code[idx[i - 1]]
+                                                                  : (int32_t)idx[i] + 1;
+        }
+    }
+    const uint32_t cap = pyset::table_size(4ull * (uint64_t)(n_a + n_b));
+    std::vector<int32_t> buf(3 * (size_t)cap);
+    auto hash = [&](int32_t c) { return (uint64_t)keys[c - 1]; };
+    auto ca = [&](uint32_t k) { return code[k]; };
+    auto cb = [&](uint32_t k) { return code[n_a + k]; };
+    const pyset::Set R = pyset::set_union((uint32_t)n_a, ca, (uint32_t)n_b, cb, hash,
+                                          buf.data(), cap);
+    int64_t n = 0;
+    for (uint32_t i = 0; i <= R.mask; i++)
+        if (R.t[i]) out[n++] = keys[R.t[i] - 1];
+    *n_out = n;
     return TAOAMD_OK;
 }
 

@@ -77,12 +77,12 @@ class HipBackend:
         self.engine.stage_ranges(dp, ws)
 
     def track_iou(self, dp, ws):
-        # with the frame-order guard (engine.apply_iou_guard): a rank's tracks
-        # are its own, so are the pairs to recompute -- one host
-        # synchronisation per pass when the boxes are not integers
+        # with the frame-order guard (engine.stage_iou_guard): a rank's tracks
+        # are its own, so are the pairs to recompute -- on the device, no host
+        # round trip (the host half only for ids Python hashes differently)
         self.engine.stage_track_iou_guarded(dp, ws)
         if dp.guard_flat is not None:
-            ws.guarded_pairs = self.engine.apply_iou_guard(dp, ws, dp.guard_flat)
+            ws.guarded_pairs = self.engine.apply_iou_guard(dp, ws)
 
     def match_into(self, dp, ws, dst, records, width):
         if dp.n_dt == 0:

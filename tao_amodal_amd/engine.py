@@ -138,7 +138,11 @@ class DeviceProblem:
 
     IOU_MODES = {"3d_iou": 0, "avg_iou": 1, "imagenetvid": 2}
 
-    def __init__(self, flat, device="cuda", iou_3d_type="3d_iou"):
+    def __init__(self, flat, device="cuda", iou_3d_type="3d_iou", guard="device"):
+        """`guard`: where the frame-order guard recomputes the listed pairs --
+        "device" (taoamd_track_iou_setorder, no host round trip; falls back to
+        the host when an image id is outside [0, 2^61 - 1)) or "host" (Python's
+        own sets, one synchronisation per pass: the cross-check of the tests)."""
         self.kind = flat.kind
         self.iou_mode = self.IOU_MODES[iou_3d_type]
         self.device = torch.device(device)
@@ -232,13 +236,12 @@ class DeviceProblem:
         self.t["groups"] = torch.from_numpy(runs).to(self.device)
         self.n_tasks = 0
         self.exact_terms = False
-        # decimal boxes: the host tables the frame-order guard recomputes the
-        # listed pairs from (apply_iou_guard); dropped again if the boxes turn
-        # out to be integers
-        self.guard_flat = flat if (self.kind == "tao" and
-                                   self.device.type == "cuda") else None
+        self.guard_flat = None         # host tables of the host-side guard
+        self.guard_on_device = False
+        self.near_ulp = 0
         if self.kind == "tao":
             self._plan_track_iou(flat)
+            self._plan_guard(flat, guard)
         # per detection {first GT of its cell, GT count, position in the cell,
         # cell}: resolved here, on the device, from the uploaded cell tables
         cell = self.t["dt_cell"].long()
@@ -303,8 +306,38 @@ class DeviceProblem:
         # (products < 2^40, tracks of at most 2^12 frames: every sum < 2^53)
         longest = int((meta[:, 1] - meta[:, 0]).max()) + 1 if len(meta) else 0
         self.exact_terms = not bool(inexact.item()) and longest <= 4096
-        if self.exact_terms:
-            self.guard_flat = None
+
+    def guard_active(self):
+        """Whether a pass runs the frame-order guard: the count-based
+        imagenetvid IoU is exact in any order, and so is the 3D IoU of integer
+        boxes (exact_terms) -- but NOT the average IoU of integer boxes, whose
+        per-frame ratios are rounded divisions."""
+        return (self.kind == "tao" and self.n_iou > 0 and self.iou_mode != 2
+                and not (self.exact_terms and self.iou_mode == 0)
+                and self.device.type == "cuda")
+
+    def _plan_guard(self, flat, guard):
+        """Tables of the frame-order guard (stage_iou_guard)."""
+        if not self.guard_active():
+            return
+        lens = [int(np.diff(np.asarray(flat[s + "_frame_off"])).max())
+                if len(flat[s + "_frame_off"]) > 1 else 0 for s in ("dt", "gt")]
+        self.max_frames = lens
+        # reordering bound of taoamd_track_iou_near (include/tao_amodal_hip.h)
+        self.near_ulp = int(min(8 * (lens[0] + lens[1]) + 8, 2 ** 31 - 1))
+        tl_id = np.ascontiguousarray(flat.tl_image_id, dtype=np.int64)
+        ids_ok = len(tl_id) == 0 or (int(tl_id.min()) >= 0
+                                     and int(tl_id.max()) < 2 ** 61 - 1)
+        if guard == "device" and ids_ok:
+            self.guard_on_device = True
+            dev = self.device
+            self.t["cell_unit"] = torch.from_numpy(
+                np.ascontiguousarray(flat.cell_unit, dtype=np.int32)).to(dev)
+            self.t["tl_vid_start"] = torch.from_numpy(
+                np.ascontiguousarray(flat.tl_vid_start, dtype=np.int64)).to(dev)
+            self.t["tl_image_id"] = torch.from_numpy(tl_id).to(dev)
+        else:
+            self.guard_flat = flat
 
     def input_bytes(self):
         return sum(v.numel() * v.element_size() for v in self.t.values()
@@ -357,8 +390,21 @@ class Workspace:
                                    device=dev)
             self.pair_frames = torch.zeros(1, dtype=torch.int64, device=dev)
             self.near_count = torch.zeros(1, dtype=torch.int32, device=dev)
-            self.near_cap = int(min(max(dp.n_iou, 1), NEAR_CAP))
+            self.guarded_pairs = 0
+            # every pair can be listed: the list never overflows, so no pass
+            # has to look at the count on the host
+            self.near_cap = int(min(max(dp.n_iou, 1), 2 ** 31 - 1)) \
+                if dp.guard_active() else 1
             self.near_list = torch.empty(self.near_cap, dtype=torch.int64, device=dev)
+            if dp.guard_on_device:
+                self.guard_table = int(lib.taoamd_track_iou_setorder_table(
+                    *dp.max_frames))
+                workers = GUARD_SCRATCH_BYTES // (12 * self.guard_table)
+                workers = int(min(max(workers // 64 * 64, 64), 4096))
+                self.guard_slots = workers * 3 * self.guard_table
+                self.guard_scratch = torch.empty(self.guard_slots, dtype=torch.int32,
+                                                 device=dev)
+                self.guard_status = torch.zeros(1, dtype=torch.int32, device=dev)
         elif dp.mask_iou:
             self.iou = torch.empty(max(dp.n_iou, 1), dtype=torch.float64,
                                    device=dev)
@@ -445,44 +491,62 @@ def stage_track_iou(dp, ws):
         _ptr(ws.pair_frames), s), "taoamd_track_iou")
 
 
-NEAR_CAP = 1 << 16     # listed near-threshold pairs (more: the list is regrown)
-NEAR_ULP = 4           # distance to a threshold / a rival IoU that is guarded
+GUARD_SCRATCH_BYTES = 64 << 20    # set tables of the device-side guard's threads
 
 
 def stage_iou_guard(dp, ws):
-    """List the track pairs whose 3D IoU a last-bit difference could move
-    across a comparison of the match (taoamd_track_iou_near).  Nothing to do
-    for integer boxes (exact sums) and for the count-based imagenetvid IoU."""
-    if dp.kind != "tao" or dp.n_iou == 0 or dp.exact_terms or dp.iou_mode == 2:
+    """The frame-order guard, all on the device: list the track pairs whose
+    IoU a reordering of the frame sums could move across a comparison of the
+    match (taoamd_track_iou_near, within dp.near_ulp of a threshold or of a
+    rival), then recompute exactly those in the reference's CPython set order
+    (taoamd_track_iou_setorder) and patch the IoU matrix -- asynchronous, no
+    host round trip.  Nothing to do for integer boxes under the 3D IoU (exact
+    sums) and for the count-based imagenetvid IoU."""
+    if not dp.guard_active():
         return
-    lib, t = _lib.load(), dp.t
+    lib, t, s = _lib.load(), dp.t, _stream()
     _lib.check(lib.taoamd_track_iou_near(
         dp.n_cells, _ptr(t["cell_gt_off"]), _ptr(t["cell_iou_off"]), dp.n_iou,
-        _ptr(ws.iou), NEAR_ULP, ws.near_cap, _ptr(ws.near_count),
-        _ptr(ws.near_list), _stream()), "taoamd_track_iou_near")
+        _ptr(ws.iou), dp.near_ulp, ws.near_cap, _ptr(ws.near_count),
+        _ptr(ws.near_list), s), "taoamd_track_iou_near")
+    if not dp.guard_on_device:
+        return
+    _lib.check(lib.taoamd_track_iou_setorder(
+        dp.n_cells, _ptr(t["cell_dt_off"]), _ptr(t["cell_gt_off"]),
+        _ptr(t["cell_iou_off"]), _ptr(t["cell_unit"]), _ptr(t["tl_vid_start"]),
+        _ptr(t["tl_image_id"]), _ptr(t["dt_frame_off"]), _ptr(t["dt_frame_pos"]),
+        _ptr(t["dt_frame_box"]), _ptr(t["gt_frame_off"]), _ptr(t["gt_frame_pos"]),
+        _ptr(t["gt_frame_box"]), dp.iou_mode, _ptr(ws.near_count), ws.near_cap,
+        _ptr(ws.near_list), _ptr(ws.iou), _ptr(ws.guard_scratch), ws.guard_slots,
+        ws.guard_table, _ptr(ws.guard_status), s), "taoamd_track_iou_setorder")
 
 
-def apply_iou_guard(dp, ws, flat):
-    """The documented deviation, closed: the kernels add a track pair's frames
-    in timeline order, the reference in CPython set-iteration order
-    (T/eval.py:83-94).  The pairs stage_iou_guard listed are recomputed on the
-    host in the reference's order -- with Python's own sets -- and patched into
-    the IoU matrix before the match.  Returns the number of guarded pairs
-    (synchronises)."""
-    if dp.kind != "tao" or dp.n_iou == 0 or dp.exact_terms or dp.iou_mode == 2:
+def apply_iou_guard(dp, ws, flat=None):
+    """Host half of the guard, for problems the device cannot recompute (an
+    image id outside [0, 2^61 - 1): hash(id) != id) or that asked for it
+    (DeviceProblem(guard="host"), the tests' cross-check): the listed pairs
+    are recomputed with Python's own sets and patched into the IoU matrix
+    before the match.  Returns the number of guarded pairs (synchronises)."""
+    if not dp.guard_active() or dp.guard_on_device:
         return 0
+    flat = flat if flat is not None else dp.guard_flat
     n = int(ws.near_count.item())
     if n == 0:
         return 0
-    if n > ws.near_cap:                 # regrow the list and list again
-        ws.near_cap = dp.n_iou
-        ws.near_list = torch.empty(ws.near_cap, dtype=torch.int64, device=dp.device)
-        stage_iou_guard(dp, ws)
-        n = int(ws.near_count.item())
     pairs = ws.near_list[:n].cpu().numpy()
     vals = set_order_iou(flat, pairs, dp.iou_mode)
     ws.iou[torch.from_numpy(pairs).to(dp.device)] = torch.from_numpy(vals).to(dp.device)
     return n
+
+
+def guarded_pairs(dp, ws):
+    """Pairs the last pass listed and recomputed (synchronises)."""
+    if not dp.guard_active():
+        return 0
+    if dp.guard_on_device and int(ws.guard_status.item()):
+        raise _lib.TaoAmdError("frame-order guard: a track pair outgrew the set "
+                               "tables sized for the longest tracks")
+    return int(ws.near_count.item())
 
 
 def set_order_iou(flat, pairs, mode=0):
@@ -590,11 +654,14 @@ STAGES = (("ranges", stage_ranges), ("sort", stage_sort),
 
 
 def run(dp, ws):
-    """Launch one evaluator pass on the current stream (asynchronous)."""
+    """Launch one evaluator pass on the current stream (asynchronous, unless
+    the problem needs the host half of the frame-order guard)."""
     if _lib.TIMING:
         _lib.kernel_timing_label(dp.kind)
-    for _, fn in STAGES:
+    for name, fn in STAGES:
         fn(dp, ws)
+        if name == "track_iou" and dp.guard_flat is not None:
+            ws.guarded_pairs = apply_iou_guard(dp, ws)
 
 
 import os as _os
@@ -651,6 +718,9 @@ class GraphedPass:
     ROCm 7.0 runtime at replay for some node counts, linear ones do not."""
 
     def __init__(self, dp, ws, aux, tail=None):
+        if dp.guard_flat is not None:
+            raise _lib.TaoAmdError("a pass with the host-side frame-order guard "
+                                   "synchronises: it cannot be captured")
         self.dp, self.aux = dp, aux
         tail = tail or (lambda: stage_accumulate(dp, ws))
         if dp.kind == "lvis":
@@ -660,7 +730,7 @@ class GraphedPass:
             def fa():
                 stage_ranges(dp, ws)
                 stage_sort(dp, ws)
-            fb = lambda: stage_track_iou(dp, ws)
+            fb = lambda: stage_track_iou_guarded(dp, ws)
 
         def fc():
             stage_match(dp, ws)
@@ -762,9 +832,9 @@ def run_forked(dp, ws, aux, head_only=False, sort_aside=False):
             stage_sort(dp, ws)
         _probed("track_iou", stage_track_iou_guarded, dp, ws)
         if dp.guard_flat is not None:
-            # decimal boxes: one host synchronisation, the listed pairs are
-            # patched in the reference's frame order before the match
-            ws.guarded_pairs = apply_iou_guard(dp, ws, dp.guard_flat)
+            # host half of the guard (ids Python does not hash to themselves):
+            # one synchronisation, the listed pairs patched before the match
+            ws.guarded_pairs = apply_iou_guard(dp, ws)
     cur.wait_stream(aux)
     _probed("match", stage_match, dp, ws)
     if not head_only:
@@ -819,26 +889,30 @@ def time_stages(dpl, wsl, dpt, wst, reps=10):
     return out
 
 
-def run_guarded(dp, ws, flat, upto=None):
-    """One evaluator pass with the frame-order guard applied (one host
-    synchronisation between the 3D IoU and the match when the boxes are not
-    integers).  Returns the number of guarded pairs."""
+def run_guarded(dp, ws, flat=None, upto=None, read_count=True):
+    """One evaluator pass; returns the number of pairs the frame-order guard
+    recomputed (synchronises at the end to read it, unless read_count=False:
+    guarded_pairs() gives it later)."""
     if _lib.TIMING:
         _lib.kernel_timing_label(dp.kind)
     stage_ranges(dp, ws)
     stage_sort(dp, ws)
     stage_track_iou_guarded(dp, ws)
-    n = apply_iou_guard(dp, ws, flat)
+    apply_iou_guard(dp, ws, flat)
     stage_match(dp, ws)
     if upto != "match":
         stage_accumulate(dp, ws)
-    return n
+    if not read_count:
+        return None
+    ws.guarded_pairs = guarded_pairs(dp, ws)
+    return ws.guarded_pairs
 
 
-def evaluate_flat(flat, device="cuda", detail=False, iou_3d_type="3d_iou"):
+def evaluate_flat(flat, device="cuda", detail=False, iou_3d_type="3d_iou",
+                  guard="device"):
     """Upload, run, download.  Returns a dict of numpy arrays shaped like the
     C oracle's outputs (tests compare the two field by field)."""
-    dp = DeviceProblem(flat, device, iou_3d_type)
+    dp = DeviceProblem(flat, device, iou_3d_type, guard=guard)
     ws = Workspace(dp, detail=detail)
     guarded = run_guarded(dp, ws, flat)
     torch.cuda.synchronize(dp.device)

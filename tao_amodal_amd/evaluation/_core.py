@@ -70,10 +70,10 @@ class GpuRun:
     def evaluate(self):
         e = self.engine
         with timed("kernels"):
-            # (frame-order guard of the 3D IoU applied before the match:
-            # engine.apply_iou_guard; 0 pairs for integer boxes)
-            self.near_threshold_pairs = e.run_guarded(self.dp, self.ws, self.flat,
-                                                      upto="match")
+            # (frame-order guard of the 3D IoU applied before the match, on
+            # the device: engine.stage_iou_guard; its count is read later)
+            e.run_guarded(self.dp, self.ws, self.flat, upto="match",
+                          read_count=False)
             import os
             if os.environ.get("TAOAMD_TIMING"):
                 self.torch.cuda.synchronize(self.device)
@@ -82,6 +82,7 @@ class GpuRun:
         with timed("kernels"):
             self.engine.stage_accumulate(self.dp, self.ws)
             self.torch.cuda.synchronize(self.device)
+            self.near_threshold_pairs = self.engine.guarded_pairs(self.dp, self.ws)
         with timed("download"):
             self.precision = self.ws.precision.cpu().numpy()
             self.recall = self.ws.recall.cpu().numpy()

@@ -123,12 +123,6 @@ class TaoEval:
         flat = self.flat
         self._run = GpuRun(flat, self.device, self.params.iou_3d_type)
         self._run.evaluate()
-        # track pairs whose 3D IoU was recomputed in the reference's frame
-        # order because it sits within a few ulp of a comparison of the match
-        self.near_threshold_pairs = self._run.near_threshold_pairs
-        if self.near_threshold_pairs:
-            self.logger.debug("%d track pairs near an IoU threshold recomputed "
-                              "in set order", self.near_threshold_pairs)
         P = self.params
         rngs = [(a, t) for a in P.area_rng for t in P.time_rng]
         view = CellView(self._run, flat.vid_ids, -1, "video_id", "rng", rngs)
@@ -136,6 +130,15 @@ class TaoEval:
         self.ious = LazyIous(view, P.vid_ids, cats)
         self.eval_vids = _EvalVids(view, len(P.vid_ids), len(cats),
                                    len(P.area_rng), len(P.time_rng))
+
+    @property
+    def near_threshold_pairs(self):
+        """Track pairs whose 3D IoU the frame-order guard recomputed in the
+        reference's set order (it sat within the reordering bound of a
+        comparison of the match).  Reads a device counter: synchronises."""
+        if self._run is None:
+            return 0
+        return self._run.engine.guarded_pairs(self._run.dp, self._run.ws)
 
     def accumulate(self):
         self.logger.info("Accumulating evaluation results.")
