@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """bench.py -- headline benchmark of the MI355X evaluation hot path.
 
-    python bench.py --gpus N --steps K --warmup W [--config 2|3s|5s]
+    python bench.py --gpus N --steps K --warmup W [--config 3s|2|5s] [--decimal]
+                    [--scaling weak|strong]
 
 One "step" = one pass of the hot path over one batch of synthetic input that
 is already resident in HBM: for BOTH evaluators (image-level LVISEval and
@@ -10,18 +11,22 @@ track-level TaoEval) range masks -> (category, -score) sort -> [3D track IoU]
 (precision[T,R,K,A] and recall materialised in the reference layout).
 
 Workloads (BASELINE.json configs):
-    --config 2   "Synthetic 200 videos x 300 frames x 50 dets" (default; the
-                 configuration the metric is quoted on that fits one GPU)
-    --config 3s  stand-in for the full validation set (its JSONs are not in the
-                 container): 2000 videos x 300 frames x 50 dets, 1203 categories
+    --config 3s  (default) the largest single-GPU configuration: the stand-in
+                 for the full validation set (its JSONs are not in the
+                 container) at the size north_star names -- 2000 videos x 300
+                 frames x 50 dets, 1203 categories, 30 M boxes in
+    --config 2   "Synthetic 200 videos x 300 frames x 50 dets" (the bit-exact
+                 parity configuration)
     --config 5s  stand-in for the stress set on ONE GPU: 10 000 videos x 1 frame
                  x 1000 dets (10 M boxes; the top-300 cut per image is part of
                  the host flatten time reported in host_s)
 
 N > 1 (one process per GPU, RCCL): launched by the driver's torchrun, or --
 when WORLD_SIZE is not set -- by this script itself, which spawns N ranks and
-fails loudly if the box has fewer GPUs.  Every rank holds one shard of the
-configuration (weak scaling).  `--shard unit` (default, the partition
+fails loudly if the box has fewer GPUs.  `--scaling weak` (default): every rank
+holds one whole shard of the configuration, the data set grows with N.
+`--scaling strong`: ONE fixed set of the configuration split by video over the
+ranks (BASELINE.json Config 4).  `--shard unit` (default, the partition
 BASELINE.json names): a rank keeps its own videos, the per-detection records
 travel to the category owners in one all_to_all, are merged run by run and
 swept, and the result tables are assembled with one run-length packed
@@ -64,15 +69,22 @@ def parse():
     p.add_argument("--gpus", type=int, default=None)
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=3)
-    p.add_argument("--config", choices=sorted(CONFIGS), default="2")
+    p.add_argument("--config", choices=sorted(CONFIGS), default="3s")
+    p.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                   help="N > 1: a shard of the configuration per rank (weak) or "
+                        "one fixed set split by video over the ranks (strong)")
+    p.add_argument("--no-wallclock", action="store_true",
+                   help="skip the end-to-end leg (the set written as JSON files, "
+                        "the drop-in CLI run on them)")
     p.add_argument("--videos", type=int, default=None)
     p.add_argument("--frames", type=int, default=None)
     p.add_argument("--dets", type=int, default=None)
     p.add_argument("--cats", type=int, default=1203)
     p.add_argument("--seed", type=int, default=20240807)
-    p.add_argument("--cpu-sample-videos", type=int, default=200,
+    p.add_argument("--cpu-sample-videos", type=int, default=2000,
                    help="videos of the same workload timed through the C "
-                        "oracle for cpu_baseline (rank 0, N=1 only)")
+                        "oracle for cpu_baseline (rank 0, N=1 only); the whole "
+                        "set when it has no more than that")
     p.add_argument("--decimal", action="store_true",
                    help="decimal box coordinates, as real prediction files have: "
                         "the track level runs with the frame-order guard active")
@@ -177,13 +189,20 @@ def kernel_models(dp, ws):
     m["acc_emit_kernel"] = rows + live * table
     m["acc_fused_kernel"] = rows + live * table
     m["acc_finalize_kernel"] = live * table + K * A * (table + 8 * T)
+    fused = dp.kind == "lvis" and not dp.mask_iou
+    variants = {"match_group_kernel": "<true>" if fused else "<false>",
+                "match_kernel": "<true>" if fused else "<false>",
+                "match_big_kernel": "<true>" if fused else "<false>"}
     grids = {"seg_tile_kernel": dp.n_tiles * 256,
+             "match_group_kernel": (dp.n_groups + 3) // 4 * 256,
+             "lvis_ranges_kernel": (max(n_gt, n_dt) + 255) // 256 * 256,
+             "tao_ranges_kernel": (max(n_gt, n_dt) + 255) // 256 * 256,
              "seg_mpass_kernel": dp.n_tiles * 256,
              "seg_bucket_kernel": dp.n_tiles * 2 * 256,
              "seg_split_kernel": K * 256,
              "seg_kmerge_kernel": (n_dt + 255) // 256 * 256,
              "acc_finalize_kernel": ((K * A + 63) // 64) * ((T * R + 63) // 64) * 256}
-    return m, grids
+    return m, grids, variants
 
 
 def step_algorithmic_bytes(dpl, dpt):
@@ -194,11 +213,15 @@ def step_algorithmic_bytes(dpl, dpt):
             + (8 + 4 + 64) * dpt.n_dt + 17 * (dpl.n_cells + dpt.n_cells) + fixed)
 
 
-def pmc_traffic(kernel, grid, workload):
+def pmc_traffic(kernel, variant, grid, workload):
     """HBM bytes per launch of `kernel` from the newest committed PMC summary
     of THIS workload (profiles/*_pmc.json written by tools/prof_summary.py
     from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this very
-    command); None when no summary of the workload is present."""
+    command); None when no summary of the workload is present or the launch
+    cannot be told from the other evaluator's.  `variant`: the template
+    arguments of the instance this pass launches ("<true>"), `grid`: its grid
+    size in work items -- the image level and the track level launch the same
+    kernels, the summary keys them by full name and grid."""
     import glob
     import re
 
@@ -211,17 +234,64 @@ def pmc_traffic(kernel, grid, workload):
             d = json.load(f)
         if d.get("workload") != workload:
             continue
-        for name, ents in d["kernels"].items():
-            if not re.match(r"(void )?%s\b" % re.escape(kernel), name):
+        ents = []
+        for name, ee in d["kernels"].items():
+            mm = re.match(r"(?:void )?%s(<[^(]*>)?\(" % re.escape(kernel), name)
+            if not mm or (variant and mm.group(1) != variant):
                 continue
-            ents = [e for e in ents if e.get("hbm_bytes_corrected") is not None]
-            if grid is not None and len(ents) > 1:
-                ents = [e for e in ents if e.get("grid") == grid] or ents
-            if len(ents) == 1:
-                return {"bytes": ents[0]["hbm_bytes_corrected"],
-                        "source": os.path.basename(path)}
+            ents += [e for e in ee if e.get("hbm_bytes_corrected") is not None]
+        if grid is not None and len(ents) > 1:
+            ents = [e for e in ents if e.get("grid") == grid]
+        if len(ents) == 1:
+            return {"bytes": ents[0]["hbm_bytes_corrected"],
+                    "source": os.path.basename(path)}
         return None
     return None
+
+
+def wallclock_leg(gt, dt):
+    """tools/eval_on_tao_amodal.py (the plugin surface) on the workload written
+    out as prediction.json / annotation JSON: total seconds and the parse /
+    flatten / upload+plan / kernels / download / summarize split."""
+    import contextlib
+    import importlib.util
+    import io
+    import shutil
+    import tempfile
+    d = tempfile.mkdtemp(prefix="taoamd_wall_", dir="/tmp")
+    try:
+        gt_p, pr_p = os.path.join(d, "gt.json"), os.path.join(d, "pred.json")
+        t0 = time.perf_counter()
+        gt.write_json(gt_p)
+        dt.write_json(pr_p)
+        t_write = time.perf_counter() - t0
+        sizes = {"gt_MB": round(os.path.getsize(gt_p) / 1e6, 1),
+                 "pred_MB": round(os.path.getsize(pr_p) / 1e6, 1)}
+        os.environ["TAOAMD_TIMING"] = "1"
+        spec = importlib.util.spec_from_file_location(
+            "taoamd_cli", os.path.join(ROOT, "tools", "eval_on_tao_amodal.py"))
+        cli = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(cli)
+        from tao_amodal_amd.evaluation._core import TIMING
+        TIMING.clear()
+        text = io.StringIO()
+        t0 = time.perf_counter()
+        with contextlib.redirect_stdout(text), contextlib.redirect_stderr(io.StringIO()):
+            cli.main(["--track_result", pr_p, "--annotation", gt_p, "--output_log",
+                      os.path.join(d, "eval.log")])
+        total = time.perf_counter() - t0
+        lines = text.getvalue().splitlines()
+        return {"total": round(total, 3),
+                "split": {k: round(v, 3) for k, v in TIMING.items()},
+                "files": sizes, "write_files_s_not_counted": round(t_write, 2),
+                "what": "tools/eval_on_tao_amodal.py in this process on the same "
+                        "workload as JSON files: both evaluators, printed tables",
+                "first_line": lines[0] if lines else None}
+    except Exception as e:      # (a full /tmp must not lose the bench line)
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+    finally:
+        os.environ.pop("TAOAMD_TIMING", None)
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def main():
@@ -276,8 +346,25 @@ def main():
     if args.emulate:
         assert by_category and world == 1, "--emulate needs --force-dist on one GPU"
         data_world, data_rank = (int(x) for x in args.emulate.split(":"))
+    strong = use_dist and args.scaling == "strong"
     t0 = time.time()
-    if by_category:
+    if strong:
+        # ONE fixed set (the configuration as named), split by video: every
+        # rank generates it from the one seed and keeps a contiguous block of
+        # videos (by-video partition) or the whole set (by-category partition,
+        # where a rank evaluates its category block of everything)
+        gt, dt = synth(seed=args.seed, V=args.videos, F=args.frames, C=args.cats,
+                       dets_per_frame=args.dets, decimal=args.decimal)
+        if not by_category:
+            lo = args.videos * data_rank // data_world
+            hi = args.videos * (data_rank + 1) // data_world
+            keep = np.zeros(args.videos, dtype=bool)
+            keep[lo:hi] = True            # (synth: vid_id ascending)
+            mine = gt.vid_id[keep]
+            dt = dt.take(np.flatnonzero((dt.video_id >= mine[0])
+                                        & (dt.video_id <= mine[-1])))
+            gt = gt.select_videos(keep)
+    elif by_category:
         # weak scaling: the data set grows with the number of ranks (one shard
         # of the configuration per rank) and every rank evaluates its category
         # block of the WHOLE set, so the work per GPU stays fixed
@@ -401,8 +488,9 @@ def main():
     ms_per_step = elapsed / timed_steps * 1e3
     value = total_pairs * timed_steps / elapsed / 1e6
 
-    workload = ("%s: %d videos x %d frames x %d dets/frame, %d categories per "
-                "GPU%s; LVISEval + TaoEval passes"
+    workload = ("%s: %d videos x %d frames x %d dets/frame, %d categories " +
+                ("split by video over the GPUs" if strong else "per GPU") +
+                "%s; LVISEval + TaoEval passes"
                 % (CONFIGS[args.config]["name"] if (args.videos, args.frames, args.dets)
                    == tuple(CONFIGS[args.config][k] for k in ("videos", "frames", "dets"))
                    else "SYNTH custom", args.videos, args.frames, args.dets,
@@ -414,15 +502,15 @@ def main():
         stages = engine.time_stages(dpl, wsl, dpt, wst, reps=10)
         models = {}
         for side, dp, ws in (("lvis", dpl, wsl), ("tao", dpt, wst)):
-            mm, gg = kernel_models(dp, ws)
+            mm, gg, vv = kernel_models(dp, ws)
             for k, v in mm.items():
-                models[side + ":" + k] = (v, gg.get(k))
+                models[side + ":" + k] = (v, gg.get(k), vv.get(k))
         cands, kernels_ms = [], {}
         probed = max(1, len(range(PROBE_EVERY // 2, timed_steps, PROBE_EVERY)))
         for name, (tot, calls) in in_step.items():
             k_ms = tot / calls
             kernels_ms[name] = round(k_ms, 4)
-            alg, grid = models.get(name, (None, None))
+            alg, grid, variant = models.get(name, (None, None, None))
             ent = {"bound": "hbm", "kernel": name, "achieved": None,
                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
                    "traffic": None, "alg_bytes_per_launch": alg,
@@ -435,7 +523,7 @@ def main():
                 ach = alg / (k_ms * 1e-3) / 1e9
                 ent["achieved"] = round(ach, 2)
                 ent["frac"] = round(ach / HBM_PEAK_GBS, 5)
-                tr = pmc_traffic(name.split(":", 1)[1], grid, workload)
+                tr = pmc_traffic(name.split(":", 1)[1], variant, grid, workload)
                 if tr:
                     ent["traffic"] = tr["bytes"]
                     ent["traffic_source"] = tr["source"]
@@ -493,17 +581,24 @@ def main():
         exchange_ok = ok
 
     # ---- verification + CPU baseline (C oracle = "port"), rank 0, N=1
-    cpu, cpu_all, verified = None, None, None
+    cpu, cpu_all, verified, t_host_flatten = None, None, None, None
     if not use_dist and rank == 0 and not args.no_cpu:
         import orclib
         nv = min(args.cpu_sample_videos, args.videos)
         if args.frames * args.dets < 3000:        # stress shape: many tiny videos
             nv = min(args.videos, max(nv, 3000000 // max(args.frames * args.dets, 1)))
-        sgt, sdt = synth(seed=args.seed, V=nv, F=args.frames, C=args.cats,
-                         dets_per_frame=args.dets, decimal=args.decimal)
+        if nv == args.videos:
+            # the whole workload: the oracle works on host tables built by the
+            # numpy statement of the flatten stage from the same columns
+            sgt, sdt = gt, dt
+        else:
+            sgt, sdt = synth(seed=args.seed, V=nv, F=args.frames, C=args.cats,
+                             dets_per_frame=args.dets, decimal=args.decimal)
+        t0 = time.perf_counter()
         sfl = flatten.flatten_lvis(sgt, sdt)
         sdt.track_id, _ = flatten.make_track_ids_unique(sdt)
         sft = flatten.flatten_tao(sgt, sdt)
+        t_host_flatten = time.perf_counter() - t0
         orclib.set_threads(1)
         t0 = time.perf_counter()
         ol = orclib.run_flat(sfl, detail=False)
@@ -528,7 +623,20 @@ def main():
                    "cores": cores, "kind": "port", "equals_single_thread": bool(same),
                    "sample": what % (nv, args.videos, sp, t_all,
                                      "OpenMP over cells / categories, %d threads" % cores)}
-        if not args.no_verify:
+        if not args.no_verify and nv == args.videos:
+            # the tensors left behind by the timed (overlapped) steps, and the
+            # IoU matrix of the track level
+            torch.cuda.synchronize()
+            verified = bool(
+                np.array_equal(wsl.precision.cpu().numpy(), ol["precision"])
+                and np.array_equal(wsl.recall.cpu().numpy(), ol["recall"])
+                and np.array_equal(wst.precision.cpu().numpy(), ot["precision"])
+                and np.array_equal(wst.recall.cpu().numpy(), ot["recall"])
+                and (engine.guarded_pairs(dpt, wst) > 0     # (set-order bits there)
+                     or np.array_equal(wst.iou[:dpt.n_iou].cpu().numpy(), ot["iou"]))
+                and np.array_equal(wsl.num_gt.cpu().numpy(), ol["num_gt"])
+                and np.array_equal(wst.num_gt.cpu().numpy(), ot["num_gt"]))
+        elif not args.no_verify:
             gl = engine.evaluate_flat(sfl, dev)
             gtt = engine.evaluate_flat(sft, dev)
             verified = bool(
@@ -540,13 +648,6 @@ def main():
                 and np.array_equal(gtt["matched"], ot["matched"])
                 and np.array_equal(gtt["precision"], ot["precision"])
                 and np.array_equal(gtt["recall"], ot["recall"]))
-            if nv == args.videos:
-                # the tensors left behind by the timed (overlapped) steps
-                verified = verified and bool(
-                    np.array_equal(wsl.precision.cpu().numpy(), ol["precision"])
-                    and np.array_equal(wsl.recall.cpu().numpy(), ol["recall"])
-                    and np.array_equal(wst.precision.cpu().numpy(), ot["precision"])
-                    and np.array_equal(wst.recall.cpu().numpy(), ot["recall"]))
 
     # ---- decimal coordinates: a sample of the same workload through the Python
     # oracle in the reference's own frame order (CPython sets), against the HIP
@@ -572,12 +673,20 @@ def main():
             "recall_equal": bool(np.array_equal(
                 gg["recall"].reshape(po["recall"].shape), po["recall"]))}
 
+    # ---- the metric's second half: end-to-end wall-clock of the drop-in CLI
+    # on this very workload as FILES (JSON -> parse -> tables -> kernels ->
+    # summaries -> printed text).  Writing the files is not part of it.
+    wall = None
+    if not use_dist and rank == 0 and not args.no_wallclock:
+        wall = wallclock_leg(gt, dt)
+
     if rank == 0:
         out = {
             "metric": "box-pair IoU+match throughput", "value": round(value, 3),
             "unit": "Mpair/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling if use_dist else "weak",
+            "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload,
                        "pairs_per_step": total_pairs,
@@ -597,6 +706,7 @@ def main():
             else "4 (image-level || track-level, ranges/sort || IoU) + RCCL all_gather" if use_dist
             else "4 (image-level || track-level, ranges/sort || IoU)",
             "host_launch_ms_per_step": round(host_ms, 4),
+            "wall_clock_s": wall,
             "bit_exact_vs_oracle": verified,
             "frame_order_guard": {
                 "exact_terms": bool(dpt.exact_terms),
@@ -617,7 +727,9 @@ def main():
                                      if by_category else None),
             "host_s": {"generate": round(t_gen, 2), "flatten": round(t_flat, 3),
                        "flatten_on": "host (numpy)" if by_category else "device",
-                       "upload": round(t_h2d, 3)},
+                       "upload": round(t_h2d, 3),
+                       "numpy_flatten_for_the_oracle": (
+                           round(t_host_flatten, 2) if cpu else None)},
         }
         real_stdout.write(json.dumps(out) + "\n")
         real_stdout.flush()

@@ -56,6 +56,19 @@ int taoamd_gt_array(void *handle, const char *name, const void **ptr,
                     int64_t *count, int *elem);
 void taoamd_gt_free(void *handle);
 
+/* ---- the inverse: columns -> JSON files (synthetic sets written out for the
+ * wall-clock runs of the CLI; csrc/jsonwrite.cpp).  Doubles are written as
+ * the shortest text that parses back to the same value; track_id / video_id
+ * may be NULL (keys omitted).  taoamd_gt_write takes the 28 arrays of
+ * GTColumns.FIELDS in that order with their element counts.  Returns 0, 1 (bad
+ * argument), 2 (cannot open), 3 (write error). */
+int taoamd_pred_write(const char *path, int64_t n, const int64_t *image_id,
+                      const int64_t *category_id, const double *bbox,
+                      const double *score, const int64_t *track_id,
+                      const int64_t *video_id);
+int taoamd_gt_write(const char *path, const void *const *arrays,
+                    const int64_t *counts, int32_t n_fields);
+
 /* ---- host-side sort used while the cell tables are built
  * order[] = np.lexsort((arange(n), -score, key)) -- the (cell, descending
  * score, stable) order of lvis_amodal/eval.py:168-174 and the top-300

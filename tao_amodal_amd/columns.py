@@ -17,11 +17,22 @@ Ragged ``neg_category_ids`` / ``not_exhaustive_category_ids`` lists are kept
 as CSR (offsets + values).
 """
 import json
+import os
 
 import numpy as np
 
 
 FREQ_MISSING, FREQ_OTHER = ord("?"), 0xFF
+
+
+def _ingest_lib():
+    import ctypes as C
+    so = os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                      "libtao_amodal_ingest.so")
+    lib = C.CDLL(so)
+    lib.taoamd_pred_write.argtypes = [C.c_char_p, C.c_int64] + [C.c_void_p] * 6
+    lib.taoamd_gt_write.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_int32]
+    return lib
 
 
 def _freq_byte(cat):
@@ -203,6 +214,61 @@ class GTColumns:
                 kw[f] = cat(f)
         return cls(**kw)
 
+    def write_json(self, path):
+        """The annotation file written by the native writer (csrc/
+        jsonwrite.cpp): what ``json.dump(self.to_json())`` holds, without the
+        dicts -- for sets of millions of annotations."""
+        import ctypes as C
+        lib = _ingest_lib()
+        arrs = [np.ascontiguousarray(getattr(self, f)) for f in self.FIELDS]
+        want = {"cat_freq": np.uint8, "trk_ignore": np.uint8, "ann_oof": np.uint8,
+                "ann_ignore": np.uint8, "img_frame": np.float64,
+                "ann_bbox": np.float64, "ann_area": np.float64,
+                "ann_vis": np.float64}
+        arrs = [np.ascontiguousarray(a, dtype=want.get(f, np.int64))
+                for f, a in zip(self.FIELDS, arrs)]
+        ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        counts = (C.c_int64 * len(arrs))(*[a.size for a in arrs])
+        rc = lib.taoamd_gt_write(os.fsencode(path), ptrs, counts, len(arrs))
+        if rc:
+            raise OSError("taoamd_gt_write(%s) failed: %d" % (path, rc))
+
+    def select_videos(self, keep):
+        """The annotation set of the videos `keep` (boolean mask over
+        ``vid_id``): their images, tracks and annotations, the category table
+        whole.  (Shards of one fixed set: the strong-scaling bench.)"""
+        keep = np.asarray(keep, dtype=bool)
+        vids = np.sort(self.vid_id[keep])
+
+        def of(col):
+            pos = np.searchsorted(vids, col)
+            pos[pos == len(vids)] = 0
+            return vids[pos] == col if len(vids) else np.zeros(len(col), bool)
+
+        def csr(off, val, m):
+            lens = np.diff(off)[m]
+            new_off = np.zeros(len(lens) + 1, dtype=np.int64)
+            np.cumsum(lens, out=new_off[1:])
+            idx = np.repeat(off[:-1][m] - new_off[:-1], lens) + np.arange(new_off[-1])
+            return new_off, val[idx]
+        mi, mt = of(self.img_vid), of(self.trk_vid)
+        imgs = np.sort(self.img_id[mi])
+        pos = np.searchsorted(imgs, self.ann_img)
+        pos[pos == len(imgs)] = 0
+        ma = imgs[pos] == self.ann_img if len(imgs) else np.zeros(len(self.ann_img), bool)
+        kw = dict(cat_id=self.cat_id, cat_freq=self.cat_freq, cat_merged=self.cat_merged)
+        kw["vid_id"] = self.vid_id[keep]
+        kw["vid_neg_off"], kw["vid_neg"] = csr(self.vid_neg_off, self.vid_neg, keep)
+        kw["vid_nel_off"], kw["vid_nel"] = csr(self.vid_nel_off, self.vid_nel, keep)
+        kw["img_neg_off"], kw["img_neg"] = csr(self.img_neg_off, self.img_neg, mi)
+        kw["img_nel_off"], kw["img_nel"] = csr(self.img_nel_off, self.img_nel, mi)
+        for f in self.FIELDS:
+            if f in kw:
+                continue
+            m = mi if f.startswith("img_") else mt if f.startswith("trk_") else ma
+            kw[f] = getattr(self, f)[m]
+        return GTColumns(**kw)
+
     def to_json(self):
         """Inverse of from_json (used by the synthetic generator and tests)."""
         def num(x):
@@ -351,6 +417,20 @@ class DTColumns:
 
     def take(self, idx):
         return DTColumns(**{f: getattr(self, f)[idx] for f in self.FIELDS})
+
+    def write_json(self, path):
+        """The prediction list written by the native writer (csrc/
+        jsonwrite.cpp)."""
+        lib = _ingest_lib()
+        i64 = lambda a: np.ascontiguousarray(a, dtype=np.int64)
+        cols = [i64(self.image_id), i64(self.category_id),
+                np.ascontiguousarray(self.bbox, dtype=np.float64),
+                np.ascontiguousarray(self.score, dtype=np.float64),
+                i64(self.track_id), i64(self.video_id)]
+        rc = lib.taoamd_pred_write(os.fsencode(path), len(cols[0]),
+                                   *[c.ctypes.data for c in cols])
+        if rc:
+            raise OSError("taoamd_pred_write(%s) failed: %d" % (path, rc))
 
     @classmethod
     def concat(cls, parts):

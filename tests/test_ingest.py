@@ -252,3 +252,42 @@ def test_reader_corner_cases_of_json_load(tmp_path):
         bad.write_text(text)
         with pytest.raises(ValueError):
             DTColumns.from_file_native(str(bad))
+
+
+def test_native_writer_round_trips_the_columns(tmp_path):
+    """csrc/jsonwrite.cpp: columns -> JSON text -> the same columns, through
+    the native reader AND through json.load (decimal boxes, merged categories,
+    shuffled ids, ignore flags)."""
+    import json
+    from tao_amodal_amd.synth import synth
+    gt, dt = synth(seed=9, V=3, F=7, C=14, dets_per_frame=6, n_present=4,
+                   decimal=True, shuffle_image_ids=True, n_merged=2)
+    gt.trk_ignore[::5] = 1
+    gt.ann_ignore[::7] = 1
+    dt.score[:3] = [1.0, 0.0, 1e-7]
+    gp, pp = str(tmp_path / "gt.json"), str(tmp_path / "pred.json")
+    gt.write_json(gp)
+    dt.write_json(pp)
+    for g2 in (GTColumns.from_file_native(gp), GTColumns.from_json(json.load(open(gp)))):
+        for f in GTColumns.FIELDS:
+            assert np.array_equal(getattr(g2, f), getattr(gt, f)), f
+    for d2 in (DTColumns.from_file_native(pp), DTColumns.from_json(json.load(open(pp)))):
+        for f in DTColumns.FIELDS:
+            assert np.array_equal(getattr(d2, f), getattr(dt, f)), f
+    assert json.load(open(gp)) == gt.to_json()
+    assert json.load(open(pp)) == dt.to_json()
+
+
+def test_select_videos_is_the_subset_of_the_annotation_file():
+    from tao_amodal_amd.synth import synth
+    gt, _ = synth(seed=9, V=6, F=5, C=14, dets_per_frame=4, n_present=4)
+    keep = np.array([0, 1, 0, 0, 1, 1], bool)
+    sub = gt.select_videos(keep)
+    j = gt.to_json()
+    vids = set(gt.vid_id[keep].tolist())
+    want = dict(j, videos=[v for v in j["videos"] if v["id"] in vids],
+                images=[i for i in j["images"] if i["video_id"] in vids],
+                tracks=[t for t in j["tracks"] if t["video_id"] in vids])
+    imgs = {i["id"] for i in want["images"]}
+    want["annotations"] = [a for a in j["annotations"] if a["image_id"] in imgs]
+    assert sub.to_json() == want
