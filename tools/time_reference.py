@@ -98,7 +98,7 @@ def main():
                    "container, pairs counted at mask_utils.iou / "
                    "bb_intersect_union; 'port' = oracle/tao_oracle.c, 1 thread, "
                    "same inputs",
-           "host": {"cpu": open("/proc/cpuinfo").read().split("model name")[1].split("\\n")[0].strip(": \\t"),
+           "host": {"cpu": open("/proc/cpuinfo").read().split("model name")[1].split("\n")[0].strip(": \t"),
                     "python": sys.version.split()[0]},
            "workloads": {}}
     work = "/tmp/taoamd_time_reference"
