@@ -488,9 +488,9 @@ def main():
     ms_per_step = elapsed / timed_steps * 1e3
     value = total_pairs * timed_steps / elapsed / 1e6
 
-    workload = ("%s: %d videos x %d frames x %d dets/frame, %d categories " +
-                ("split by video over the GPUs" if strong else "per GPU") +
-                "%s; LVISEval + TaoEval passes"
+    workload = (("%s: %d videos x %d frames x %d dets/frame, %d categories " +
+                 ("split by video over the GPUs" if strong else "per GPU") +
+                 "%s; LVISEval + TaoEval passes")
                 % (CONFIGS[args.config]["name"] if (args.videos, args.frames, args.dets)
                    == tuple(CONFIGS[args.config][k] for k in ("videos", "frames", "dets"))
                    else "SYNTH custom", args.videos, args.frames, args.dets,

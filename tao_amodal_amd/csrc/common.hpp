@@ -124,6 +124,21 @@ __device__ __forceinline__ double pr_value(uint64_t p)
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
 
+// XCD-aware block order.  The dispatcher deals workgroups to the 8 XCDs round
+// robin (block b runs on XCD b % 8 -- observed, MI355X_MICROARCH.md; a matter
+// of speed only, nothing here depends on it for correctness).  Kernels whose
+// consecutive blocks work on one category -- scattered 8..16-byte stores into
+// that category's segment of the sorted layout -- want those blocks behind ONE
+// L2, so that a line is completed there and leaves for HBM once instead of as
+// eight partial lines from eight L2s.  xcd_block() renumbers: XCD x gets the
+// x-th contiguous eighth of the logical blocks.  Bijective for any n.
+#define N_XCD 8u
+__device__ __forceinline__ uint32_t xcd_block(uint32_t b, uint32_t n)
+{
+    const uint32_t x = b % N_XCD, q = n / N_XCD, r = n % N_XCD;
+    return x * q + (x < r ? x : r) + b / N_XCD;
+}
+
 __device__ __forceinline__ double readlane_f64(double v, int lane)
 {
     int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);

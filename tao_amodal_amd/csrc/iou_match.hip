@@ -14,6 +14,8 @@
 //                       per-lane "taken" bitsets staged in LDS
 //
 // HBM-bound integer/compare work: nothing here is shaped into a GEMM.
+#include <cstdlib>
+
 #include "common.hpp"
 
 using namespace taoamd;
@@ -188,6 +190,7 @@ struct MatchArgs {
     const int32_t *groups;    // [n_groups][4] first detection, count, first GT, count of a run
     const int32_t *singles;   // [n_singles] cells handled one per wavefront
     int32_t n_groups, n_singles;
+    int32_t xcd;              // blocks renumbered per XCD (xcd_block)
 };
 
 #define GRP_GCAP 8   // most GTs of one cell inside a multi-cell group
@@ -313,7 +316,10 @@ __global__ __launch_bounds__(256) void match_group_kernel(MatchArgs a, IouThr th
     __shared__ double s_iou[4][WAVE * GRP_GCAP];
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t item = (int64_t)blockIdx.x * 4 + wave;
+    // runs are category-major and a run's rows are scattered into its
+    // category's segment: consecutive runs behind one L2 (common.hpp)
+    const uint32_t blk = a.xcd ? xcd_block(blockIdx.x, gridDim.x) : blockIdx.x;
+    const int64_t item = (int64_t)blk * 4 + wave;
     if (item >= (int64_t)a.n_groups * a.n_words) return;
     const int64_t grp = item / a.n_words;
     const int word = (int)(item - grp * a.n_words);
@@ -765,6 +771,8 @@ extern "C" int taoamd_match(int64_t n_cells, const int32_t *cell_dt_off,
     if (a.out_stride < a.n_words) return TAOAMD_ERR_ARG;
     a.dt_group = dt_group; a.groups = groups; a.n_groups = planned ? n_groups : 0;
     a.singles = planned ? singles : nullptr; a.n_singles = planned ? n_singles : 0;
+    static const int xcd_env = getenv("TAOAMD_XCD") ? atoi(getenv("TAOAMD_XCD")) : 1;
+    a.xcd = xcd_env;
     hipStream_t s = (hipStream_t)stream;
     if (planned && n_groups > 0) {
         const unsigned gb = (unsigned)(((int64_t)n_groups * a.n_words + 3) / 4);

@@ -9,7 +9,7 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$R/gpurun_out/prof_$PREFIX
 rm -rf $OUT; mkdir -p $OUT $R/profiles
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 20 --warmup 5 --no-cpu $@"
+CMD="python $R/bench.py --steps 20 --warmup 5 --no-cpu --no-wallclock $@"
 python $R/bench.py --steps 20 --warmup 5 "$@" > $OUT/bench.json 2> $OUT/bench.err
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/ktr -o ktr -- $CMD > /dev/null 2>&1
 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/fetch -o fetch -- $CMD > /dev/null 2>&1
