@@ -498,6 +498,36 @@ int taoamd_sort_by_cat_score(int64_t n, const int32_t *dt_cat,
                              int32_t *dst, void *workspace,
                              size_t workspace_bytes, void *stream);
 
+/* The same order by SAMPLE SORT (round 3; what the evaluator passes call):
+ * every category -- or chunk of TAOAMD_SORT_CHUNK elements of a longer one --
+ * is cut into buckets of ~416 elements by splitters taken from a sorted sample,
+ * one pass scatters the elements into their buckets, one wavefront sorts a
+ * bucket in registers (bitonic network over <= 1024 (key, index) pairs) and
+ * writes order / dst; categories longer than a chunk are finished by the
+ * merge-path passes of taoamd_sort_segments.  Replaces np.argsort(-dt_scores,
+ * kind="mergesort") of lvis_amodal/eval.py:353-361 / tao_amodal/eval.py:508-518.
+ * The plan depends on cat_off alone: taoamd_sort_plan_host (host, synchronous;
+ * call with chunks == NULL for sizes[0..4] = chunks, split chunks, scatter
+ * tiles, buckets, 1 if some category is longer than a chunk; then with buffers
+ * of 8 * sizes[0], sizes[1], sizes[2], sizes[3] int32) -- the tables are
+ * uploaded by the caller and stay valid while cat_off does.  tile_off / n_tiles
+ * as for taoamd_sort_segments (used by the merge passes only).
+ * taoamd_sort_sampled_cap_limit: test seam -- buckets beyond `limit` elements
+ * take the overflow path (ranking by counting); 0 restores the default. */
+#define TAOAMD_SORT_CHUNK (16 * 2816)
+int taoamd_sort_plan_host(int32_t n_cat, const int32_t *cat_off_host, int64_t *sizes,
+                          int32_t *chunks, int32_t *split_list, int32_t *stile_chunk,
+                          int32_t *bucket_chunk);
+size_t taoamd_sort_sampled_workspace(int64_t n, int64_t n_buckets, int32_t merge);
+int taoamd_sort_sampled_cap_limit(int32_t limit);
+int taoamd_sort_sampled(int64_t n, int32_t n_cat, const int32_t *cat_off,
+                        const int32_t *tile_off, int32_t n_tiles, int32_t max_segment,
+                        const double *dt_score, int32_t n_chunks, const int32_t *chunks,
+                        int32_t n_split, const int32_t *split_list, int32_t n_stiles,
+                        const int32_t *stile_chunk, int32_t n_buckets,
+                        const int32_t *bucket_chunk, int32_t *order, int32_t *dst,
+                        void *workspace, size_t workspace_bytes, void *stream);
+
 /* Same result for detections that are already grouped by category (the
  * category-major cell tables).  cat_off (int32[n_cat+1], device) delimits the
  * runs; every run is cut into tiles of TAOAMD_SEGMENT_TILE elements,

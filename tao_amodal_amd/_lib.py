@@ -38,6 +38,12 @@ SIGNATURES = {
     "taoamd_sort_segments_workspace": (_sz, [_i64]),
     "taoamd_sort_segments": (C.c_int, [_i64, _i32, _vp, _vp, _i32, _i32, _vp,
                                        _vp, _vp, _vp, _vp, _sz, _vp]),
+    "taoamd_sort_plan_host": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "taoamd_sort_sampled_workspace": (_sz, [_i64, _i64, _i32]),
+    "taoamd_sort_sampled_cap_limit": (C.c_int, [_i32]),
+    "taoamd_sort_sampled": (C.c_int, [_i64, _i32, _vp, _vp, _i32, _i32, _vp, _i32, _vp,
+                                      _i32, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp,
+                                      _sz, _vp]),
     "taoamd_track_iou": (C.c_int, [_i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp,
                                    _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
     "taoamd_track_iou_planned": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp,

@@ -17,6 +17,10 @@
 // Per pass: (1) per-block digit histogram, (2) one block per digit scans its
 // row of block counts, (3) scatter with wave-level match-any ranking
 // (8 ballots per 64 elements) so that equal digits keep their order.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+
 #include "common.hpp"
 
 using namespace taoamd;
@@ -961,6 +965,724 @@ extern "C" int taoamd_sort_segments(int64_t n, int32_t n_cat,
             for (int p = 0; p < passes; p++)
                 TAO_TIMED("seg_mpass_kernel", s, seg_mpass_kernel<<<(unsigned)n_tiles, 256, 0, s>>>(a, p, p == passes - 1, longer_than));
         }
+    }
+    TAO_LAUNCH_CHECK();
+    return TAOAMD_OK;
+}
+
+// ===========================================================================
+// SAMPLE SORT of the categories (round 3): one pass moves an element next to
+// its final neighbours, one wavefront finishes a bucket in registers.
+//
+// The tile + bucket path above sorts every element of a long category twice
+// in LDS (its tile, then its splitter bucket): 0.67 + 0.11 + 0.48 ms of a
+// 2.28 ms step at 2000 videos, the tile sort at 6 % of HBM speed.  Here:
+//
+//   ss_split_kernel    one workgroup per chunk (a category, or SS_CHUNK elements
+//                      of a longer one): SS_OVER jittered samples per bucket,
+//                      sorted in LDS (<= 1760 of them); every SS_OVER-th is a
+//                      splitter -- an actual element (key, index), so equal
+//                      scores split by their input order;
+//   ss_scatter_kernel  one workgroup per 2816 elements: bucket of an element =
+//                      number of splitters before it (binary search in LDS), its
+//                      slot claimed with an LDS counter per tile and one global
+//                      cursor add per (tile, bucket) -- no order is kept, none
+//                      is needed: (key, index) is a total order;
+//   ss_sort_kernel     one wavefront per bucket (<= SS_CAP = 1024 elements, 416
+//                      on average): bitonic network over 1..16 elements per lane
+//                      held in registers, partners fetched with DPP-class lane
+//                      exchanges; writes order[] / dst[] at the bucket's base =
+//                      the category's start + the counts of the buckets before it.
+//
+// A chunk of <= SS_DIRECT elements is ONE bucket read straight from the scores
+// (the whole track level: ~30 .. 300 tracks per category).  Categories longer
+// than SS_CHUNK = 8 tiles are sorted chunk by chunk into the merge buffers and
+// finished by the merge-path passes above (seg_mpass_kernel from pass 3 on).
+//
+// Bucket sizes: SS_OVER = 32 uniformly placed samples per bucket make a
+// bucket's size Gamma(32)-distributed around SS_TARGET; SS_CAP is 8 sigma out
+// (~1e-11 per bucket).  A bucket that does overflow is not lost: every
+// wavefront of its chunk sees the cursor beyond the limit and ranks its slice
+// of the chunk by counting, straight from the scores (slow, correct).
+// ===========================================================================
+#define SS_CAP 1024
+#define SS_FAST 512                    // most elements the one-word network takes
+#define SS_TARGET 352
+#define SS_OVER 32
+#define SS_DIRECT 1024
+#define SS_CHUNK (16 * SEG_TILE)       // 45056 = SS_MAXB * SS_TARGET
+#define SS_MAXB 128
+#define SS_HALF_CHUNK (8 * SEG_TILE)   // chunks up to here: SS_OVER samples per bucket, beyond: half
+#define SS_FIRST_MERGE_PASS 4          // log2(SS_CHUNK / SEG_TILE)
+
+struct SsChunk {                       // 32 bytes
+    int32_t begin, n;                  // elements [begin, begin + n)
+    int32_t bucket0, n_buckets;
+    int32_t stile0;                    // first scatter tile (split chunks)
+    int32_t final;                     // 1: order / dst, 0: merge buffers
+    int32_t cat, pad;
+};
+
+struct SsArgs {
+    const double *score;
+    const SsChunk *chunks;
+    const int32_t *split_list, *stile_chunk, *bucket_chunk;
+    int32_t *cursor;                   // [n_buckets] elements claimed
+    uint64_t *spl_key;                 // [n_buckets] splitter ahead of bucket b (b >= 1 in its chunk)
+    int32_t *spl_idx;
+    uint64_t *slot_key;                // [n_buckets][SS_CAP]
+    int32_t *slot_idx;
+    uint64_t *key_out;                 // merge buffers of the chunked categories
+    int32_t *idx_out;
+    int32_t *order, *dst;
+    int32_t *redo;                     // buckets left to ss_redo_kernel, redo[-1] = their number
+    int32_t n_buckets, n_stiles, cap_limit;
+    int32_t dbg;                       // ablation switches (TAOAMD_SS_DBG, timing experiments)
+};
+
+static int g_ss_cap_limit = SS_CAP;
+
+// samples per bucket: SS_OVER, half of it in the long chunks (<= 2048 samples
+// either way: one wavefront sorts them, 32 per lane)
+__host__ __device__ inline int ss_over(int32_t n) { return n > SS_HALF_CHUNK ? SS_OVER / 2 : SS_OVER; }
+
+__device__ __forceinline__ uint32_t ss_mix(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+
+__device__ __forceinline__ uint64_t ss_shfl_xor64(uint64_t v, int j)
+{
+    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, j, WAVE);
+    const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), j, WAVE);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// ---- one-word bitonic network ------------------------------------------------
+// What is sorted is ONE 64-bit word per element,
+//     1 << 61 | ((key - lo) >> shift) << 16 | (index - chunk begin)
+// (lo = the bucket's smallest key, shift so that the key part fits 45 bits, a
+// chunk has < 2^16 elements; ss_sort_bucket), which read as fp64 are positive normal numbers in
+// [2^-511, 2^-510): v_min_f64 / v_max_f64 return one of their operands bit for
+// bit, so a compare-exchange is two VALU instructions and no select -- against
+// ~11 for a (64-bit key, 32-bit index) pair with its three conditional moves.
+// Equal keys are ordered by the index bits: exactly the stable order.  Only
+// when shift > 0 can two different keys share a key part; the sorted bucket is
+// then checked against the full keys and, if a pair is out of order, ranked
+// again with full comparisons (ss_rank_bucket).
+//
+// Layout: element e = lane * R + r.  "Flip" form of the network -- every merge
+// starts with the mirror partner e ^ (size - 1), then e ^ j for j = size / 4
+// .. 1, all ascending -- so partners below R are register pairs of one lane
+// with compile-time roles, above that lane exchanges (xor / mirror masks).
+__device__ __forceinline__ double ss_fmin(double a, double b)
+{
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double ss_fmax(double a, double b)
+{
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double ss_shfl_xor_f64(double v, int m)
+{
+    const int lo = __shfl_xor(__double2loint(v), m, WAVE);
+    const int hi = __shfl_xor(__double2hiint(v), m, WAVE);
+    return __hiloint2double(hi, lo);
+}
+
+template <int R>
+__device__ __forceinline__ void ss_bitonic_packed(double (&p)[R], int lane)
+{
+    // (loops over the exponents: trip counts the unroller can see)
+    constexpr int LOG_N = 6 + (R == 1 ? 0 : R == 2 ? 1 : R == 4 ? 2 : R == 8 ? 3 : R == 16 ? 4 : 5);
+#pragma unroll
+    for (int ls = 1; ls <= LOG_N; ls++) {
+        const int size = 1 << ls;
+        if (size <= R) {
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int r2 = r ^ (size - 1);
+                if (r < r2) {
+                    const double lo = ss_fmin(p[r], p[r2]), hi = ss_fmax(p[r], p[r2]);
+                    p[r] = lo;
+                    p[r2] = hi;
+                }
+            }
+        } else {
+            const int m = size / R - 1;
+            const bool lower = (lane & (size / R / 2)) == 0;
+            if (R == 1) {
+                const double o = ss_shfl_xor_f64(p[0], m);
+                p[0] = ((o < p[0]) == lower) ? o : p[0];
+            }
+            // my register r meets the partner lane's register R - 1 - r
+#pragma unroll
+            for (int r = 0; r < R / 2; r++) {
+                const double o1 = ss_shfl_xor_f64(p[R - 1 - r], m);
+                const double o2 = ss_shfl_xor_f64(p[r], m);
+                // (take the partner's if it is the smaller one and I am the lower
+                // lane, or the larger one and I am the upper: compare + select)
+                p[r] = ((o1 < p[r]) == lower) ? o1 : p[r];
+                p[R - 1 - r] = ((o2 < p[R - 1 - r]) == lower) ? o2 : p[R - 1 - r];
+            }
+        }
+#pragma unroll
+        for (int lj = ls - 2; lj >= 0; lj--) {
+            const int j = 1 << lj;
+            if (j >= R) {
+                const int m = j / R;
+                const bool lower = (lane & m) == 0;
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const double o = ss_shfl_xor_f64(p[r], m);
+                    p[r] = ((o < p[r]) == lower) ? o : p[r];
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    if ((r & j) == 0) {
+                        const double lo = ss_fmin(p[r], p[r | j]), hi = ss_fmax(p[r], p[r | j]);
+                        p[r] = lo;
+                        p[r | j] = hi;
+                    }
+                }
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ uint64_t ss_shfl_up64(uint64_t v)
+{
+    const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)v, 1, WAVE);
+    const uint32_t hi = (uint32_t)__shfl_up((int)(uint32_t)(v >> 32), 1, WAVE);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t ss_shfl_down64(uint64_t v)
+{
+    const uint32_t lo = (uint32_t)__shfl_down((int)(uint32_t)v, 1, WAVE);
+    const uint32_t hi = (uint32_t)__shfl_down((int)(uint32_t)(v >> 32), 1, WAVE);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t ss_wave_min_u64(uint64_t v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint64_t o = ss_shfl_xor64(v, off);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ uint64_t ss_wave_max_u64(uint64_t v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint64_t o = ss_shfl_xor64(v, off);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+#define SS_SPLIT_KEY_BITS 45              // ss_split_chunk: key part | position in the chunk
+#define SS_IDX_BITS 16
+#define SS_PAD 0x3fffffffffffffffull       // sorts last; still a normal fp64
+__device__ __forceinline__ int ss_shift_for(uint64_t range)
+{
+    const int bits = range ? 64 - __clzll((long long)range) : 0;
+    return bits > 45 ? bits - 45 : 0;           // SS_KEY_BITS
+}
+__device__ __forceinline__ double ss_pack(uint64_t key, uint64_t lo, int shift, int32_t rel)
+{
+    return __longlong_as_double((long long)((1ull << 61) | (((key - lo) >> shift) << SS_IDX_BITS) |
+                                            (uint64_t)rel));
+}
+
+// Splitters of one chunk: its samples sorted by ONE wavefront in registers.
+// The samples only have to be ordered well enough to cut the chunk evenly: key
+// parts that tie after the shift are not repaired here (the scatter kernel
+// checks that the splitters ascend and hands the chunk to the counting path if
+// not -- scores that differ in their last 19 bits only).
+template <int R>
+__device__ __forceinline__ void ss_split_chunk(const SsArgs &a, const SsChunk &c, int lane)
+{
+    const int32_t S = ss_over(c.n), B = c.n_buckets, m = S * B;
+    const int32_t stride = c.n / m;
+    // (the top 45 key bits -- sign, exponent, 33 bits of mantissa -- are plenty
+    // to cut a chunk evenly; no pass over the samples for their range)
+    double p[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int j = lane * R + r;               // samples in ascending position
+        p[r] = __longlong_as_double((long long)SS_PAD);
+        if (j < m) {
+            const int32_t rel = j * stride +
+                (int32_t)(ss_mix((uint32_t)j * 0x9e3779b9u ^ (uint32_t)c.begin) % (uint32_t)stride);
+            p[r] = ss_pack(desc_key(a.score[c.begin + rel]), 0, 64 - SS_SPLIT_KEY_BITS, rel);
+        }
+    }
+    ss_bitonic_packed<R>(p, lane);
+    // splitter b = the sample of rank b * S - 1 (b = 1 .. B - 1)
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int q = lane * R + r + 1;
+        if (q % S == 0 && q / S < B) {
+            const int32_t at = c.begin + (int32_t)((uint64_t)__double_as_longlong(p[r]) &
+                                                   ((1u << SS_IDX_BITS) - 1));
+            a.spl_key[c.bucket0 + q / S] = desc_key(a.score[at]);
+            a.spl_idx[c.bucket0 + q / S] = at;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void ss_split_kernel(SsArgs a, int32_t n_split)
+{
+    const int lane = lane_id();
+    const int32_t w = (int32_t)blockIdx.x * 4 + (int32_t)(threadIdx.x >> 6);
+    if (w >= n_split) return;
+    const SsChunk c = a.chunks[a.split_list[w]];
+    const int32_t m = ss_over(c.n) * c.n_buckets;  // <= 2048 samples
+    if (m <= 128) ss_split_chunk<2>(a, c, lane);
+    else if (m <= 256) ss_split_chunk<4>(a, c, lane);
+    else if (m <= 512) ss_split_chunk<8>(a, c, lane);
+    else if (m <= 1024) ss_split_chunk<16>(a, c, lane);
+    else ss_split_chunk<32>(a, c, lane);
+}
+
+__global__ __launch_bounds__(SEG_THREADS) void ss_scatter_kernel(SsArgs a)
+{
+    __shared__ uint64_t s_key[SS_MAXB];
+    __shared__ int32_t s_idx[SS_MAXB];
+    __shared__ int32_t s_cnt[SS_MAXB], s_base[SS_MAXB];
+    // a chunk's tiles behind one L2: the buckets they fill are shared
+    const uint32_t blk = xcd_block(blockIdx.x, gridDim.x);
+    const SsChunk c = a.chunks[a.stile_chunk[blk]];
+    const int32_t B = c.n_buckets;
+    const int32_t t0 = c.begin + ((int32_t)blk - c.stile0) * SEG_TILE;
+    const int32_t t1 = min(t0 + SEG_TILE, c.begin + c.n);
+    if (threadIdx.x < SS_MAXB) {
+        const int b = threadIdx.x;
+        s_cnt[b] = 0;
+        if (b >= 1 && b < B) {
+            s_key[b] = a.spl_key[c.bucket0 + b];
+            s_idx[b] = a.spl_idx[c.bucket0 + b];
+        }
+    }
+    __syncthreads();
+    // the splitters must ascend (ss_split_chunk sorts the samples by a shortened
+    // key): if two are out of order the chunk goes to the counting path
+    if (threadIdx.x >= 1 && (int)threadIdx.x + 1 < B) {
+        const int b = threadIdx.x;
+        const bool ok = s_key[b] < s_key[b + 1] ||
+                        (s_key[b] == s_key[b + 1] && s_idx[b] < s_idx[b + 1]);
+        if (!ok) atomicMax(&a.cursor[c.bucket0], 1 << 30);
+    }
+    uint64_t kr[SEG_ROUNDS];
+    int32_t br[SEG_ROUNDS], rr[SEG_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < SEG_ROUNDS; r++) {
+        const int32_t i = t0 + r * SEG_THREADS + (int32_t)threadIdx.x;
+        br[r] = -1;
+        if (i < t1) {
+            const uint64_t k = desc_key(a.score[i]);
+            // splitters 1 .. B-1 that precede (k, i); an element equal to a
+            // splitter closes the lower bucket
+            int lo = 1, hi = B;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                const uint64_t sk = s_key[mid];
+                const bool before = sk < k || (sk == k && s_idx[mid] < i);
+                if (before) lo = mid + 1; else hi = mid;
+            }
+            kr[r] = k;
+            br[r] = lo - 1;
+            rr[r] = atomicAdd(&s_cnt[lo - 1], 1);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < B) {
+        const int32_t n = s_cnt[threadIdx.x];
+        s_base[threadIdx.x] = n ? atomicAdd(&a.cursor[c.bucket0 + threadIdx.x], n) : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < SEG_ROUNDS; r++) {
+        if (br[r] >= 0) {
+            const int32_t at = s_base[br[r]] + rr[r];
+            if (at < SS_CAP) {
+                const int64_t s = (int64_t)(c.bucket0 + br[r]) * SS_CAP + at;
+                a.slot_key[s] = kr[r];
+                a.slot_idx[s] = t0 + r * SEG_THREADS + (int32_t)threadIdx.x;
+            }
+        }
+    }
+}
+
+// One bucket, one wavefront: the words
+//     1 << 61 | ((key - lo) >> shift) << 16 | (index - chunk begin)
+// (45 bits of key part; a chunk has < 2^16 elements) through the network.
+// Equal keys are ordered by their index bits: the stable order.  A bucket whose
+// keys span less than 2^45 loses nothing; a wider one shifts bits out, and two
+// DIFFERENT keys may then share a key part: sorted neighbours with equal key
+// parts fetch their full keys (one gather each) and a bucket with such a pair
+// out of order is left to ss_rank_bucket.
+#define SS_KEY_BITS 45
+template <int R>
+__device__ __forceinline__ bool ss_sort_bucket(const SsArgs &a, const SsChunk &c,
+                                               int32_t count, int32_t out0, int lane,
+                                               const uint64_t *__restrict__ sk,
+                                               const int32_t *__restrict__ si)
+{
+    const double pad = __longlong_as_double((long long)SS_PAD);
+    uint64_t k[R];
+    int32_t x[R];
+    uint64_t kmin = ~0ull, kmax = 0;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int e = lane * R + r;
+        k[r] = ~0ull;
+        x[r] = INT32_MAX;
+        if (e < count) {
+            if (sk == nullptr) {         // a direct chunk: read from the scores
+                k[r] = desc_key(a.score[c.begin + e]);
+                x[r] = c.begin + e;
+            } else {
+                k[r] = sk[e];
+                x[r] = si[e];
+            }
+            kmin = k[r] < kmin ? k[r] : kmin;
+            kmax = k[r] > kmax ? k[r] : kmax;
+        }
+    }
+    kmin = ss_wave_min_u64(kmin);
+    kmax = ss_wave_max_u64(kmax);
+    const int shift = ss_shift_for(kmax - kmin);
+    double p[R];
+#pragma unroll
+    for (int r = 0; r < R; r++)
+        p[r] = lane * R + r < count ? ss_pack(k[r], kmin, shift, x[r] - c.begin) : pad;
+    if (!(a.dbg & 1)) ss_bitonic_packed<R>(p, lane);
+    uint64_t kp[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const uint64_t bits = (uint64_t)__double_as_longlong(p[r]);
+        const bool ok = lane * R + r < count;
+        x[r] = ok ? c.begin + (int32_t)(bits & ((1u << SS_IDX_BITS) - 1)) : INT32_MAX;
+        kp[r] = ok ? bits >> SS_IDX_BITS : ~0ull - (uint64_t)(lane * R + r);   // (pads: all different)
+        k[r] = kmin + ((bits >> SS_IDX_BITS) & ((1ull << SS_KEY_BITS) - 1));     // exact when shift == 0
+    }
+    if (shift > 0 && !(a.dbg & 2)) {
+        // neighbours (in sorted order) with equal key parts
+        const uint64_t up = ss_shfl_up64(kp[R - 1]), dn = ss_shfl_down64(kp[0]);
+        bool tie_next[R];
+        bool any = false;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const uint64_t nx = r + 1 < R ? kp[r + 1 < R ? r + 1 : r] : dn;
+            const bool has = r + 1 < R ? true : lane < WAVE - 1;
+            tie_next[r] = has && nx == kp[r];
+            any |= tie_next[r];
+        }
+        if (__ballot(any) != 0) {
+            uint64_t f[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const uint64_t pv = r > 0 ? kp[r > 0 ? r - 1 : 0] : up;
+                const bool tie_prev = (r > 0 || lane > 0) && pv == kp[r];
+                f[r] = (tie_next[r] || tie_prev) ? desc_key(a.score[x[r]]) : 0;
+            }
+            const uint64_t fdn = ss_shfl_down64(f[0]);
+            bool bad = false;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const uint64_t fn = r + 1 < R ? f[r + 1 < R ? r + 1 : r] : fdn;
+                bad |= tie_next[r] && fn < f[r];       // (equal keys: index order, as packed)
+            }
+            if (__ballot(bad) != 0) return false;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int e = lane * R + r;
+        if (e < count) {
+            const int32_t pp = out0 + e;
+            if (c.final) {
+                if (a.order && !(a.dbg & 8)) a.order[pp] = x[r];
+                if (a.dst && !(a.dbg & 4)) a.dst[x[r]] = pp;
+            } else {
+                a.key_out[pp] = shift > 0 ? desc_key(a.score[x[r]]) : k[r];
+                a.idx_out[pp] = x[r];
+            }
+        }
+    }
+    return true;
+}
+
+// A bucket whose shortened key parts tied between different keys: every
+// element is ranked by counting, with full (key, index) comparisons (scores
+// that agree in 45 leading bits of their range and differ below: rare, slow,
+// correct).  Rounds of 64 elements, the bucket read through the caches.
+__device__ __forceinline__ void ss_rank_bucket(const SsArgs &a, const SsChunk &c,
+                                               int32_t count, int32_t out0, int lane,
+                                               const uint64_t *__restrict__ sk,
+                                               const int32_t *__restrict__ si)
+{
+    auto get = [&](int32_t e, uint64_t &k, int32_t &x) {
+        if (sk == nullptr) {
+            k = desc_key(a.score[c.begin + e]);
+            x = c.begin + e;
+        } else {
+            k = sk[e];
+            x = si[e];
+        }
+    };
+    for (int32_t base = 0; base < count; base += WAVE) {
+        const int32_t e = base + lane;
+        uint64_t k = 0;
+        int32_t x = 0, rank = 0;
+        if (e < count) get(e, k, x);
+        for (int32_t j = 0; j < count; j++) {
+            uint64_t kj;
+            int32_t xj;
+            get(j, kj, xj);
+            rank += (kj < k || (kj == k && xj < x)) ? 1 : 0;
+        }
+        if (e < count) {
+            const int32_t pp = out0 + rank;
+            if (c.final) {
+                if (a.order) a.order[pp] = x;
+                if (a.dst) a.dst[x] = pp;
+            } else {
+                a.key_out[pp] = k;
+                a.idx_out[pp] = x;
+            }
+        }
+    }
+}
+
+// bucket gb of the plan: its chunk, element count and first output place
+// (false: a bucket of the chunk overflowed -- handled by ss_sort_kernel)
+__device__ __forceinline__ bool ss_bucket_geom(const SsArgs &a, int64_t gb, int lane,
+                                               SsChunk &c, int32_t &count, int32_t &before,
+                                               bool &overflow)
+{
+    c = a.chunks[a.bucket_chunk[gb]];
+    const int32_t b = (int32_t)gb - c.bucket0;
+    count = c.n;
+    before = 0;
+    if (c.n_buckets > 1) {
+        // (<= SS_MAXB = 128 buckets: two per lane)
+        const int32_t m0 = lane < c.n_buckets ? a.cursor[c.bucket0 + lane] : 0;
+        const int32_t m1 = lane + WAVE < c.n_buckets ? a.cursor[c.bucket0 + WAVE + lane] : 0;
+        overflow = __ballot(m0 > a.cap_limit || m1 > a.cap_limit) != 0;
+        count = b < WAVE ? __shfl(m0, b, WAVE) : __shfl(m1, b - WAVE, WAVE);
+        int32_t pre = (lane < b ? m0 : 0) + (lane + WAVE < b ? m1 : 0);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) pre += __shfl_xor(pre, off, WAVE);
+        before = pre;
+    } else {
+        overflow = count > a.cap_limit;
+    }
+    return !overflow;
+}
+
+// Buckets ss_sort_kernel did not finish: more than SS_FAST elements (a few
+// per cent: the one-word network over 16 registers) or key parts that tied
+// between different keys (ranking by counting).  A fixed grid walks the list whose length lives on
+// the device.
+__global__ __launch_bounds__(256) void ss_redo_kernel(SsArgs a)
+{
+    const int lane = lane_id();
+    const int32_t n = a.redo[-1];
+    for (int32_t i = (int32_t)blockIdx.x * 4 + (int32_t)(threadIdx.x >> 6); i < n;
+         i += (int32_t)gridDim.x * 4) {
+        const int64_t gb = a.redo[i];
+        SsChunk c;
+        int32_t count, before;
+        bool overflow;
+        if (!ss_bucket_geom(a, gb, lane, c, count, before, overflow) || count <= 0) continue;
+        const uint64_t *sk = nullptr;
+        const int32_t *si = nullptr;
+        if (c.n_buckets > 1) {
+            sk = a.slot_key + gb * SS_CAP;
+            si = a.slot_idx + gb * SS_CAP;
+        }
+        const int32_t out0 = c.begin + before;
+        if (count > SS_FAST && ss_sort_bucket<16>(a, c, count, out0, lane, sk, si)) continue;
+        ss_rank_bucket(a, c, count, out0, lane, sk, si);
+    }
+}
+
+__global__ __launch_bounds__(256) void ss_sort_kernel(SsArgs a)
+{
+    const int lane = lane_id();
+    // a category's buckets behind one L2: dst[] of the category is scattered
+    const int64_t gb = (int64_t)xcd_block(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
+    if (gb >= a.n_buckets) return;
+    SsChunk c;
+    int32_t count, before;
+    bool overflow;
+    ss_bucket_geom(a, gb, lane, c, count, before, overflow);
+    const int32_t b = (int32_t)gb - c.bucket0;
+    if (overflow) {
+        // a bucket of this chunk outgrew its slots: wavefront b ranks the b-th
+        // slice of the chunk by counting, straight from the scores
+        const int32_t s0 = (int32_t)((int64_t)c.n * b / c.n_buckets);
+        const int32_t s1 = (int32_t)((int64_t)c.n * (b + 1) / c.n_buckets);
+        for (int32_t i = s0 + lane; i < s1; i += WAVE) {
+            const uint64_t ki = desc_key(a.score[c.begin + i]);
+            int32_t rank = 0;
+            for (int32_t j = 0; j < c.n; j++) {
+                const uint64_t kj = desc_key(a.score[c.begin + j]);
+                rank += (kj < ki || (kj == ki && j < i)) ? 1 : 0;
+            }
+            const int32_t p = c.begin + rank, d = c.begin + i;
+            if (c.final) {
+                if (a.order) a.order[p] = d;
+                if (a.dst) a.dst[d] = p;
+            } else {
+                a.key_out[p] = ki;
+                a.idx_out[p] = d;
+            }
+        }
+        return;
+    }
+    if (count <= 0) return;
+    const int32_t out0 = c.begin + before;
+    const uint64_t *sk = nullptr;
+    const int32_t *si = nullptr;
+    if (c.n_buckets > 1) {
+        sk = a.slot_key + gb * SS_CAP;
+        si = a.slot_idx + gb * SS_CAP;
+    }
+    bool done = false;
+    if (count <= 64) done = ss_sort_bucket<1>(a, c, count, out0, lane, sk, si);
+    else if (count <= 128) done = ss_sort_bucket<2>(a, c, count, out0, lane, sk, si);
+    else if (count <= 256) done = ss_sort_bucket<4>(a, c, count, out0, lane, sk, si);
+    else if (count <= SS_FAST) done = ss_sort_bucket<8>(a, c, count, out0, lane, sk, si);
+    if (!done && lane == 0) a.redo[atomicAdd(&a.redo[-1], 1)] = (int32_t)gb;
+}
+
+// ---- the plan: chunks, buckets and scatter tiles from the category offsets
+extern "C" int taoamd_sort_plan_host(int32_t n_cat, const int32_t *cat_off_host,
+                                     int64_t *sizes, int32_t *chunks,
+                                     int32_t *split_list, int32_t *stile_chunk,
+                                     int32_t *bucket_chunk)
+{
+    if (n_cat < 0 || !cat_off_host || !sizes) return TAOAMD_ERR_ARG;
+    const bool fill = chunks != nullptr;
+    if (fill && (!split_list || !stile_chunk || !bucket_chunk)) return TAOAMD_ERR_ARG;
+    int64_t nc = 0, ns = 0, nt = 0, nb = 0, merge = 0;
+    for (int32_t k = 0; k < n_cat; k++) {
+        const int64_t sb = cat_off_host[k], len = cat_off_host[k + 1] - sb;
+        if (len < 0) return TAOAMD_ERR_ARG;
+        if (len > SS_CHUNK) merge = 1;
+        for (int64_t o = 0; o < len; o += SS_CHUNK) {
+            const int32_t n = (int32_t)std::min<int64_t>(SS_CHUNK, len - o);
+            const int32_t B = n <= SS_DIRECT ? 1 : (n + SS_TARGET - 1) / SS_TARGET;
+            const int32_t tiles = B > 1 ? (n + SEG_TILE - 1) / SEG_TILE : 0;
+            if (fill) {
+                SsChunk c;
+                c.begin = (int32_t)(sb + o); c.n = n; c.bucket0 = (int32_t)nb;
+                c.n_buckets = B; c.stile0 = (int32_t)nt; c.final = len <= SS_CHUNK;
+                c.cat = k; c.pad = 0;
+                memcpy(chunks + 8 * nc, &c, sizeof c);
+                if (B > 1) split_list[ns] = (int32_t)nc;
+                for (int32_t t = 0; t < tiles; t++) stile_chunk[nt + t] = (int32_t)nc;
+                for (int32_t b = 0; b < B; b++) bucket_chunk[nb + b] = (int32_t)nc;
+            }
+            nc++;
+            ns += B > 1;
+            nt += tiles;
+            nb += B;
+        }
+    }
+    if (nb >= INT32_MAX / 2) return TAOAMD_ERR_TOO_LARGE;
+    sizes[0] = nc; sizes[1] = ns; sizes[2] = nt; sizes[3] = nb; sizes[4] = merge;
+    return TAOAMD_OK;
+}
+
+extern "C" size_t taoamd_sort_sampled_workspace(int64_t n, int64_t n_buckets, int32_t merge)
+{
+    if (n < 1) n = 1;
+    if (n_buckets < 1) n_buckets = 1;
+    size_t b = align256((size_t)n_buckets * 4 + 256)           // cursor, redo count
+               + align256((size_t)n_buckets * 4)                // redo list
+               + align256((size_t)n_buckets * 8) + align256((size_t)n_buckets * 4)
+               + align256((size_t)n_buckets * SS_CAP * 8) + align256((size_t)n_buckets * SS_CAP * 4);
+    if (merge) b += 2 * align256((size_t)n * 8) + 2 * align256((size_t)n * 4);
+    return b + 4096;
+}
+
+extern "C" int taoamd_sort_sampled_cap_limit(int32_t limit)
+{
+    g_ss_cap_limit = limit > 0 && limit < SS_CAP ? limit : SS_CAP;
+    return TAOAMD_OK;
+}
+
+extern "C" int taoamd_sort_sampled(int64_t n, int32_t n_cat, const int32_t *cat_off,
+                                   const int32_t *tile_off, int32_t n_tiles,
+                                   int32_t max_segment, const double *dt_score,
+                                   int32_t n_chunks, const int32_t *chunks,
+                                   int32_t n_split, const int32_t *split_list,
+                                   int32_t n_stiles, const int32_t *stile_chunk,
+                                   int32_t n_buckets, const int32_t *bucket_chunk,
+                                   int32_t *order, int32_t *dst, void *workspace,
+                                   size_t workspace_bytes, void *stream)
+{
+    if (n == 0 || n_cat == 0 || n_chunks == 0) return TAOAMD_OK;
+    if (n > 0x7fffffff) return TAOAMD_ERR_TOO_LARGE;
+    if (!cat_off || !dt_score || !chunks || !bucket_chunk || !workspace ||
+        (n_split > 0 && (!split_list || !stile_chunk)))
+        return TAOAMD_ERR_ARG;
+    const int merge = max_segment > SS_CHUNK;
+    if (merge && (!tile_off || n_tiles <= 0)) return TAOAMD_ERR_ARG;
+    if (workspace_bytes < taoamd_sort_sampled_workspace(n, n_buckets, merge))
+        return TAOAMD_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    unsigned char *w = (unsigned char *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    SsArgs a;
+    a.score = dt_score; a.chunks = (const SsChunk *)chunks; a.split_list = split_list;
+    a.stile_chunk = stile_chunk; a.bucket_chunk = bucket_chunk;
+    a.order = order; a.dst = dst; a.n_buckets = n_buckets; a.n_stiles = n_stiles;
+    a.cap_limit = g_ss_cap_limit;
+    static const int dbg_env = getenv("TAOAMD_SS_DBG") ? atoi(getenv("TAOAMD_SS_DBG")) : 0;
+    a.dbg = dbg_env;
+    a.cursor = (int32_t *)w;    w += align256((size_t)n_buckets * 4 + 256);
+    a.redo = (int32_t *)w;      w += align256((size_t)n_buckets * 4);
+    // (the redo count sits in the last int of the cursor block, right ahead of the list)
+    a.spl_key = (uint64_t *)w;  w += align256((size_t)n_buckets * 8);
+    a.spl_idx = (int32_t *)w;   w += align256((size_t)n_buckets * 4);
+    a.slot_key = (uint64_t *)w; w += align256((size_t)n_buckets * SS_CAP * 8);
+    a.slot_idx = (int32_t *)w;  w += align256((size_t)n_buckets * SS_CAP * 4);
+    SegArgs m;
+    m.cat_off = cat_off; m.tile_off = tile_off; m.cat = nullptr; m.score = dt_score;
+    m.order = order; m.dst = dst; m.n = n; m.n_cat = n_cat; m.n_tiles = n_tiles;
+    m.key[0] = m.key[1] = nullptr; m.idx[0] = m.idx[1] = nullptr; m.bnd = nullptr;
+    a.key_out = nullptr; a.idx_out = nullptr;
+    if (merge) {
+        m.key[0] = (uint64_t *)w; w += align256((size_t)n * 8);
+        m.key[1] = (uint64_t *)w; w += align256((size_t)n * 8);
+        m.idx[0] = (int32_t *)w;  w += align256((size_t)n * 4);
+        m.idx[1] = (int32_t *)w;  w += align256((size_t)n * 4);
+        a.key_out = m.key[SS_FIRST_MERGE_PASS & 1];
+        a.idx_out = m.idx[SS_FIRST_MERGE_PASS & 1];
+    }
+    TAO_HIP(hipMemsetAsync(a.cursor, 0, align256((size_t)n_buckets * 4 + 256), s));
+    if (n_split > 0) {
+        TAO_TIMED("ss_split_kernel", s, ss_split_kernel<<<(unsigned)((n_split + 3) / 4), 256, 0, s>>>(a, n_split));
+        TAO_TIMED("ss_scatter_kernel", s, ss_scatter_kernel<<<(unsigned)n_stiles, SEG_THREADS, 0, s>>>(a));
+    }
+    TAO_TIMED("ss_sort_kernel", s, ss_sort_kernel<<<(unsigned)((n_buckets + 3) / 4), 256, 0, s>>>(a));
+    TAO_TIMED("ss_redo_kernel", s, ss_redo_kernel<<<(unsigned)std::min<int64_t>(1024, (n_buckets + 3) / 4), 256, 0, s>>>(a));
+    if (merge) {
+        int passes = 0;
+        for (int64_t L = SEG_TILE; L < max_segment; L <<= 1) passes++;
+        for (int p = SS_FIRST_MERGE_PASS; p < passes; p++)
+            TAO_TIMED("seg_mpass_kernel", s, seg_mpass_kernel<<<(unsigned)n_tiles, 256, 0, s>>>(m, p, p == passes - 1, SS_CHUNK));
     }
     TAO_LAUNCH_CHECK();
     return TAOAMD_OK;

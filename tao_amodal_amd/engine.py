@@ -82,6 +82,29 @@ def match_plan(cell_dt_off, cell_gt_off, cap_d=64, cap_g=64, cap_cell_g=8):
     return groups[:ng], singles[:ns]
 
 
+def sort_plan(cat_off):
+    """Chunks / buckets / scatter tiles of taoamd_sort_sampled from the host
+    copy of the category offsets (taoamd_sort_plan_host).  Returns the four
+    int32 tables and whether some category needs the merge passes."""
+    lib = _lib.load()
+    off = np.ascontiguousarray(cat_off, dtype=np.int32)
+    sizes = np.zeros(5, dtype=np.int64)
+    _lib.check(lib.taoamd_sort_plan_host(len(off) - 1, off.ctypes.data,
+                                         sizes.ctypes.data, None, None, None, None),
+               "taoamd_sort_plan_host")
+    nc, ns, nt, nb = (int(x) for x in sizes[:4])
+    chunks = np.zeros((max(nc, 1), 8), dtype=np.int32)
+    split = np.zeros(max(ns, 1), dtype=np.int32)
+    stile = np.zeros(max(nt, 1), dtype=np.int32)
+    bucket = np.zeros(max(nb, 1), dtype=np.int32)
+    if nc:
+        _lib.check(lib.taoamd_sort_plan_host(
+            len(off) - 1, off.ctypes.data, sizes.ctypes.data, chunks.ctypes.data,
+            split.ctypes.data, stile.ctypes.data, bucket.ctypes.data),
+            "taoamd_sort_plan_host")
+    return (chunks, split, stile, bucket), (nc, ns, nt, nb), bool(sizes[4])
+
+
 def track_meta(flat):
     """{first, last, base - first, is detection} of every track (detection
     tracks first, then GT) for the padded frame table: track t owns the slots
@@ -259,6 +282,12 @@ class DeviceProblem:
         self.t["gt_cat_off"] = torch.from_numpy(gt_cat_off).to(self.device)
         self.t["tile_off"] = torch.from_numpy(tile_off).to(self.device)
         self.cat_off_host = cat_off
+        # plan of the sample sort (depends on cat_off alone)
+        self.ss_sizes, self.ss_merge = (0, 0, 0, 0), False
+        if self.grouped and self.n_dt:
+            tabs, self.ss_sizes, self.ss_merge = sort_plan(cat_off)
+            for name, tab in zip(("ss_chunks", "ss_split", "ss_stile", "ss_bucket"), tabs):
+                self.t[name] = torch.from_numpy(tab).to(self.device)
 
     def _plan_track_iou(self, flat):
         """Padded frame table + launch plan of taoamd_track_iou_planned."""
@@ -361,7 +390,9 @@ class Workspace:
         self.order = torch.empty(max(dp.n_dt, 1), dtype=torch.int32, device=dev)
         self.dst = torch.empty(max(dp.n_dt, 1), dtype=torch.int32, device=dev)
         self.sort_bytes = max(lib.taoamd_sort_workspace(dp.n_dt),
-                              lib.taoamd_sort_segments_workspace(dp.n_dt))
+                              lib.taoamd_sort_segments_workspace(dp.n_dt),
+                              lib.taoamd_sort_sampled_workspace(
+                                  dp.n_dt, dp.ss_sizes[3], int(dp.ss_merge)))
         self.sort_ws = buf(self.sort_bytes)
         self.matched = torch.empty((max(dp.n_dt, 1), dp.n_words),
                                    dtype=torch.int64, device=dev)
@@ -439,8 +470,22 @@ def stage_ranges(dp, ws):
             "taoamd_tao_ranges")
 
 
+import os as _os0
+# TAOAMD_SORT=segments: the round-2 tile + bucket sort (A/B timing)
+SORT_SAMPLED = _os0.environ.get("TAOAMD_SORT", "sampled") != "segments"
+
+
 def stage_sort(dp, ws):
     lib, t, s = _lib.load(), dp.t, _stream()
+    if dp.grouped and SORT_SAMPLED and dp.n_dt:
+        nc, ns, nt, nb = dp.ss_sizes
+        _lib.check(lib.taoamd_sort_sampled(
+            dp.n_dt, dp.n_cat, _ptr(t["cat_off"]), _ptr(t["tile_off"]), dp.n_tiles,
+            dp.max_segment, _ptr(t["dt_score"]), nc, _ptr(t["ss_chunks"]), ns,
+            _ptr(t["ss_split"]), nt, _ptr(t["ss_stile"]), nb, _ptr(t["ss_bucket"]),
+            _ptr(ws.order), _ptr(ws.dst), _ptr(ws.sort_ws), ws.sort_bytes, s),
+            "taoamd_sort_sampled")
+        return
     if dp.grouped:
         _lib.check(lib.taoamd_sort_segments(
             dp.n_dt, dp.n_cat, _ptr(t["cat_off"]), _ptr(t["tile_off"]),

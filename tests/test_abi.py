@@ -45,3 +45,33 @@ def test_status_strings():
     assert lib.taoamd_strerror(0) == b"ok"
     assert b"workspace" in lib.taoamd_strerror(4)
     assert lib.taoamd_version() >= 100
+
+
+def test_sort_plan_covers_every_category():
+    """taoamd_sort_plan_host (host only): the chunks tile every category, a
+    chunk's buckets and scatter tiles are consecutive, sizes agree."""
+    from tao_amodal_amd import engine
+    chunk, tile = 16 * _lib.SEGMENT_TILE, _lib.SEGMENT_TILE
+    sizes = [0, 5, 1024, 1025, 2817, chunk, chunk + 1, 0, 2 * chunk + 3000, 352 * 3 + 1]
+    cat_off = np.zeros(len(sizes) + 1, np.int32)
+    np.cumsum(sizes, out=cat_off[1:])
+    (chunks, split, stile, bucket), (nc, ns, nt, nb), merge = engine.sort_plan(cat_off)
+    assert merge and len(chunks) == nc and len(bucket) == nb and len(stile) == nt
+    at, b0, t0, splits = {}, 0, 0, []
+    for i, c in enumerate(chunks):
+        begin, n, bucket0, nbk, stile0, final, cat = (int(x) for x in c[:7])
+        assert bucket0 == b0 and 0 < n <= chunk
+        assert begin == at.get(cat, int(cat_off[cat]))
+        at[cat] = begin + n
+        assert nbk == (1 if n <= 1024 else -(-n // 352)) and nbk <= 128
+        assert final == (sizes[cat] <= chunk)
+        assert (bucket[b0:b0 + nbk] == i).all()
+        if nbk > 1:
+            splits.append(i)
+            assert stile0 == t0
+            k = -(-n // tile)
+            assert (stile[t0:t0 + k] == i).all()
+            t0 += k
+        b0 += nbk
+    assert split[:ns].tolist() == splits and b0 == nb and t0 == nt
+    assert all(at.get(k, int(cat_off[k])) == cat_off[k + 1] for k in range(len(sizes)))

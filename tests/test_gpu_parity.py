@@ -320,6 +320,74 @@ def test_both_sorts_are_the_stable_mergesort_order(n, n_cat, quant):
     torch.cuda.synchronize()
     assert np.array_equal(order.cpu().numpy(), want)
     assert np.array_equal(dst.cpu().numpy()[want], np.arange(n))
+    # the sample sort (what the evaluator passes call)
+    o2, d2 = _sampled_sort(cat_off, tile_off, d_score)
+    assert np.array_equal(o2, want)
+    assert np.array_equal(d2[want], np.arange(n))
+
+
+def _sampled_sort(cat_off, tile_off, d_score, repeat=1):
+    """taoamd_sort_sampled on device scores; returns order, dst (numpy)."""
+    import torch
+    from tao_amodal_amd import _lib, engine
+    lib = _lib.load()
+    n = int(cat_off[-1])
+    tabs, (nc, ns, nt, nb), merge = engine.sort_plan(cat_off)
+    dev = [torch.from_numpy(t).cuda() for t in tabs]
+    d_co = torch.from_numpy(np.ascontiguousarray(cat_off, np.int32)).cuda()
+    d_to = torch.from_numpy(np.ascontiguousarray(tile_off, np.int32)).cuda()
+    order = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    dst = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    nbytes = lib.taoamd_sort_sampled_workspace(n, nb, int(merge))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    for _ in range(repeat):
+        _lib.check(lib.taoamd_sort_sampled(
+            n, len(cat_off) - 1, d_co.data_ptr(), d_to.data_ptr(), int(tile_off[-1]),
+            int(np.diff(cat_off).max()), d_score.data_ptr(), nc, dev[0].data_ptr(), ns,
+            dev[1].data_ptr(), nt, dev[2].data_ptr(), nb, dev[3].data_ptr(),
+            order.data_ptr(), dst.data_ptr(), ws.data_ptr(), nbytes, None), "sampled")
+    torch.cuda.synchronize()
+    return order.cpu().numpy(), dst.cpu().numpy()
+
+
+@pytest.mark.parametrize("limit", [0, 300, 40])
+def test_sample_sort_every_kind_of_category(limit):
+    """One launch sequence: empty, tiny (one wavefront, 1..16 elements per
+    lane), just around the direct limit, split into buckets, exactly one chunk,
+    one element more (two chunks + a merge pass), many chunks.  Scores with
+    heavy exact ties, and all-equal categories (the splitters are (key, index)
+    pairs).  limit > 0: buckets beyond it take the overflow path (ranking by
+    counting) -- with 40 nearly every chunk does."""
+    import torch
+    from tao_amodal_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(31)
+    chunk = 16 * _lib.SEGMENT_TILE
+    sizes = [0, 1, 63, 64, 65, 129, 500, 1024, 1025, 1300, 0, 2816, 2817, 9000,
+             chunk, chunk + 1, 3 * chunk + 77, 20000, 7]
+    if limit:
+        sizes = [0, 1, 65, 500, 1025, 1300, 2817, 5000, 7]
+    n, n_cat = int(np.sum(sizes)), len(sizes)
+    cat = np.repeat(np.arange(n_cat), sizes)
+    score = rng.random(n)
+    score[rng.random(n) < 0.3] = 0.5
+    score[rng.random(n) < 0.2] = np.round(score[rng.random(n) < 0.2][:1], 2)
+    score[cat == 9] = 0.125                      # one value for a whole category
+    score[cat == n_cat - 2] = np.round(score[cat == n_cat - 2], 1)
+    want = np.lexsort((np.arange(n), -score, cat))
+    cat_off = np.zeros(n_cat + 1, np.int32)
+    np.cumsum(sizes, out=cat_off[1:])
+    tiles = (np.diff(cat_off) + _lib.SEGMENT_TILE - 1) // _lib.SEGMENT_TILE
+    tile_off = np.zeros(n_cat + 1, np.int32)
+    np.cumsum(tiles, out=tile_off[1:])
+    d_score = torch.from_numpy(score).cuda()
+    try:
+        lib.taoamd_sort_sampled_cap_limit(limit)
+        order, dst = _sampled_sort(cat_off, tile_off, d_score, repeat=2)
+    finally:
+        lib.taoamd_sort_sampled_cap_limit(0)
+    assert np.array_equal(order, want)
+    assert np.array_equal(dst[want], np.arange(n))
 
 
 from goldenio import MODE_FIXTURES, MODES, load_modes
