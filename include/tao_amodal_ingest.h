@@ -31,6 +31,13 @@ extern "C" {
  * Missing track_id / video_id become -1 (results.py's r.get(...)).
  * "results is not a list." when the document is not a list. */
 void *taoamd_pred_parse(const char *path, char *err, size_t errlen);
+/* One rank's share of the list in a multi-process run (torchrun
+ * tools/eval_on_tao_amodal.py): every process scans the file's structure, the
+ * elements [n * part / n_parts, n * (part + 1) / n_parts) are converted;
+ * taoamd_pred_part_info gives the share's first position and n. */
+void *taoamd_pred_parse_part(const char *path, int64_t part, int64_t n_parts, char *err,
+                             size_t errlen);
+void taoamd_pred_part_info(void *handle, int64_t *first, int64_t *total);
 int64_t taoamd_pred_count(void *handle);
 /* copies the columns into caller memory: n int64 / 4n double / n double / ... */
 int taoamd_pred_copy(void *handle, int64_t *image_id, int64_t *category_id,

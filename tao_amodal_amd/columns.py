@@ -236,30 +236,43 @@ class GTColumns:
     def select_videos(self, keep):
         """The annotation set of the videos `keep` (boolean mask over
         ``vid_id``): their images, tracks and annotations, the category table
-        whole.  (Shards of one fixed set: the strong-scaling bench.)"""
+        whole.  (A rank's share of one set split by video.)"""
         keep = np.asarray(keep, dtype=bool)
         vids = np.sort(self.vid_id[keep])
 
         def of(col):
+            if len(vids) == 0:
+                return np.zeros(len(col), bool)
             pos = np.searchsorted(vids, col)
             pos[pos == len(vids)] = 0
-            return vids[pos] == col if len(vids) else np.zeros(len(col), bool)
+            return vids[pos] == col
+        return self._select(keep, of(self.img_vid), of(self.trk_vid))
 
+    def select_images(self, keep):
+        """The annotation set of the images `keep` (boolean mask over
+        ``img_id``) with their annotations; videos, tracks and categories
+        whole.  (A rank's share of the image level, split by image id.)"""
+        return self._select(np.ones(len(self.vid_id), bool), np.asarray(keep, bool),
+                            np.ones(len(self.trk_id), bool))
+
+    def _select(self, mv, mi, mt):
         def csr(off, val, m):
             lens = np.diff(off)[m]
             new_off = np.zeros(len(lens) + 1, dtype=np.int64)
             np.cumsum(lens, out=new_off[1:])
             idx = np.repeat(off[:-1][m] - new_off[:-1], lens) + np.arange(new_off[-1])
             return new_off, val[idx]
-        mi, mt = of(self.img_vid), of(self.trk_vid)
         imgs = np.sort(self.img_id[mi])
-        pos = np.searchsorted(imgs, self.ann_img)
-        pos[pos == len(imgs)] = 0
-        ma = imgs[pos] == self.ann_img if len(imgs) else np.zeros(len(self.ann_img), bool)
+        if len(imgs):
+            pos = np.searchsorted(imgs, self.ann_img)
+            pos[pos == len(imgs)] = 0
+            ma = imgs[pos] == self.ann_img
+        else:
+            ma = np.zeros(len(self.ann_img), bool)
         kw = dict(cat_id=self.cat_id, cat_freq=self.cat_freq, cat_merged=self.cat_merged)
-        kw["vid_id"] = self.vid_id[keep]
-        kw["vid_neg_off"], kw["vid_neg"] = csr(self.vid_neg_off, self.vid_neg, keep)
-        kw["vid_nel_off"], kw["vid_nel"] = csr(self.vid_nel_off, self.vid_nel, keep)
+        kw["vid_id"] = self.vid_id[mv]
+        kw["vid_neg_off"], kw["vid_neg"] = csr(self.vid_neg_off, self.vid_neg, mv)
+        kw["vid_nel_off"], kw["vid_nel"] = csr(self.vid_nel_off, self.vid_nel, mv)
         kw["img_neg_off"], kw["img_neg"] = csr(self.img_neg_off, self.img_neg, mi)
         kw["img_nel_off"], kw["img_nel"] = csr(self.img_nel_off, self.img_nel, mi)
         for f in self.FIELDS:
@@ -336,9 +349,12 @@ class DTColumns:
         return len(self.image_id)
 
     @classmethod
-    def from_file_native(cls, path):
+    def from_file_native(cls, path, part=0, n_parts=1):
         """Parse a prediction file with the native columnar reader
-        (csrc/ingest.cpp); returns None when that library is not built."""
+        (csrc/ingest.cpp); returns None when that library is not built.
+        ``part`` of ``n_parts``: one process's share of the list (multi-process
+        CLI) -- the result then carries ``first`` (position of its first record
+        in the file) and ``total`` (records in the file)."""
         import ctypes as C
         import os
         so = os.path.join(os.path.dirname(os.path.abspath(__file__)),
@@ -346,14 +362,16 @@ class DTColumns:
         if not os.path.exists(so):
             return None
         lib = C.CDLL(so)
-        lib.taoamd_pred_parse.restype = C.c_void_p
-        lib.taoamd_pred_parse.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
+        lib.taoamd_pred_parse_part.restype = C.c_void_p
+        lib.taoamd_pred_parse_part.argtypes = [C.c_char_p, C.c_int64, C.c_int64,
+                                               C.c_char_p, C.c_size_t]
+        lib.taoamd_pred_part_info.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         lib.taoamd_pred_count.restype = C.c_int64
         lib.taoamd_pred_count.argtypes = [C.c_void_p]
         lib.taoamd_pred_copy.argtypes = [C.c_void_p] + [C.c_void_p] * 6
         lib.taoamd_pred_free.argtypes = [C.c_void_p]
         err = C.create_string_buffer(512)
-        h = lib.taoamd_pred_parse(os.fsencode(path), err, 512)
+        h = lib.taoamd_pred_parse_part(os.fsencode(path), part, n_parts, err, 512)
         if not h:
             msg = err.value.decode()
             if "is not a list" in msg:
@@ -375,6 +393,9 @@ class DTColumns:
                                  out.bbox.ctypes.data, out.score.ctypes.data,
                                  out.track_id.ctypes.data,
                                  out.video_id.ctypes.data)
+            first, total = C.c_int64(0), C.c_int64(0)
+            lib.taoamd_pred_part_info(h, C.byref(first), C.byref(total))
+            out.first, out.total = first.value, total.value
         finally:
             lib.taoamd_pred_free(h)
         return out

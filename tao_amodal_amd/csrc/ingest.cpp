@@ -46,6 +46,7 @@ struct Columns {
     std::vector<int64_t> image_id, category_id, track_id, video_id;
     std::vector<double> bbox, score;
     std::string error;
+    int64_t first = 0, total = 0;     // a share of the list (taoamd_pred_parse_part)
 };
 
 struct Cursor {
@@ -596,7 +597,30 @@ void parse_annotations(const Ranges &r, GT &g, Fail &fl)
 
 extern "C" {
 
+static void *pred_parse_impl(const char *path, int64_t part, int64_t n_parts, char *err,
+                             size_t errlen);
+
 void *taoamd_pred_parse(const char *path, char *err, size_t errlen)
+{
+    return pred_parse_impl(path, 0, 1, err, errlen);
+}
+
+// One share of the list for one rank of a multi-process run: the structural
+// scan covers the whole file (exact element boundaries, OpenMP), the numbers of
+// elements [n * part / n_parts, n * (part + 1) / n_parts) only are converted.
+void *taoamd_pred_parse_part(const char *path, int64_t part, int64_t n_parts, char *err,
+                             size_t errlen)
+{
+    if (n_parts < 1 || part < 0 || part >= n_parts) {
+        if (err && errlen) snprintf(err, errlen, "bad part %lld of %lld", (long long)part,
+                                    (long long)n_parts);
+        return nullptr;
+    }
+    return pred_parse_impl(path, part, n_parts, err, errlen);
+}
+
+static void *pred_parse_impl(const char *path, int64_t part, int64_t n_parts, char *err,
+                             size_t errlen)
 {
     auto fail = [&](const std::string &m) -> void * {
         if (err && errlen) snprintf(err, errlen, "%s", m.c_str());
@@ -647,7 +671,11 @@ void *taoamd_pred_parse(const char *path, char *err, size_t errlen)
             objs[i] = {(size_t)(el[i].first - buf), (size_t)(el[i].second - buf)};
     }
     Columns *c = new Columns;
-    const int64_t n = (int64_t)objs.size();
+    const int64_t total = (int64_t)objs.size();
+    const int64_t i0 = total * part / n_parts, i1 = total * (part + 1) / n_parts;
+    const int64_t n = i1 - i0;
+    c->first = i0;
+    c->total = total;
     c->image_id.resize(n); c->category_id.resize(n); c->track_id.resize(n);
     c->video_id.resize(n); c->score.resize(n); c->bbox.resize(4 * n);
     bool ok = true;
@@ -655,10 +683,11 @@ void *taoamd_pred_parse(const char *path, char *err, size_t errlen)
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < n; i++) {
         std::string er;
-        if (buf[objs[i].first] != '{') er = "list element is not an object";
-        if (!er.empty() || !parse_object(buf + objs[i].first, buf + objs[i].second, i, *c, er)) {
+        const auto &o = objs[i0 + i];
+        if (buf[o.first] != '{') er = "list element is not an object";
+        if (!er.empty() || !parse_object(buf + o.first, buf + o.second, i, *c, er)) {
 #pragma omp critical
-            { if (ok) { ok = false; first_err = "prediction " + std::to_string(i) + ": " + er; } }
+            { if (ok) { ok = false; first_err = "prediction " + std::to_string(i0 + i) + ": " + er; } }
         }
     }
     done();
@@ -667,6 +696,13 @@ void *taoamd_pred_parse(const char *path, char *err, size_t errlen)
 }
 
 int64_t taoamd_pred_count(void *h) { return (int64_t)((Columns *)h)->image_id.size(); }
+
+// position of the share's first element in the whole list, and the list's length
+void taoamd_pred_part_info(void *h, int64_t *first, int64_t *total)
+{
+    if (first) *first = ((Columns *)h)->first;
+    if (total) *total = ((Columns *)h)->total;
+}
 
 int taoamd_pred_copy(void *h, int64_t *image_id, int64_t *category_id, double *bbox,
                      double *score, int64_t *track_id, int64_t *video_id)

@@ -1,13 +1,14 @@
 """Multi-GPU evaluation: one process per GPU, RCCL (``torch.distributed``
 backend "nccl") over xGMI.  Two partitions of the path are implemented:
 
-* BY CATEGORY (``CategoryPlan``, default of bench.py): the match and the AP
+* BY CATEGORY (``CategoryPlan``, ``bench.py --shard category``): the match and the AP
   sweep are independent per category and the cell tables are category-major,
   so a rank evaluates a contiguous category block with no record exchange at
   all; the only collectives are the in-place all-gathers that assemble the
   category-major result tables.  This is the natural mode when one
   prediction file is evaluated on several GPUs.
-* BY UNIT (``ExchangePlan``): every rank holds the detections of its own
+* BY UNIT (``ExchangePlan``, the default of bench.py and what the CLI runs
+  under torchrun, evaluation/_dist.py): every rank holds the detections of its own
   images / videos (e.g. produced by data-parallel inference) and the records
   meet at the category owners -- described next.
 
@@ -49,6 +50,14 @@ The collective plumbing is backend-agnostic: ``tests/test_dist_gloo.py`` runs
 this very module with world_size 2 on CPU tensors over gloo, with the oracle
 standing in for the kernels.
 """
+import os
+
+# the by-video step keeps 4 compute streams + RCCL's busy: with the default of
+# 4 hardware queues per process they alias and serialise (1.25 -> 0.94 ms/step
+# with 8).  Read by the HIP runtime when it starts, i.e. this has to run before
+# the first device call of the process.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -311,6 +320,30 @@ class ShardedEval:
         if int(self.overflow.item()):
             raise _lib.TaoAmdError("exchange chunk overflow: the ground truth "
                                    "changed after the plan was built")
+
+
+_PLAIN_ALL_TO_ALL = None
+
+
+def stage_all_to_all_through_host():
+    """gloo moves no device tensors through all_to_all: when the ranks of a
+    job share one GPU (a development box, the 2-rank tests) and therefore talk
+    over gloo, the record exchange is staged on the host.  RCCL jobs -- one GPU
+    per rank -- never come here."""
+    global _PLAIN_ALL_TO_ALL
+    if _PLAIN_ALL_TO_ALL is not None:
+        return
+    _PLAIN_ALL_TO_ALL = plain = dist.all_to_all_single
+
+    def staged(output, input, output_split_sizes=None, input_split_sizes=None,
+               group=None):
+        if not output.is_cuda:
+            return plain(output, input, output_split_sizes, input_split_sizes,
+                         group=group)
+        o = torch.empty(output.shape, dtype=output.dtype)
+        plain(o, input.cpu(), output_split_sizes, input_split_sizes, group=group)
+        output.copy_(o)
+    dist.all_to_all_single = staged
 
 
 def gather_visit_universe(gt, device, group=None):

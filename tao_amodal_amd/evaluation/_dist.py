@@ -1,0 +1,294 @@
+"""One evaluation on several GPUs behind the plugin surface:
+
+    torchrun --nproc_per_node=N tools/eval_on_tao_amodal.py --track_result ...
+
+(and ``LVISEval(..., dist=ctx)`` / ``TaoEval(..., dist=ctx)`` in the class
+API).  One process per GPU, RCCL over xGMI (``torch.distributed`` backend
+"nccl"); the partition is the one BASELINE.json names -- by video -- with the
+per-detection records meeting at the category owners (``dist.ShardedEval``).
+
+What a rank holds:
+
+  image level   the images of one contiguous block of the SORTED IMAGE IDS, the
+                annotations on them and the predictions for them;
+  track level   the videos of one contiguous block of the sorted video ids,
+                their images / tracks / annotations and predictions.
+
+Blocks of sorted ids, lower ids on lower ranks: the reference concatenates a
+category's cells in sorted image / video id order before its stable score
+sort (lvis_amodal/eval.py:343-361, tao_amodal/eval.py:498-518), and the owner
+of a category merges the ranks' runs "lower rank first on ties".
+
+Every rank reads the whole annotation file (it needs the id universe and the
+category table) and converts only ITS share of the prediction list
+(``DTColumns.from_file_native(part=rank)``: the structural scan of the file is
+shared work, the number conversion is split); the records then travel to the
+rank that owns their image / video in one all_to_all per level, arriving in
+file order.  ``make_track_ids_unique`` (tools/eval_on_tao_amodal.py:44-66) is a
+statement about the WHOLE list -- ids shared by two videos are renumbered in
+order of first appearance -- so the ranks pool their (track, video) pairs with
+the position of their first record and each applies the same renumbering.
+"""
+import os
+
+import numpy as np
+
+
+class Ctx:
+    """Process group of one evaluation: the ranks, the device of this rank, a
+    host-side (gloo) group for small numpy exchanges."""
+
+    def __init__(self, rank, world, device, group=None, host_group=None, backend="nccl"):
+        self.rank, self.world, self.device = rank, world, device
+        self.group, self.host_group, self.backend = group, host_group, backend
+
+
+def init_from_env():
+    """Process group from the launcher's environment (torchrun).  One GPU per
+    rank -> RCCL; fewer GPUs than ranks (a development box) -> the ranks share
+    GPU 0 and talk over gloo, device tensors staged through the host."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ["WORLD_SIZE"])
+    rank = int(os.environ["RANK"])
+    local = int(os.environ.get("LOCAL_RANK", rank))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    n_gpu = torch.cuda.device_count()
+    if n_gpu == 0:
+        raise RuntimeError("tao_amodal_amd evaluates on AMD GPUs; none is visible")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    own_gpu = n_gpu >= local_world
+    dev = torch.device("cuda", local if own_gpu else 0)
+    torch.cuda.set_device(dev)
+    if not dist.is_initialized():
+        if own_gpu:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    backend = dist.get_backend()
+    host = dist.new_group(backend="gloo") if backend != "gloo" else None
+    if backend == "gloo":
+        from .. import dist as tdist
+        tdist.stage_all_to_all_through_host()
+    return Ctx(rank, world, dev, None, host, backend)
+
+
+# --------------------------------------------------------------------------
+# host-side exchanges
+# --------------------------------------------------------------------------
+def _gather_arrays(arr, ctx):
+    """Every rank's array (any length), in rank order."""
+    import torch.distributed as dist
+    out = [None] * ctx.world
+    dist.all_gather_object(out, np.ascontiguousarray(arr), group=ctx.host_group)
+    return out
+
+
+def _route_rows(mat, owner, ctx):
+    """Rows of `mat` (int64 [n, W]) sent to their owner rank; what arrives is
+    ordered by source rank, each source's rows in its own order -- shares of a
+    list cut in order arrive in list order."""
+    import torch
+    import torch.distributed as dist
+    order = np.argsort(owner, kind="stable")
+    send = np.ascontiguousarray(mat[order])
+    counts = np.bincount(owner, minlength=ctx.world).astype(np.int64)
+    got = torch.zeros(ctx.world, dtype=torch.int64)
+    dist.all_to_all_single(got, torch.from_numpy(counts), group=ctx.host_group)
+    recv_counts = got.tolist()
+    n_in, W = int(sum(recv_counts)), mat.shape[1]
+    on_dev = ctx.backend == "nccl"
+    src = torch.from_numpy(send)
+    dst = torch.empty((n_in, W), dtype=torch.int64)
+    if on_dev:          # over xGMI: device buffers
+        src = src.to(ctx.device)
+        dst = dst.to(ctx.device)
+    dist.all_to_all_single(dst, src, output_split_sizes=recv_counts,
+                           input_split_sizes=counts.tolist(),
+                           group=ctx.group if on_dev else ctx.host_group)
+    return dst.cpu().numpy()
+
+
+def block_owner(sorted_ids, ids, world):
+    """Rank owning each id: the sorted universe cut into `world` contiguous
+    blocks of equal count; -1 for an id outside the universe."""
+    n = len(sorted_ids)
+    pos = np.searchsorted(sorted_ids, ids)
+    pos_c = np.minimum(pos, max(n - 1, 0))
+    known = (n > 0) & (sorted_ids[pos_c] == ids) if n else np.zeros(len(ids), bool)
+    # block r = positions [n * r // world, n * (r + 1) // world)
+    bounds = np.array([n * r // world for r in range(1, world)], dtype=np.int64)
+    owner = np.searchsorted(bounds, pos_c, side="right")
+    return np.where(known, owner, -1)
+
+
+def block_mask(sorted_ids, ids, rank, world):
+    return block_owner(sorted_ids, ids, world) == rank
+
+
+def unique_track_ids(dt, first, ctx):
+    """make_track_ids_unique over the whole list from the ranks' shares.
+    Returns (new track ids of this share, number of ids shared by videos)."""
+    import torch
+    import torch.distributed as dist
+    tid, vid = np.asarray(dt.track_id), np.asarray(dt.video_id)
+    if len(tid):
+        pairs, pfirst = np.unique(np.stack([tid, vid], 1), axis=0, return_index=True)
+        mine = np.concatenate([pairs, (first + pfirst)[:, None]], 1)
+    else:
+        mine = np.zeros((0, 3), dtype=np.int64)
+    allp = np.concatenate(_gather_arrays(mine, ctx))
+    top = torch.tensor([int(tid.max()) if len(tid) else 0], dtype=torch.int64)
+    dist.all_reduce(top, op=dist.ReduceOp.MAX, group=ctx.host_group)
+    top = max(int(top.item()), 0)
+    if len(allp) == 0:
+        return tid.copy(), 0
+    # first position of every (track, video) pair in the whole list
+    o = np.lexsort((allp[:, 2], allp[:, 1], allp[:, 0]))
+    allp = allp[o]
+    head = np.ones(len(allp), bool)
+    head[1:] = (allp[1:, 0] != allp[:-1, 0]) | (allp[1:, 1] != allp[:-1, 1])
+    allp = allp[head]
+    t_first = np.ones(len(allp), bool)
+    t_first[1:] = allp[1:, 0] != allp[:-1, 0]
+    per_track = np.add.reduceat(np.ones(len(allp), np.int64), np.flatnonzero(t_first))
+    clash = np.repeat(per_track > 1, per_track)
+    if not clash.any():
+        return tid.copy(), 0
+    cp = allp[clash]
+    cp = cp[np.argsort(cp[:, 2], kind="stable")]          # order of first appearance
+    new_id = top + 1 + np.arange(len(cp))
+    # look the share's records up among the renumbered pairs
+    out = tid.copy()
+    if len(tid):
+        comp = cp[:, :2]
+        q = np.stack([tid, vid], 1)
+        _, inv = np.unique(np.concatenate([comp, q]), axis=0, return_inverse=True)
+        inv = inv.reshape(-1)
+        new_of = np.full(int(inv.max()) + 1, -1, dtype=np.int64)
+        new_of[inv[:len(comp)]] = new_id
+        hit = new_of[inv[len(comp):]]
+        out = np.where(hit >= 0, hit, tid)
+    return out, int((per_track > 1).sum())
+
+
+class Shares:
+    """This rank's inputs of both levels."""
+
+    def __init__(self, gt_lvis, dt_lvis, gt_tao, dt_tao, n_changed, total):
+        self.gt_lvis, self.dt_lvis = gt_lvis, dt_lvis
+        self.gt_tao, self.dt_tao = gt_tao, dt_tao
+        self.n_changed, self.total = n_changed, total
+
+
+def shard_inputs(gt, dt, first, ctx):
+    """`gt`: the whole annotation file (GTColumns), `dt`: this rank's share of
+    the prediction list starting at list position `first`.  Returns Shares."""
+    import torch
+    import torch.distributed as dist
+    from ..columns import DTColumns
+    # The reference keeps images, videos, tracks and annotations in dicts keyed
+    # by id: of two entries with one id the last replaces the first -- also
+    # when they sit in different videos.  A split by video cannot reproduce
+    # that replacement across ranks, so such a file (every rank sees it whole
+    # and decides alike) is evaluated on one GPU only.
+    for what, ids in (("image", gt.img_id), ("video", gt.vid_id), ("track", gt.trk_id),
+                      ("annotation", gt.ann_id)):
+        if len(np.unique(ids)) != len(ids):
+            raise NotImplementedError(
+                "the annotation file holds two %ss with one id; the reference "
+                "lets the last replace the first wherever they are, which a "
+                "multi-GPU split by video does not reproduce -- run on one GPU"
+                % what)
+    img_sorted = np.unique(gt.img_id)
+    vid_sorted = np.unique(gt.vid_id)
+    own_img = block_owner(img_sorted, np.asarray(dt.image_id), ctx.world)
+    own_vid = block_owner(vid_sorted, np.asarray(dt.video_id), ctx.world)
+    bad = torch.tensor([int((own_img < 0).sum()), int((own_vid < 0).sum()), len(dt)],
+                       dtype=torch.int64)
+    dist.all_reduce(bad, group=ctx.host_group)
+    if int(bad[2]) == 0:
+        raise IndexError("list index out of range")      # results.py:61 of both
+    if int(bad[0]):
+        raise AssertionError("Results do not correspond to current LVIS set.")
+    if int(bad[1]):
+        raise AssertionError("Results do not correspond to current Tao set.")
+    new_tid, n_changed = unique_track_ids(dt, first, ctx)
+
+    def pack(track_id):
+        m = np.empty((len(dt), 9), dtype=np.int64)
+        m[:, 0] = dt.image_id
+        m[:, 1] = dt.category_id
+        m[:, 2:6] = np.ascontiguousarray(dt.bbox, dtype=np.float64).view(np.int64)
+        m[:, 6] = np.ascontiguousarray(dt.score, dtype=np.float64).view(np.int64)
+        m[:, 7] = track_id
+        m[:, 8] = dt.video_id
+        return m
+
+    def unpack(m):
+        return DTColumns(image_id=m[:, 0].copy(), category_id=m[:, 1].copy(),
+                         bbox=np.ascontiguousarray(m[:, 2:6]).view(np.float64),
+                         score=np.ascontiguousarray(m[:, 6]).view(np.float64),
+                         track_id=m[:, 7].copy(), video_id=m[:, 8].copy())
+    # (the image level never looks at track ids: it gets the renumbered ones too)
+    mat = pack(new_tid)
+    dt_l = unpack(_route_rows(mat, own_img, ctx))
+    dt_t = unpack(_route_rows(mat, own_vid, ctx))
+    gt_l = gt.select_images(block_mask(img_sorted, gt.img_id, ctx.rank, ctx.world))
+    gt_t = gt.select_videos(block_mask(vid_sorted, gt.vid_id, ctx.rank, ctx.world))
+    return Shares(gt_l, dt_l, gt_t, dt_t, n_changed, int(bad[2]))
+
+
+# --------------------------------------------------------------------------
+# the evaluator pass of one rank
+# --------------------------------------------------------------------------
+class DistRun:
+    """What ``_core.GpuRun`` is to one GPU: evaluate() runs this rank's share
+    through ranges / sort / [3D IoU] / match, the record exchange, the owner's
+    sweep and the result exchange (dist.ShardedEval.step); accumulate() waits
+    and downloads the assembled tables, identical on every rank.  The lazy
+    per-cell views show the rank's own cells."""
+
+    def __init__(self, flat, ctx, iou_3d_type="3d_iou"):
+        import torch
+        from .. import dist as tdist, engine
+        from ._core import timed
+        self.engine, self.torch = engine, torch
+        self.flat, self.iou_3d_type, self.ctx = flat, iou_3d_type, ctx
+        self.device = ctx.device
+        with timed("upload+plan"):
+            self.dp = engine.DeviceProblem(flat, self.device, iou_3d_type)
+            self.ws = engine.Workspace(self.dp)
+            self.sharded = tdist.ShardedEval(self.dp, self.ws, ctx.rank, ctx.world,
+                                             tdist.HipBackend(), ctx.group)
+            torch.cuda.synchronize(self.device)
+        self._detail = None
+        self.near_threshold_pairs = 0
+        self.precision = self.recall = None
+
+    def evaluate(self):
+        from ._core import timed
+        with timed("kernels"):
+            self.sharded.step()
+
+    def accumulate(self):
+        from ._core import timed
+        with timed("kernels"):
+            self.torch.cuda.synchronize(self.device)
+            self.sharded.check()
+            self.near_threshold_pairs = self.engine.guarded_pairs(self.dp, self.ws)
+        with timed("download"):
+            self.precision = self.sharded.precision.cpu().numpy()
+            self.recall = self.sharded.recall.cpu().numpy()
+
+    def detail(self):
+        if self._detail is None:
+            self._detail = self.engine.evaluate_flat(
+                self.flat, self.device, detail=True, iou_3d_type=self.iou_3d_type)
+        return self._detail
+
+    def sorted_rows(self):
+        raise NotImplementedError(
+            "eval['dt_pointers'] is not assembled in a multi-GPU run: a "
+            "category's rows live on its owner rank (run on one GPU to inspect "
+            "them)")

@@ -62,10 +62,14 @@ class _EvalImgs(Sequence):
 
 
 class LVISEval:
-    def __init__(self, lvis_gt, lvis_dt, iou_type="segm", device=None):
+    def __init__(self, lvis_gt, lvis_dt, iou_type="segm", device=None, dist=None):
         """lvis_gt: LVIS instance or annotation path; lvis_dt: LVISResults
         instance, result path or list of dicts; iou_type: only "bbox" is
-        evaluated on this path (the reference's CLI passes "bbox")."""
+        evaluated on this path (the reference's CLI passes "bbox").
+        ``dist`` (evaluation/_dist.Ctx): this process is one rank of a
+        multi-GPU evaluation and lvis_gt / lvis_dt are its share (images of one
+        block of the sorted image ids); precision / recall come out complete
+        and identical on every rank."""
         self.logger = logging.getLogger(__name__)
         if iou_type not in ["bbox", "segm"]:
             raise ValueError("iou_type: {} is not supported.".format(iou_type))
@@ -81,7 +85,8 @@ class LVISEval:
             self.lvis_dt = LVISResults(self.lvis_gt, lvis_dt)
         else:
             raise TypeError("Unsupported type {} of lvis_dt.".format(lvis_dt))
-        self.device = device
+        self.device = device if dist is None else dist.device
+        self.dist = dist
         self.eval_imgs = []
         self.eval = {}
         self.params = Params(iou_type=iou_type)
@@ -118,7 +123,13 @@ class LVISEval:
                 flat.masks = self._masks(flat)
         self.flat = flat
         self.freq_groups = self._prepare_freq_group()
-        self._run = GpuRun(flat, self.device)
+        if self.dist is not None:
+            if self.params.iou_type != "bbox":
+                raise NotImplementedError("multi-GPU runs evaluate iou_type='bbox'")
+            from .._dist import DistRun
+            self._run = DistRun(flat, self.dist)
+        else:
+            self._run = GpuRun(flat, self.device)
         self._run.evaluate()
         view = CellView(self._run, flat.img_ids, 0, "image_id", "visibility_rng",
                         self.params.visibility_rng)

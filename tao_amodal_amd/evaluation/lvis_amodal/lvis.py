@@ -14,12 +14,14 @@ from ...columns import GTColumns
 
 
 class LVIS:
-    def __init__(self, annotation_path):
+    def __init__(self, annotation_path, columns=None):
         """annotation_path: location of the annotation file (the reference
-        accepts a path only; an already parsed dict is accepted as well)."""
+        accepts a path only; an already parsed dict is accepted as well).
+        ``columns``: an already parsed GTColumns (a rank's share of the file in
+        a multi-GPU run)."""
         self.logger = logging.getLogger(__name__)
         self.logger.info("Loading annotations.")
-        self._columns = None
+        self._columns = columns
         self._index = None
         self._dataset = None
         self._path = None
@@ -28,8 +30,8 @@ class LVIS:
         else:
             # the native reader goes straight to columns; the dict form of the
             # file is only parsed if somebody asks for ``dataset``
-            self._columns = GTColumns.from_file_native(annotation_path) \
-                if isinstance(annotation_path, str) else None
+            if self._columns is None and isinstance(annotation_path, str):
+                self._columns = GTColumns.from_file_native(annotation_path)
             if self._columns is None:
                 self._dataset = self._load_json(annotation_path)
             else:

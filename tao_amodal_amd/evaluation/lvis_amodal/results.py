@@ -16,7 +16,9 @@ from .lvis import LVIS
 
 
 class LVISResults(LVIS):
-    def __init__(self, lvis_gt, results, max_dets=300):
+    def __init__(self, lvis_gt, results, max_dets=300, _share=False):
+        """``_share``: the columns are one rank's share of a multi-GPU run (it
+        may be empty; the whole list was checked in evaluation/_dist.py)."""
         if isinstance(lvis_gt, LVIS):
             self.gt = lvis_gt
         elif isinstance(lvis_gt, str):
@@ -48,7 +50,7 @@ class LVISResults(LVIS):
             else:
                 self.columns_dt = DTColumns.from_json(results)
         self.max_dets = max_dets
-        if len(self.columns_dt) == 0:
+        if len(self.columns_dt) == 0 and not _share:
             raise IndexError("list index out of range")  # results.py:42
         from ...flatten import _lookup
         assert (_lookup(np.unique(self.gt.columns.img_id),

@@ -69,7 +69,10 @@ class _EvalVids(Mapping):
 
 class TaoEval:
     def __init__(self, tao_gt, tao_dt, logger=None, iou_type="bbox",
-                 iou_3d_type="3d_iou", device=None):
+                 iou_3d_type="3d_iou", device=None, dist=None):
+        """``dist`` (evaluation/_dist.Ctx): this process is one rank of a
+        multi-GPU evaluation, tao_gt / tao_dt are its share (videos of one
+        block of the sorted video ids)."""
         if not logger:
             self.logger = logging.getLogger("tao.eval")
         elif isinstance(logger, str):
@@ -90,7 +93,8 @@ class TaoEval:
             self.tao_dt = TaoResults(self.tao_gt, tao_dt)
         else:
             raise TypeError("Unsupported type {} of tao_dt.".format(tao_dt))
-        self.device = device
+        self.device = device if dist is None else dist.device
+        self.dist = dist
         self.eval_vids = {}
         self.eval = {}
         self.params = Params(iou_type=iou_type, iou_3d_type=iou_3d_type)
@@ -121,7 +125,11 @@ class TaoEval:
                 self.tao_gt.columns, self.tao_dt.columns_dt,
                 self.tao_dt.max_dets, use_cats=False)
         flat = self.flat
-        self._run = GpuRun(flat, self.device, self.params.iou_3d_type)
+        if self.dist is not None:
+            from .._dist import DistRun
+            self._run = DistRun(flat, self.dist, self.params.iou_3d_type)
+        else:
+            self._run = GpuRun(flat, self.device, self.params.iou_3d_type)
         self._run.evaluate()
         P = self.params
         rngs = [(a, t) for a in P.area_rng for t in P.time_rng]

@@ -17,7 +17,7 @@ from .tao import Tao
 
 
 class TaoResults(Tao):
-    def __init__(self, tao_gt, results, max_dets=300, _flat=None):
+    def __init__(self, tao_gt, results, max_dets=300, _flat=None, _share=False):
         if isinstance(tao_gt, Tao):
             self.gt = tao_gt
         elif isinstance(tao_gt, str):
@@ -36,7 +36,7 @@ class TaoResults(Tao):
             assert isinstance(results, list), "results is not a list."
             self.columns_dt = DTColumns.from_json(results)
         self.max_dets = max_dets
-        if len(self.columns_dt) == 0:
+        if len(self.columns_dt) == 0 and not _share:
             raise IndexError("list index out of range")  # results.py:61
         if len(self.gt.columns.cat_merged) == 0:
             # TaoResults rebuilds the merge map twice (results.py:47 and, via

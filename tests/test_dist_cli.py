@@ -1,0 +1,130 @@
+"""The drop-in CLI on several ranks (torchrun tools/eval_on_tao_amodal.py):
+
+* not gpu -- the input side over gloo, world sizes 2 and 3: every rank converts
+  its share of the prediction file, the records meet at the rank that owns
+  their image / video in file order, and make_track_ids_unique over the shares
+  equals the single-process statement (fixtures with track ids shared by
+  videos, shuffled image ids);
+* gpu -- the whole command on 2 and 3 ranks (sharing the box's GPU over gloo
+  when it has fewer GPUs than ranks): rank 0's stdout and log file are the
+  reference's text, byte for byte."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+from goldenio import FIXTURES, input_paths, path
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _share_worker(rank, world, port, gt_p, pr_p, out):
+    sys.path[:0] = [ROOT, HERE]
+    import torch
+    import torch.distributed as dist
+    from tao_amodal_amd.columns import DTColumns, GTColumns
+    from tao_amodal_amd.evaluation import _dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ctx = _dist.Ctx(rank, world, torch.device("cpu"), None, None, "gloo")
+    gt = GTColumns.from_file_native(gt_p)
+    dt = DTColumns.from_file_native(pr_p, rank, world)
+    sh = _dist.shard_inputs(gt, dt, dt.first, ctx)
+    np.savez(os.path.join(out, "r%d.npz" % rank), first=dt.first, total=dt.total, n=len(dt),
+             n_changed=sh.n_changed,
+             **{"l_" + f: getattr(sh.dt_lvis, f) for f in DTColumns.FIELDS},
+             **{"t_" + f: getattr(sh.dt_tao, f) for f in DTColumns.FIELDS},
+             l_img=sh.gt_lvis.img_id, t_vid=sh.gt_tao.vid_id, t_img=sh.gt_tao.img_id,
+             l_ann=sh.gt_lvis.ann_id, t_ann=sh.gt_tao.ann_id)
+    dist.destroy_process_group()
+
+
+def _dup_worker(rank, world, port, gt_p, pr_p, out):
+    try:
+        _share_worker(rank, world, port, gt_p, pr_p, out)
+    except NotImplementedError as e:
+        open(os.path.join(out, "err%d.txt" % rank), "w").write(str(e))
+
+
+def test_duplicate_ids_are_refused_on_every_rank(tmp_path):
+    """F2 holds two annotations with one id in different images (the
+    reference's dict keeps the last): refused alike by all ranks, no hang."""
+    gt_p, pr_p = input_paths("f2", tmp_path)
+    mp.spawn(_dup_worker, args=(2, _port(), gt_p, pr_p, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert "one id" in open(os.path.join(str(tmp_path), "err%d.txt" % r)).read()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("name", ["f1", "f3", "f5"])
+def test_shares_are_the_file_cut_by_owner(name, world, tmp_path):
+    from tao_amodal_amd import flatten
+    from tao_amodal_amd.columns import DTColumns, GTColumns
+    from tao_amodal_amd.evaluation._dist import block_owner
+    gt_p, pr_p = input_paths(name, tmp_path)
+    mp.spawn(_share_worker, args=(world, _port(), gt_p, pr_p, str(tmp_path)),
+             nprocs=world, join=True)
+    gt, dt = GTColumns.from_file_native(gt_p), DTColumns.from_file_native(pr_p)
+    want_tid, n_changed = flatten.make_track_ids_unique(dt)
+    own_i = block_owner(np.unique(gt.img_id), dt.image_id, world)
+    own_v = block_owner(np.unique(gt.vid_id), dt.video_id, world)
+    at = 0
+    for r in range(world):
+        z = np.load(os.path.join(str(tmp_path), "r%d.npz" % r))
+        assert int(z["first"]) == at and int(z["total"]) == len(dt)
+        at += int(z["n"])
+        assert int(z["n_changed"]) == n_changed
+        for pre, own in (("l_", own_i), ("t_", own_v)):
+            sel = np.flatnonzero(own == r)                 # file order
+            for f in DTColumns.FIELDS:
+                want = want_tid[sel] if f == "track_id" else getattr(dt, f)[sel]
+                assert np.array_equal(z[pre + f], want), (r, pre, f)
+        # ground truth: blocks of the sorted ids
+        assert np.array_equal(np.sort(z["l_img"]),
+                              np.unique(gt.img_id)[block_owner(np.unique(gt.img_id), np.unique(gt.img_id), world) == r])
+        assert np.array_equal(np.sort(z["t_vid"]),
+                              np.unique(gt.vid_id)[block_owner(np.unique(gt.vid_id), np.unique(gt.vid_id), world) == r])
+        assert np.array_equal(z["l_ann"], gt.ann_id[np.isin(gt.ann_img, z["l_img"])])
+        assert np.array_equal(z["t_ann"], gt.ann_id[np.isin(gt.ann_img, z["t_img"])])
+    assert at == len(dt)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("name", [n for n in FIXTURES if n != "f2"] + ["f8"])
+def test_cli_under_a_launcher_prints_the_reference_text(name, world, tmp_path):
+    gt_p, pr_p = input_paths(name, tmp_path)
+    log = tmp_path / "out" / "eval.log"
+    port = _port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world),
+                   LOCAL_WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen(
+            [sys.executable, os.path.join(ROOT, "tools", "eval_on_tao_amodal.py"),
+             "--track_result", pr_p, "--annotation", gt_p, "--output_log", str(log)],
+            env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=800) for p in procs]
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, (r, outs[r][1][-3000:])
+    assert outs[0][0] == open(path(name, "cli_stdout.txt")).read()
+    for r in range(1, world):
+        assert outs[r][0] == ""
+    want = open(path(name, "cli_log.txt")).read()
+    got = log.read_text().replace(os.path.dirname(gt_p) + os.sep, "<DIR>/")
+    assert got == want

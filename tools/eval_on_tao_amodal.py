@@ -11,6 +11,11 @@ lines in the log; then ``make_track_ids_unique`` and the track-level TaoEval,
 its 19 lines and the four ``TAO 3DmAP...`` lines in the log.  Both JSON files
 are parsed once and shared by the two evaluators (the reference parses each of
 them twice and deep-copies the ground truth twice).
+
+Several GPUs: the same command under ``torchrun --nproc_per_node=N`` (one
+process per GPU, RCCL).  The evaluation is split by video over the ranks
+(tao_amodal_amd/evaluation/_dist.py); rank 0 prints the same text and writes
+the same log file, the other ranks are silent.
 """
 import argparse
 import logging
@@ -125,9 +130,100 @@ def eval_tao_track(ann_path, gt_dataset, gt_columns, dt_columns, logger,
     return results
 
 
+def main_distributed(args, annotation):
+    """One rank of ``torchrun ... tools/eval_on_tao_amodal.py``."""
+    import contextlib
+    import io
+    from tao_amodal_amd.columns import GTColumns
+    from tao_amodal_amd.evaluation import _dist
+    from tao_amodal_amd.evaluation._core import timed
+    from tao_amodal_amd import dist as tdist, flatten_dev
+    # stdout carries the result lines only: gloo / RCCL / the HIP runtime print
+    # their banners to the C-level stdout, so descriptor 1 is pointed at stderr
+    # for the run and Python's stdout at a copy of the real one
+    sys.stdout.flush()
+    py_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    sys.stdout = py_stdout
+    ctx = _dist.init_from_env()
+    logger = logging.getLogger("__main__")
+    logger.setLevel(logging.INFO if ctx.rank == 0 else logging.ERROR)
+    handler = None
+    if ctx.rank == 0:
+        output_log = Path(args.output_log)
+        output_log.parent.mkdir(parents=True, exist_ok=True)
+        handler = logging.FileHandler(output_log, mode="w")
+        logger.addHandler(handler)
+    else:
+        for name in ("tao.tao", "tao.results", "tao.eval", "root"):
+            logging.getLogger(name).setLevel(logging.CRITICAL)
+        logging.getLogger().setLevel(logging.CRITICAL)
+    quiet = contextlib.redirect_stdout(io.StringIO()) if ctx.rank else contextlib.nullcontext()
+    try:
+        with quiet:
+            with timed("parse"):
+                gt = GTColumns.from_file_native(annotation)
+                if gt is None:
+                    with open(annotation) as f:
+                        gt = GTColumns.from_json(json.load(f))
+                dt = DTColumns.from_file_native(args.track_result, ctx.rank, ctx.world)
+            with timed("exchange"):
+                sh = _dist.shard_inputs(gt, dt, dt.first, ctx)
+            # ---- image level
+            lvis_gt = LVIS(annotation, columns=sh.gt_lvis)
+            logger.info("Evaluating {} on LVIS...".format(args.track_result))
+            lvis_eval = LVISEval(lvis_gt, LVISResults(lvis_gt, sh.dt_lvis, _share=True),
+                                 "bbox", dist=ctx)
+            lvis_eval.run()
+            lvis_eval.print_results()
+            results = lvis_eval.get_results()
+            results = {m: float(results[m] * 100) for m in LVIS_METRICS}
+            logger.info("Evaluation results for {}: \n".format("bbox")
+                        + create_small_table(results))
+            logger.info("copypaste: " + ",".join(LVIS_METRICS))
+            logger.info("copypaste: " + ",".join(
+                "{0:.4f}".format(results[m]) for m in LVIS_METRICS))
+            # ---- track level
+            logger.info("Loading gt {}...".format(annotation))
+            tao_gt = Tao(annotation, columns=sh.gt_tao)
+            logger.info("Done")
+            logger.info("Loading results...")
+            logger.info("Done")
+            logger.info("Building")
+            with timed("flatten"):
+                universe = tdist.gather_visit_universe(sh.gt_tao, ctx.device, ctx.group)
+                flat = flatten_dev.flatten_tao(sh.gt_tao, sh.dt_tao, device=ctx.device,
+                                               visit_universe=universe)
+            tao_eval = TaoEval(tao_gt, TaoResults(tao_gt, sh.dt_tao, _flat=flat, _share=True),
+                               logger=logger, dist=ctx)
+            logger.info("Done")
+            tao_eval.run()
+            tao_eval.print_results()
+            res = tao_eval.get_results()
+            out = {"TAO 3DmAP50": res["AP50"] * 100, "TAO 3DmAP50-HP": res["AP50-HP"] * 100,
+                   "TAO 3DmAP": res["AP"] * 100, "TAO 3DmAP-HP": res["AP-HP"] * 100}
+            for k, v in out.items():
+                logger.info("{}:{:.4f}".format(k, v))
+            logger.info("copypaste: " + ",".join(out))
+            logger.info("copypaste: " + ",".join("{:.4f}".format(v) for v in out.values()))
+    finally:
+        if handler is not None:
+            logger.removeHandler(handler)
+            handler.close()
+    sys.stdout.flush()
+    import torch.distributed as dist
+    dist.barrier(group=ctx.host_group)
+    if os.environ.get("TAOAMD_TIMING") and ctx.rank == 0:
+        from tao_amodal_amd.evaluation._core import TIMING
+        print("taoamd timing (s): " + json.dumps(
+            {k: round(v, 3) for k, v in TIMING.items()}), file=sys.stderr)
+
+
 def main(argv=None):
     args = default_arg_parser(argv)
     annotation = args.annotation if args.annotation else DEFAULT_ANNOTATION
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        return main_distributed(args, annotation)
     output_log = Path(args.output_log)
     logger = logging.getLogger("__main__")
     logger.setLevel(logging.INFO)
