@@ -111,9 +111,57 @@ def _bit(words, combo):
             & np.uint64(1)).astype(bool)
 
 
+def restrict_to_params(gt, dt, unit, unit_ids, cat_ids, use_cats):
+    """The reference's ``_prepare`` (lvis_amodal/eval.py:59-105,
+    tao_amodal/eval.py:178-233) for edited ``params``: the ground truth and the
+    predictions of the images / videos in ``unit_ids`` only.  ``unit`` is
+    "image" or "video"; ``cat_ids`` = params.cat_ids in the caller's order.
+    Returns (gt columns, dt columns, cat_pos): cat_pos[i] = index of
+    cat_ids[i] in the sorted category table -- the category axis of the result
+    tables is taken through it (categories are independent of each other when
+    use_cats = 1, so a category subset is a selection of result columns; the
+    class-agnostic pool of use_cats = 0 is formed from all categories and a
+    subset there raises).  Unknown ids raise KeyError like the reference's
+    load_imgs / load_vids / load_cats."""
+    all_units = np.unique(gt.img_id if unit == "image" else gt.vid_id)
+    unit_ids = np.asarray(unit_ids, dtype=np.int64).reshape(-1)
+    pos = np.searchsorted(all_units, unit_ids)
+    bad = (pos >= len(all_units)) | (all_units[np.minimum(pos, len(all_units) - 1)] != unit_ids) \
+        if len(all_units) else np.ones(len(unit_ids), bool)
+    if bad.any():
+        raise KeyError(int(unit_ids[np.flatnonzero(bad)[0]]))
+    all_cats = np.unique(gt.cat_id)
+    cat_ids = np.asarray(cat_ids, dtype=np.int64).reshape(-1)
+    if len(cat_ids) == 0:
+        raise NotImplementedError("an empty params.cat_ids is not evaluated")
+    cpos = np.searchsorted(all_cats, cat_ids)
+    cbad = (cpos >= len(all_cats)) | (all_cats[np.minimum(cpos, len(all_cats) - 1)] != cat_ids)
+    if cbad.any():
+        raise KeyError(int(cat_ids[np.flatnonzero(cbad)[0]]))
+    whole_cats = len(cat_ids) == len(all_cats) and np.array_equal(cat_ids, all_cats)
+    if not whole_cats and not use_cats:
+        raise NotImplementedError(
+            "params.cat_ids restricts the categories while use_cats = 0 pools "
+            "them: not evaluated on the HIP path")
+    if len(unit_ids) != len(all_units):
+        if unit == "image":
+            keep = np.isin(gt.img_id, unit_ids)
+            gt = gt.select_images(keep)
+            dt = dt.take(np.flatnonzero(np.isin(dt.image_id, unit_ids)))
+        else:
+            gt = gt.select_videos(np.isin(gt.vid_id, unit_ids))
+            # predictions on the images of those videos (T/tao.py:224-235)
+            dt = dt.take(np.flatnonzero(np.isin(dt.image_id, gt.img_id)))
+    return gt, dt, (None if whole_cats else cpos)
+
+
 class CellView:
     """What the reference stores per (unit, category, range) in eval_imgs /
-    eval_vids, rebuilt on demand from the device results."""
+    eval_vids, rebuilt on demand from the device results.  ``cat_pos``: index
+    of the caller's i-th category (params.cat_ids) in the tables' category
+    axis, when params.cat_ids is not the whole sorted table."""
+
+    cat_pos = None
 
     def __init__(self, run, unit_ids, sentinel, unit_key, rng_key, rng_values):
         self.run = run
@@ -124,7 +172,9 @@ class CellView:
         self.K = len(self.flat.cat_ids)
         self._index = None
 
-    def cell_of(self, unit_idx, cat_idx):
+    def cell_of(self, unit_idx, cat_idx, table_index=False):
+        if self.cat_pos is not None and not table_index:
+            cat_idx = self.cat_pos[cat_idx]
         if self._index is None:     # built on first inspection only
             f = self.flat
             self._index = {int(u) * self.K + int(c): k for k, (u, c) in
@@ -189,7 +239,7 @@ class LazyIous(Mapping):
         u, c = key
         if u not in self.upos or c not in self.cpos:
             raise KeyError(key)
-        k = self.view.cell_of(self.upos[u], self.cpos[c])
+        k = self.view.cell_of(self.upos[u], self.cpos[c], table_index=True)
         return [] if k is None else self.view.iou(k)
 
     def __iter__(self):
@@ -202,8 +252,9 @@ class LazyIous(Mapping):
 class LazyPointers(Mapping):
     """eval['dt_pointers'][cat_idx][range...] = {dt_ids, tps, fps}."""
 
-    def __init__(self, run, n_rng, shape):
+    def __init__(self, run, n_rng, shape, cat_pos=None):
         self.run, self.n_rng, self.shape = run, n_rng, shape
+        self.cat_pos = cat_pos
         self._rows = None
 
     def _data(self):
@@ -224,6 +275,8 @@ class LazyPointers(Mapping):
     def __getitem__(self, k):
         if not 0 <= k < len(self):
             raise KeyError(k)
+        if self.cat_pos is not None:
+            k = int(self.cat_pos[k])
         if len(self.shape) == 1:
             return {r: self.leaf(k, r) for r in range(self.shape[0])}
         A, T = self.shape
@@ -234,28 +287,21 @@ class LazyPointers(Mapping):
         return iter(range(len(self)))
 
     def __len__(self):
-        return self.run.dp.n_cat
+        return self.run.dp.n_cat if self.cat_pos is None else len(self.cat_pos)
 
 
 def now():
     return datetime.datetime.now().strftime("%Y-%m-%d %H:%M:%S")
 
 
-def require_default_params(params, fresh, id_fields):
-    """The kernels evaluate every image / video and category of the ground
-    truth at the reference's default thresholds and ranges (compiled in).  The
-    reference lets a caller edit ``params`` before ``evaluate()``; edits this
-    path cannot honour must not pass silently, so they raise.  ``fresh`` is a
-    newly built Params of the same kind, ``id_fields`` maps a params field to
-    the ids the ground truth defines (``use_cats`` and ``iou_3d_type`` ARE
-    honoured)."""
-    for name, want in id_fields.items():
-        got = np.unique(np.asarray(getattr(params, name)))
-        if not np.array_equal(got, np.unique(np.asarray(want))):
-            raise NotImplementedError(
-                "params.%s restricts the evaluation to a subset; the HIP path "
-                "evaluates the whole ground truth (filter the inputs instead)"
-                % name)
+def require_default_params(params, fresh, id_fields=None):
+    """The kernels evaluate at the reference's default thresholds and ranges
+    (compiled in).  The reference lets a caller edit ``params`` before
+    ``evaluate()``; ``img_ids`` / ``vid_ids`` / ``cat_ids`` subsets,
+    ``max_dets`` (a label), ``use_cats`` and ``iou_3d_type`` ARE honoured
+    (restrict_to_params); edits of the thresholds and ranges cannot be and must
+    not pass silently, so they raise.  ``fresh`` is a newly built Params of the
+    same kind."""
     for name in ("iou_thrs", "rec_thrs"):
         if not np.array_equal(np.asarray(getattr(params, name), dtype=np.float64),
                               getattr(fresh, name)):

@@ -12,7 +12,7 @@ import numpy as np
 
 from ... import flatten
 from .._core import (N_REC, N_THR, CellView, GpuRun, LazyIous, LazyPointers,
-                     require_default_params,
+                     require_default_params, restrict_to_params,
                      masked_mean, now, timed)
 from .lvis import LVIS
 from .results import LVISResults
@@ -95,6 +95,7 @@ class LVISEval:
         self.params.img_ids = sorted(self.lvis_gt.get_img_ids())
         self.params.cat_ids = sorted(self.lvis_gt.get_cat_ids())
         self._run = None
+        self._cat_pos = None
 
     # ------------------------------------------------------------ stages
     def evaluate(self):
@@ -103,19 +104,21 @@ class LVISEval:
         if self.params.iou_type not in ("bbox", "segm"):
             raise ValueError("Unknown iou_type for iou computation.")
         self.params.img_ids = list(np.unique(self.params.img_ids))
-        require_default_params(
-            self.params, Params(self.params.iou_type),
-            {"img_ids": self.lvis_gt.get_img_ids(),
-             "cat_ids": self.lvis_gt.get_cat_ids()})
+        require_default_params(self.params, Params(self.params.iou_type))
         use_cats = bool(self.params.use_cats)
         with timed("flatten"):
+            # params.img_ids / cat_ids subsets (reference eval.py:59-105)
+            gt_cols, dt_cols, self._cat_pos = restrict_to_params(
+                self.lvis_gt.columns, self.lvis_dt.columns_dt, "image",
+                self.params.img_ids, self.params.cat_ids, use_cats)
+            if gt_cols is not self.lvis_gt.columns and self.params.iou_type == "segm":
+                raise NotImplementedError("iou_type='segm' with an image subset")
             # use_cats = 0: class-agnostic cells, one per image (reference
             # eval.py:125-128,147-166)
             # (built on the device: flatten_dev; flatten.py for the inputs it
             # does not cover)
             from ... import flatten_dev
-            flat = flatten_dev.flatten_lvis(self.lvis_gt.columns,
-                                            self.lvis_dt.columns_dt,
+            flat = flatten_dev.flatten_lvis(gt_cols, dt_cols,
                                             self.lvis_dt.max_dets,
                                             use_cats=use_cats, device=self.device)
         if self.params.iou_type == "segm":
@@ -133,6 +136,7 @@ class LVISEval:
         self._run.evaluate()
         view = CellView(self._run, flat.img_ids, 0, "image_id", "visibility_rng",
                         self.params.visibility_rng)
+        view.cat_pos = self._cat_pos
         cats = self.params.cat_ids if use_cats else [-1]
         self.ious = LazyIous(view, self.params.img_ids, cats)
         self.eval_imgs = _EvalImgs(view, len(self.params.img_ids),
@@ -178,7 +182,10 @@ class LVISEval:
     def _prepare_freq_group(self):
         groups = [[] for _ in self.params.img_count_lbl]
         from ...columns import FREQ_MISSING, FREQ_OTHER
-        for idx, fr in enumerate(self.flat.cat_freq.tolist()):
+        freq = np.asarray(self.flat.cat_freq)
+        if self._cat_pos is not None:          # params.cat_ids, in the caller's order
+            freq = freq[self._cat_pos]
+        for idx, fr in enumerate(freq.tolist()):
             if fr == FREQ_MISSING:
                 raise KeyError("frequency")       # reference: cat["frequency"]
             if fr == FREQ_OTHER:
@@ -193,15 +200,20 @@ class LVISEval:
             return
         self._run.accumulate()
         n_rng = len(self.params.visibility_rng)
+        precision, recall = self._run.precision, self._run.recall
+        if self._cat_pos is not None:
+            # the category axis in the order of params.cat_ids
+            precision = np.ascontiguousarray(precision[:, :, self._cat_pos])
+            recall = np.ascontiguousarray(recall[:, self._cat_pos])
         self.eval = {
             "params": self.params,
             "counts": [N_THR, N_REC,
                        len(self.params.cat_ids) if self.params.use_cats else 1,
                        n_rng],
             "date": now(),
-            "precision": self._run.precision,
-            "recall": self._run.recall,
-            "dt_pointers": LazyPointers(self._run, n_rng, (n_rng,)),
+            "precision": precision,
+            "recall": recall,
+            "dt_pointers": LazyPointers(self._run, n_rng, (n_rng,), self._cat_pos),
         }
 
     def _summarize(self, summary_type, iou_thr=None, visibility_rng="all",

@@ -113,10 +113,41 @@ class LVIS:
     def load_imgs(self, ids):
         return self._load_helper(self.imgs, ids)
 
-    # segmentation / download helpers of the reference (lvis.py:155-205) are
-    # outside the bbox evaluation path
     def ann_to_rle(self, ann):
-        raise NotImplementedError("segm evaluation is out of scope")
+        """Polygons / uncompressed RLE of an annotation to a compressed RLE
+        (reference lvis.py:171-193: mask_utils.frPyObjects + merge): a dict
+        {"size": [h, w], "counts": bytes} as pycocotools returns it; an
+        annotation that already holds a compressed RLE comes back as it is.
+        Rasterisation, union and the text form are native (csrc/rle.cpp)."""
+        img_data = self.imgs[ann["image_id"]]
+        h, w = img_data["height"], img_data["width"]
+        segm = ann["segmentation"]
+        if not isinstance(segm, list) and not isinstance(segm["counts"], list):
+            return segm
+        from ...masks import MaskBatch
+        batch = MaskBatch()
+        try:
+            batch.add(segm, h, w)
+            text = batch.text(0)
+        finally:
+            batch.close()
+        size = [int(h), int(w)] if isinstance(segm, list) else \
+            [int(segm["size"][0]), int(segm["size"][1])]
+        return {"size": size, "counts": text.encode("ascii")}
 
     def ann_to_mask(self, ann):
-        raise NotImplementedError("segm evaluation is out of scope")
+        """Binary mask of an annotation, uint8 [h, w] in Fortran order like
+        mask_utils.decode (reference lvis.py:195-205)."""
+        import numpy as np
+        from ...masks import MaskBatch
+        rle = self.ann_to_rle(ann)
+        batch = MaskBatch()
+        try:
+            batch.add(rle, 0, 0)
+            m = batch.arrays()
+        finally:
+            batch.close()
+        h, w = int(m.hw[0, 0]), int(m.hw[0, 1])
+        runs = m.counts[m.off[0]:m.off[1]].astype(np.int64)
+        bits = np.repeat(np.arange(len(runs), dtype=np.uint8) & 1, runs)
+        return np.asfortranarray(bits.reshape((h, w), order="F"))

@@ -104,6 +104,7 @@ class TaoEval:
         self.params.cat_ids = sorted(self.tao_gt.get_cat_ids())
         self.flat = self.tao_dt.flat
         self._run = None
+        self._cat_pos = None
 
     # ------------------------------------------------------------ stages
     def evaluate(self, show_progress=False):
@@ -114,16 +115,29 @@ class TaoEval:
         if self.params.iou_3d_type not in ("3d_iou", "avg_iou", "imagenetvid"):
             raise ValueError("Unknown iou_3d_type %r" % self.params.iou_3d_type)
         self.params.vid_ids = list(np.unique(self.params.vid_ids))
-        require_default_params(
-            self.params, Params(self.params.iou_type),
-            {"vid_ids": self.tao_gt.get_vid_ids(),
-             "cat_ids": self.tao_gt.get_cat_ids()})
+        require_default_params(self.params, Params(self.params.iou_type))
+        # params.vid_ids / cat_ids subsets (reference eval.py:178-233)
+        from .._core import restrict_to_params
+        gt_cols, dt_cols, self._cat_pos = restrict_to_params(
+            self.tao_gt.columns, self.tao_dt.columns_dt, "video",
+            self.params.vid_ids, self.params.cat_ids, bool(self.params.use_cats))
+        subset = gt_cols is not self.tao_gt.columns
+        if subset:
+            if len(gt_cols.ann_id) == 0:
+                raise ValueError("Found no groundtruth annotations for given params")
+            if len(dt_cols) == 0:
+                raise ValueError("Found no predicted annotations for given params")
+            if self.dist is not None:
+                raise NotImplementedError("params.vid_ids subsets in a multi-GPU run")
         if not self.params.use_cats:
             # class-agnostic cells (reference eval.py:257-260,293-303)
             from ... import flatten
             self.flat = flatten.flatten_tao(
-                self.tao_gt.columns, self.tao_dt.columns_dt,
-                self.tao_dt.max_dets, use_cats=False)
+                gt_cols, dt_cols, self.tao_dt.max_dets, use_cats=False)
+        elif subset:
+            from ... import flatten_dev
+            self.flat = flatten_dev.flatten_tao(gt_cols, dt_cols, self.tao_dt.max_dets,
+                                                device=self.device)
         flat = self.flat
         if self.dist is not None:
             from .._dist import DistRun
@@ -134,6 +148,7 @@ class TaoEval:
         P = self.params
         rngs = [(a, t) for a in P.area_rng for t in P.time_rng]
         view = CellView(self._run, flat.vid_ids, -1, "video_id", "rng", rngs)
+        view.cat_pos = self._cat_pos
         cats = P.cat_ids if P.use_cats else [-1]
         self.ious = LazyIous(view, P.vid_ids, cats)
         self.eval_vids = _EvalVids(view, len(P.vid_ids), len(cats),
@@ -157,13 +172,18 @@ class TaoEval:
         P = self.params
         A, T = len(P.area_rng), len(P.time_rng)
         K = len(P.cat_ids) if P.use_cats else 1
+        precision, recall = self._run.precision, self._run.recall
+        if self._cat_pos is not None:
+            # the category axis in the order of params.cat_ids
+            precision = np.ascontiguousarray(precision[:, :, self._cat_pos])
+            recall = np.ascontiguousarray(recall[:, self._cat_pos])
         self.eval = {
             "params": P,
             "counts": [N_THR, N_REC, K, A, T],
             "date": now(),
-            "precision": self._run.precision.reshape(N_THR, N_REC, K, A, T),
-            "recall": self._run.recall.reshape(N_THR, K, A, T),
-            "dt_pointers": LazyPointers(self._run, A * T, (A, T)),
+            "precision": precision.reshape(N_THR, N_REC, K, A, T),
+            "recall": recall.reshape(N_THR, K, A, T),
+            "dt_pointers": LazyPointers(self._run, A * T, (A, T), self._cat_pos),
         }
 
     def _summarize(self, summary_type, iou_thr=None, area_rng="all",

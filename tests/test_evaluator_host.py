@@ -109,13 +109,13 @@ def test_product_path_refuses_to_run_without_gpu():
 
 
 @pytest.mark.parametrize("edit", [
-    ("img_ids", lambda v: v[:1]), ("cat_ids", lambda v: v[:1]),
     ("iou_thrs", lambda v: v[:3]), ("rec_thrs", lambda v: v[::2]),
     ("visibility_rng", lambda v: v[:2])])
 def test_lvis_params_edits_the_kernels_cannot_honour_raise(edit):
-    """The reference lets a caller restrict / change params before evaluate();
-    this path evaluates the whole ground truth at the compiled-in thresholds,
-    so such edits must raise instead of silently giving full-set numbers."""
+    """The reference lets a caller change params before evaluate(); id subsets
+    are honoured (tests/test_gpu_cli.py, goldens from the reference), the
+    thresholds and ranges are compiled into the kernels, so such edits must
+    raise instead of silently giving default numbers."""
     ev = LVISEval(path("f1", "gt.json"), path("f1", "pred.json"), "bbox")
     name, fn = edit
     setattr(ev.params, name, fn(getattr(ev.params, name)))
@@ -124,7 +124,6 @@ def test_lvis_params_edits_the_kernels_cannot_honour_raise(edit):
 
 
 @pytest.mark.parametrize("edit", [
-    ("vid_ids", lambda v: v[:1]), ("cat_ids", lambda v: v[1:]),
     ("iou_thrs", lambda v: v + 0.01), ("area_rng", lambda v: v[:1]),
     ("time_rng", lambda v: [[0, 5]])])
 def test_tao_params_edits_the_kernels_cannot_honour_raise(edit):
@@ -137,3 +136,36 @@ def test_tao_params_edits_the_kernels_cannot_honour_raise(edit):
     setattr(ev.params, name, fn(getattr(ev.params, name)))
     with pytest.raises(NotImplementedError, match="params." + name):
         ev.evaluate()
+
+
+def test_restrict_to_params_is_the_references_prepare_filter():
+    """_core.restrict_to_params on columns == the reference's get_ann_ids
+    filter (images of the subset, annotations on them, predictions on them);
+    category subsets become a selection of result columns."""
+    from tao_amodal_amd.columns import GTColumns
+    from tao_amodal_amd.evaluation._core import restrict_to_params
+    gtj, predj = load_inputs("f1")
+    gt, dt = GTColumns.from_json(gtj), DTColumns.from_json(predj)
+    imgs = sorted(i["id"] for i in gtj["images"])[3:17]
+    cats = sorted(c["id"] for c in gtj["categories"])
+    g2, d2, pos = restrict_to_params(gt, dt, "image", imgs, cats[::-1][:2], True)
+    assert sorted(g2.img_id.tolist()) == imgs
+    assert g2.ann_id.tolist() == [a["id"] for a in gtj["annotations"] if a["image_id"] in imgs]
+    assert d2.image_id.tolist() == [p["image_id"] for p in predj if p["image_id"] in imgs]
+    assert pos.tolist() == [len(cats) - 1, len(cats) - 2]
+    vids = sorted(v["id"] for v in gtj["videos"])[1:3]
+    g3, d3, pos = restrict_to_params(gt, dt, "video", vids, cats, True)
+    in_v = {i["id"] for i in gtj["images"] if i["video_id"] in vids}
+    assert pos is None and sorted(g3.vid_id.tolist()) == vids
+    assert sorted(g3.img_id.tolist()) == sorted(in_v)
+    assert g3.trk_id.tolist() == [t["id"] for t in gtj["tracks"] if t["video_id"] in vids]
+    assert d3.image_id.tolist() == [p["image_id"] for p in predj if p["image_id"] in in_v]
+    g4, d4, pos = restrict_to_params(gt, dt, "image", sorted(i["id"] for i in gtj["images"]),
+                                     cats, True)
+    assert g4 is gt and d4 is dt and pos is None
+    with pytest.raises(KeyError):
+        restrict_to_params(gt, dt, "video", [10 ** 9], cats, True)
+    with pytest.raises(KeyError):
+        restrict_to_params(gt, dt, "image", imgs, [10 ** 9], True)
+    with pytest.raises(NotImplementedError):
+        restrict_to_params(gt, dt, "image", imgs, cats[:1], False)

@@ -96,3 +96,62 @@ def test_tao_class_api_state_matches_reference(name):
         g = ev.eval["dt_pointers"][k][a][t]
         assert list(g["dt_ids"]) == p_["dt_ids"]
         assert np.array_equal(g["tps"].astype(int), np.asarray(p_["tps"]).reshape(g["tps"].shape))
+
+
+def _subset_golden(name):
+    import json
+    z = np.load(path(name, "params_subset.npz"))
+    gt = json.load(open(path(name, "gt.json")))
+    return z, gt
+
+
+@pytest.mark.parametrize("name", ["f1", "f5"])
+def test_edited_params_subsets_match_the_reference(name):
+    """params.img_ids / vid_ids / cat_ids edited before run() (reference
+    lvis_amodal/eval.py:59-105, tao_amodal/eval.py:178-233): golden vectors
+    from the reference run with the same subsets (tests/golden/
+    make_golden_params.py) -- a subset of the images / videos, every other
+    category in descending order."""
+    from tao_amodal_amd import flatten
+    from tao_amodal_amd.columns import DTColumns
+    from tao_amodal_amd.evaluation.lvis_amodal import LVISEval
+    from tao_amodal_amd.evaluation.tao_amodal import Tao, TaoEval, TaoResults
+    z, _ = _subset_golden(name)
+    ev = LVISEval(path(name, "gt.json"), path(name, "pred.json"), "bbox")
+    ev.params.img_ids = z["img_ids"].tolist()
+    ev.params.cat_ids = z["cat_ids"].tolist()
+    ev.run()
+    assert np.array_equal(ev.eval["precision"], z["lvis_precision"])
+    assert np.array_equal(ev.eval["recall"], z["lvis_recall"])
+    assert [float(v) for v in ev.results.values()] == z["lvis_results"].tolist()
+    assert [len(g) for g in ev.freq_groups] == z["lvis_freq_groups"].tolist()
+    # the views follow params.cat_ids' order
+    c0 = int(z["cat_ids"][0])
+    assert all(e is None or e["category_id"] == c0
+               for e in ev.eval_imgs[: len(ev.params.img_ids)])
+    dt = DTColumns.from_json(path(name, "pred.json"))
+    dt.track_id, _ = flatten.make_track_ids_unique(dt)
+    gt = Tao(path(name, "gt.json"))
+    te = TaoEval(gt, TaoResults(gt, dt))
+    te.params.vid_ids = z["vid_ids"].tolist()
+    te.params.cat_ids = z["cat_ids"].tolist()
+    te.run()
+    assert np.array_equal(te.eval["precision"], z["tao_precision"])
+    assert np.array_equal(te.eval["recall"], z["tao_recall"])
+    assert [float(v) for v in te.results.values()] == z["tao_results"].tolist()
+
+
+def test_edited_params_the_path_cannot_honour_still_raise():
+    from tao_amodal_amd.evaluation.lvis_amodal import LVISEval
+    ev = LVISEval(path("f1", "gt.json"), path("f1", "pred.json"), "bbox")
+    ev.params.iou_thrs = np.array([0.5, 0.6])
+    with pytest.raises(NotImplementedError):
+        ev.evaluate()
+    ev = LVISEval(path("f1", "gt.json"), path("f1", "pred.json"), "bbox")
+    ev.params.img_ids = [10 ** 9]
+    with pytest.raises(KeyError):
+        ev.evaluate()
+    ev = LVISEval(path("f1", "gt.json"), path("f1", "pred.json"), "bbox")
+    ev.params.max_dets = 100            # a label only (eval.py:464-545)
+    ev.run()
+    assert "AR@100" in ev.results

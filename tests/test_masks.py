@@ -171,3 +171,34 @@ def test_add_many_equals_add_in_a_loop():
     bad = MaskBatch()
     with pytest.raises(TypeError):
         bad.add_many([([[1, 2, 3, 4, 5, 6]], 5, 5), ([[1, 2, 3, 4]], 5, 5)])
+
+
+def test_lvis_ann_to_rle_and_ann_to_mask_equal_the_reference():
+    """LVIS.ann_to_rle (reference lvis.py:171-193) on the four forms F6's
+    ground truth holds -- one polygon, several polygons, uncompressed RLE,
+    compressed RLE -- against the compressed text the reference produced;
+    ann_to_mask against the oracle's decoder."""
+    from oracle import rle as orle
+    from tao_amodal_amd.evaluation.lvis_amodal import LVIS
+    with gzip.open(path("f6", "lvis_segm.json.gz")) as f:
+        w = json.load(f)["pred"]
+    gt = LVIS(path("f6", "gt.json"))
+    n = 0
+    for a in gt.dataset["annotations"]:
+        if str(a["id"]) not in w["gt_rle"]:
+            continue
+        r = gt.ann_to_rle(a)
+        im = gt.imgs[a["image_id"]]
+        text = r["counts"].decode() if isinstance(r["counts"], bytes) else r["counts"]
+        assert text == w["gt_rle"][str(a["id"])]
+        assert list(r["size"]) == [im["height"], im["width"]]
+        m = gt.ann_to_mask(a)
+        assert m.shape == (im["height"], im["width"]) and m.dtype == np.uint8
+        assert m.flags["F_CONTIGUOUS"]
+        runs = orle.fr_string(text, im["height"], im["width"])["counts"]
+        want = np.repeat(np.arange(len(runs)) % 2, runs).astype(np.uint8).reshape(
+            (im["height"], im["width"]), order="F")
+        assert np.array_equal(m, want) and int(m.sum()) == orle.area(
+            orle.fr_string(text, im["height"], im["width"]))
+        n += 1
+    assert n >= 4
