@@ -200,6 +200,18 @@ int taoamd_track_iou_planned(int64_t n_tasks, const int32_t *tasks,
                              const int32_t *trk_meta, int32_t mode, double *iou,
                              int64_t *pair_frames, void *stream);
 
+/* The same IoUs when EVERY detection and ground-truth track has exactly one
+ * frame (frame k of the lists = the frame of track k): a pair is one box IoU
+ * if the two frames are the same timeline position, else 0 -- a single term,
+ * so the value does not depend on any order of summation.  dt_group
+ * (int32[n_dt][4], device) = {first GT track of the detection's cell, GT
+ * tracks of the cell, the detection's place in its cell, the cell}. */
+int taoamd_track_iou_single(int64_t n_dt, const int32_t *dt_group,
+                            const int64_t *cell_iou_off, const int32_t *dt_frame_pos,
+                            const double *dt_frame_box, const int32_t *gt_frame_pos,
+                            const double *gt_frame_box, int32_t mode, double *iou,
+                            int64_t *pair_frames, void *stream);
+
 /* Padded frame table of a set of CSR tracks: track t owns the slots
  * meta[t].base_minus_first + p for p = first .. last (its first and last
  * timeline position); a slot holds the frame's box (x, y, w, h) or, where the

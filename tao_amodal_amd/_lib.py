@@ -46,6 +46,8 @@ SIGNATURES = {
                                       _sz, _vp]),
     "taoamd_track_iou": (C.c_int, [_i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp,
                                    _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
+    "taoamd_track_iou_single": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32,
+                                          _vp, _vp, _vp]),
     "taoamd_track_iou_planned": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp,
                                            _i32, _vp, _vp, _vp]),
     "taoamd_track_pad": (C.c_int, [_i64, _i64, _vp, _vp, _vp, _vp, _i64, _i64,

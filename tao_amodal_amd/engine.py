@@ -13,6 +13,8 @@ which covers reference LVISEval.evaluate()+accumulate() (lvis_amodal/eval.py:
 115-145,305-426) or TaoEval.evaluate()+accumulate() (tao_amodal/eval.py:
 246-276,459-584) for the non-empty cells.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -258,6 +260,7 @@ class DeviceProblem:
             runs[:, 3] = flat.cell_gt_off[c1] - flat.cell_gt_off[c0]
         self.t["groups"] = torch.from_numpy(runs).to(self.device)
         self.n_tasks = 0
+        self.single_frame = False
         self.exact_terms = False
         self.guard_flat = None         # host tables of the host-side guard
         self.guard_on_device = False
@@ -304,6 +307,16 @@ class DeviceProblem:
         # take the two-pointer merge kernel instead (no plan)
         if n_slots > 4 * n_frames + (1 << 20) or n_slots >= 2 ** 31 - 1:
             return
+        # every track a single frame (the stress shape: 10 000 one-frame
+        # videos): a pair is ONE box IoU or 0 -- no sum, no order of summation,
+        # nothing to guard; taoamd_track_iou_single instead of the task kernel,
+        # whose LDS pipeline would be all prologue (1.05 ms for 2.9 M tracks)
+        self.single_frame = (len(meta) > 0 and n_frames == len(meta)
+                             and bool((meta[:, 0] == meta[:, 1]).all())
+                             and os.environ.get("TAOAMD_SINGLE_FRAME", "1") != "0")
+        if self.single_frame:
+            self.exact_terms = True
+            return
         tasks, rows, pairs, out = track_iou_plan(flat, meta)
         self.n_tasks = len(tasks)
         if self.n_tasks == 0:
@@ -340,10 +353,11 @@ class DeviceProblem:
         """Whether a pass runs the frame-order guard: the count-based
         imagenetvid IoU is exact in any order, and so is the 3D IoU of integer
         boxes (exact_terms) -- but NOT the average IoU of integer boxes, whose
-        per-frame ratios are rounded divisions."""
+        per-frame ratios are rounded divisions.  One-frame tracks have a
+        single term in every mode."""
         return (self.kind == "tao" and self.n_iou > 0 and self.iou_mode != 2
                 and not (self.exact_terms and self.iou_mode == 0)
-                and self.device.type == "cuda")
+                and not self.single_frame and self.device.type == "cuda")
 
     def _plan_guard(self, flat, guard):
         """Tables of the frame-order guard (stage_iou_guard)."""
@@ -520,6 +534,13 @@ def stage_track_iou(dp, ws):
     if dp.kind != "tao" or dp.n_iou == 0:
         return
     lib, t, s = _lib.load(), dp.t, _stream()
+    if dp.single_frame:
+        _lib.check(lib.taoamd_track_iou_single(
+            dp.n_dt, _ptr(t["dt_group"]), _ptr(t["cell_iou_off"]),
+            _ptr(t["dt_frame_pos"]), _ptr(t["dt_frame_box"]), _ptr(t["gt_frame_pos"]),
+            _ptr(t["gt_frame_box"]), dp.iou_mode, _ptr(ws.iou), _ptr(ws.pair_frames), s),
+            "taoamd_track_iou_single")
+        return
     if t["tasks"] is not None:
         _lib.check(lib.taoamd_track_iou_planned(
             dp.n_tasks, _ptr(t["tasks"]), _ptr(t["task_rows"]),

@@ -702,3 +702,23 @@ def test_segment_sort_mixes_the_three_ways_of_finishing_a_category():
     torch.cuda.synchronize()
     assert np.array_equal(order.cpu().numpy(), want)
     assert np.array_equal(dst.cpu().numpy()[want], np.arange(n))
+
+
+@pytest.mark.parametrize("mode", ["3d_iou", "avg_iou", "imagenetvid"])
+@pytest.mark.parametrize("decimal", [False, True])
+def test_one_frame_tracks_take_the_single_frame_kernel(mode, decimal):
+    """Videos of one frame (the stress shape): every track pair is one box IoU
+    or 0 (taoamd_track_iou_single), no frame sums -- equal to the oracle in
+    every IoU mode, decimal boxes included, and nothing for the guard to do."""
+    from tao_amodal_amd import engine
+    from tao_amodal_amd.synth import synth
+    gt, dt = synth(seed=8, V=60, F=1, C=15, dets_per_frame=40, n_present=5, decimal=decimal)
+    dt.track_id, _ = fl.make_track_ids_unique(dt)
+    f = fl.flatten_tao(gt, dt)
+    dp = engine.DeviceProblem(f, "cuda:0", iou_3d_type=mode)
+    assert dp.single_frame and not dp.guard_active()
+    got = engine.evaluate_flat(f, "cuda:0", iou_3d_type=mode)
+    want = orclib.run_flat(f, iou_3d_type=mode)
+    assert got["pairs"] == want["pairs"] > 0
+    for k in ("iou", "matched", "ignored", "precision", "recall"):
+        assert np.array_equal(got[k], want[k]), k
