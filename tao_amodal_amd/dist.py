@@ -575,6 +575,8 @@ def step(plan):
 def shard_flat(flat, c0, c1):
     """The sub-problem made of cells [c0, c1)."""
     from .flatten import Flat
+    if hasattr(flat, "to_host"):        # a device-built flat: its tables downloaded
+        flat = flat.to_host()
     f = Flat()
     d0, d1 = int(flat.cell_dt_off[c0]), int(flat.cell_dt_off[c1])
     g0, g1 = int(flat.cell_gt_off[c0]), int(flat.cell_gt_off[c1])

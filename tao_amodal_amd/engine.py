@@ -49,12 +49,7 @@ def _to_device(v, device):
         _RAW_TABLES[key] = ent
     dev = torch.device(device)
     if dev not in ent[1]:
-        import warnings
-        with warnings.catch_warnings():       # (frozen by an earlier upload)
-            warnings.simplefilter("ignore")
-            ent[1][dev] = torch.from_numpy(np.ascontiguousarray(v.source)).to(dev)
-        if isinstance(v.source, np.ndarray):
-            v.source.setflags(write=False)     # cached by identity: no silent edits
+        ent[1][dev] = torch.from_numpy(np.ascontiguousarray(v.source)).to(dev)
     if len(v.index) == 0:
         return torch.zeros((0,) + tuple(v.source.shape[1:]), dtype=ent[1][dev].dtype,
                            device=dev)
@@ -485,13 +480,25 @@ def stage_ranges(dp, ws):
 
 
 import os as _os0
-# TAOAMD_SORT=segments: the round-2 tile + bucket sort (A/B timing)
-SORT_SAMPLED = _os0.environ.get("TAOAMD_SORT", "sampled") != "segments"
+# Which segment sort a pass takes.  The sample sort (taoamd_sort_sampled: one
+# scatter pass + one register sort per bucket) wins where categories span many
+# LDS tiles -- 2000 videos, 21 M detections: 0.62 against 0.79 ms -- but is four
+# dependent launches; below SORT_SAMPLED_MIN detections the tile sort + one
+# rank-merge pass (taoamd_sort_segments) is the shorter chain (Config 2, 2.1 M
+# detections: 107 against 130 us).  TAOAMD_SORT=sampled / segments forces one.
+SORT_SAMPLED_MIN = 6_000_000
+_SORT_FORCE = _os0.environ.get("TAOAMD_SORT", "")
+
+
+def sort_is_sampled(dp):
+    if _SORT_FORCE in ("sampled", "segments"):
+        return _SORT_FORCE == "sampled"
+    return dp.n_dt >= SORT_SAMPLED_MIN
 
 
 def stage_sort(dp, ws):
     lib, t, s = _lib.load(), dp.t, _stream()
-    if dp.grouped and SORT_SAMPLED and dp.n_dt:
+    if dp.grouped and dp.n_dt and sort_is_sampled(dp):
         nc, ns, nt, nb = dp.ss_sizes
         _lib.check(lib.taoamd_sort_sampled(
             dp.n_dt, dp.n_cat, _ptr(t["cat_off"]), _ptr(t["tile_off"]), dp.n_tiles,

@@ -149,9 +149,13 @@ def limit_dets_per_image(dt, max_dets=MAX_DETS):
     n = len(dt)
     if n == 0:
         return np.zeros(0, dtype=np.int64)
+    # (the cut is reused for the same arrays: a caller that rebinds a column
+    # gets a fresh one; editing a column in place after a cut is not seen)
+    ident = tuple((id(c), c.__array_interface__["data"][0]) if isinstance(c, np.ndarray)
+                  else id(c) for c in (dt.image_id, dt.score))
     cache = getattr(dt, "_limit_cache", None)
-    if cache is not None and cache[0] == max_dets and cache[1] == n:
-        return cache[2]
+    if cache is not None and cache[0] == (max_dets, n, ident):
+        return cache[1]
     uniq, first, inv = first_inverse(dt.image_id)
     cnt = np.bincount(inv, minlength=len(uniq))
     rank_of_img = np.empty(len(uniq), dtype=np.int64)
@@ -167,12 +171,7 @@ def limit_dets_per_image(dt, max_dets=MAX_DETS):
     else:
         order = sort_key_score(img_rank)
     try:
-        dt._limit_cache = (max_dets, n, order)
-        # the cut is reused for this DTColumns: the columns it depends on
-        # become read-only, so an in-place edit fails instead of going stale
-        for col in (dt.image_id, dt.score):
-            if isinstance(col, np.ndarray):
-                col.setflags(write=False)
+        dt._limit_cache = ((max_dets, n, ident), order)
     except AttributeError:
         pass
     return order

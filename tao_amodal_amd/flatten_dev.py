@@ -72,27 +72,42 @@ class DeviceFlat(Flat):
 _RAW = {}      # id(DTColumns) -> (weakref, {device: dict of tensors})
 
 
+def _column_key(dt):
+    """Identity of the arrays behind a DTColumns' columns: the cached device
+    copy is that of THESE arrays -- a caller that rebinds a column (dt.score =
+    other) gets a fresh upload.  (Editing an uploaded array in place is not
+    seen: call forget_columns(dt) after such an edit.)"""
+    key = []
+    for name in ("image_id", "category_id", "score", "bbox", "video_id", "area"):
+        v = getattr(dt, name, None)
+        key.append(None if v is None else
+                   (id(v), v.__array_interface__["data"][0] if isinstance(v, np.ndarray)
+                    else 0, getattr(v, "shape", None)))
+    return tuple(key)
+
+
+def forget_columns(dt):
+    """Drop the cached device copy of a DTColumns' columns."""
+    _RAW.pop(id(dt), None)
+
+
 def raw_columns(dt, device):
-    """The prediction columns on the device, uploaded once per DTColumns and
-    shared by the image-level and the track-level build."""
+    """The prediction columns on the device, uploaded once per DTColumns (and
+    set of column arrays) and shared by the image-level and the track-level
+    build."""
     dev = torch.device(device)
     key = id(dt)
+    cols_key = _column_key(dt)
     ent = _RAW.get(key)
-    if ent is None or ent[0]() is not dt:
-        ent = (weakref.ref(dt, lambda _r, k=key: _RAW.pop(k, None)), {})
+    if ent is None or ent[0]() is not dt or ent[2] != cols_key:
+        ent = (weakref.ref(dt, lambda _r, k=key: _RAW.pop(k, None)), {}, cols_key)
         _RAW[key] = ent
     if dev not in ent[1]:
         cols = {}
         for name in ("image_id", "category_id", "score", "bbox", "video_id"):
             v = getattr(dt, name, None)
-            with warnings.catch_warnings():      # (a column frozen by an earlier
-                warnings.simplefilter("ignore")  # upload: read-only is intended)
-                cols[name] = None if v is None else torch.from_numpy(
-                    np.ascontiguousarray(v)).to(dev, non_blocking=True)
-            if isinstance(v, np.ndarray):
-                # the device copy is reused for this DTColumns: an in-place
-                # edit of the host column must fail loudly, not go stale
-                v.setflags(write=False)
+            cols[name] = None if v is None else torch.from_numpy(
+                np.ascontiguousarray(v)).to(dev, non_blocking=True)
         area = getattr(dt, "area", None)
         cols["area"] = None if area is None else torch.from_numpy(
             np.ascontiguousarray(area, dtype=np.float64)).to(dev)
