@@ -38,6 +38,18 @@ void *taoamd_pred_parse(const char *path, char *err, size_t errlen);
 void *taoamd_pred_parse_part(const char *path, int64_t part, int64_t n_parts, char *err,
                              size_t errlen);
 void taoamd_pred_part_info(void *handle, int64_t *first, int64_t *total);
+/* The same in two steps, converting straight into caller memory (what
+ * DTColumns.from_file_native does: numpy arrays, first touched by all cores):
+ * scan -> info (first position, records of the share, records of the file) ->
+ * convert into n int64 / 4n double / n double / n int64 / n int64 arrays
+ * (0 = ok, 2 = malformed record, message in err) -> free. */
+void *taoamd_pred_scan(const char *path, int64_t part, int64_t n_parts, char *err,
+                       size_t errlen);
+void taoamd_pred_scan_info(void *handle, int64_t *first, int64_t *count, int64_t *total);
+int taoamd_pred_convert(void *handle, int64_t *image_id, int64_t *category_id,
+                        double *bbox, double *score, int64_t *track_id,
+                        int64_t *video_id, char *err, size_t errlen);
+void taoamd_pred_scan_free(void *handle);
 int64_t taoamd_pred_count(void *handle);
 /* copies the columns into caller memory: n int64 / 4n double / n double / ... */
 int taoamd_pred_copy(void *handle, int64_t *image_id, int64_t *category_id,
@@ -61,6 +73,8 @@ void taoamd_pred_free(void *handle);
 void *taoamd_gt_parse(const char *path, char *err, size_t errlen);
 int taoamd_gt_array(void *handle, const char *name, const void **ptr,
                     int64_t *count, int *elem);
+/* the named array copied into caller memory (count * |elem| bytes) by all cores */
+int taoamd_gt_copy(void *handle, const char *name, void *dst);
 void taoamd_gt_free(void *handle);
 
 /* ---- the inverse: columns -> JSON files (synthetic sets written out for the

@@ -94,6 +94,7 @@ class GTColumns:
                                         C.POINTER(C.c_void_p),
                                         C.POINTER(C.c_int64), C.POINTER(C.c_int)]
         lib.taoamd_gt_free.argtypes = [C.c_void_p]
+        lib.taoamd_gt_copy.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
         err = C.create_string_buffer(512)
         h = lib.taoamd_gt_parse(os.fsencode(path), err, 512)
         if not h:
@@ -115,11 +116,9 @@ class GTColumns:
                                        C.byref(el)):
                     raise RuntimeError("native reader has no array " + f)
                 dtype = {8: np.int64, -8: np.float64, 1: np.uint8}[el.value]
+                kw[f] = np.empty(n.value, dtype=dtype)
                 if n.value:
-                    buf = (C.c_char * (n.value * abs(el.value))).from_address(ptr.value)
-                    kw[f] = np.frombuffer(buf, dtype=dtype).copy()
-                else:
-                    kw[f] = np.zeros(0, dtype=dtype)
+                    lib.taoamd_gt_copy(h, f.encode(), kw[f].ctypes.data)
             kw["cat_merged"] = kw["cat_merged"].reshape(-1, 2)
             kw["ann_bbox"] = kw["ann_bbox"].reshape(-1, 4)
         finally:
@@ -362,18 +361,15 @@ class DTColumns:
         if not os.path.exists(so):
             return None
         lib = C.CDLL(so)
-        lib.taoamd_pred_parse_part.restype = C.c_void_p
-        lib.taoamd_pred_parse_part.argtypes = [C.c_char_p, C.c_int64, C.c_int64,
-                                               C.c_char_p, C.c_size_t]
-        lib.taoamd_pred_part_info.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
-        lib.taoamd_pred_count.restype = C.c_int64
-        lib.taoamd_pred_count.argtypes = [C.c_void_p]
-        lib.taoamd_pred_copy.argtypes = [C.c_void_p] + [C.c_void_p] * 6
-        lib.taoamd_pred_free.argtypes = [C.c_void_p]
+        lib.taoamd_pred_scan.restype = C.c_void_p
+        lib.taoamd_pred_scan.argtypes = [C.c_char_p, C.c_int64, C.c_int64, C.c_char_p,
+                                         C.c_size_t]
+        lib.taoamd_pred_scan_info.argtypes = [C.c_void_p] * 4
+        lib.taoamd_pred_convert.argtypes = [C.c_void_p] * 7 + [C.c_char_p, C.c_size_t]
+        lib.taoamd_pred_scan_free.argtypes = [C.c_void_p]
         err = C.create_string_buffer(512)
-        h = lib.taoamd_pred_parse_part(os.fsencode(path), part, n_parts, err, 512)
-        if not h:
-            msg = err.value.decode()
+
+        def refuse(msg):
             if "is not a list" in msg:
                 raise AssertionError("results is not a list.")
             if msg.startswith("cannot open"):
@@ -382,22 +378,28 @@ class DTColumns:
                 # a required key is absent: what the reference's dict access raises
                 raise KeyError(msg.split("KeyError: '")[1].split("'")[0])
             raise ValueError("malformed prediction file: " + msg)
+        h = lib.taoamd_pred_scan(os.fsencode(path), part, n_parts, err, 512)
+        if not h:
+            refuse(err.value.decode())
         try:
-            n = lib.taoamd_pred_count(h)
+            first, n, total = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+            lib.taoamd_pred_scan_info(h, C.byref(first), C.byref(n), C.byref(total))
+            n = n.value
             i64, f64 = np.int64, np.float64
+            # (the numbers are converted straight into these arrays, every
+            # core touching its own rows first)
             out = cls(image_id=np.empty(n, i64), category_id=np.empty(n, i64),
                       bbox=np.empty((n, 4), f64), score=np.empty(n, f64),
                       track_id=np.empty(n, i64), video_id=np.empty(n, i64))
-            lib.taoamd_pred_copy(h, out.image_id.ctypes.data,
-                                 out.category_id.ctypes.data,
-                                 out.bbox.ctypes.data, out.score.ctypes.data,
-                                 out.track_id.ctypes.data,
-                                 out.video_id.ctypes.data)
-            first, total = C.c_int64(0), C.c_int64(0)
-            lib.taoamd_pred_part_info(h, C.byref(first), C.byref(total))
+            rc = lib.taoamd_pred_convert(
+                h, out.image_id.ctypes.data, out.category_id.ctypes.data,
+                out.bbox.ctypes.data, out.score.ctypes.data, out.track_id.ctypes.data,
+                out.video_id.ctypes.data, err, 512)
+            if rc:
+                refuse(err.value.decode())
             out.first, out.total = first.value, total.value
         finally:
-            lib.taoamd_pred_free(h)
+            lib.taoamd_pred_scan_free(h)
         return out
 
     @classmethod

@@ -32,6 +32,7 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -41,6 +42,31 @@
 #include <unistd.h>
 
 namespace {
+
+// std::vector whose resize() leaves trivial elements uninitialised: a vector of
+// 30 M element ranges or annotation columns is hundreds of MB, and value-
+// initialising it is ONE thread touching every page first (the page faults of
+// the big arrays were most of the parse time at 30 M predictions); the
+// parallel loops that fill the arrays fault them in instead.
+template <class T>
+struct NoInit {
+    typedef T value_type;
+    NoInit() = default;
+    template <class U> NoInit(const NoInit<U> &) {}
+    T *allocate(size_t n) { return static_cast<T *>(::operator new(n * sizeof(T))); }
+    void deallocate(T *p, size_t) { ::operator delete(p); }
+    template <class U> void construct(U *p) { ::new ((void *)p) U; }       // default-init: nothing
+    template <class U, class... A> void construct(U *p, A &&... a) { ::new ((void *)p) U(std::forward<A>(a)...); }
+    template <class U> bool operator==(const NoInit<U> &) const { return true; }
+    template <class U> bool operator!=(const NoInit<U> &) const { return false; }
+};
+template <class T> using Vec = std::vector<T, NoInit<T>>;
+
+// byte range [first, second) of one element of a JSON list
+struct Span {
+    const char *first, *second;
+};
+typedef Vec<Span> Ranges;
 
 struct Columns {
     std::vector<int64_t> image_id, category_id, track_id, video_id;
@@ -145,9 +171,7 @@ struct Cursor {
 // absolute depth at every chunk start and the chunk holding the closing
 // bracket; (C) element starts / ends.  Chunk starts are moved past backslash
 // runs, so an escape never straddles two chunks.
-const char *find_elements(const char *p0, const char *e,
-                          std::vector<std::pair<const char *, const char *>> &out,
-                          char *closed_by)
+const char *find_elements(const char *p0, const char *e, Ranges &out, char *closed_by)
 {
     out.clear();
     *closed_by = 0;
@@ -221,11 +245,24 @@ const char *find_elements(const char *p0, const char *e,
     size_t ns = 0, ne = 0;
     for (int t = 0; t <= last; t++) { ns += starts[t].size(); ne += ends[t].size(); }
     if (ns != ne) return nullptr;
+    // (an element may start in one chunk and end in a later one: starts and
+    // ends are laid out independently, each chunk's at its own offset)
     out.resize(ns);
-    size_t k = 0;
-    for (int t = 0; t <= last; t++) for (const char *q : starts[t]) out[k++].first = q;
-    k = 0;
-    for (int t = 0; t <= last; t++) for (const char *q : ends[t]) out[k++].second = q;
+    std::vector<size_t> so((size_t)last + 2, 0), eo((size_t)last + 2, 0);
+    for (int t = 0; t <= last; t++) {
+        so[t + 1] = so[t] + starts[t].size();
+        eo[t + 1] = eo[t] + ends[t].size();
+    }
+#pragma omp parallel for schedule(static, 1) if (T > 1)
+    for (int t = 0; t <= last; t++) {
+        size_t k = so[t];
+        for (const char *q : starts[t]) out[k++].first = q;
+    }
+#pragma omp parallel for schedule(static, 1) if (T > 1)
+    for (int t = 0; t <= last; t++) {
+        size_t k = eo[t];
+        for (const char *q : ends[t]) out[k++].second = q;
+    }
     *closed_by = *close_pos;
     return close_pos;
 }
@@ -271,8 +308,14 @@ bool key_is(const char *b, const char *e, const char *name)
     return unescape(b, e) == name;        // "\u0069mage_id" is image_id too
 }
 
+// the columns as raw arrays (a Columns' vectors, or the caller's numpy arrays)
+struct ColView {
+    int64_t *image_id, *category_id, *track_id, *video_id;
+    double *bbox, *score;
+};
+
 // one prediction object [b, e) -> row i of the columns
-bool parse_object(const char *b, const char *e, int64_t i, Columns &c, std::string &err)
+bool parse_object(const char *b, const char *e, int64_t i, const ColView &c, std::string &err)
 {
     Cursor cur{b, e};
     if (!cur.eat('{')) { err = "expected object"; return false; }
@@ -329,16 +372,17 @@ struct GT {
     std::vector<int64_t> cat_id, cat_merged;
     std::vector<uint8_t> cat_freq;
     std::vector<int64_t> vid_id, vid_neg_off, vid_neg, vid_nel_off, vid_nel;
-    std::vector<int64_t> img_id, img_vid, img_neg_off, img_neg, img_nel_off, img_nel;
-    std::vector<double> img_frame;
+    // (per-image / per-annotation columns: filled by parallel loops, Vec)
+    Vec<int64_t> img_id, img_vid;
+    std::vector<int64_t> img_neg_off, img_neg, img_nel_off, img_nel;
+    Vec<double> img_frame;
     std::vector<int64_t> trk_id, trk_cat, trk_vid;
     std::vector<uint8_t> trk_ignore;
-    std::vector<int64_t> ann_id, ann_img, ann_trk, ann_cat;
-    std::vector<double> ann_bbox, ann_area, ann_vis;
+    Vec<int64_t> ann_id, ann_img, ann_trk, ann_cat;
+    Vec<double> ann_bbox, ann_area, ann_vis;
     std::vector<uint8_t> ann_oof, ann_ignore;
 };
 
-typedef std::vector<std::pair<const char *, const char *>> Ranges;
 
 // Python truthiness of a JSON value (`1 if a.get("ignore", 0) else 0`)
 bool truthy(Cursor &c)
@@ -597,8 +641,113 @@ void parse_annotations(const Ranges &r, GT &g, Fail &fl)
 
 extern "C" {
 
+// A prediction file scanned: the mapping, the byte range of every element and
+// the share [i0, i1) of them this process converts.
+struct PredScan {
+    const char *buf = nullptr;
+    size_t len = 0;
+    Ranges objs;
+    int64_t i0 = 0, i1 = 0;
+    ~PredScan() { if (len) munmap((void *)buf, len); }
+};
+
+static PredScan *pred_scan(const char *path, int64_t part, int64_t n_parts, char *err,
+                           size_t errlen)
+{
+    auto fail = [&](const std::string &m) -> PredScan * {
+        if (err && errlen) snprintf(err, errlen, "%s", m.c_str());
+        return nullptr;
+    };
+    if (n_parts < 1 || part < 0 || part >= n_parts) return fail("bad part");
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) return fail(std::string("cannot open ") + path);
+    struct stat st;
+    fstat(fd, &st);
+    std::unique_ptr<PredScan> ps(new PredScan);
+    const size_t len = (size_t)st.st_size;
+    const char *buf = len ? (const char *)mmap(nullptr, len, PROT_READ, MAP_PRIVATE, fd, 0) : "";
+    close(fd);
+    if (len && buf == MAP_FAILED) return fail("mmap failed");
+    ps->buf = buf;
+    ps->len = len;
+    const char *p = buf, *e = buf + len;
+    while (p < e && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) p++;
+    if (p >= e || *p != '[') return fail("results is not a list.");
+    p++;
+    // byte range of every element of the list
+    Ranges &el = ps->objs;
+    char closer = 0;
+    const char *close_pos = find_elements(p, e, el, &closer);
+    if (!close_pos || closer != ']') return fail("unterminated list");
+    // between the objects only commas and white space may stand: a bare
+    // number or string in the list is not a prediction (json.load would hand
+    // it to the evaluator, which fails on it), and nothing but white space may
+    // follow the list
+    auto blank = [](const char *a, const char *b, bool commas) {
+        for (; a < b; a++)
+            if (!(*a == ' ' || *a == '\n' || *a == '\t' || *a == '\r' || (commas && *a == ',')))
+                return false;
+        return true;
+    };
+    if (!blank(close_pos + 1, e, false)) return fail("Extra data after the list");
+    const int64_t n = (int64_t)el.size();
+    bool clean = true;
+#pragma omp parallel for schedule(static) reduction(&& : clean)
+    for (int64_t i = 0; i < n; i++)
+        clean = clean && blank(i ? el[i - 1].second : p, el[i].first, true);
+    if (clean) clean = blank(n ? el[n - 1].second : p, close_pos, true);
+    if (!clean) return fail("list element is not an object");
+    ps->i0 = n * part / n_parts;
+    ps->i1 = n * (part + 1) / n_parts;
+    return ps.release();
+}
+
+// the share's numbers into the arrays of `c` (every thread touches its own
+// rows first: freshly allocated arrays are faulted in by all cores)
+static bool pred_convert(const PredScan &ps, const ColView &c, std::string &first_err)
+{
+    bool ok = true;
+    const int64_t n = ps.i1 - ps.i0;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; i++) {
+        std::string er;
+        const Span &o = ps.objs[ps.i0 + i];
+        if (*o.first != '{') er = "list element is not an object";
+        if (!er.empty() || !parse_object(o.first, o.second, i, c, er)) {
+#pragma omp critical
+            { if (ok) { ok = false; first_err = "prediction " + std::to_string(ps.i0 + i) + ": " + er; } }
+        }
+    }
+    return ok;
+}
+
 static void *pred_parse_impl(const char *path, int64_t part, int64_t n_parts, char *err,
-                             size_t errlen);
+                             size_t errlen)
+{
+    const bool timing = getenv("TAOAMD_INGEST_TIMING") != nullptr;
+    const double t_begin = omp_get_wtime();
+    std::unique_ptr<PredScan> ps(pred_scan(path, part, n_parts, err, errlen));
+    if (!ps) return nullptr;
+    const double t_scan = omp_get_wtime();
+    std::unique_ptr<Columns> c(new Columns);
+    const int64_t n = ps->i1 - ps->i0;
+    c->first = ps->i0;
+    c->total = (int64_t)ps->objs.size();
+    c->image_id.resize(n); c->category_id.resize(n); c->track_id.resize(n);
+    c->video_id.resize(n); c->score.resize(n); c->bbox.resize(4 * n);
+    const ColView v{c->image_id.data(), c->category_id.data(), c->track_id.data(),
+                    c->video_id.data(), c->bbox.data(), c->score.data()};
+    std::string first_err;
+    const bool ok = pred_convert(*ps, v, first_err);
+    if (timing)
+        fprintf(stderr, "taoamd ingest: %s: scan %.3f s, convert %.3f s (%d threads)\n", path,
+                t_scan - t_begin, omp_get_wtime() - t_scan, omp_get_max_threads());
+    if (!ok) {
+        if (err && errlen) snprintf(err, errlen, "%s", first_err.c_str());
+        return nullptr;
+    }
+    return c.release();
+}
 
 void *taoamd_pred_parse(const char *path, char *err, size_t errlen)
 {
@@ -611,89 +760,42 @@ void *taoamd_pred_parse(const char *path, char *err, size_t errlen)
 void *taoamd_pred_parse_part(const char *path, int64_t part, int64_t n_parts, char *err,
                              size_t errlen)
 {
-    if (n_parts < 1 || part < 0 || part >= n_parts) {
-        if (err && errlen) snprintf(err, errlen, "bad part %lld of %lld", (long long)part,
-                                    (long long)n_parts);
-        return nullptr;
-    }
     return pred_parse_impl(path, part, n_parts, err, errlen);
 }
 
-static void *pred_parse_impl(const char *path, int64_t part, int64_t n_parts, char *err,
-                             size_t errlen)
+// The same in two steps, the numbers converted straight into the caller's
+// arrays (no intermediate copy: 56 bytes a prediction): scan, ask for the
+// share's length, convert, free.
+void *taoamd_pred_scan(const char *path, int64_t part, int64_t n_parts, char *err, size_t errlen)
 {
-    auto fail = [&](const std::string &m) -> void * {
-        if (err && errlen) snprintf(err, errlen, "%s", m.c_str());
-        return nullptr;
-    };
-    int fd = open(path, O_RDONLY);
-    if (fd < 0) return fail(std::string("cannot open ") + path);
-    struct stat st;
-    fstat(fd, &st);
-    size_t len = (size_t)st.st_size;
-    const char *buf = len ? (const char *)mmap(nullptr, len, PROT_READ, MAP_PRIVATE, fd, 0) : "";
-    close(fd);
-    if (len && buf == MAP_FAILED) return fail("mmap failed");
-    const char *p = buf, *e = buf + len;
-    auto done = [&]() { if (len) munmap((void *)buf, len); };
-    while (p < e && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) p++;
-    if (p >= e || *p != '[') { done(); return fail("results is not a list."); }
-    p++;
-    // pass 1: byte range of every element of the list
-    std::vector<std::pair<size_t, size_t>> objs;
-    {
-        std::vector<std::pair<const char *, const char *>> el;
-        char closer = 0;
-        const char *close_pos = find_elements(p, e, el, &closer);
-        if (!close_pos || closer != ']') { done(); return fail("unterminated list"); }
-        // between the objects only commas and white space may stand: a bare
-        // number or string in the list is not a prediction (json.load would
-        // hand it to the evaluator, which fails on it), and nothing but white
-        // space may follow the list
-        auto blank = [](const char *a, const char *b, bool commas) {
-            for (; a < b; a++)
-                if (!(*a == ' ' || *a == '\n' || *a == '\t' || *a == '\r' ||
-                      (commas && *a == ',')))
-                    return false;
-            return true;
-        };
-        bool clean = blank(close_pos + 1, e, false);
-        if (!clean) { done(); return fail("Extra data after the list"); }
-        const char *prev = p;
-        for (size_t i = 0; i < el.size() && clean; i++) {
-            clean = blank(prev, el[i].first, true);
-            prev = el[i].second;
-        }
-        if (clean) clean = blank(prev, close_pos, true);
-        if (!clean) { done(); return fail("list element is not an object"); }
-        objs.resize(el.size());
-        for (size_t i = 0; i < el.size(); i++)
-            objs[i] = {(size_t)(el[i].first - buf), (size_t)(el[i].second - buf)};
-    }
-    Columns *c = new Columns;
-    const int64_t total = (int64_t)objs.size();
-    const int64_t i0 = total * part / n_parts, i1 = total * (part + 1) / n_parts;
-    const int64_t n = i1 - i0;
-    c->first = i0;
-    c->total = total;
-    c->image_id.resize(n); c->category_id.resize(n); c->track_id.resize(n);
-    c->video_id.resize(n); c->score.resize(n); c->bbox.resize(4 * n);
-    bool ok = true;
-    std::string first_err;
-#pragma omp parallel for schedule(static)
-    for (int64_t i = 0; i < n; i++) {
-        std::string er;
-        const auto &o = objs[i0 + i];
-        if (buf[o.first] != '{') er = "list element is not an object";
-        if (!er.empty() || !parse_object(buf + o.first, buf + o.second, i, *c, er)) {
-#pragma omp critical
-            { if (ok) { ok = false; first_err = "prediction " + std::to_string(i0 + i) + ": " + er; } }
-        }
-    }
-    done();
-    if (!ok) { delete c; return fail(first_err); }
-    return c;
+    return pred_scan(path, part, n_parts, err, errlen);
 }
+
+void taoamd_pred_scan_info(void *h, int64_t *first, int64_t *count, int64_t *total)
+{
+    const PredScan *ps = (const PredScan *)h;
+    if (first) *first = ps->i0;
+    if (count) *count = ps->i1 - ps->i0;
+    if (total) *total = (int64_t)ps->objs.size();
+}
+
+int taoamd_pred_convert(void *h, int64_t *image_id, int64_t *category_id, double *bbox,
+                        double *score, int64_t *track_id, int64_t *video_id, char *err,
+                        size_t errlen)
+{
+    const PredScan *ps = (const PredScan *)h;
+    if (ps->i1 > ps->i0 && (!image_id || !category_id || !bbox || !score || !track_id || !video_id))
+        return 1;
+    const ColView v{image_id, category_id, track_id, video_id, bbox, score};
+    std::string first_err;
+    if (!pred_convert(*ps, v, first_err)) {
+        if (err && errlen) snprintf(err, errlen, "%s", first_err.c_str());
+        return 2;
+    }
+    return 0;
+}
+
+void taoamd_pred_scan_free(void *h) { delete (PredScan *)h; }
 
 int64_t taoamd_pred_count(void *h) { return (int64_t)((Columns *)h)->image_id.size(); }
 
@@ -798,6 +900,22 @@ int taoamd_gt_array(void *h, const char *name, const void **ptr, int64_t *count,
 #undef F64
 #undef U8
     return -1;
+}
+
+// copy of one named array into caller memory, by all cores (the destination's
+// pages are first touched in parallel)
+int taoamd_gt_copy(void *h, const char *name, void *dst)
+{
+    const void *src;
+    int64_t count;
+    int elem;
+    if (taoamd_gt_array(h, name, &src, &count, &elem)) return -1;
+    const int64_t bytes = count * (elem < 0 ? -elem : elem);
+    const int64_t chunk = 1 << 20;
+#pragma omp parallel for schedule(static)
+    for (int64_t o = 0; o < bytes; o += chunk)
+        memcpy((char *)dst + o, (const char *)src + o, (size_t)std::min(chunk, bytes - o));
+    return 0;
 }
 
 void taoamd_gt_free(void *h) { delete (GT *)h; }
