@@ -779,68 +779,6 @@ class Overlap:
         cur.wait_stream(st)
 
 
-class GraphedPass:
-    """One evaluator pass as three LINEAR hipGraphs replayed on two streams:
-
-        aux :  A = ranges            (track level: ranges, sort)
-        main:  B = sort              (track level: 3D IoU)
-        main:  wait(aux);  C = match, `tail` (default: accumulate)
-
-    The fork / join stays outside the graphs (events between graph launches):
-    graphs with parallel branches captured from forked streams crash the
-    ROCm 7.0 runtime at replay for some node counts, linear ones do not."""
-
-    def __init__(self, dp, ws, aux, tail=None):
-        if dp.guard_flat is not None:
-            raise _lib.TaoAmdError("a pass with the host-side frame-order guard "
-                                   "synchronises: it cannot be captured")
-        self.dp, self.aux = dp, aux
-        tail = tail or (lambda: stage_accumulate(dp, ws))
-        if dp.kind == "lvis":
-            fa = lambda: stage_ranges(dp, ws)
-            fb = lambda: stage_sort(dp, ws)
-        else:
-            def fa():
-                stage_ranges(dp, ws)
-                stage_sort(dp, ws)
-            fb = lambda: stage_track_iou_guarded(dp, ws)
-
-        def fc():
-            stage_match(dp, ws)
-            tail()
-        self.ga, self.gb, self.gc = (Graphed(dp.device, f) for f in (fa, fb, fc))
-
-    def run(self):
-        main = torch.cuda.current_stream(self.dp.device)
-        self.aux.wait_stream(main)
-        with torch.cuda.stream(self.aux):
-            self.ga.run()
-        self.gb.run()
-        main.wait_stream(self.aux)
-        self.gc.run()
-
-
-class GraphedPair:
-    """Overlap.run_pair with the launch sequences captured into hipGraphs
-    (GraphedPass): a step is six graph launches on four streams instead of
-    ~45 kernel launches."""
-
-    def __init__(self, overlap, dpl, wsl, dpt, wst):
-        self.device = overlap.device
-        self.main = overlap.streams[:2]
-        self.passes = [GraphedPass(dpl, wsl, overlap.streams[2]),
-                       GraphedPass(dpt, wst, overlap.streams[3])]
-
-    def run(self):
-        cur = torch.cuda.current_stream(self.device)
-        for s, g in zip(self.main, self.passes):
-            s.wait_stream(cur)
-            with torch.cuda.stream(s):
-                g.run()
-        for s in self.main:
-            cur.wait_stream(s)
-
-
 class StageProbe:
     """HIP events around single-kernel stages, recorded on the stream the
     kernel is launched on while the (overlapped) steps run: the dominant
@@ -912,32 +850,6 @@ def run_forked(dp, ws, aux, head_only=False, sort_aside=False):
     _probed("match", stage_match, dp, ws)
     if not head_only:
         stage_accumulate(dp, ws)
-
-
-class Graphed:
-    """A launch sequence captured once into a hipGraph and replayed.
-
-    One pass of both evaluators is ~40 short kernels; launched one by one the
-    host's launch latency and the gaps between dependent kernels are a large
-    part of the step.  The sequence is fixed for a plan (same tables, same
-    workspaces), so it is captured -- including the stream forks / joins, which
-    become parallel branches of the graph -- and a step is one graph launch.
-    `fn` must only launch work on the current stream and streams forked from
-    it and joined back (no host synchronisation, no allocation)."""
-
-    def __init__(self, device, fn, warmup=2):
-        self.device = torch.device(device)
-        for _ in range(warmup):     # lazy initialisation happens outside capture
-            fn()
-        torch.cuda.synchronize(self.device)
-        self.graph = torch.cuda.CUDAGraph()
-        # thread_local: the RCCL watchdog thread of a process group may query
-        # events while we capture
-        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-            fn()
-
-    def run(self):
-        self.graph.replay()
 
 
 def time_stages(dpl, wsl, dpt, wst, reps=10):

@@ -492,20 +492,6 @@ def test_overlapped_streams_give_the_same_tensors():
     assert np.array_equal(wsl.recall.cpu().numpy(), wl["recall"])
     assert np.array_equal(wst.precision.cpu().numpy(), wt["precision"])
     assert np.array_equal(wst.recall.cpu().numpy(), wt["recall"])
-    # the same launch sequence captured into a hipGraph and replayed
-    g = engine.GraphedPair(ov, dpl, wsl, dpt, wst)
-    for t in (wsl.precision, wsl.recall, wst.precision, wst.recall, wsl.matched,
-              wst.matched, wst.iou):
-        t.zero_()
-    g.run()
-    g.run()
-    torch.cuda.synchronize()
-    assert np.array_equal(wsl.precision.cpu().numpy(), wl["precision"])
-    assert np.array_equal(wsl.recall.cpu().numpy(), wl["recall"])
-    assert np.array_equal(wst.precision.cpu().numpy(), wt["precision"])
-    assert np.array_equal(wst.recall.cpu().numpy(), wt["recall"])
-    # (the pair counter is not checked here: its memset node is unreliable under
-    # replay on ROCm 7.0)
 
 
 @pytest.mark.parametrize("world", [1, 2, 3, 8])
