@@ -98,6 +98,11 @@ int taoamd_gt_write(const char *path, const void *const *arrays,
 int taoamd_host_sort_key_score(int64_t n, const int64_t *key, const double *score,
                                int64_t *order);
 
+/* OpenMP threads the host-side entry points of this library start: the
+ * logical CPUs of the process capped by its affinity mask and by the control
+ * group's CPU quota (csrc/host_threads.hpp; TAOAMD_HOST_THREADS overrides). */
+int taoamd_host_threads(void);
+
 /* ---- run-length masks (csrc/rle.cpp): the host side of iou_type="segm"
  * A batch collects masks in the order they are added and keeps them back to
  * back; taoamd_rle_copy hands out the CSR arrays the device kernel

@@ -22,6 +22,7 @@
 // value Python's float() gives), so the columns are bit-identical to what
 // `json.load` + numpy conversion produce (tests/test_ingest.py).
 #include "../../include/tao_amodal_ingest.h"
+#include "host_threads.hpp"
 
 #include <omp.h>
 #include <parallel/algorithm>
@@ -159,18 +160,62 @@ struct Cursor {
     }
 };
 
+// Large inputs are scanned in parallel, simdjson-style, in two sweeps over
+// per-thread chunks.  (A) unescaped quotes per chunk -> is a chunk's first
+// byte inside a string (a chunk without a backslash, i.e. every chunk of a
+// typical prediction file, is a plain vectorised count).  (B) one bracket
+// walk per chunk that does not know the depth `base` its chunk starts at: it
+// tracks the depth relative to the chunk start and its running minimum m.
+// The absolute depth inside the list is never negative, so base >= -m at any
+// time, and an element boundary (absolute depth 0) can only be an event AT the
+// running minimum: opens at relative depth m are the candidate starts, closes
+// that return to m -- or lower it -- the candidate ends.  Every lowering of m
+// opens a new segment of candidates; once the serial prefix over the chunks'
+// depth changes has given `base`, the segment of level -base is the chunk's
+// true boundary list and the close that opened the segment of level -base-1
+// (if any) is the list's closing bracket.  Chunk starts are moved past
+// backslash runs, so an escape never straddles two chunks.
+struct ChunkWalk {
+    struct Seg { int64_t level; size_t s0, e0; const char *opened_by; };
+    std::vector<const char *> starts, ends;
+    std::vector<Seg> segs;
+    int64_t delta = 0, lowest = 0;
+
+    void run(const char *b, const char *e, bool s)
+    {
+        int64_t d = 0, m = 0;
+        segs.push_back(Seg{0, 0, 0, nullptr});
+        for (const char *p = b; p < e; p++) {
+            const char c = *p;
+            if (s) { if (c == '\\') p++; else if (c == '"') s = false; continue; }
+            if (c == '"') s = true;
+            else if (c == '{' || c == '[') { if (d == m) starts.push_back(p); d++; }
+            else if (c == '}' || c == ']') {
+                d--;
+                if (d < m) {
+                    m = d;
+                    segs.push_back(Seg{m, starts.size(), ends.size(), p});
+                    ends.push_back(p + 1);
+                } else if (d == m) ends.push_back(p + 1);
+            }
+        }
+        delta = d;
+        lowest = m;
+    }
+    // index of the segment of `level`, -1 if the chunk never was that low
+    int find(int64_t level) const
+    {
+        for (size_t k = 0; k < segs.size(); k++)
+            if (segs[k].level == level) return (int)k;
+        return -1;
+    }
+};
+
 // Byte ranges of the container elements of a JSON list, `p0` = first byte
 // after the list's '['.  Returns the position of the list's closing bracket
 // (nullptr: unterminated); *closed_by is that character (']' for a well
 // formed list).  Elements that are not containers (numbers, strings) are not
 // reported, like the one-pass scan this replaces.
-//
-// Large inputs are scanned in parallel, simdjson-style, in three sweeps over
-// per-thread chunks: (A) unescaped quotes per chunk -> is a chunk's first
-// byte inside a string; (B) bracket depth change and minimum per chunk ->
-// absolute depth at every chunk start and the chunk holding the closing
-// bracket; (C) element starts / ends.  Chunk starts are moved past backslash
-// runs, so an escape never straddles two chunks.
 const char *find_elements(const char *p0, const char *e, Ranges &out, char *closed_by)
 {
     out.clear();
@@ -192,76 +237,59 @@ const char *find_elements(const char *p0, const char *e, Ranges &out, char *clos
 #pragma omp parallel for schedule(static, 1)
         for (int t = 0; t < T; t++) {
             size_t q = 0;
-            for (const char *p = cb[t]; p < cb[t + 1]; p++) {
-                if (*p == '\\') p++;
-                else if (*p == '"') q++;
+            const char *b = cb[t], *en = cb[t + 1];
+            if (!memchr(b, '\\', (size_t)(en - b))) {
+                for (const char *p = b; p < en; p++) q += *p == '"';
+            } else {
+                for (const char *p = b; p < en; p++) {
+                    if (*p == '\\') p++;
+                    else if (*p == '"') q++;
+                }
             }
             quotes[t] = q;
         }
         size_t acc = 0;
         for (int t = 0; t < T; t++) { in_str[t] = acc & 1; acc += quotes[t]; }
     }
-    // (B) depth change / minimum of every chunk
-    std::vector<int64_t> delta((size_t)T, 0), lowest((size_t)T, 0), base((size_t)T + 1, 0);
+    // (B) candidate boundaries of every chunk
+    std::vector<ChunkWalk> walk((size_t)T);
 #pragma omp parallel for schedule(static, 1) if (T > 1)
-    for (int t = 0; t < T; t++) {
-        bool s = in_str[t];
-        int64_t d = 0, lo = 0;
-        for (const char *p = cb[t]; p < cb[t + 1]; p++) {
-            const char c = *p;
-            if (s) { if (c == '\\') p++; else if (c == '"') s = false; continue; }
-            if (c == '"') s = true;
-            else if (c == '{' || c == '[') d++;
-            else if (c == '}' || c == ']') { d--; if (d < lo) lo = d; }
-        }
-        delta[t] = d; lowest[t] = lo;
-    }
+    for (int t = 0; t < T; t++) walk[t].run(cb[t], cb[t + 1], in_str[t]);
+    std::vector<int64_t> base((size_t)T + 1, 0);
     int last = -1;                  // chunk in which the depth reaches -1
     for (int t = 0; t < T; t++) {
-        if (base[t] + lowest[t] < 0) { last = t; break; }
-        base[t + 1] = base[t] + delta[t];
+        if (base[t] + walk[t].lowest < 0) { last = t; break; }
+        base[t + 1] = base[t] + walk[t].delta;
     }
     if (last < 0) return nullptr;
-    // (C) element boundaries
-    std::vector<std::vector<const char *>> starts((size_t)last + 1), ends((size_t)last + 1);
-    const char *close_pos = nullptr;
-#pragma omp parallel for schedule(static, 1) if (T > 1)
+    const int closing = walk[last].find(-base[last] - 1);
+    if (closing < 0) return nullptr;
+    const char *close_pos = walk[last].segs[closing].opened_by;
+    // the true segment of every chunk: [s_lo, s_hi) of its starts, [e_lo, e_hi) of its ends
+    std::vector<size_t> s_lo((size_t)last + 1, 0), s_hi((size_t)last + 1, 0),
+        e_lo((size_t)last + 1, 0), e_hi((size_t)last + 1, 0), so((size_t)last + 2, 0),
+        eo((size_t)last + 2, 0);
     for (int t = 0; t <= last; t++) {
-        bool s = in_str[t];
-        int64_t d = base[t];
-        for (const char *p = cb[t]; p < cb[t + 1]; p++) {
-            const char c = *p;
-            if (s) { if (c == '\\') p++; else if (c == '"') s = false; continue; }
-            if (c == '"') s = true;
-            else if (c == '{' || c == '[') { if (d == 0) starts[t].push_back(p); d++; }
-            else if (c == '}' || c == ']') {
-                if (d == 0) { close_pos = p; break; }      // only in chunk `last`
-                d--;
-                if (d == 0) ends[t].push_back(p + 1);
-            }
+        const ChunkWalk &w = walk[t];
+        const int k = w.find(-base[t]);
+        if (k >= 0) {
+            const bool more = (size_t)k + 1 < w.segs.size();
+            s_lo[t] = w.segs[k].s0; s_hi[t] = more ? w.segs[k + 1].s0 : w.starts.size();
+            e_lo[t] = w.segs[k].e0; e_hi[t] = more ? w.segs[k + 1].e0 : w.ends.size();
         }
+        so[t + 1] = so[t] + (s_hi[t] - s_lo[t]);
+        eo[t + 1] = eo[t] + (e_hi[t] - e_lo[t]);
     }
-    if (!close_pos) return nullptr;
-    size_t ns = 0, ne = 0;
-    for (int t = 0; t <= last; t++) { ns += starts[t].size(); ne += ends[t].size(); }
-    if (ns != ne) return nullptr;
     // (an element may start in one chunk and end in a later one: starts and
     // ends are laid out independently, each chunk's at its own offset)
-    out.resize(ns);
-    std::vector<size_t> so((size_t)last + 2, 0), eo((size_t)last + 2, 0);
-    for (int t = 0; t <= last; t++) {
-        so[t + 1] = so[t] + starts[t].size();
-        eo[t + 1] = eo[t] + ends[t].size();
-    }
+    if (so[last + 1] != eo[last + 1]) return nullptr;
+    out.resize(so[last + 1]);
 #pragma omp parallel for schedule(static, 1) if (T > 1)
     for (int t = 0; t <= last; t++) {
         size_t k = so[t];
-        for (const char *q : starts[t]) out[k++].first = q;
-    }
-#pragma omp parallel for schedule(static, 1) if (T > 1)
-    for (int t = 0; t <= last; t++) {
-        size_t k = eo[t];
-        for (const char *q : ends[t]) out[k++].second = q;
+        for (size_t a = s_lo[t]; a < s_hi[t]; a++) out[k++].first = walk[t].starts[a];
+        k = eo[t];
+        for (size_t a = e_lo[t]; a < e_hi[t]; a++) out[k++].second = walk[t].ends[a];
     }
     *closed_by = *close_pos;
     return close_pos;
@@ -659,6 +687,8 @@ static PredScan *pred_scan(const char *path, int64_t part, int64_t n_parts, char
         return nullptr;
     };
     if (n_parts < 1 || part < 0 || part >= n_parts) return fail("bad part");
+    const bool timing = getenv("TAOAMD_INGEST_TIMING") != nullptr;
+    const double t0 = omp_get_wtime();
     int fd = open(path, O_RDONLY);
     if (fd < 0) return fail(std::string("cannot open ") + path);
     struct stat st;
@@ -679,6 +709,7 @@ static PredScan *pred_scan(const char *path, int64_t part, int64_t n_parts, char
     char closer = 0;
     const char *close_pos = find_elements(p, e, el, &closer);
     if (!close_pos || closer != ']') return fail("unterminated list");
+    const double t1 = omp_get_wtime();
     // between the objects only commas and white space may stand: a bare
     // number or string in the list is not a prediction (json.load would hand
     // it to the evaluator, which fails on it), and nothing but white space may
@@ -699,6 +730,9 @@ static PredScan *pred_scan(const char *path, int64_t part, int64_t n_parts, char
     if (!clean) return fail("list element is not an object");
     ps->i0 = n * part / n_parts;
     ps->i1 = n * (part + 1) / n_parts;
+    if (timing)
+        fprintf(stderr, "taoamd ingest: %s: elements %.3f s, gaps %.3f s (%d threads)\n", path,
+                t1 - t0, omp_get_wtime() - t1, omp_get_max_threads());
     return ps.release();
 }
 
@@ -708,6 +742,7 @@ static bool pred_convert(const PredScan &ps, const ColView &c, std::string &firs
 {
     bool ok = true;
     const int64_t n = ps.i1 - ps.i0;
+    const double t0 = omp_get_wtime();
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < n; i++) {
         std::string er;
@@ -718,6 +753,9 @@ static bool pred_convert(const PredScan &ps, const ColView &c, std::string &firs
             { if (ok) { ok = false; first_err = "prediction " + std::to_string(ps.i0 + i) + ": " + er; } }
         }
     }
+    if (getenv("TAOAMD_INGEST_TIMING"))
+        fprintf(stderr, "taoamd ingest: convert %lld predictions %.3f s\n", (long long)n,
+                omp_get_wtime() - t0);
     return ok;
 }
 
@@ -751,6 +789,7 @@ static void *pred_parse_impl(const char *path, int64_t part, int64_t n_parts, ch
 
 void *taoamd_pred_parse(const char *path, char *err, size_t errlen)
 {
+    taoamd::ThreadScope threads;
     return pred_parse_impl(path, 0, 1, err, errlen);
 }
 
@@ -760,6 +799,7 @@ void *taoamd_pred_parse(const char *path, char *err, size_t errlen)
 void *taoamd_pred_parse_part(const char *path, int64_t part, int64_t n_parts, char *err,
                              size_t errlen)
 {
+    taoamd::ThreadScope threads;
     return pred_parse_impl(path, part, n_parts, err, errlen);
 }
 
@@ -768,6 +808,7 @@ void *taoamd_pred_parse_part(const char *path, int64_t part, int64_t n_parts, ch
 // share's length, convert, free.
 void *taoamd_pred_scan(const char *path, int64_t part, int64_t n_parts, char *err, size_t errlen)
 {
+    taoamd::ThreadScope threads;
     return pred_scan(path, part, n_parts, err, errlen);
 }
 
@@ -783,6 +824,7 @@ int taoamd_pred_convert(void *h, int64_t *image_id, int64_t *category_id, double
                         double *score, int64_t *track_id, int64_t *video_id, char *err,
                         size_t errlen)
 {
+    taoamd::ThreadScope threads;
     const PredScan *ps = (const PredScan *)h;
     if (ps->i1 > ps->i0 && (!image_id || !category_id || !bbox || !score || !track_id || !video_id))
         return 1;
@@ -809,6 +851,7 @@ void taoamd_pred_part_info(void *h, int64_t *first, int64_t *total)
 int taoamd_pred_copy(void *h, int64_t *image_id, int64_t *category_id, double *bbox,
                      double *score, int64_t *track_id, int64_t *video_id)
 {
+    taoamd::ThreadScope threads;
     Columns *c = (Columns *)h;
     size_t n = c->image_id.size();
     memcpy(image_id, c->image_id.data(), n * 8);
@@ -827,10 +870,14 @@ void taoamd_pred_free(void *h) { delete (Columns *)h; }
 // accesses would raise).
 void *taoamd_gt_parse(const char *path, char *err, size_t errlen)
 {
+    taoamd::ThreadScope threads;
     auto fail = [&](const std::string &m) -> void * {
         if (err && errlen) snprintf(err, errlen, "%s", m.c_str());
         return nullptr;
     };
+    const bool timing = getenv("TAOAMD_INGEST_TIMING") != nullptr;
+    double tt[8];
+    tt[0] = omp_get_wtime();
     int fd = open(path, O_RDONLY);
     if (fd < 0) return fail(std::string("cannot open ") + path);
     struct stat st;
@@ -873,12 +920,21 @@ void *taoamd_gt_parse(const char *path, char *err, size_t errlen)
     if (missing) { done(); return fail(std::string("KeyError: '") + missing + "'"); }
     GT *g = new GT;
     Fail fl;
+    tt[1] = omp_get_wtime();
     parse_categories(cats, *g, fl);
     parse_videos(vids, *g, fl);
+    tt[2] = omp_get_wtime();
     parse_images(imgs, *g, fl);
+    tt[3] = omp_get_wtime();
     parse_tracks(trks, *g, fl);
+    tt[4] = omp_get_wtime();
     parse_annotations(anns, *g, fl);
+    tt[5] = omp_get_wtime();
     done();
+    if (timing)
+        fprintf(stderr, "taoamd ingest: %s: scan %.3f s, categories+videos %.3f, images %.3f, "
+                "tracks %.3f, annotations %.3f, unmap %.3f\n", path, tt[1] - tt[0], tt[2] - tt[1],
+                tt[3] - tt[2], tt[4] - tt[3], tt[5] - tt[4], omp_get_wtime() - tt[5]);
     if (!fl.ok) { delete g; return fail(fl.msg); }
     return g;
 }
@@ -906,6 +962,7 @@ int taoamd_gt_array(void *h, const char *name, const void **ptr, int64_t *count,
 // pages are first touched in parallel)
 int taoamd_gt_copy(void *h, const char *name, void *dst)
 {
+    taoamd::ThreadScope threads;
     const void *src;
     int64_t count;
     int elem;
@@ -920,6 +977,8 @@ int taoamd_gt_copy(void *h, const char *name, void *dst)
 
 void taoamd_gt_free(void *h) { delete (GT *)h; }
 
+int taoamd_host_threads(void) { return taoamd::host_threads(); }
+
 // order[] = np.lexsort((arange(n), -score, key)): ascending key, descending
 // score inside a key (NaN scores last, -0.0 == 0.0), input order on ties.
 // score may be NULL (plain stable argsort of key).  Records are sorted by
@@ -928,10 +987,11 @@ void taoamd_gt_free(void *h) { delete (GT *)h; }
 int taoamd_host_sort_key_score(int64_t n, const int64_t *key, const double *score,
                                int64_t *order)
 {
+    taoamd::ThreadScope threads;
     if (n < 0 || (n > 0 && (!key || !order))) return 1;
     struct Rec { int64_t key; double neg; int64_t idx; };
     std::vector<Rec> r((size_t)n);
-#pragma omp parallel for schedule(static) num_threads(std::min(32, omp_get_max_threads()))
+#pragma omp parallel for schedule(static) num_threads(std::min(32, taoamd::host_threads()))
     for (int64_t i = 0; i < n; i++) r[i] = Rec{key[i], score ? -score[i] : 0.0, i};
     // a team sized to the input: on a 256-core host the full team costs more
     // in start-up and merge steps than it saves below a few million records
@@ -947,7 +1007,7 @@ int taoamd_host_sort_key_score(int64_t n, const int64_t *key, const double *scor
         __gnu_parallel::stable_sort(r.begin(), r.end(),
                                     [](const Rec &a, const Rec &b) { return a.key < b.key; },
                                     tag);
-#pragma omp parallel for schedule(static) num_threads(std::min(32, omp_get_max_threads()))
+#pragma omp parallel for schedule(static) num_threads(std::min(32, taoamd::host_threads()))
     for (int64_t i = 0; i < n; i++) order[i] = r[i].idx;
     return 0;
 }

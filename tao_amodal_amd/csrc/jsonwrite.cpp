@@ -8,6 +8,7 @@
 // parses back to the same double, what Python's repr gives); an integral double
 // is written without a fraction.  OpenMP: rows are formatted in blocks by all
 // threads, blocks written in order.
+#include "host_threads.hpp"
 #include <charconv>
 #include <cmath>
 #include <cstdint>
@@ -83,6 +84,7 @@ extern "C" int taoamd_pred_write(const char *path, int64_t n, const int64_t *ima
                                  const double *score, const int64_t *track_id,
                                  const int64_t *video_id)
 {
+    taoamd::ThreadScope threads;
     if (!path || n < 0 || (n && (!image_id || !category_id || !bbox || !score)))
         return 1;
     FILE *f = fopen(path, "wb");
@@ -134,6 +136,7 @@ enum {
 extern "C" int taoamd_gt_write(const char *path, const void *const *a, const int64_t *cnt,
                                int32_t n_fields)
 {
+    taoamd::ThreadScope threads;
     if (!path || !a || !cnt || n_fields != N_FIELDS) return 1;
     auto I = [&](int f) { return (const int64_t *)a[f]; };
     auto D = [&](int f) { return (const double *)a[f]; };

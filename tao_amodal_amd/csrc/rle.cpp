@@ -15,6 +15,7 @@
 // A mask = column-major run lengths starting with a (possibly empty) run of
 // zeros.  A batch keeps its masks back to back (CSR), which is the layout the
 // device kernel taoamd_rle_iou reads.
+#include "host_threads.hpp"
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -269,6 +270,7 @@ int64_t taoamd_rle_add_polygon_batch(void *handle, int64_t n_masks,
                                      const int64_t *part_off, const double *xy,
                                      const int32_t *hw)
 {
+    taoamd::ThreadScope threads;
     Batch *b = (Batch *)handle;
     if (n_masks < 0) return -1;
     for (int64_t m = 0; m < n_masks; m++) {

@@ -27,10 +27,33 @@ def lib():
     return _lib
 
 
+def host_cpus():
+    """CPUs this process can actually use: the logical CPUs OpenMP sees,
+    capped by the control group's CPU-time quota (cgroup v2 cpu.max, v1
+    cfs_quota_us / cfs_period_us) -- threads beyond the quota are throttled,
+    not run."""
+    n = int(lib().orc_max_threads())
+    quota = period = None
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota, period = int(q), int(p)
+    except (OSError, ValueError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        except (OSError, ValueError):
+            pass
+    if quota and period and quota > 0:
+        n = min(n, -(-quota // period))
+    return max(1, n)
+
+
 def set_threads(n):
     """OpenMP threads of the oracle's cell / category loops (1 = the scalar
-    port; 0 = all host cores).  Returns the number now in use."""
-    n = int(n) if n else int(lib().orc_max_threads())
+    port; 0 = every CPU the host grants this process).  Returns the number now
+    in use."""
+    n = int(n) if n else host_cpus()
     lib().orc_set_threads(C.c_int(n))
     return n
 

@@ -231,6 +231,46 @@ def test_parallel_boundary_scan_with_hostile_strings(tmp_path):
         DTColumns.from_file_native(str(p))
 
 
+def test_boundary_scan_with_chunks_starting_at_any_depth(tmp_path):
+    """The bracket walk of a chunk does not know the depth it starts at
+    (ingest.cpp ChunkWalk): elements with nested lists / objects several levels
+    deep and hostile strings, cut into 64 KB chunks by 40 threads, must give
+    the boundaries json.load gives.  A separate process: the thread count is
+    read once per process."""
+    import subprocess
+    import sys
+    rng = np.random.default_rng(5)
+    _, dt = synth(seed=3, V=4, F=80, C=30, dets_per_frame=40, n_present=5)
+    preds = dt.to_json()
+    for k, q in enumerate(preds):
+        depth = int(rng.integers(0, 5))
+        v = [k, 'x]"{' + "\\" * (k % 3)]
+        for lvl in range(depth):
+            v = {"l%d" % lvl: [v, {"s": "}" * (k % 7)}]} if lvl % 2 else [v, [], {}]
+        if k % 3:
+            q["extra"] = v
+        if k % 11 == 0:
+            q["pad"] = "p" * int(rng.integers(0, 3000))
+    p = tmp_path / "p.json"
+    p.write_text(json.dumps(preds))
+    assert p.stat().st_size > (2 << 20)
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); "
+            "from tao_amodal_amd.columns import DTColumns; "
+            "d = DTColumns.from_file_native(%r); "
+            "np.savez(%r, image_id=d.image_id, bbox=d.bbox, score=d.score, "
+            "track_id=d.track_id)" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                      str(p), str(tmp_path / "out.npz")))
+    for threads in ("40", "3"):
+        subprocess.run([sys.executable, "-c", code], check=True,
+                       env=dict(os.environ, TAOAMD_HOST_THREADS=threads))
+        z = np.load(tmp_path / "out.npz")
+        want = DTColumns.from_json(preds)
+        assert np.array_equal(z["image_id"], want.image_id)
+        assert np.array_equal(z["bbox"], want.bbox)
+        assert np.array_equal(z["score"], want.score)
+        assert np.array_equal(z["track_id"], want.track_id)
+
+
 def test_reader_corner_cases_of_json_load(tmp_path):
     """What json.load accepts the reader accepts with the same values, what the
     evaluator cannot use it rejects: out-of-range exponents (inf / 0.0 as

@@ -200,6 +200,7 @@ def main():
     out = os.path.join(ROOT, "tools", "trace", "_lib_trace.so")
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
            "-shared", "-ffp-contract=off", "-fno-fast-math", "-Wno-unused-result",
+           "-mllvm", "-pragma-unroll-threshold=262144",
            "api.hip", "iou_match.hip", "track_iou.hip", "flatten.hip", "sort.hip",
            "accumulate.hip", "exchange.hip", "rle_iou.hip", "-o", out]
     subprocess.check_call(cmd, cwd=work)
