@@ -171,6 +171,90 @@ def _cells_from_runs(lib, dev, n_keep, dt_key, gkeys_sorted):
     return cell_keys, dt_cell[:n_keep], d_off
 
 
+# ---------------------------------------------------------------------------
+# ground-truth halves, buildable before the predictions are there
+# ---------------------------------------------------------------------------
+def _gt_key(gt):
+    """Identity of the arrays behind a GTColumns (see _column_key)."""
+    return tuple((k, id(v), v.__array_interface__["data"][0], v.shape)
+                 for k, v in sorted(vars(gt).items()) if isinstance(v, np.ndarray))
+
+
+def _lvis_gt_ready(gt):
+    """Everything of the image-level tables that depends on the annotation
+    file alone: lvis_gt_side, the cell order of the ground truths and their
+    columns."""
+    G = flatten.lvis_gt_side(gt)
+    U = len(G.img_ids)
+    keys_g = G.g_cat * U + G.g_img
+    og = flatten.sort_key_score(keys_g)
+    g_sel, keys_g = G.g_sel[og], keys_g[og]
+    R = Flat()
+    R.G, R.g_sel, R.keys_g = G, g_sel, keys_g
+    R.gkeys = np.unique(keys_g).astype(np.int32)
+    R.tables = Flat()
+    flatten.lvis_gt_tables(R.tables, gt, g_sel, keys_g, max(U, 1))
+    return R
+
+
+def _tao_gt_ready(gt, visit_universe=None):
+    """The same for the track level."""
+    T = flatten.tao_gt_side(gt, visit_universe)
+    U = len(T.vid_ids)
+    keys_g = T.g_cat * U + T.g_vid
+    og = flatten.sort_key_score(keys_g)
+    keys_g = keys_g[og]
+    R = Flat()
+    R.T, R.og, R.keys_g = T, og, keys_g
+    R.gkeys = np.unique(keys_g).astype(np.int32)
+    R.img_frame = gt.img_frame[T.img_row]
+    R.frames = flatten.track_frames(T.tl_pos, og, T.g_trk_of_ann, T.g_aoff, T.g_ann,
+                                    T.a_img[T.g_ann], gt.ann_bbox)
+    t = R.tables = Flat()
+    t.gt_area = np.ascontiguousarray(T.g_area[og])
+    t.gt_len = T.g_len[og].astype(I32)
+    t.gt_nhp = T.g_nhp[og].astype(I32)
+    t.gt_flags = (np.where(T.g_ign[og] != 0, flatten.GT_IGNORE, 0)
+                  | np.where(T.g_ids[og] == -1, flatten.GT_ID_HIDDEN, 0)
+                  ).astype(np.uint8)
+    t.gt_id = T.g_ids[og]
+    t.gt_cat = (keys_g // max(U, 1)).astype(I32)
+    return R
+
+
+_READY = {"lvis": _lvis_gt_ready, "tao": _tao_gt_ready}
+
+
+def prepare_gt(gt, kinds=("lvis", "tao")):
+    """Build the ground-truth halves of the cell tables ahead of time -- the
+    CLI calls this while the prediction file is still being parsed (0.5 s of
+    numpy at 3 M annotations that otherwise sits between the parse and the
+    first kernel).  The bundles are handed to the NEXT flatten_*_device call on
+    the same columns and dropped there (single use: a caller who edits the
+    columns afterwards never meets a stale table).  Errors are not raised
+    here: the build that needs the bundle runs into them at the place the
+    reference does."""
+    made = {}
+    for kind in kinds:
+        try:
+            made[kind] = _READY[kind](gt)
+        except Exception:
+            pass
+    vars(gt)["_prepared_gt"] = (_gt_key(gt), made)
+
+
+def _gt_ready(gt, kind):
+    slot = vars(gt).get("_prepared_gt")
+    if slot is not None:
+        key, made = slot
+        R = made.pop(kind, None)
+        if not made:
+            vars(gt).pop("_prepared_gt", None)
+        if R is not None and key == _gt_key(gt):
+            return R
+    return _READY[kind](gt)
+
+
 def flatten_lvis_device(gt, dt, device="cuda", max_dets=MAX_DETS):
     """flatten.flatten_lvis(gt, dt, max_dets) with the detection side built on
     the device.  Raises Unsupported for inputs the kernels do not cover."""
@@ -178,15 +262,12 @@ def flatten_lvis_device(gt, dt, device="cuda", max_dets=MAX_DETS):
         raise IndexError("list index out of range")  # L/results.py:42
     lib = _lib.load()
     dev = torch.device(device)
-    G = flatten.lvis_gt_side(gt)
+    ready = _gt_ready(gt, "lvis")
+    G, keys_g, gkeys = ready.G, ready.keys_g, ready.gkeys
     img_ids, cat_ids = G.img_ids, G.cat_ids
     U, K, n = len(img_ids), len(cat_ids), len(dt)
     if U == 0 or K == 0 or K * U >= 2 ** 31 - 1 or n >= 2 ** 31 - 1:
         raise Unsupported("cell keys do not fit 31 bits")
-    keys_g = G.g_cat * U + G.g_img
-    og = flatten.sort_key_score(keys_g)
-    g_sel, keys_g = G.g_sel[og], keys_g[og]
-    gkeys = np.unique(keys_g).astype(np.int32)
 
     with torch.cuda.device(dev):
         raw = raw_columns(dt, dev)
@@ -260,7 +341,7 @@ def flatten_lvis_device(gt, dt, device="cuda", max_dets=MAX_DETS):
     f.cell_cat = (cell_keys // U).astype(I32)
     f.cell_dt_off = d_off.astype(I32)
     f.cell_gt_off = g_off.astype(I32)
-    flatten.lvis_gt_tables(f, gt, g_sel, keys_g, U)
+    f.update(ready.tables)
     f.gt_cell = g_cell.astype(I32)
     f.n_pairs = int(np.sum(np.diff(d_off) * np.diff(g_off)))
     f.dev.update(dt_box=dt_box[:n_keep], dt_score=dt_score[:n_keep],
@@ -308,18 +389,17 @@ def flatten_tao_device(gt, dt, device="cuda", max_dets=MAX_DETS,
         raise IndexError("list index out of range")  # T/results.py:61
     lib = _lib.load()
     dev = torch.device(device)
-    T = flatten.tao_gt_side(gt, visit_universe)
+    # (a rank's share of the annotation file takes its visiting order from the
+    # whole set: never prepared ahead)
+    ready = _gt_ready(gt, "tao") if visit_universe is None \
+        else _tao_gt_ready(gt, visit_universe)
+    T, keys_g, gkeys, img_frame = ready.T, ready.keys_g, ready.gkeys, ready.img_frame
     vid_ids, cat_ids, img_ids = T.vid_ids, T.cat_ids, T.img_ids
     U, K, NI, n = len(vid_ids), len(cat_ids), len(img_ids), len(dt)
     tid_host = np.ascontiguousarray(dt.track_id, dtype=np.int64)
     if U == 0 or K == 0 or K * U >= 2 ** 31 - 1 or n >= 2 ** 31 - 1 or \
             int(tid_host.min()) < 0 or int(tid_host.max()) >= 2 ** 62:
         raise Unsupported("keys do not fit")
-    keys_g = T.g_cat * U + T.g_vid
-    og = flatten.sort_key_score(keys_g)
-    keys_g = keys_g[og]
-    gkeys = np.unique(keys_g).astype(np.int32)
-    img_frame = gt.img_frame[T.img_row]
 
     def reject():
         raise Rejected("predictions break a rule of TaoResults")
@@ -552,9 +632,7 @@ def flatten_tao_device(gt, dt, device="cuda", max_dets=MAX_DETS,
     g_cell = np.searchsorted(cell_keys, keys_g)
     g_off = np.zeros(n_cells + 1, dtype=np.int64)
     np.cumsum(np.bincount(g_cell, minlength=n_cells), out=g_off[1:])
-    g_fpos, g_fbox, g_foff = flatten.track_frames(
-        T.tl_pos, og, T.g_trk_of_ann, T.g_aoff, T.g_ann, T.a_img[T.g_ann],
-        gt.ann_bbox)
+    g_fpos, g_fbox, g_foff = ready.frames
 
     f = DeviceFlat()
     f.kind = "tao"
@@ -570,14 +648,7 @@ def flatten_tao_device(gt, dt, device="cuda", max_dets=MAX_DETS,
     iou_off = np.zeros(n_cells + 1, dtype=np.int64)
     np.cumsum(np.diff(d_off) * np.diff(g_off), out=iou_off[1:])
     f.cell_iou_off = iou_off
-    f.gt_area = np.ascontiguousarray(T.g_area[og])
-    f.gt_len = T.g_len[og].astype(I32)
-    f.gt_nhp = T.g_nhp[og].astype(I32)
-    f.gt_flags = (np.where(T.g_ign[og] != 0, flatten.GT_IGNORE, 0)
-                  | np.where(T.g_ids[og] == -1, flatten.GT_ID_HIDDEN, 0)
-                  ).astype(np.uint8)
-    f.gt_id = T.g_ids[og]
-    f.gt_cat = (keys_g // U).astype(I32)
+    f.update(ready.tables)
     f.gt_cell = g_cell.astype(I32)
     f.gt_frame_off, f.gt_frame_pos, f.gt_frame_box = g_foff, g_fpos, g_fbox
     f.n_pairs = int(iou_off[-1])

@@ -1,0 +1,63 @@
+"""flatten_dev.prepare_gt: the ground-truth halves of the cell tables built
+ahead of the predictions (the CLI builds them while prediction.json is still
+being parsed) are handed over once and never to edited columns."""
+import numpy as np
+
+from tao_amodal_amd import flatten, flatten_dev
+from tao_amodal_amd.synth import synth
+
+
+def _same(a, b):
+    assert sorted(a) == sorted(b)
+    for k in a:
+        x, y = a[k], b[k]
+        if isinstance(x, dict):
+            _same(x, y)
+        elif isinstance(x, tuple):
+            for p, q in zip(x, y):
+                assert np.array_equal(np.asarray(p), np.asarray(q)), k
+        else:
+            assert np.array_equal(np.asarray(x), np.asarray(y)), k
+
+
+def test_bundles_equal_a_fresh_build_and_are_single_use():
+    gt, _ = synth(seed=4, V=5, F=12, C=9, dets_per_frame=6, n_present=4)
+    flatten_dev.prepare_gt(gt)
+    for kind in ("lvis", "tao"):
+        key, made = vars(gt)["_prepared_gt"]
+        stored = made[kind]
+        got = flatten_dev._gt_ready(gt, kind)
+        assert got is stored
+        again = flatten_dev._gt_ready(gt, kind)     # gone: built afresh
+        assert again is not stored
+        _same(got, again)
+    assert "_prepared_gt" not in vars(gt)
+    # the halves are what the host statement computes
+    G = flatten.lvis_gt_side(gt)
+    R = flatten_dev._lvis_gt_ready(gt)
+    assert np.array_equal(np.sort(R.g_sel), np.sort(G.g_sel))
+
+
+def test_a_rebound_column_is_not_served_from_the_bundle():
+    gt, _ = synth(seed=4, V=5, F=12, C=9, dets_per_frame=6, n_present=4)
+    flatten_dev.prepare_gt(gt)
+    stored = vars(gt)["_prepared_gt"][1]["lvis"]
+    gt.ann_area = gt.ann_area.copy()
+    gt.ann_area[:] = 0.0                    # every ground truth filtered out
+    got = flatten_dev._gt_ready(gt, "lvis")
+    assert got is not stored
+    assert len(got.g_sel) == 0
+
+
+def test_errors_wait_for_the_build_that_needs_the_bundle():
+    gt, _ = synth(seed=4, V=5, F=12, C=9, dets_per_frame=6, n_present=4)
+    gt.ann_trk = gt.ann_trk.copy()
+    gt.ann_trk[0] = 10 ** 9                 # annotation of a track that is not listed
+    flatten_dev.prepare_gt(gt)              # silent
+    assert "tao" not in vars(gt)["_prepared_gt"][1]
+    try:
+        flatten_dev._gt_ready(gt, "tao")
+    except KeyError as e:
+        assert e.args[0] == 10 ** 9
+    else:
+        raise AssertionError("KeyError expected")

@@ -241,6 +241,11 @@ def main(argv=None):
             lvis_gt = LVIS(annotation)      # native reader when built
             lvis_gt.columns
             gt_dataset = annotation          # the track level shares the columns
+            if not dt_future.done():
+                # the annotation file is the smaller one: its halves of the
+                # cell tables are built while the predictions are still read
+                from tao_amodal_amd import flatten_dev
+                flatten_dev.prepare_gt(lvis_gt.columns)
             dt_columns = dt_future.result()
         prepared = None
         if len(dt_columns):
