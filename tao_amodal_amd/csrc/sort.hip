@@ -1190,11 +1190,6 @@ __device__ __forceinline__ uint64_t ss_wave_max_u64(uint64_t v)
 #define SS_SPLIT_KEY_BITS 45              // ss_split_chunk: key part | position in the chunk
 #define SS_IDX_BITS 16
 #define SS_PAD 0x3fffffffffffffffull       // sorts last; still a normal fp64
-__device__ __forceinline__ int ss_shift_for(uint64_t range)
-{
-    const int bits = range ? 64 - __clzll((long long)range) : 0;
-    return bits > 45 ? bits - 45 : 0;           // SS_KEY_BITS
-}
 __device__ __forceinline__ double ss_pack(uint64_t key, uint64_t lo, int shift, int32_t rel)
 {
     return __longlong_as_double((long long)((1ull << 61) | (((key - lo) >> shift) << SS_IDX_BITS) |
@@ -1266,10 +1261,10 @@ __global__ __launch_bounds__(SEG_THREADS) void ss_scatter_kernel(SsArgs a)
     if (threadIdx.x < SS_MAXB) {
         const int b = threadIdx.x;
         s_cnt[b] = 0;
-        if (b >= 1 && b < B) {
-            s_key[b] = a.spl_key[c.bucket0 + b];
-            s_idx[b] = a.spl_idx[c.bucket0 + b];
-        }
+        // entries past the last splitter precede nothing
+        const bool real = b >= 1 && b < B;
+        s_key[b] = real ? a.spl_key[c.bucket0 + b] : ~0ull;
+        s_idx[b] = real ? a.spl_idx[c.bucket0 + b] : INT32_MAX;
     }
     __syncthreads();
     // the splitters must ascend (ss_split_chunk sorts the samples by a shortened
@@ -1285,22 +1280,33 @@ __global__ __launch_bounds__(SEG_THREADS) void ss_scatter_kernel(SsArgs a)
 #pragma unroll
     for (int r = 0; r < SEG_ROUNDS; r++) {
         const int32_t i = t0 + r * SEG_THREADS + (int32_t)threadIdx.x;
-        br[r] = -1;
-        if (i < t1) {
-            const uint64_t k = desc_key(a.score[i]);
-            // splitters 1 .. B-1 that precede (k, i); an element equal to a
-            // splitter closes the lower bucket
-            int lo = 1, hi = B;
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                const uint64_t sk = s_key[mid];
-                const bool before = sk < k || (sk == k && s_idx[mid] < i);
-                if (before) lo = mid + 1; else hi = mid;
-            }
-            kr[r] = k;
-            br[r] = lo - 1;
-            rr[r] = atomicAdd(&s_cnt[lo - 1], 1);
+        kr[r] = i < t1 ? desc_key(a.score[i]) : 0;
+        br[r] = 0;
+    }
+    // bucket = number of splitters 1 .. B-1 that precede (k, i) (an element
+    // equal to a splitter closes the lower bucket): a fixed-depth search, all
+    // rounds of the thread in step so that their LDS reads are in flight together
+    static_assert(SS_MAXB == 128, "seven steps");
+    if (!(a.dbg & 64))
+#pragma unroll
+    for (int step = SS_MAXB / 2; step >= 1; step >>= 1) {
+        uint64_t sk[SEG_ROUNDS];
+#pragma unroll
+        for (int r = 0; r < SEG_ROUNDS; r++) sk[r] = s_key[br[r] + step];
+#pragma unroll
+        for (int r = 0; r < SEG_ROUNDS; r++) {
+            bool before = sk[r] < kr[r];
+            if (sk[r] == kr[r])
+                before = s_idx[br[r] + step] < t0 + r * SEG_THREADS + (int32_t)threadIdx.x;
+            br[r] = before ? br[r] + step : br[r];
         }
+    }
+#pragma unroll
+    for (int r = 0; r < SEG_ROUNDS; r++) {
+        const int32_t i = t0 + r * SEG_THREADS + (int32_t)threadIdx.x;
+        if ((a.dbg & 64) && i < t1) br[r] = (int32_t)((kr[r] >> 40) % (uint64_t)B);
+        if (i < t1) rr[r] = (a.dbg & 32) ? (int32_t)threadIdx.x >> 4 : atomicAdd(&s_cnt[br[r]], 1);
+        else br[r] = -1;
     }
     __syncthreads();
     if (threadIdx.x < B) {
@@ -1312,7 +1318,7 @@ __global__ __launch_bounds__(SEG_THREADS) void ss_scatter_kernel(SsArgs a)
     for (int r = 0; r < SEG_ROUNDS; r++) {
         if (br[r] >= 0) {
             const int32_t at = s_base[br[r]] + rr[r];
-            if (at < SS_CAP) {
+            if (at < SS_CAP && !(a.dbg & 16)) {
                 const int64_t s = (int64_t)(c.bucket0 + br[r]) * SS_CAP + at;
                 a.slot_key[s] = kr[r];
                 a.slot_idx[s] = t0 + r * SEG_THREADS + (int32_t)threadIdx.x;
@@ -1322,27 +1328,47 @@ __global__ __launch_bounds__(SEG_THREADS) void ss_scatter_kernel(SsArgs a)
 }
 
 // One bucket, one wavefront: the words
-//     1 << 61 | ((key - lo) >> shift) << 16 | (index - chunk begin)
-// (45 bits of key part; a chunk has < 2^16 elements) through the network.
-// Equal keys are ordered by their index bits: the stable order.  A bucket whose
-// keys span less than 2^45 loses nothing; a wider one shifts bits out, and two
-// DIFFERENT keys may then share a key part: sorted neighbours with equal key
-// parts fetch their full keys (one gather each) and a bucket with such a pair
-// out of order is left to ss_rank_bucket.
-#define SS_KEY_BITS 45
+//     1 << 61 | ((key - lo) >> shift) << 26 | (index - chunk begin) << 10 | slot
+// (35 bits of key part; a chunk has < 2^16 elements; slot = the place the
+// element was read from, < 1024) through the network.  Equal key parts are
+// ordered by their index bits: the stable order for equal keys.  A bucket's
+// keys usually span more than 2^35 (one binade of fp64 scores holds 2^52 bit
+// patterns), so bits are shifted out and two DIFFERENT keys may share a key
+// part: every wavefront keeps the full keys of its bucket in LDS under the
+// slot number, reads them back in sorted order and checks that they ascend --
+// a bucket with a pair out of order is left to ss_rank_bucket.  (Round 3 first
+// fetched the full keys of tied neighbours from the score array: tracks that
+// give all their boxes one score make ties the common case, and the dependent
+// gather was 0.10 of the kernel's 0.35 ms.)
+// The slots are read lane-contiguous (slot = r * 64 + lane: any arrangement is
+// as good as another BEFORE the network); the sorted place of register r of a
+// lane is lane * R + r, so a lane stores R consecutive order[] entries at once.
+#define SS_KEY_BITS 35
+#define SS_E_BITS 10
+typedef int32_t ss_i4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef int32_t ss_i2 __attribute__((ext_vector_type(2), aligned(4)));
+
+__device__ __forceinline__ int ss_shift_for(uint64_t range)
+{
+    const int bits = range ? 64 - __clzll((long long)range) : 0;
+    return bits > SS_KEY_BITS ? bits - SS_KEY_BITS : 0;
+}
+
 template <int R>
 __device__ __forceinline__ bool ss_sort_bucket(const SsArgs &a, const SsChunk &c,
                                                int32_t count, int32_t out0, int lane,
                                                const uint64_t *__restrict__ sk,
-                                               const int32_t *__restrict__ si)
+                                               const int32_t *__restrict__ si,
+                                               uint64_t *__restrict__ full)
 {
+    static_assert(WAVE * R <= (1 << SS_E_BITS), "slot bits");
     const double pad = __longlong_as_double((long long)SS_PAD);
     uint64_t k[R];
     int32_t x[R];
     uint64_t kmin = ~0ull, kmax = 0;
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        const int e = lane * R + r;
+        const int e = r * WAVE + lane;
         k[r] = ~0ull;
         x[r] = INT32_MAX;
         if (e < count) {
@@ -1356,53 +1382,45 @@ __device__ __forceinline__ bool ss_sort_bucket(const SsArgs &a, const SsChunk &c
             kmin = k[r] < kmin ? k[r] : kmin;
             kmax = k[r] > kmax ? k[r] : kmax;
         }
+        full[e] = k[r];
     }
     kmin = ss_wave_min_u64(kmin);
     kmax = ss_wave_max_u64(kmax);
     const int shift = ss_shift_for(kmax - kmin);
     double p[R];
 #pragma unroll
-    for (int r = 0; r < R; r++)
-        p[r] = lane * R + r < count ? ss_pack(k[r], kmin, shift, x[r] - c.begin) : pad;
+    for (int r = 0; r < R; r++) {
+        const int e = r * WAVE + lane;
+        p[r] = e < count
+            ? __longlong_as_double((long long)((1ull << 61) |
+                  (((k[r] - kmin) >> shift) << (SS_IDX_BITS + SS_E_BITS)) |
+                  ((uint64_t)(x[r] - c.begin) << SS_E_BITS) | (uint64_t)e))
+            : pad;
+    }
     if (!(a.dbg & 1)) ss_bitonic_packed<R>(p, lane);
-    uint64_t kp[R];
+    // (the wavefront's own LDS writes are complete before its reads: one
+    // wavefront, program order; the waitcnt is the compiler's)
+    bool bad = false;
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const uint64_t bits = (uint64_t)__double_as_longlong(p[r]);
         const bool ok = lane * R + r < count;
-        x[r] = ok ? c.begin + (int32_t)(bits & ((1u << SS_IDX_BITS) - 1)) : INT32_MAX;
-        kp[r] = ok ? bits >> SS_IDX_BITS : ~0ull - (uint64_t)(lane * R + r);   // (pads: all different)
-        k[r] = kmin + ((bits >> SS_IDX_BITS) & ((1ull << SS_KEY_BITS) - 1));     // exact when shift == 0
+        x[r] = c.begin + (int32_t)((bits >> SS_E_BITS) & ((1u << SS_IDX_BITS) - 1));
+        k[r] = ok ? full[bits & ((1u << SS_E_BITS) - 1) & (WAVE * R - 1)] : ~0ull;
+        if (r > 0) bad |= k[r] < k[r - 1];
     }
-    if (shift > 0 && !(a.dbg & 2)) {
-        // neighbours (in sorted order) with equal key parts
-        const uint64_t up = ss_shfl_up64(kp[R - 1]), dn = ss_shfl_down64(kp[0]);
-        bool tie_next[R];
-        bool any = false;
+    if (!(a.dbg & 2)) {
+        const uint64_t up = ss_shfl_up64(k[R - 1]);
+        bad |= lane > 0 && k[0] < up;
+        if (__ballot(bad) != 0) return false;
+    }
+    if (lane * R + R <= count && c.final && a.order && !(a.dbg & 8)) {
+        int32_t *o = a.order + out0 + lane * R;
+        if (R == 2) *(ss_i2 *)o = ss_i2{x[0], x[1]};
 #pragma unroll
-        for (int r = 0; r < R; r++) {
-            const uint64_t nx = r + 1 < R ? kp[r + 1 < R ? r + 1 : r] : dn;
-            const bool has = r + 1 < R ? true : lane < WAVE - 1;
-            tie_next[r] = has && nx == kp[r];
-            any |= tie_next[r];
-        }
-        if (__ballot(any) != 0) {
-            uint64_t f[R];
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-                const uint64_t pv = r > 0 ? kp[r > 0 ? r - 1 : 0] : up;
-                const bool tie_prev = (r > 0 || lane > 0) && pv == kp[r];
-                f[r] = (tie_next[r] || tie_prev) ? desc_key(a.score[x[r]]) : 0;
-            }
-            const uint64_t fdn = ss_shfl_down64(f[0]);
-            bool bad = false;
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-                const uint64_t fn = r + 1 < R ? f[r + 1 < R ? r + 1 : r] : fdn;
-                bad |= tie_next[r] && fn < f[r];       // (equal keys: index order, as packed)
-            }
-            if (__ballot(bad) != 0) return false;
-        }
+        for (int q = 0; q + 4 <= R; q += 4)
+            *(ss_i4 *)(o + q) = ss_i4{x[q], x[q + 1], x[q + 2], x[q + 3]};
+        if (R == 1) o[0] = x[0];
     }
 #pragma unroll
     for (int r = 0; r < R; r++) {
@@ -1410,10 +1428,10 @@ __device__ __forceinline__ bool ss_sort_bucket(const SsArgs &a, const SsChunk &c
         if (e < count) {
             const int32_t pp = out0 + e;
             if (c.final) {
-                if (a.order && !(a.dbg & 8)) a.order[pp] = x[r];
+                if (a.order && !(a.dbg & 8) && lane * R + R > count) a.order[pp] = x[r];
                 if (a.dst && !(a.dbg & 4)) a.dst[x[r]] = pp;
             } else {
-                a.key_out[pp] = shift > 0 ? desc_key(a.score[x[r]]) : k[r];
+                a.key_out[pp] = k[r];
                 a.idx_out[pp] = x[r];
             }
         }
@@ -1495,6 +1513,8 @@ __device__ __forceinline__ bool ss_bucket_geom(const SsArgs &a, int64_t gb, int 
 // the device.
 __global__ __launch_bounds__(256) void ss_redo_kernel(SsArgs a)
 {
+    __shared__ uint64_t s_full[4][WAVE * 16];
+    uint64_t *full = s_full[threadIdx.x >> 6];
     const int lane = lane_id();
     const int32_t n = a.redo[-1];
     for (int32_t i = (int32_t)blockIdx.x * 4 + (int32_t)(threadIdx.x >> 6); i < n;
@@ -1511,13 +1531,15 @@ __global__ __launch_bounds__(256) void ss_redo_kernel(SsArgs a)
             si = a.slot_idx + gb * SS_CAP;
         }
         const int32_t out0 = c.begin + before;
-        if (count > SS_FAST && ss_sort_bucket<16>(a, c, count, out0, lane, sk, si)) continue;
+        if (count > SS_FAST && ss_sort_bucket<16>(a, c, count, out0, lane, sk, si, full)) continue;
         ss_rank_bucket(a, c, count, out0, lane, sk, si);
     }
 }
 
 __global__ __launch_bounds__(256) void ss_sort_kernel(SsArgs a)
 {
+    __shared__ uint64_t s_full[4][WAVE * 8];
+    uint64_t *full = s_full[threadIdx.x >> 6];
     const int lane = lane_id();
     // a category's buckets behind one L2: dst[] of the category is scattered
     const int64_t gb = (int64_t)xcd_block(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
@@ -1559,10 +1581,10 @@ __global__ __launch_bounds__(256) void ss_sort_kernel(SsArgs a)
         si = a.slot_idx + gb * SS_CAP;
     }
     bool done = false;
-    if (count <= 64) done = ss_sort_bucket<1>(a, c, count, out0, lane, sk, si);
-    else if (count <= 128) done = ss_sort_bucket<2>(a, c, count, out0, lane, sk, si);
-    else if (count <= 256) done = ss_sort_bucket<4>(a, c, count, out0, lane, sk, si);
-    else if (count <= SS_FAST) done = ss_sort_bucket<8>(a, c, count, out0, lane, sk, si);
+    if (count <= 64) done = ss_sort_bucket<1>(a, c, count, out0, lane, sk, si, full);
+    else if (count <= 128) done = ss_sort_bucket<2>(a, c, count, out0, lane, sk, si, full);
+    else if (count <= 256) done = ss_sort_bucket<4>(a, c, count, out0, lane, sk, si, full);
+    else if (count <= SS_FAST) done = ss_sort_bucket<8>(a, c, count, out0, lane, sk, si, full);
     if (!done && lane == 0) a.redo[atomicAdd(&a.redo[-1], 1)] = (int32_t)gb;
 }
 
