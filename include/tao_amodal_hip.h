@@ -125,7 +125,11 @@ int taoamd_bb_iou_host(const double *dt, const double *gt, size_t m, size_t n,
  * gt_cat_off (optional, int32[n_cat+1], device): when the GTs are grouped by
  * category (category-major cell tables) the counts are formed by one
  * wavefront per category with ballots -- no atomics; NULL selects the
- * atomicAdd histogram over gt_cat. */
+ * atomicAdd histogram over gt_cat.
+ * Image level: a detection's mask is "every range" iff TAOAMD_DT_IGNORE_UNMATCHED
+ * is set in dt_flags and 0 otherwise, so the table is optional -- dt_rng NULL in
+ * taoamd_lvis_ranges skips it, dt_rng NULL in taoamd_match derives the mask
+ * from dt_flags (240 MB less traffic per pass at 30 M detections). */
 int taoamd_lvis_ranges(int64_t n_gt, const double *gt_vis,
                        const uint8_t *gt_flags, const int32_t *gt_cat,
                        const int32_t *gt_cat_off, int64_t n_dt,
@@ -313,8 +317,13 @@ int taoamd_track_iou_plan_host(int64_t n_cells, const int32_t *cell_dt_off_host,
  *                      (always in identity order)
  *   ious_out (opt.)  : LVIS only, double at cell_iou_off like `iou`
  * out_stride: distance, in 64-bit words, between consecutive output rows of
- * matched / ignored (0 = n_words, i.e. dense); lets the kernel write straight
- * into an interleaved exchange record.
+ * matched / ignored (0 = dense); lets the kernel write straight into an
+ * interleaved exchange record.
+ * Paired rows: when ignored == matched + 1 (and matched is 16-byte aligned) the
+ * two tables are read as ONE table of (matched, ignored) pairs -- word w of row
+ * r is the pair at matched[r * out_stride + 2 * w], dense out_stride =
+ * 2 * n_words -- and a pair is written with one 16-byte store;
+ * taoamd_accumulate* recognise the same layout by the same pointer relation.
  * max_gt_per_cell must be >= the largest GT count of a cell (host knows it
  * from the CSR table); cells with more than 64 GTs take a slower kernel and
  * more than TAOAMD_MAX_GT_PER_CELL is an error.

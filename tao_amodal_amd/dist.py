@@ -105,7 +105,8 @@ class HipBackend:
             _ptr(t["dt_box"]) if fused else None,
             _ptr(t["gt_box"]) if fused else None,
             None if fused else _ptr(ws.iou), dp.n_rng, _ptr(ws.gt_rng),
-            _ptr(ws.dt_rng), _ptr(t["gt_flags"]), _ptr(t["dt_flags"]),
+            None if dp.kind == "lvis" else _ptr(ws.dt_rng),   # (image level: from the flags)
+            _ptr(t["gt_flags"]), _ptr(t["dt_flags"]),
             _ptr(dst), width, base + 16, base + 16 + 8 * dp.n_words, None, None,
             _ptr(t["dt_group"]), _ptr(t["groups"]), dp.n_groups,
             _ptr(t["singles"]), dp.n_singles, self._s()), "taoamd_match")

@@ -385,7 +385,7 @@ class DeviceProblem:
 class Workspace:
     """Output and scratch buffers of one evaluator pass, allocated once."""
 
-    def __init__(self, dp, detail=False):
+    def __init__(self, dp, detail=False, dt_rng_table=False):
         lib = _lib.load()
         dev = dp.device
         u8 = torch.uint8
@@ -393,7 +393,10 @@ class Workspace:
         def buf(nbytes):
             return torch.empty(max(int(nbytes), 256), dtype=u8, device=dev)
         self.gt_rng = torch.empty(max(dp.n_gt, 1), dtype=torch.int32, device=dev)
-        self.dt_rng = torch.empty(max(dp.n_dt, 1), dtype=torch.int32, device=dev)
+        # (image level: the match derives a detection's range mask from its
+        # flags -- no table unless the caller wants to look at it)
+        self.dt_rng = None if dp.kind == "lvis" and not (detail or dt_rng_table) \
+            else torch.empty(max(dp.n_dt, 1), dtype=torch.int32, device=dev)
         self.num_gt = torch.empty((dp.n_cat, dp.n_rng), dtype=torch.int32,
                                   device=dev)
         self.order = torch.empty(max(dp.n_dt, 1), dtype=torch.int32, device=dev)
@@ -403,9 +406,12 @@ class Workspace:
                               lib.taoamd_sort_sampled_workspace(
                                   dp.n_dt, dp.ss_sizes[3], int(dp.ss_merge)))
         self.sort_ws = buf(self.sort_bytes)
-        self.matched = torch.empty((max(dp.n_dt, 1), dp.n_words),
-                                   dtype=torch.int64, device=dev)
-        self.ignored = torch.empty_like(self.matched)
+        # rows of (matched, ignored) pairs, one pair per 64 combos: the match
+        # stores a pair with one 16-byte store and the sweep loads it with one
+        # load (the C ABI sees two tables, the second one word behind the first)
+        self.rows = torch.empty((max(dp.n_dt, 1), dp.n_words, 2),
+                                dtype=torch.int64, device=dev)
+        self.matched, self.ignored = self.rows[..., 0], self.rows[..., 1]
         self.acc_bytes = lib.taoamd_accumulate_workspace(dp.n_dt, dp.n_cat,
                                                          dp.n_rng)
         self.acc_ws = buf(self.acc_bytes)
@@ -687,7 +693,8 @@ def stage_match(dp, ws, scatter=True):
         _ptr(t["dt_box"]) if fused else None,
         _ptr(t["gt_box"]) if fused else None,
         None if fused else _ptr(ws.iou), dp.n_rng, _ptr(ws.gt_rng),
-        _ptr(ws.dt_rng), _ptr(t["gt_flags"]), _ptr(t["dt_flags"]),
+        None if dp.kind == "lvis" else _ptr(ws.dt_rng),   # (image level: from the flags)
+        _ptr(t["gt_flags"]), _ptr(t["dt_flags"]),
         _ptr(ws.dst) if scatter else None, 0, _ptr(ws.matched),
         _ptr(ws.ignored), _ptr(ws.match_gt), _ptr(ws.ious_out),
         _ptr(t["dt_group"]), _ptr(t["groups"]), dp.n_groups, _ptr(t["singles"]),
@@ -898,7 +905,7 @@ def evaluate_flat(flat, device="cuda", detail=False, iou_3d_type="3d_iou",
     """Upload, run, download.  Returns a dict of numpy arrays shaped like the
     C oracle's outputs (tests compare the two field by field)."""
     dp = DeviceProblem(flat, device, iou_3d_type, guard=guard)
-    ws = Workspace(dp, detail=detail)
+    ws = Workspace(dp, detail=detail, dt_rng_table=True)
     guarded = run_guarded(dp, ws, flat)
     torch.cuda.synchronize(dp.device)
     n = dp.n_dt

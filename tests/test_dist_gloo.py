@@ -24,6 +24,7 @@ N_THR, N_REC = 10, 101
 class OracleBackend:
     def __init__(self, flats):
         self.flats = flats          # id(dp) -> Flat
+        self.dt_rng = {}            # id(dp) -> range masks of the detections
 
     def _f(self, dp):
         return self.flats[id(dp)]
@@ -32,7 +33,9 @@ class OracleBackend:
         f = self._f(dp)
         g, d = orclib.ranges(f)
         ws.gt_rng[:len(g)] = torch.from_numpy(g.view(np.int32))
-        ws.dt_rng[:len(d)] = torch.from_numpy(d.view(np.int32))
+        # (the image-level workspace keeps no table: the HIP match derives
+        # the masks from the flags)
+        self.dt_rng[id(dp)] = d
         num = np.zeros((dp.n_cat, dp.n_rng), np.int32)
         for r in range(dp.n_rng):
             np.add.at(num[:, r], f.gt_cat[((g >> np.uint32(r)) & 1) == 0], 1)
@@ -47,7 +50,7 @@ class OracleBackend:
     def match_into(self, dp, ws, dst, records, width):
         f = self._f(dp)
         g = ws.gt_rng[:dp.n_gt].numpy().view(np.uint32)
-        d = ws.dt_rng[:dp.n_dt].numpy().view(np.uint32)
+        d = self.dt_rng[id(dp)]
         iou = ws.iou[:dp.n_iou].numpy() if dp.kind == "tao" else None
         m, i, _, _ = orclib.match(f, g, d, iou, detail=False)
         nw = dp.n_words
@@ -239,7 +242,7 @@ class OracleCategoryBackend(OracleBackend):
     def match_local(self, dp, ws):
         f = self._f(dp)
         g = ws.gt_rng[:dp.n_gt].numpy().view(np.uint32)
-        d = ws.dt_rng[:dp.n_dt].numpy().view(np.uint32)
+        d = self.dt_rng[id(dp)]
         iou = ws.iou[:dp.n_iou].numpy() if dp.kind == "tao" else None
         m, i, _, _ = orclib.match(f, g, d, iou, detail=False)
         dst = ws.dst[:dp.n_dt].numpy().astype(np.int64)
