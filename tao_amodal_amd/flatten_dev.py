@@ -11,6 +11,7 @@ The ground-truth side (10^5 rows, dict / alias semantics) is taken from
 PyTorch only allocates; every pass is a kernel of the C ABI
 (``taoamd_flat_*``, ``taoamd_sort_by_cat_score``).
 """
+import threading
 import warnings
 import weakref
 
@@ -70,6 +71,7 @@ class DeviceFlat(Flat):
 
 
 _RAW = {}      # id(DTColumns) -> (weakref, {device: dict of tensors})
+_RAW_LOCK = threading.Lock()     # (the CLI builds both levels' tables side by side)
 
 
 def _column_key(dt):
@@ -95,6 +97,11 @@ def raw_columns(dt, device):
     """The prediction columns on the device, uploaded once per DTColumns (and
     set of column arrays) and shared by the image-level and the track-level
     build."""
+    with _RAW_LOCK:
+        return _raw_columns(dt, device)
+
+
+def _raw_columns(dt, device):
     dev = torch.device(device)
     key = id(dt)
     cols_key = _column_key(dt)

@@ -74,15 +74,6 @@ def make_track_ids_unique(dt):
     return n
 
 
-def prepare_track_level(dt_columns):
-    """Worker-thread body: the unique track ids (reference :44-66), computed
-    while the main thread runs the image-level evaluator (numpy releases the
-    GIL in its sorts / gathers).  ``dt_columns.track_id`` itself is only
-    replaced where the reference does it."""
-    ids, _ = flatten.make_track_ids_unique(dt_columns)
-    return ids
-
-
 def evaluate_predictions_on_lvis(lvis_gt, track_result, dt_columns, iou_type,
                                  logger):
     logger.info("Evaluating {} on LVIS...".format(track_result))
@@ -99,18 +90,14 @@ def evaluate_predictions_on_lvis(lvis_gt, track_result, dt_columns, iou_type,
     return results
 
 
-def eval_tao_track(ann_path, gt_dataset, gt_columns, dt_columns, logger,
-                   prepared=None):
+def eval_tao_track(ann_path, gt_dataset, gt_columns, dt_columns, logger):
     logger.setLevel(logging.INFO)
     results = {}
     logger.info("Loading gt {}...".format(ann_path))
     tao_gt = Tao(gt_dataset, columns=gt_columns)
     logger.info("Done")
     logger.info("Loading results...")
-    if prepared is not None:
-        dt_columns.track_id = prepared.result()
-    else:
-        make_track_ids_unique(dt_columns)
+    make_track_ids_unique(dt_columns)
     logger.info("Done")
     logger.info("Building")
     tao_eval = TaoEval(tao_gt, TaoResults(tao_gt, dt_columns), logger=logger)
@@ -128,6 +115,57 @@ def eval_tao_track(ann_path, gt_dataset, gt_columns, dt_columns, logger,
     logger.info("copypaste: " + ",".join(keys))
     logger.info("copypaste: " + ",".join("{:.4f}".format(results[k]) for k in keys))
     return results
+
+
+class HeldLogs:
+    """Holds back the log records of ONE thread on every handler in use and
+    emits them later, in the order and on the handlers they were bound for."""
+
+    class _Gate(logging.Filter):
+        def __init__(self, owner, handler):
+            super().__init__()
+            self.owner, self.handler = owner, handler
+
+        def filter(self, record):
+            if self.owner.thread is not None and record.thread == self.owner.thread:
+                self.owner.records.append((self.handler, record))
+                return False
+            return True
+
+    def __init__(self, *loggers):
+        import threading
+        self._ident = threading.get_ident
+        self.thread, self.records, self.gates = None, [], []
+        seen = set()
+        named = [logging.getLogger()] + list(loggers) + [
+            lg for lg in logging.root.manager.loggerDict.values()
+            if isinstance(lg, logging.Logger)]
+        handlers = [h for lg in named for h in lg.handlers]
+        if logging.lastResort is not None:
+            handlers.append(logging.lastResort)
+        for h in handlers:
+            if id(h) not in seen:
+                seen.add(id(h))
+                gate = self._Gate(self, h)
+                h.addFilter(gate)
+                self.gates.append((h, gate))
+
+    def run(self, fn, *args):
+        self.thread = self._ident()
+        return fn(*args)
+
+    def close(self, replay):
+        self.thread = None
+        for h, gate in self.gates:
+            h.removeFilter(gate)
+        if replay:
+            for h, record in self.records:
+                h.acquire()
+                try:
+                    h.emit(record)
+                finally:
+                    h.release()
+        self.records = []
 
 
 def main_distributed(args, annotation):
@@ -247,18 +285,30 @@ def main(argv=None):
                 from tao_amodal_amd import flatten_dev
                 flatten_dev.prepare_gt(lvis_gt.columns)
             dt_columns = dt_future.result()
-        prepared = None
-        if len(dt_columns):
-            prepared = pool.submit(prepare_track_level, dt_columns)
-        try:
+        if len(dt_columns) and not os.environ.get("TAOAMD_CLI_SERIAL"):
+            # the track level runs beside the image level on the worker
+            # thread (most of either is numpy or the GPU: no GIL held); what
+            # it logs is held back and written once the image level is done,
+            # so every stream and the log file read as if one followed the other
+            held = HeldLogs(logger)
+            track = pool.submit(held.run, eval_tao_track, annotation, gt_dataset,
+                                lvis_gt.columns, dt_columns, logger)
+            try:
+                evaluate_predictions_on_lvis(lvis_gt, args.track_result, dt_columns,
+                                             "bbox", logger)
+            except BaseException:
+                track.exception()       # (wait: nothing of it is shown)
+                held.close(replay=False)
+                raise
+            failed = track.exception()
+            held.close(replay=True)
+            if failed is not None:
+                raise failed
+        else:
             evaluate_predictions_on_lvis(lvis_gt, args.track_result, dt_columns,
                                          "bbox", logger)
-        except BaseException:
-            if prepared is not None:
-                prepared.cancel()
-            raise
-        eval_tao_track(annotation, gt_dataset, lvis_gt.columns, dt_columns,
-                       logger, prepared)
+            eval_tao_track(annotation, gt_dataset, lvis_gt.columns, dt_columns,
+                           logger)
     finally:
         if "pool" in locals():
             pool.shutdown(wait=False)
