@@ -105,7 +105,7 @@ SIGNATURES = {
                                          _vp, _vp]),
     "taoamd_match": (C.c_int, [_i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32,
                                _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp,
-                               _vp, _vp, _vp, _i32, _vp, _i32, _vp]),
+                               _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp]),
     "taoamd_gather_rows": (C.c_int, [_i64, _i32, _vp, _vp, _i64, _vp, _vp,
                                      _vp, _vp]),
     "taoamd_compact_elems": (_sz, [_i32, _i32]),

@@ -188,6 +188,7 @@ struct MatchArgs {
     int32_t paired;      // ignored == matched + 1: word w of a row is the pair at 2 * w
     // optional launch plan (built by the host from the cell table)
     const int32_t *dt_group;  // [n_dt][4] first GT / GT count of the cell, position in it, cell
+    const uint32_t *dt_meta;  // optional [n_dt]: flags | first GT - run's << 8 | GTs << 14 | position << 18
     const int32_t *groups;    // [n_groups][4] first detection, count, first GT, count of a run
     const int32_t *singles;   // [n_singles] cells handled one per wavefront
     int32_t n_groups, n_singles;
@@ -372,15 +373,25 @@ __global__ __launch_bounds__(256) void match_group_kernel(MatchArgs a, IouThr th
     double4 B = make_double4(0, 0, 0, 0);
     if (lane < nD) {
         const int32_t d = d0 + lane;
-        const int4 dg = reinterpret_cast<const int4 *>(a.dt_group)[d];
-        t_flags = a.dt_flags[d];
+        if (FUSED && a.dt_meta != nullptr) {
+            // one word instead of the 16-byte row and the flag byte (the cell
+            // index is only needed to find IoUs in memory)
+            const uint32_t mt = a.dt_meta[d];
+            t_flags = (int32_t)(mt & 0xffu);
+            gb = (int32_t)((mt >> 8) & 63u);
+            Gc = (int32_t)((mt >> 14) & 15u);
+            dloc = (int32_t)(mt >> 18);
+        } else {
+            const int4 dg = reinterpret_cast<const int4 *>(a.dt_group)[d];
+            t_flags = a.dt_flags[d];
+            Gc = dg.y;
+            gb = dg.x - g0;
+            dloc = dg.z;
+            if (a.cell_iou_off != nullptr) t_ioff = a.cell_iou_off[dg.w];
+        }
         t_rng = (int32_t)dt_rng_of(a, d, (uint32_t)t_flags);
         t_row = a.dst != nullptr ? a.dst[d] : d;
-        Gc = dg.y;
-        gb = dg.x - g0;
         ge = gb + Gc;
-        dloc = dg.z;
-        if (a.cell_iou_off != nullptr) t_ioff = a.cell_iou_off[dg.w];
         if (FUSED) B = reinterpret_cast<const double4 *>(a.dt_box)[d];
     }
     // ---- lane = GT of the run
@@ -774,6 +785,7 @@ extern "C" int taoamd_match(int64_t n_cells, const int32_t *cell_dt_off,
                             int64_t out_stride, uint64_t *matched,
                             uint64_t *ignored, int32_t *match_gt,
                             double *ious_out, const int32_t *dt_group,
+                            const uint32_t *dt_meta,
                             const int32_t *groups, int32_t n_groups,
                             const int32_t *singles, int32_t n_singles,
                             void *stream)
@@ -798,6 +810,8 @@ extern "C" int taoamd_match(int64_t n_cells, const int32_t *cell_dt_off,
     a.out_stride = out_stride > 0 ? out_stride : (a.paired ? 2 : 1) * a.n_words;
     if (a.out_stride < (a.paired ? 2 : 1) * a.n_words) return TAOAMD_ERR_ARG;
     if (a.paired && ((((uintptr_t)matched) & 15) != 0 || (a.out_stride & 1))) return TAOAMD_ERR_ARG;
+    // (the packed word carries no cell index: not where IoUs are read or written)
+    a.dt_meta = fused && ious_out == nullptr ? dt_meta : nullptr;
     a.dt_group = dt_group; a.groups = groups; a.n_groups = planned ? n_groups : 0;
     a.singles = planned ? singles : nullptr; a.n_singles = planned ? n_singles : 0;
     static const int xcd_env = getenv("TAOAMD_XCD") ? atoi(getenv("TAOAMD_XCD")) : 1;

@@ -108,7 +108,7 @@ class HipBackend:
             None if dp.kind == "lvis" else _ptr(ws.dt_rng),   # (image level: from the flags)
             _ptr(t["gt_flags"]), _ptr(t["dt_flags"]),
             _ptr(dst), width, base + 16, base + 16 + 8 * dp.n_words, None, None,
-            _ptr(t["dt_group"]), _ptr(t["groups"]), dp.n_groups,
+            _ptr(t["dt_group"]), _ptr(t["dt_meta"]), _ptr(t["groups"]), dp.n_groups,
             _ptr(t["singles"]), dp.n_singles, self._s()), "taoamd_match")
 
     def sort_local(self, dp, ws):

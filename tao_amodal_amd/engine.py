@@ -273,6 +273,19 @@ class DeviceProblem:
              - d_off[cell], self.t["dt_cell"]], dim=1).to(torch.int32).contiguous() \
             if self.n_dt else torch.zeros((1, 4), dtype=torch.int32,
                                           device=self.device)
+        # image level: the same (relative to the run's first GT) and the flag
+        # byte packed into one word per detection, all the group kernel reads
+        # when it computes the IoUs itself (taoamd_match: dt_meta)
+        self.t["dt_meta"] = None
+        if self.kind == "lvis" and not self.mask_iou and self.n_dt and len(groups):
+            dg, runs_t = self.t["dt_group"], self.t["groups"]
+            d = torch.arange(self.n_dt, dtype=torch.int32, device=self.device)
+            rid = (torch.searchsorted(runs_t[:, 0].contiguous(), d, right=True) - 1
+                   ).clamp_(min=0)
+            self.t["dt_meta"] = (
+                self.t["dt_flags"].to(torch.int32)
+                | (((dg[:, 0] - runs_t[:, 2][rid]) & 63) << 8)
+                | (dg[:, 1].clamp(max=15) << 14) | ((dg[:, 2] & 63) << 18)).contiguous()
         self.t["singles"] = torch.from_numpy(
             singles if len(singles) else np.zeros(1, np.int32)).to(self.device)
         self.t["cell_iou_off"] = torch.from_numpy(iou_off).to(self.device)
@@ -697,8 +710,8 @@ def stage_match(dp, ws, scatter=True):
         _ptr(t["gt_flags"]), _ptr(t["dt_flags"]),
         _ptr(ws.dst) if scatter else None, 0, _ptr(ws.matched),
         _ptr(ws.ignored), _ptr(ws.match_gt), _ptr(ws.ious_out),
-        _ptr(t["dt_group"]), _ptr(t["groups"]), dp.n_groups, _ptr(t["singles"]),
-        dp.n_singles, s), "taoamd_match")
+        _ptr(t["dt_group"]), _ptr(t["dt_meta"]), _ptr(t["groups"]), dp.n_groups,
+        _ptr(t["singles"]), dp.n_singles, s), "taoamd_match")
 
 
 def stage_accumulate_by_order(dp, ws):
