@@ -1039,6 +1039,14 @@ struct SsArgs {
     int32_t n_buckets, n_stiles, cap_limit;
     int32_t dbg;                       // ablation switches (TAOAMD_SS_DBG, timing experiments)
 };
+// Ablation switches for timing experiments (results are wrong with any bit
+// set): compiled in only by `bash build.sh -DTAOAMD_ABLATE`, constant 0 in the
+// library that ships.
+#ifdef TAOAMD_ABLATE
+#define SS_DBG(a, bit) ((a).dbg & (bit))
+#else
+#define SS_DBG(a, bit) 0
+#endif
 
 static int g_ss_cap_limit = SS_CAP;
 
@@ -1287,7 +1295,7 @@ __global__ __launch_bounds__(SEG_THREADS) void ss_scatter_kernel(SsArgs a)
     // equal to a splitter closes the lower bucket): a fixed-depth search, all
     // rounds of the thread in step so that their LDS reads are in flight together
     static_assert(SS_MAXB == 128, "seven steps");
-    if (!(a.dbg & 64))
+    if (!SS_DBG(a, 64))
 #pragma unroll
     for (int step = SS_MAXB / 2; step >= 1; step >>= 1) {
         uint64_t sk[SEG_ROUNDS];
@@ -1304,8 +1312,8 @@ __global__ __launch_bounds__(SEG_THREADS) void ss_scatter_kernel(SsArgs a)
 #pragma unroll
     for (int r = 0; r < SEG_ROUNDS; r++) {
         const int32_t i = t0 + r * SEG_THREADS + (int32_t)threadIdx.x;
-        if ((a.dbg & 64) && i < t1) br[r] = (int32_t)((kr[r] >> 40) % (uint64_t)B);
-        if (i < t1) rr[r] = (a.dbg & 32) ? (int32_t)threadIdx.x >> 4 : atomicAdd(&s_cnt[br[r]], 1);
+        if (SS_DBG(a, 64) && i < t1) br[r] = (int32_t)((kr[r] >> 40) % (uint64_t)B);
+        if (i < t1) rr[r] = SS_DBG(a, 32) ? (int32_t)threadIdx.x >> 4 : atomicAdd(&s_cnt[br[r]], 1);
         else br[r] = -1;
     }
     __syncthreads();
@@ -1318,7 +1326,7 @@ __global__ __launch_bounds__(SEG_THREADS) void ss_scatter_kernel(SsArgs a)
     for (int r = 0; r < SEG_ROUNDS; r++) {
         if (br[r] >= 0) {
             const int32_t at = s_base[br[r]] + rr[r];
-            if (at < SS_CAP && !(a.dbg & 16)) {
+            if (at < SS_CAP && !SS_DBG(a, 16)) {
                 const int64_t s = (int64_t)(c.bucket0 + br[r]) * SS_CAP + at;
                 a.slot_key[s] = kr[r];
                 a.slot_idx[s] = t0 + r * SEG_THREADS + (int32_t)threadIdx.x;
@@ -1397,7 +1405,7 @@ __device__ __forceinline__ bool ss_sort_bucket(const SsArgs &a, const SsChunk &c
                   ((uint64_t)(x[r] - c.begin) << SS_E_BITS) | (uint64_t)e))
             : pad;
     }
-    if (!(a.dbg & 1)) ss_bitonic_packed<R>(p, lane);
+    if (!SS_DBG(a, 1)) ss_bitonic_packed<R>(p, lane);
     // (the wavefront's own LDS writes are complete before its reads: one
     // wavefront, program order; the waitcnt is the compiler's)
     bool bad = false;
@@ -1409,12 +1417,12 @@ __device__ __forceinline__ bool ss_sort_bucket(const SsArgs &a, const SsChunk &c
         k[r] = ok ? full[bits & ((1u << SS_E_BITS) - 1) & (WAVE * R - 1)] : ~0ull;
         if (r > 0) bad |= k[r] < k[r - 1];
     }
-    if (!(a.dbg & 2)) {
+    if (!SS_DBG(a, 2)) {
         const uint64_t up = ss_shfl_up64(k[R - 1]);
         bad |= lane > 0 && k[0] < up;
         if (__ballot(bad) != 0) return false;
     }
-    if (lane * R + R <= count && c.final && a.order && !(a.dbg & 8)) {
+    if (lane * R + R <= count && c.final && a.order && !SS_DBG(a, 8)) {
         int32_t *o = a.order + out0 + lane * R;
         if (R == 2) *(ss_i2 *)o = ss_i2{x[0], x[1]};
 #pragma unroll
@@ -1428,8 +1436,8 @@ __device__ __forceinline__ bool ss_sort_bucket(const SsArgs &a, const SsChunk &c
         if (e < count) {
             const int32_t pp = out0 + e;
             if (c.final) {
-                if (a.order && !(a.dbg & 8) && lane * R + R > count) a.order[pp] = x[r];
-                if (a.dst && !(a.dbg & 4)) a.dst[x[r]] = pp;
+                if (a.order && !SS_DBG(a, 8) && lane * R + R > count) a.order[pp] = x[r];
+                if (a.dst && !SS_DBG(a, 4)) a.dst[x[r]] = pp;
             } else {
                 a.key_out[pp] = k[r];
                 a.idx_out[pp] = x[r];
@@ -1671,8 +1679,12 @@ extern "C" int taoamd_sort_sampled(int64_t n, int32_t n_cat, const int32_t *cat_
     a.stile_chunk = stile_chunk; a.bucket_chunk = bucket_chunk;
     a.order = order; a.dst = dst; a.n_buckets = n_buckets; a.n_stiles = n_stiles;
     a.cap_limit = g_ss_cap_limit;
+#ifdef TAOAMD_ABLATE
     static const int dbg_env = getenv("TAOAMD_SS_DBG") ? atoi(getenv("TAOAMD_SS_DBG")) : 0;
     a.dbg = dbg_env;
+#else
+    a.dbg = 0;
+#endif
     a.cursor = (int32_t *)w;    w += align256((size_t)n_buckets * 4 + 256);
     a.redo = (int32_t *)w;      w += align256((size_t)n_buckets * 4);
     // (the redo count sits in the last int of the cursor block, right ahead of the list)
