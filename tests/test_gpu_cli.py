@@ -155,3 +155,36 @@ def test_edited_params_the_path_cannot_honour_still_raise():
     ev.params.max_dets = 100            # a label only (eval.py:464-545)
     ev.run()
     assert "AR@100" in ev.results
+
+
+def test_cli_image_level_failure_shows_nothing_of_the_track_level(tmp_path):
+    """The track level runs beside the image level (worker thread); when the
+    image level fails -- here: a prediction on an image the annotation file
+    does not have, reference lvis_amodal/results.py:62-65 -- its exception
+    leaves the CLI and nothing the track level logged reaches the log file,
+    as in the reference, which never got that far."""
+    import json
+    preds = json.load(open(path("f1", "pred.json")))
+    preds[3]["image_id"] = 10 ** 9
+    bad = tmp_path / "pred.json"
+    bad.write_text(json.dumps(preds))
+    log = tmp_path / "out" / "eval.log"
+    with pytest.raises(AssertionError, match="Results do not correspond"):
+        with contextlib.redirect_stdout(io.StringIO()):
+            _cli().main(["--track_result", str(bad), "--annotation",
+                         path("f1", "gt.json"), "--output_log", str(log)])
+    text = log.read_text()
+    assert "Evaluating" in text
+    assert "Loading gt" not in text and "Running per video evaluation" not in text
+
+
+def test_cli_serial_switch_gives_the_same_text(tmp_path, monkeypatch):
+    monkeypatch.setenv("TAOAMD_CLI_SERIAL", "1")
+    log = tmp_path / "out" / "eval.log"
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        _cli().main(["--track_result", path("f5", "pred.json"), "--annotation",
+                     path("f5", "gt.json"), "--output_log", str(log)])
+    assert buf.getvalue() == open(path("f5", "cli_stdout.txt")).read()
+    got = log.read_text().replace(os.path.join(path("f5", "")), "<DIR>/")
+    assert got == open(path("f5", "cli_log.txt")).read()
