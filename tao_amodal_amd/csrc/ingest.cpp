@@ -100,6 +100,37 @@ struct Cursor {
     {
         ws();
         const char *s = p;
+        {
+            // The common case in one pass: [-]digits[.digits], at most 15 digits
+            // in all and no exponent.  The digits are an integer m < 10^15 < 2^53
+            // and 10^k (k <= 22) is a double too, so m / 10^k is ONE correctly
+            // rounded IEEE operation on exact operands: the double strtod /
+            // Python's float() give (Clinger's fast path).  Everything else --
+            // 16-17 digit scores, exponents, NaN -- takes the general route.
+            static const double P10[16] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7,
+                                           1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15};
+            const char *q = s;
+            const bool neg = q < e && *q == '-';
+            if (neg) q++;
+            uint64_t m = 0;
+            int nd = 0, frac = 0;
+            while (q < e && (unsigned)(*q - '0') <= 9u && nd < 16) { m = m * 10 + (uint64_t)(*q - '0'); q++; nd++; }
+            bool ok = nd > 0 && nd <= 15;
+            if (ok && q < e && *q == '.') {
+                q++;
+                while (q < e && (unsigned)(*q - '0') <= 9u && nd < 16) {
+                    m = m * 10 + (uint64_t)(*q - '0'); q++; nd++; frac++;
+                }
+                ok = frac > 0 && nd <= 15;
+            }
+            if (ok && q < e && (*q == ',' || *q == ']' || *q == '}' || *q == ' ' || *q == '\n' ||
+                                *q == '\t' || *q == '\r')) {
+                const double x = frac ? (double)m / P10[frac] : (double)m;
+                v = neg ? -x : x;
+                p = q;
+                return true;
+            }
+        }
         if (p < e && *p == '-') p++;
         while (p < e && ((*p >= '0' && *p <= '9') || *p == '.' || *p == 'e' ||
                          *p == 'E' || *p == '+' || *p == '-')) p++;
@@ -224,42 +255,53 @@ const char *find_elements(const char *p0, const char *e, Ranges &out, char *clos
     int T = omp_get_max_threads();
     if (len < (1u << 20) || T < 2) T = 1;
     if ((size_t)T > len / 65536 + 1) T = (int)(len / 65536 + 1);
-    std::vector<const char *> cb((size_t)T + 1);
-    for (int t = 0; t <= T; t++) {
-        const char *q = t == T ? e : p0 + len / T * t;
-        while (t > 0 && t < T && q < e && q[-1] == '\\') q++;
+    // Chunks of at most 8 MB, walked T at a time; the rounds stop with the one
+    // in which the list closes, so a table at the head of a large file costs
+    // its own bytes and not the file's (the five tables of the annotation file
+    // were five scans to the end of the file).
+    const size_t piece = std::min<size_t>(std::max<size_t>(len / (size_t)T, 1), (size_t)8 << 20);
+    const size_t nC = std::max<size_t>(1, (len + piece - 1) / piece);
+    std::vector<const char *> cb(nC + 1);
+    for (size_t t = 0; t <= nC; t++) {
+        const char *q = t == nC ? e : p0 + piece * t;
+        while (t > 0 && t < nC && q < e && q[-1] == '\\') q++;
         cb[t] = q;
     }
-    for (int t = 1; t <= T; t++) if (cb[t] < cb[t - 1]) cb[t] = cb[t - 1];
-    std::vector<uint8_t> in_str((size_t)T + 1, 0);
-    if (T > 1) {
-        std::vector<size_t> quotes((size_t)T, 0);
-#pragma omp parallel for schedule(static, 1)
-        for (int t = 0; t < T; t++) {
-            size_t q = 0;
-            const char *b = cb[t], *en = cb[t + 1];
-            if (!memchr(b, '\\', (size_t)(en - b))) {
-                for (const char *p = b; p < en; p++) q += *p == '"';
-            } else {
-                for (const char *p = b; p < en; p++) {
-                    if (*p == '\\') p++;
-                    else if (*p == '"') q++;
-                }
-            }
-            quotes[t] = q;
-        }
-        size_t acc = 0;
-        for (int t = 0; t < T; t++) { in_str[t] = acc & 1; acc += quotes[t]; }
-    }
-    // (B) candidate boundaries of every chunk
-    std::vector<ChunkWalk> walk((size_t)T);
-#pragma omp parallel for schedule(static, 1) if (T > 1)
-    for (int t = 0; t < T; t++) walk[t].run(cb[t], cb[t + 1], in_str[t]);
-    std::vector<int64_t> base((size_t)T + 1, 0);
+    for (size_t t = 1; t <= nC; t++) if (cb[t] < cb[t - 1]) cb[t] = cb[t - 1];
+    std::vector<uint8_t> in_str(nC + 1, 0);
+    std::vector<size_t> quotes(nC, 0);
+    std::vector<ChunkWalk> walk(nC);
+    std::vector<int64_t> base(nC + 1, 0);
     int last = -1;                  // chunk in which the depth reaches -1
-    for (int t = 0; t < T; t++) {
-        if (base[t] + walk[t].lowest < 0) { last = t; break; }
-        base[t + 1] = base[t] + walk[t].delta;
+    size_t acc = 0;                 // unescaped quotes before the round
+    for (size_t r0 = 0; r0 < nC && last < 0; r0 += (size_t)T) {
+        const int n = (int)std::min<size_t>((size_t)T, nC - r0);
+        // (A) unescaped quotes per chunk -> does a chunk start inside a string
+        if (nC > 1) {
+#pragma omp parallel for schedule(static, 1) if (n > 1)
+            for (int u = 0; u < n; u++) {
+                size_t q = 0;
+                const char *b = cb[r0 + u], *en = cb[r0 + u + 1];
+                if (!memchr(b, '\\', (size_t)(en - b))) {
+                    for (const char *p = b; p < en; p++) q += *p == '"';
+                } else {
+                    for (const char *p = b; p < en; p++) {
+                        if (*p == '\\') p++;
+                        else if (*p == '"') q++;
+                    }
+                }
+                quotes[r0 + u] = q;
+            }
+            for (int u = 0; u < n; u++) { in_str[r0 + u] = acc & 1; acc += quotes[r0 + u]; }
+        }
+        // (B) candidate boundaries of every chunk
+#pragma omp parallel for schedule(static, 1) if (n > 1)
+        for (int u = 0; u < n; u++)
+            walk[r0 + u].run(cb[r0 + u], cb[r0 + u + 1], in_str[r0 + u]);
+        for (size_t t = r0; t < r0 + (size_t)n; t++) {
+            if (base[t] + walk[t].lowest < 0) { last = (int)t; break; }
+            base[t + 1] = base[t] + walk[t].delta;
+        }
     }
     if (last < 0) return nullptr;
     const int closing = walk[last].find(-base[last] - 1);
@@ -356,11 +398,31 @@ bool parse_object(const char *b, const char *e, int64_t i, const ColView &c, std
             if (!cur.str(kb, ke) || !cur.eat(':')) { cur.bad("expected key"); break; }
             double v;
             int64_t iv;
-            if (key_is(kb, ke, "image_id")) { if (cur.integer(iv)) { c.image_id[i] = iv; has_img = true; } }
-            else if (key_is(kb, ke, "category_id")) { if (cur.integer(iv)) { c.category_id[i] = iv; has_cat = true; } }
-            else if (key_is(kb, ke, "track_id")) { if (cur.integer(iv)) c.track_id[i] = iv; }
-            else if (key_is(kb, ke, "video_id")) { if (cur.integer(iv)) c.video_id[i] = iv; }
-            else if (key_is(kb, ke, "score")) {
+            // the six known keys by length and text; anything else (or a key
+            // spelt with escapes) through the general comparison
+            const size_t kl = (size_t)(ke - kb);
+            int which = -1;
+            if (kl == 8) {
+                which = !memcmp(kb, "image_id", 8) ? 0 : !memcmp(kb, "track_id", 8) ? 2
+                        : !memcmp(kb, "video_id", 8) ? 3 : -1;
+            } else if (kl == 11) {
+                which = !memcmp(kb, "category_id", 11) ? 1 : -1;
+            } else if (kl == 5) {
+                which = !memcmp(kb, "score", 5) ? 4 : -1;
+            } else if (kl == 4) {
+                which = !memcmp(kb, "bbox", 4) ? 5 : -1;
+            }
+            if (which < 0 && memchr(kb, '\\', kl)) {
+                static const char *const names[6] = {"image_id", "category_id", "track_id",
+                                                     "video_id", "score", "bbox"};
+                for (int w = 0; w < 6 && which < 0; w++)
+                    if (key_is(kb, ke, names[w])) which = w;
+            }
+            if (which == 0) { if (cur.integer(iv)) { c.image_id[i] = iv; has_img = true; } }
+            else if (which == 1) { if (cur.integer(iv)) { c.category_id[i] = iv; has_cat = true; } }
+            else if (which == 2) { if (cur.integer(iv)) c.track_id[i] = iv; }
+            else if (which == 3) { if (cur.integer(iv)) c.video_id[i] = iv; }
+            else if (which == 4) {
                 cur.ws();
                 if (cur.p < cur.e && (*cur.p == 't' || *cur.p == 'f')) {
                     c.score[i] = *cur.p == 't' ? 1.0 : 0.0;     // True == 1
@@ -368,7 +430,7 @@ bool parse_object(const char *b, const char *e, int64_t i, const ColView &c, std
                     has_score = true;
                 } else if (cur.number(v)) { c.score[i] = v; has_score = true; }
             }
-            else if (key_is(kb, ke, "bbox")) {
+            else if (which == 5) {
                 if (!cur.eat('[')) cur.bad("bbox is not a list");
                 for (int k = 0; k < 4 && !cur.fail; k++) {
                     if (k && !cur.eat(',')) cur.bad("bbox needs 4 numbers");

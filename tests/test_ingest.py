@@ -331,3 +331,41 @@ def test_select_videos_is_the_subset_of_the_annotation_file():
     imgs = {i["id"] for i in want["images"]}
     want["annotations"] = [a for a in j["annotations"] if a["image_id"] in imgs]
     assert sub.to_json() == want
+
+
+def test_numbers_equal_pythons_float_bit_for_bit(tmp_path):
+    """The reader's short-decimal fast path (<= 15 digits, no exponent: one
+    exact division) and its general route give the double Python's float()
+    gives for the same text -- random texts of 1..17 significant digits, with
+    and without exponents, signs, leading / trailing zeros."""
+    rng = np.random.default_rng(11)
+    texts = ["0", "-0", "0.0", "-0.0", "0.000", "1", "-1", "10", "123456789012345",
+             "1234567890123456", "0.1", "0.30000000000000004", "999999999999999",
+             "99999999999999.9", "0.000000000000001", "0.0000000000000000000001",
+             "4.35", "2.675", "1e3", "1E-3", "1.5e+10", "-2.5E-7", "1e22", "1e23",
+             "123456789.123456789", "9007199254740993", "0.1e1", "5e-324", "1.7976931348623157e308"]
+    for _ in range(4000):
+        nd = int(rng.integers(1, 18))
+        digits = "".join(str(int(d)) for d in rng.integers(0, 10, nd))
+        cut = int(rng.integers(0, nd + 1))
+        t = (digits[:cut] or "0") + ("." + digits[cut:] if cut < nd else "")
+        if rng.random() < 0.3:
+            t = "-" + t
+        if rng.random() < 0.15:
+            t += "e%d" % int(rng.integers(-30, 30))
+        texts.append(t)
+    rows = ['{"image_id": 1, "category_id": 1, "score": %s, "bbox": [%s, %s , %s\t,%s]}'
+            % (texts[(k + 1) % len(texts)], texts[k], texts[(k + 2) % len(texts)],
+               texts[(k + 3) % len(texts)], texts[(k + 4) % len(texts)])
+            for k in range(len(texts))]
+    p = tmp_path / "p.json"
+    p.write_text("[" + ",\n".join(rows) + "]")
+    d = DTColumns.from_file_native(str(p))
+    want = np.array([float(t) for t in texts])
+    n = len(texts)
+    got = d.bbox[:, 0]
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+    assert np.array_equal(d.score.view(np.uint64), np.roll(want, -1).view(np.uint64))
+    for k, sh in ((1, 2), (2, 3), (3, 4)):
+        assert np.array_equal(d.bbox[:, k].view(np.uint64), np.roll(want, -sh).view(np.uint64))
+    assert len(d.score) == n
