@@ -271,6 +271,42 @@ def test_boundary_scan_with_chunks_starting_at_any_depth(tmp_path):
         assert np.array_equal(z["track_id"], want.track_id)
 
 
+def test_boundary_scan_of_backslash_free_chunks(tmp_path):
+    """Chunks without a backslash take the 64-bytes-at-a-time walk (quote /
+    bracket bit masks, in-string mask as the running parity of the quotes):
+    strings full of brackets, of every length around the block size, nested
+    values, and chunk / block boundaries that fall inside strings."""
+    import subprocess
+    import sys
+    rng = np.random.default_rng(6)
+    _, dt = synth(seed=7, V=4, F=80, C=30, dets_per_frame=40, n_present=5)
+    preds = dt.to_json()
+    for k, q in enumerate(preds):
+        q["note"] = "]}[{" * (k % 5) + "x" * int(rng.integers(0, 200)) + "{[" * (k % 3)
+        if k % 4 == 0:
+            q["deep"] = [[{"a": ["}]", {"b": "[" * (k % 70)}]}], "]" * (k % 130)]
+    text = json.dumps(preds)
+    assert "\\" not in text
+    p = tmp_path / "p.json"
+    p.write_text(text)
+    assert p.stat().st_size > (2 << 20)
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); "
+            "from tao_amodal_amd.columns import DTColumns; "
+            "d = DTColumns.from_file_native(%r); "
+            "np.savez(%r, image_id=d.image_id, bbox=d.bbox, score=d.score, "
+            "track_id=d.track_id)" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                      str(p), str(tmp_path / "out.npz")))
+    want = DTColumns.from_json(preds)
+    for threads in ("37", "2"):
+        subprocess.run([sys.executable, "-c", code], check=True,
+                       env=dict(os.environ, TAOAMD_HOST_THREADS=threads))
+        z = np.load(tmp_path / "out.npz")
+        assert np.array_equal(z["image_id"], want.image_id)
+        assert np.array_equal(z["bbox"], want.bbox)
+        assert np.array_equal(z["score"], want.score)
+        assert np.array_equal(z["track_id"], want.track_id)
+
+
 def test_reader_corner_cases_of_json_load(tmp_path):
     """What json.load accepts the reader accepts with the same values, what the
     evaluator cannot use it rejects: out-of-range exponents (inf / 0.0 as
