@@ -241,12 +241,20 @@ def prepare_gt(gt, kinds=("lvis", "tao")):
     columns afterwards never meets a stale table).  Errors are not raised
     here: the build that needs the bundle runs into them at the place the
     reference does."""
-    made = {}
-    for kind in kinds:
+    def build(kind):
         try:
-            made[kind] = _READY[kind](gt)
+            return _READY[kind](gt)
         except Exception:
-            pass
+            return None
+    if len(kinds) > 1:
+        # (numpy's sorts, searches and gathers run without the GIL: the two
+        # levels' halves side by side)
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=len(kinds)) as pool:
+            built = list(pool.map(build, kinds))
+    else:
+        built = [build(k) for k in kinds]
+    made = {k: b for k, b in zip(kinds, built) if b is not None}
     vars(gt)["_prepared_gt"] = (_gt_key(gt), made)
 
 
