@@ -103,6 +103,12 @@ int taoamd_host_sort_key_score(int64_t n, const int64_t *key, const double *scor
  * group's CPU quota (csrc/host_threads.hpp; TAOAMD_HOST_THREADS overrides). */
 int taoamd_host_threads(void);
 
+/* 1 if every one of values[0..n) occurs in keys[0..n_keys) (ascending), 0 if
+ * one does not, -1 on a bad argument: the membership test behind "Results do
+ * not correspond to current LVIS set." (reference lvis_amodal/results.py:62-65). */
+int taoamd_host_all_in_sorted(int64_t n_keys, const int64_t *keys, int64_t n,
+                              const int64_t *values);
+
 /* ---- run-length masks (csrc/rle.cpp): the host side of iou_type="segm"
  * A batch collects masks in the order they are added and keeps them back to
  * back; taoamd_rle_copy hands out the CSR arrays the device kernel

@@ -1097,6 +1097,36 @@ void taoamd_gt_free(void *h) { delete (GT *)h; }
 
 int taoamd_host_threads(void) { return taoamd::host_threads(); }
 
+// 1 if every value occurs in `keys` (ascending), 0 if one does not: the
+// "Results do not correspond to current LVIS set." test of LVISResults
+// (reference lvis_amodal/results.py:62-65) over 30 M image ids on all threads.
+int taoamd_host_all_in_sorted(int64_t n_keys, const int64_t *keys, int64_t n,
+                              const int64_t *values)
+{
+    taoamd::ThreadScope threads;
+    if (n_keys < 0 || n < 0 || (n_keys && !keys) || (n && !values)) return -1;
+    if (n == 0) return 1;
+    if (n_keys == 0) return 0;
+    const int64_t lo = keys[0], hi = keys[n_keys - 1];
+    int missing = 0;
+    // ids in a modest range: membership bits; otherwise a binary search each
+    if ((uint64_t)(hi - lo) < (uint64_t)1 << 31) {
+        std::vector<uint8_t> has((size_t)(hi - lo) + 1, 0);
+#pragma omp parallel for schedule(static)
+        for (int64_t i = 0; i < n_keys; i++) has[(size_t)(keys[i] - lo)] = 1;
+#pragma omp parallel for schedule(static) reduction(| : missing)
+        for (int64_t i = 0; i < n; i++) {
+            const int64_t v = values[i];
+            missing |= (v < lo || v > hi || !has[(size_t)(v - lo)]) ? 1 : 0;
+        }
+    } else {
+#pragma omp parallel for schedule(static) reduction(| : missing)
+        for (int64_t i = 0; i < n; i++)
+            missing |= std::binary_search(keys, keys + n_keys, values[i]) ? 0 : 1;
+    }
+    return missing ? 0 : 1;
+}
+
 // order[] = np.lexsort((arange(n), -score, key)): ascending key, descending
 // score inside a key (NaN scores last, -0.0 == 0.0), input order on ties.
 // score may be NULL (plain stable argsort of key).  Records are sorted by

@@ -232,8 +232,22 @@ class LazyIous(Mapping):
 
     def __init__(self, view, unit_list, cat_list):
         self.view, self.units, self.cats = view, unit_list, cat_list
-        self.upos = {int(u): i for i, u in enumerate(view.unit_ids)}
-        self.cpos = {int(c): i for i, c in enumerate(view.flat.cat_ids)}
+        self._pos = None
+
+    def _positions(self):
+        # (600 k images at full scale: built when somebody looks something up)
+        if self._pos is None:
+            self._pos = ({int(u): i for i, u in enumerate(self.view.unit_ids)},
+                         {int(c): i for i, c in enumerate(self.view.flat.cat_ids)})
+        return self._pos
+
+    @property
+    def upos(self):
+        return self._positions()[0]
+
+    @property
+    def cpos(self):
+        return self._positions()[1]
 
     def __getitem__(self, key):
         u, c = key

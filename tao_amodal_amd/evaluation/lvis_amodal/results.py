@@ -15,6 +15,25 @@ from ...flatten import limit_dets_per_image
 from .lvis import LVIS
 
 
+def _all_known(sorted_ids, values):
+    """every value is one of sorted_ids (native: 30 M image ids on all
+    threads; numpy when the reader library is not built)"""
+    from ...columns import _ingest_lib
+    try:
+        lib = _ingest_lib()
+    except OSError:
+        from ...flatten import _lookup
+        return bool((_lookup(sorted_ids, values) >= 0).all())
+    import ctypes as C
+    k = np.ascontiguousarray(sorted_ids, dtype=np.int64)
+    v = np.ascontiguousarray(values, dtype=np.int64)
+    lib.taoamd_host_all_in_sorted.restype = C.c_int
+    lib.taoamd_host_all_in_sorted.argtypes = [C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
+    rc = lib.taoamd_host_all_in_sorted(len(k), k.ctypes.data, len(v), v.ctypes.data)
+    assert rc >= 0
+    return rc == 1
+
+
 class LVISResults(LVIS):
     def __init__(self, lvis_gt, results, max_dets=300, _share=False):
         """``_share``: the columns are one rank's share of a multi-GPU run (it
@@ -52,9 +71,7 @@ class LVISResults(LVIS):
         self.max_dets = max_dets
         if len(self.columns_dt) == 0 and not _share:
             raise IndexError("list index out of range")  # results.py:42
-        from ...flatten import _lookup
-        assert (_lookup(np.unique(self.gt.columns.img_id),
-                        self.columns_dt.image_id) >= 0).all(), \
+        assert _all_known(np.unique(self.gt.columns.img_id), self.columns_dt.image_id), \
             "Results do not correspond to current LVIS set."
         self._index = None
         self._columns = None

@@ -26,7 +26,7 @@ def test_ingest_header_symbols_are_exported():
     text = open(os.path.join(ROOT, "include", "tao_amodal_ingest.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     declared = set(re.findall(r"\b(taoamd_[a-z_0-9]+)\s*\(", text))
-    assert len(declared) == 28, declared
+    assert len(declared) == 29, declared
     lib = ctypes.CDLL(os.path.join(ROOT, "tao_amodal_amd", "libtao_amodal_ingest.so"))
     for name in sorted(declared):
         assert hasattr(lib, name), name
@@ -75,3 +75,27 @@ def test_sort_plan_covers_every_category():
         b0 += nbk
     assert split[:ns].tolist() == splits and b0 == nb and t0 == nt
     assert all(at.get(k, int(cat_off[k])) == cat_off[k + 1] for k in range(len(sizes)))
+
+
+def test_all_in_sorted_is_the_membership_test():
+    import ctypes as C
+    from tao_amodal_amd.columns import _ingest_lib
+    lib = _ingest_lib()
+    lib.taoamd_host_all_in_sorted.restype = C.c_int
+    lib.taoamd_host_all_in_sorted.argtypes = [C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
+    rng = np.random.default_rng(3)
+
+    def ask(keys, values):
+        k = np.ascontiguousarray(keys, dtype=np.int64)
+        v = np.ascontiguousarray(values, dtype=np.int64)
+        return lib.taoamd_host_all_in_sorted(len(k), k.ctypes.data, len(v), v.ctypes.data)
+    for span in (50, 1 << 20, 1 << 40):            # bitmap and binary-search branches
+        keys = np.unique(rng.integers(-span, span, 2000))
+        inside = rng.choice(keys, 100000)
+        assert ask(keys, inside) == 1
+        outside = inside.copy()
+        missing = np.setdiff1d(np.arange(keys[0] - 2, keys[-1] + 3), keys)[:1] if span == 50 \
+            else np.array([keys[-1] + 1])
+        outside[77777] = missing[0]
+        assert ask(keys, outside) == 0
+    assert ask([], []) == 1 and ask([1], []) == 1 and ask([], [1]) == 0
