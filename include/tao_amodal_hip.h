@@ -319,10 +319,11 @@ int taoamd_track_iou_plan_host(int64_t n_cells, const int32_t *cell_dt_off_host,
  * out_stride: distance, in 64-bit words, between consecutive output rows of
  * matched / ignored (0 = dense); lets the kernel write straight into an
  * interleaved exchange record.
- * Paired rows: when ignored == matched + 1 (and matched is 16-byte aligned) the
- * two tables are read as ONE table of (matched, ignored) pairs -- word w of row
- * r is the pair at matched[r * out_stride + 2 * w], dense out_stride =
- * 2 * n_words -- and a pair is written with one 16-byte store;
+ * Paired rows: when ignored == matched + 1 the two tables are read as ONE table
+ * of (matched, ignored) pairs -- word w of row r is the pair at
+ * matched[r * out_stride + 2 * w], dense out_stride = 2 * n_words -- and,
+ * where matched is 16-byte aligned and out_stride even, a pair is written with
+ * one 16-byte store;
  * taoamd_accumulate* recognise the same layout by the same pointer relation.
  * max_gt_per_cell must be >= the largest GT count of a cell (host knows it
  * from the CSR table); cells with more than 64 GTs take a slower kernel and
@@ -691,8 +692,9 @@ int taoamd_exchange_unpack(int32_t n_cat, int32_t n_rng, int32_t block_cats,
 
 /* By-video partition, owner side.  `records` = what one all_to_all delivered:
  * for source s the rows [src_base[s], src_base[s + 1]), each `width` int64
- * {score bits, category, n_words matched words, n_words ignored words}, sorted
- * by (category, -score) inside the source; run_off[s * (block_cats + 1) + kb] =
+ * {score bits, n_words matched words, n_words ignored words} (24 bytes at the
+ * image level), sorted by (category, -score) inside the source -- a record
+ * carries no category, the run it lies in says it; run_off[s * (block_cats + 1) + kb] =
  * offset of the run of category k0 + kb inside source s's rows; cat_base[kb] =
  * first row of that category in the merged layout.  Writes every record's
  * words at its place in the reference's order (stable -score sort of the

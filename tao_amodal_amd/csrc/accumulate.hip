@@ -61,6 +61,7 @@ struct AccArgs {
     int64_t n_dt;
     int32_t n_cat, n_rng, n_words, n_chunks_max;
     int32_t paired;          // rows are (matched, ignored) pairs: ignored == matched + 1
+    int32_t wide;            // ... 16-byte aligned: one load per pair
     const int32_t *cat_off;
     const uint64_t *matched;
     const uint64_t *ignored;
@@ -154,12 +155,15 @@ __device__ __forceinline__ void load_rows(const AccArgs &a, int64_t first, int w
     if (lane < n) {
         int64_t r = first + lane;
         if (a.order) r = a.order[r];
-        if (a.paired) {
+        if (a.wide) {
             // one 16-byte load of the pair the match stored with one store
             const ulonglong2 v =
                 *reinterpret_cast<const ulonglong2 *>(a.matched + 2 * (r * a.n_words + word));
             m = v.x;
             i = v.y;
+        } else if (a.paired) {
+            m = a.matched[2 * (r * a.n_words + word)];
+            i = a.matched[2 * (r * a.n_words + word) + 1];
         } else {
             m = a.matched[r * a.n_words + word];
             i = a.ignored[r * a.n_words + word];
@@ -1003,8 +1007,8 @@ static int accumulate_compact(int64_t n_dt, int32_t n_cat, int32_t n_rng,
     a.n_words = (n_rng * N_THR + 63) / 64;
     a.n_chunks_max = max_chunks(n_dt, n_cat);
     a.cat_off = cat_off; a.matched = matched; a.ignored = ignored; a.order = order;
-    a.paired = matched != nullptr && ignored == matched + 1 &&
-               ((uintptr_t)matched & 15) == 0;
+    a.paired = matched != nullptr && ignored == matched + 1;
+    a.wide = a.paired && ((uintptr_t)matched & 15) == 0;
     a.num_gt = num_gt; a.val = (uint64_t *)val; a.rec = rec;
     a.k_begin = k_begin; a.k_end = k_end;
     a.inline_scans = 0;

@@ -424,13 +424,22 @@ __global__ void ex_merge_kernel(int64_t n_recv, int32_t world, int32_t block_cat
 {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= n_recv) return;
+    (void)k0;          // (the block's first category: part of the ABI, not needed here)
     int s = 0;
     while (s + 1 < world && src_base[s + 1] <= i) s++;
     const int64_t *rec = records + i * width;
-    const int32_t kb = (int32_t)rec[1] - k0;
     const uint64_t key = ex_desc_key(rec[0]);
     const int64_t *ro = run_off + (int64_t)s * (block_cats + 1);
-    int64_t pos = cat_base[kb] + (i - src_base[s] - ro[kb]);
+    // the record's category is the run it lies in (a record carries none: the
+    // sender lays its records out category by category): last kb with
+    // ro[kb] <= place inside the source's rows
+    const int64_t at = i - src_base[s];
+    int32_t kb = 0;
+    for (int32_t lo = 0, hi = block_cats; lo < hi;) {
+        const int32_t mid = (lo + hi + 1) >> 1;
+        if (ro[mid] <= at) { lo = mid; kb = mid; } else hi = mid - 1;
+    }
+    int64_t pos = cat_base[kb] + (at - ro[kb]);
     for (int o = 0; o < world; o++) {
         if (o == s) continue;
         const int64_t *oo = run_off + (int64_t)o * (block_cats + 1);
@@ -445,8 +454,8 @@ __global__ void ex_merge_kernel(int64_t n_recv, int32_t world, int32_t block_cat
         pos += lo - b;
     }
     for (int w = 0; w < n_words; w++) {
-        matched[pos * n_words + w] = (uint64_t)rec[2 + w];
-        ignored[pos * n_words + w] = (uint64_t)rec[2 + n_words + w];
+        matched[pos * n_words + w] = (uint64_t)rec[1 + w];
+        ignored[pos * n_words + w] = (uint64_t)rec[1 + n_words + w];
     }
 }
 
@@ -457,7 +466,7 @@ extern "C" int taoamd_exchange_merge(int64_t n_recv, int32_t world, int32_t bloc
                                      uint64_t *matched, uint64_t *ignored, void *stream)
 {
     if (n_recv < 0 || world < 1 || block_cats < 1 || n_words < 1 ||
-        width < 2 + 2 * (int64_t)n_words)
+        width < 1 + 2 * (int64_t)n_words)
         return TAOAMD_ERR_ARG;
     if (n_recv == 0) return TAOAMD_OK;
     if (!records || !src_base || !run_off || !cat_base || !matched || !ignored)

@@ -186,6 +186,7 @@ struct MatchArgs {
     int32_t n_words;
     int64_t out_stride;  // words between consecutive output rows
     int32_t paired;      // ignored == matched + 1: word w of a row is the pair at 2 * w
+    int32_t wide;        // ... and every pair is 16-byte aligned: one store
     // optional launch plan (built by the host from the cell table)
     const int32_t *dt_group;  // [n_dt][4] first GT / GT count of the cell, position in it, cell
     const uint32_t *dt_meta;  // optional [n_dt]: flags | first GT - run's << 8 | GTs << 14 | position << 18
@@ -205,11 +206,15 @@ struct MatchArgs {
 __device__ __forceinline__ void store_row(const MatchArgs &a, int64_t row, int word,
                                           uint64_t m, uint64_t i)
 {
-    if (a.paired) {
+    if (a.wide) {
         ulonglong2 v;
         v.x = m;
         v.y = i;
         *reinterpret_cast<ulonglong2 *>(a.matched + row * a.out_stride + 2 * word) = v;
+    } else if (a.paired) {
+        // (a 24-byte exchange record: pairs at 8 mod 16)
+        a.matched[row * a.out_stride + 2 * word] = m;
+        a.matched[row * a.out_stride + 2 * word + 1] = i;
     } else {
         a.matched[row * a.out_stride + word] = m;
         a.ignored[row * a.out_stride + word] = i;
@@ -809,7 +814,7 @@ extern "C" int taoamd_match(int64_t n_cells, const int32_t *cell_dt_off,
     a.paired = matched != nullptr && ignored == matched + 1;
     a.out_stride = out_stride > 0 ? out_stride : (a.paired ? 2 : 1) * a.n_words;
     if (a.out_stride < (a.paired ? 2 : 1) * a.n_words) return TAOAMD_ERR_ARG;
-    if (a.paired && ((((uintptr_t)matched) & 15) != 0 || (a.out_stride & 1))) return TAOAMD_ERR_ARG;
+    a.wide = a.paired && (((uintptr_t)matched) & 15) == 0 && (a.out_stride & 1) == 0;
     // (the packed word carries no cell index: not where IoUs are read or written)
     a.dt_meta = fused && ious_out == nullptr ? dt_meta : nullptr;
     a.dt_group = dt_group; a.groups = groups; a.n_groups = planned ? n_groups : 0;

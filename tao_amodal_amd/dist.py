@@ -27,7 +27,8 @@ Per evaluator pass and rank:
      send buffer AT ITS SORTED PLACE, so what a rank sends to an owner is the
      runs of the owner's categories, each in (-score, concatenation) order
   3. ONE ``all_to_all_single`` of the records
-         [score | category | matched words | ignored words]   (int64 cols)
+         [score | matched words | ignored words]   (int64 cols; 24 bytes at
+         the image level -- the category is the run a record lies in)
      Category k is owned by rank k // ceil(K / world): contiguous blocks.
   4. owner: k-way merge of the received runs (taoamd_exchange_merge): a
      record's row = its place in its run + the records of the other sources'
@@ -65,6 +66,9 @@ import torch.distributed as dist
 from . import _lib
 
 N_THR, N_REC = _lib.N_THR, _lib.N_REC
+
+
+REC_HEAD = 1        # int64 columns ahead of a record's words: the score
 
 
 def _ptr(t):
@@ -107,7 +111,8 @@ class HipBackend:
             None if fused else _ptr(ws.iou), dp.n_rng, _ptr(ws.gt_rng),
             None if dp.kind == "lvis" else _ptr(ws.dt_rng),   # (image level: from the flags)
             _ptr(t["gt_flags"]), _ptr(t["dt_flags"]),
-            _ptr(dst), width, base + 16, base + 16 + 8 * dp.n_words, None, None,
+            _ptr(dst), width, base + 8 * REC_HEAD,
+            base + 8 * REC_HEAD + 8 * dp.n_words, None, None,
             _ptr(t["dt_group"]), _ptr(t["dt_meta"]), _ptr(t["groups"]), dp.n_groups,
             _ptr(t["singles"]), dp.n_singles, self._s()), "taoamd_match")
 
@@ -136,7 +141,8 @@ class HipBackend:
     def gather_rows(self, n, n_words, records, width, order, matched, ignored):
         base = records.data_ptr()
         _lib.check(self.lib.taoamd_gather_rows(
-            n, n_words, base + 16, base + 16 + 8 * n_words, width, _ptr(order),
+            n, n_words, base + 8 * REC_HEAD, base + 8 * REC_HEAD + 8 * n_words, width,
+            _ptr(order),
             _ptr(matched), _ptr(ignored), self._s()), "taoamd_gather_rows")
 
     def accumulate_compact(self, n, n_cat, n_rng, cat_off, matched, ignored,
@@ -191,7 +197,7 @@ class ShardedEval:
         self.be, self.group = backend, group
         dev = dp.device
         K, nw, R = dp.n_cat, dp.n_words, dp.n_rng
-        self.W = 2 + 2 * nw                       # int64 columns of a record
+        self.W = REC_HEAD + 2 * nw                # int64 columns of a record
         self.k0, self.k1, self.Kb = category_block(K, rank, world)
         Kb = self.Kb
         # ---- who sends what: records per (owner, category of its block)
@@ -288,11 +294,10 @@ class ShardedEval:
             self._global_num_gt()
         be.sort_local(dp, ws)
         if not self._static and dp.n_dt:
-            # the inputs of the exchange that no pass changes: a record's
-            # score and category, at the record's sorted place
+            # the input of the exchange that no pass changes: a record's score,
+            # at the record's sorted place
             slot = ws.dst[:dp.n_dt].long()
             self.send[slot, 0] = dp.t["dt_score"].view(torch.int64)
-            self.send[slot, 1] = dp.t["dt_cat"].to(torch.int64)
             self._static = True
         be.track_iou(dp, ws)
         if cur is not None:

@@ -18,6 +18,8 @@ import torch.multiprocessing as mp
 import exchange_ref
 import orclib
 
+from tao_amodal_amd.dist import REC_HEAD as H    # int64 columns ahead of a record's words
+
 N_THR, N_REC = 10, 101
 
 
@@ -56,8 +58,8 @@ class OracleBackend:
         nw = dp.n_words
         slot = dst.numpy().astype(np.int64)
         rec = records.numpy()
-        rec[slot, 2:2 + nw] = m.view(np.int64)
-        rec[slot, 2 + nw:2 + 2 * nw] = i.view(np.int64)
+        rec[slot, H:H + nw] = m.view(np.int64)
+        rec[slot, H + nw:H + 2 * nw] = i.view(np.int64)
 
     def sort(self, n, cat, score, order, ws_buf, ws_bytes):
         c, s = cat[:n].numpy(), score[:n].numpy()
@@ -76,14 +78,14 @@ class OracleBackend:
             sc = np.ascontiguousarray(rec[idx, 0]).view(np.float64)
             rows = idx[np.argsort(-(sc + 0.0), kind="stable")]
             at = cb[kb] + np.arange(len(rows))
-            matched[at] = torch.from_numpy(rec[rows, 2:2 + n_words].copy())
-            ignored[at] = torch.from_numpy(rec[rows, 2 + n_words:2 + 2 * n_words].copy())
+            matched[at] = torch.from_numpy(rec[rows, H:H + n_words].copy())
+            ignored[at] = torch.from_numpy(rec[rows, H + n_words:H + 2 * n_words].copy())
 
     def gather_rows(self, n, n_words, records, width, order, matched, ignored):
         o = order[:n].numpy().astype(np.int64)
         rec = records.numpy()
-        matched[:n] = torch.from_numpy(rec[o, 2:2 + n_words].copy())
-        ignored[:n] = torch.from_numpy(rec[o, 2 + n_words:2 + 2 * n_words].copy())
+        matched[:n] = torch.from_numpy(rec[o, H:H + n_words].copy())
+        ignored[:n] = torch.from_numpy(rec[o, H + n_words:H + 2 * n_words].copy())
 
     def accumulate_compact(self, n, n_cat, n_rng, cat_off, matched, ignored,
                            num_gt, k0, k1, val, rec, ws_buf, ws_bytes,
