@@ -381,6 +381,7 @@ __global__ __launch_bounds__(256) void match_group_kernel(MatchArgs a, IouThr th
         if (FUSED && a.dt_meta != nullptr) {
             // one word instead of the 16-byte row and the flag byte (the cell
             // index is only needed to find IoUs in memory)
+            static_assert(GRP_GCAP <= 15 && WAVE <= 64, "fields of dt_meta");
             const uint32_t mt = a.dt_meta[d];
             t_flags = (int32_t)(mt & 0xffu);
             gb = (int32_t)((mt >> 8) & 63u);
