@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256) void match_group_kernel(MatchArgs a, IouThr th
     const double thr0 = fmin(thr.v[t], 1 - 1e-10);
 
     // ---- lane = detection of the run
-    int32_t t_flags = 0, t_rng = 0, gb = 0, ge = 0, dloc = 0, Gc = 0;
+    int32_t t_flags = 0, t_rng = 0, gb = 0, dloc = 0, Gc = 0;
     int64_t t_row = 0, t_ioff = 0;
     double4 B = make_double4(0, 0, 0, 0);
     if (lane < nD) {
@@ -397,7 +397,6 @@ __global__ __launch_bounds__(256) void match_group_kernel(MatchArgs a, IouThr th
         }
         t_rng = (int32_t)dt_rng_of(a, d, (uint32_t)t_flags);
         t_row = a.dst != nullptr ? a.dst[d] : d;
-        ge = gb + Gc;
         if (FUSED) B = reinterpret_cast<const double4 *>(a.dt_box)[d];
     }
     // ---- lane = GT of the run
@@ -461,14 +460,13 @@ __global__ __launch_bounds__(256) void match_group_kernel(MatchArgs a, IouThr th
     const int ca = lane - dloc;
     const uint64_t above = lane >= 63 ? 0ull : starts & ~((2ull << lane) - 1);
     const int ce = above ? __builtin_ctzll(above) : nD;
-    const uint64_t below_me = (1ull << lane) - 1, below_ca = (1ull << ca) - 1;
+    const uint64_t below_ca = (1ull << ca) - 1;
     const uint64_t cell_all = (ce >= 64 ? ~0ull : ((1ull << ce) - 1)) & ~below_ca;
     const uint64_t multi = __ballot(lane < nD && ncand >= 2);
     const bool simple = lane < nD && (multi & cell_all) == 0;
     {
         uint32_t mygrng = 0;
         bool myghid = false;
-        const uint64_t cellmask = below_me & ~below_ca;     // earlier ones of my cell
         // the candidate's range mask / hidden flag sit in the GT lane gb + cand
         const uint32_t grng_c = (uint32_t)__shfl((int)grng, (gb + max(cand, 0)) & 63);
         if (simple && cand >= 0) {
