@@ -346,7 +346,12 @@ template <bool FUSED>
 __global__ __launch_bounds__(256) void match_group_kernel(MatchArgs a, IouThr thr)
 {
     __shared__ double4 s_gt[4][WAVE];
-    __shared__ double s_iou[4][WAVE * GRP_GCAP];
+    // IoU tile of the run: only where the IoUs come from memory.  The fused
+    // kernel keeps a detection's candidate in registers and, in the rare cell
+    // that needs the sequential loop, computes the IoU again from the boxes --
+    // without the 4 KB tile per wavefront it is the registers (7 wavefronts per
+    // SIMD) and no longer the LDS (6) that bound its occupancy.
+    __shared__ double s_iou[4][FUSED ? 1 : WAVE * GRP_GCAP];
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // runs are category-major and a run's rows are scattered into its
@@ -415,7 +420,11 @@ __global__ __launch_bounds__(256) void match_group_kernel(MatchArgs a, IouThr th
     const uint64_t HID = __ballot(ghid);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
-    // ---- IoU of every detection against the GTs of its own cell
+    // ---- IoU of every detection against the GTs of its own cell, and its
+    // CANDIDATES on the way (see below)
+    const double tmin = fmin(thr.v[0], 1 - 1e-10);
+    int cand = -1, ncand = 0;
+    double vc = 0.0;
     for (int k = 0; k < GRP_GCAP; k++) {
         const bool has = lane < nD && k < Gc;
         if (__ballot(has) == 0) break;
@@ -428,12 +437,15 @@ __global__ __launch_bounds__(256) void match_group_kernel(MatchArgs a, IouThr th
                     a.ious_out[t_ioff + (int64_t)dloc * Gc + k] = v;
             } else {
                 v = a.iou[t_ioff + (int64_t)dloc * Gc + k];
+                s_iou[wave][lane * GRP_GCAP + k] = v;
             }
-            s_iou[wave][lane * GRP_GCAP + k] = v;
+            if (!(v < tmin)) { ncand++; cand = k; vc = v; }
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    __builtin_amdgcn_wave_barrier();
+    if (!FUSED) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
     // ---- closed form, lane = detection, for every cell in which no detection
     // has more than one CANDIDATE -- a GT whose IoU reaches the lowest
     // threshold (a GT below it can never be chosen).  With at most one
@@ -447,14 +459,6 @@ __global__ __launch_bounds__(256) void match_group_kernel(MatchArgs a, IouThr th
     // run at once; only cells where some detection overlaps two GTs by the
     // lowest threshold or more go through the sequential loop below.
     uint64_t my_m = 0, my_i = 0;
-    const double tmin = fmin(thr.v[0], 1 - 1e-10);
-    int cand = -1, ncand = 0;
-    double vc = 0.0;
-    if (lane < nD)
-        for (int k = 0; k < Gc && k < GRP_GCAP; k++) {
-            const double v = s_iou[wave][lane * GRP_GCAP + k];
-            if (!(v < tmin)) { ncand++; cand = k; vc = v; }
-        }
     // lanes [ca, ce) hold the detections of my cell
     const uint64_t starts = __ballot(lane < nD && dloc == 0);
     const int ca = lane - dloc;
@@ -539,9 +543,21 @@ __global__ __launch_bounds__(256) void match_group_kernel(MatchArgs a, IouThr th
         const uint32_t free1 = freel & ~igl, free2 = freel & igl;
         double best1 = thr0, best2 = thr0;
         int m1 = -1, m2 = -1;
-        const double *__restrict__ row = &s_iou[wave][i * GRP_GCAP];
+        const double *__restrict__ row = &s_iou[wave][FUSED ? 0 : i * GRP_GCAP];
+        double bx = 0, by = 0, bw = 0, bh = 0;
+        if (FUSED) {
+            bx = readlane_f64(B.x, i); by = readlane_f64(B.y, i);
+            bw = readlane_f64(B.z, i); bh = readlane_f64(B.w, i);
+        }
         for (int g = 0; g < gci; g++) {
-            const double v = row[g];
+            double v;
+            if (FUSED) {
+                // (the same operands through the same function as above: the same bits)
+                const double4 A = s_gt[wave][gbi + g];
+                v = box_iou(bx, by, bw, bh, A.x, A.y, A.z, A.w);
+            } else {
+                v = row[g];
+            }
             const bool ok1 = ((free1 >> g) & 1u) && !(v < best1);
             const bool ok2 = ((free2 >> g) & 1u) && !(v < best2);
             best1 = ok1 ? v : best1;  m1 = ok1 ? g : m1;

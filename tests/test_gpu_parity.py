@@ -708,3 +708,49 @@ def test_one_frame_tracks_take_the_single_frame_kernel(mode, decimal):
     assert got["pairs"] == want["pairs"] > 0
     for k in ("iou", "matched", "ignored", "precision", "recall"):
         assert np.array_equal(got[k], want[k]), k
+
+
+@pytest.mark.parametrize("detail", [False, True])
+def test_cells_whose_detections_overlap_two_ground_truths(detail):
+    """The run kernel's closed form covers cells in which no detection has two
+    candidate GTs; the others go through its sequential greedy loop, which --
+    image level -- computes the IoUs again from the boxes instead of keeping a
+    tile of them.  GTs of one (image, category) cell are made near-duplicates
+    of each other so that most detections overlap two or more of them."""
+    gt, dt = synth(seed=33, V=4, F=20, C=6, dets_per_frame=30, n_present=3)
+    order = np.lexsort((gt.ann_cat, gt.ann_img))
+    img, cat = gt.ann_img[order], gt.ann_cat[order]
+    box = gt.ann_bbox.copy()
+    same = np.flatnonzero((img[1:] == img[:-1]) & (cat[1:] == cat[:-1])) + 1
+    assert len(same) > 50
+    for k in same:                        # (in order: chains of near-duplicates)
+        box[order[k]] = box[order[k - 1]] + np.array([1.0, 2.0, 0.0, 1.0])
+    gt.ann_bbox = box
+    gt.ann_area = box[:, 2] * box[:, 3]
+    # detections: copies of ground-truth boxes of their image and category, jittered
+    rng = np.random.default_rng(5)
+    key_g = gt.ann_img * 10 ** 6 + gt.ann_cat
+    key_d = dt.image_id * 10 ** 6 + dt.category_id
+    first = {}
+    for j, k in enumerate(key_g.tolist()):
+        first.setdefault(k, j)
+    src = np.array([first.get(k, -1) for k in key_d.tolist()])
+    has = src >= 0
+    dbox = dt.bbox.copy()
+    dbox[has] = box[src[has]] + rng.integers(-2, 3, (int(has.sum()), 4))
+    dbox[:, 2:] = np.maximum(dbox[:, 2:], 1.0)
+    dt.bbox = dbox
+    f = fl.flatten_lvis(gt, dt)
+    want = orclib.run_flat(f)
+    # the shape is there: detections with two or more IoUs >= 0.5 inside their cell
+    multi, at = 0, 0
+    for c in range(f.n_cells):
+        D = int(f.cell_dt_off[c + 1] - f.cell_dt_off[c])
+        G = int(f.cell_gt_off[c + 1] - f.cell_gt_off[c])
+        if D and G > 1:
+            m = want["iou"][at:at + D * G].reshape(D, G)
+            multi += int(((m >= 0.5).sum(1) >= 2).sum())
+        at += D * G
+    assert at == len(want["iou"]) and multi > 100
+    got = _engine().evaluate_flat(f, detail=detail)
+    _compare_with_oracle(f, got, detail=detail)
