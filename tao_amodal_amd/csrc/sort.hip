@@ -1288,33 +1288,24 @@ __global__ __launch_bounds__(SEG_THREADS) void ss_scatter_kernel(SsArgs a)
 #pragma unroll
     for (int r = 0; r < SEG_ROUNDS; r++) {
         const int32_t i = t0 + r * SEG_THREADS + (int32_t)threadIdx.x;
-        kr[r] = i < t1 ? desc_key(a.score[i]) : 0;
-        br[r] = 0;
-    }
-    // bucket = number of splitters 1 .. B-1 that precede (k, i) (an element
-    // equal to a splitter closes the lower bucket): a fixed-depth search, all
-    // rounds of the thread in step so that their LDS reads are in flight together
-    static_assert(SS_MAXB == 128, "seven steps");
-    if (!SS_DBG(a, 64))
-#pragma unroll
-    for (int step = SS_MAXB / 2; step >= 1; step >>= 1) {
-        uint64_t sk[SEG_ROUNDS];
-#pragma unroll
-        for (int r = 0; r < SEG_ROUNDS; r++) sk[r] = s_key[br[r] + step];
-#pragma unroll
-        for (int r = 0; r < SEG_ROUNDS; r++) {
-            bool before = sk[r] < kr[r];
-            if (sk[r] == kr[r])
-                before = s_idx[br[r] + step] < t0 + r * SEG_THREADS + (int32_t)threadIdx.x;
-            br[r] = before ? br[r] + step : br[r];
+        br[r] = -1;
+        if (i < t1) {
+            const uint64_t k = desc_key(a.score[i]);
+            // splitters 1 .. B-1 that precede (k, i); an element equal to a
+            // splitter closes the lower bucket.  (A fixed-depth search with all
+            // rounds of a thread in step -- their LDS reads in flight together --
+            // took 79 instead of 61 VGPRs and was no faster: 0.139 vs 0.143 ms.)
+            int lo = 1, hi = B;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                const uint64_t sk = s_key[mid];
+                const bool before = sk < k || (sk == k && s_idx[mid] < i);
+                if (before) lo = mid + 1; else hi = mid;
+            }
+            kr[r] = k;
+            br[r] = lo - 1;
+            rr[r] = SS_DBG(a, 32) ? (int32_t)threadIdx.x >> 4 : atomicAdd(&s_cnt[lo - 1], 1);
         }
-    }
-#pragma unroll
-    for (int r = 0; r < SEG_ROUNDS; r++) {
-        const int32_t i = t0 + r * SEG_THREADS + (int32_t)threadIdx.x;
-        if (SS_DBG(a, 64) && i < t1) br[r] = (int32_t)((kr[r] >> 40) % (uint64_t)B);
-        if (i < t1) rr[r] = SS_DBG(a, 32) ? (int32_t)threadIdx.x >> 4 : atomicAdd(&s_cnt[br[r]], 1);
-        else br[r] = -1;
     }
     __syncthreads();
     if (threadIdx.x < B) {
