@@ -183,7 +183,7 @@ int taoamd_rle_iou(int64_t n_cells, const int32_t *cell_dt_off,
  * taoamd_track_iou_planned is the fast form.  It reads the tracks from the
  * PADDED frame table built by taoamd_track_pad and follows a launch plan built
  * by taoamd_track_iou_plan_host, one wavefront per task:
- *   tasks      int32[n_tasks][4] {first row, rows (<= 36), first pair, pairs (<= 64)}
+ *   tasks      int32[n_tasks][4] {first row, rows (<= 32), first pair, pairs (<= 64)}
  *   task_rows  int32  the tasks' tracks: t for detection track t, n_dt + t for
  *              GT track t (= the row of trk_meta)
  *   task_pairs int32  detection row | GT row << 8 (rows local to the task)

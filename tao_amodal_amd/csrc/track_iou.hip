@@ -1,6 +1,6 @@
 // 3D IoU of track pairs (reference tao_amodal/eval.py:15-117, 306-335), gfx950.
 //
-//   track_iou_task_kernel  the planned path: one wavefront per task (<= 36
+//   track_iou_task_kernel  the planned path: one wavefront per task (<= 32
 //                          tracks, <= 64 track pairs), frames staged in LDS
 //                          chunk by chunk of the timeline from the padded frame
 //                          table, lane = pair adds the per-frame terms in order
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256) void track_iou_single_kernel(
 // Chunks in which no track of the task has a frame are skipped by the adder;
 // chunks that only hold GT frames add the areas alone.
 #define TT_P 8                   // timeline positions per chunk
-#define TT_ROWS 36               // tracks of a task
+#define TT_ROWS 32               // tracks of a task
 #define TT_RS (5 * TT_P + 2)     // doubles per row: rows 16-byte aligned, 20 banks apart
 #define TT_GROUPS (64 / TT_P)    // rows served by one round of the stager
 #define TT_ROUNDS ((TT_ROWS + TT_GROUPS - 1) / TT_GROUPS)

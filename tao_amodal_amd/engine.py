@@ -129,7 +129,7 @@ def track_meta(flat):
 
 def track_iou_plan(flat, meta):
     """Launch plan of taoamd_track_iou_planned (one wavefront per task: up to
-    36 tracks, up to 64 track pairs).  Returns tasks[n, 4], task_rows,
+    32 tracks, up to 64 track pairs).  Returns tasks[n, 4], task_rows,
     task_pairs (int32) and task_out (int64)."""
     import ctypes as C
     lib = _lib.load()

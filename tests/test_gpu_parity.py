@@ -98,7 +98,7 @@ def _check_plan(f, meta, tasks, rows, pairs, out):
     seen = np.zeros(int(f.cell_iou_off[-1]), dtype=np.int32)
     cell_of = np.repeat(np.arange(f.n_cells), np.diff(f.cell_iou_off))
     for r0, nr, p0, npair in tasks:
-        assert 0 < nr <= 36 and 0 < npair <= 64
+        assert 0 < nr <= 32 and 0 < npair <= 64
         trk = rows[r0:r0 + nr]
         assert len(set(trk.tolist())) == nr
         assert (np.diff(meta[trk, 0]) >= 0).all()        # by first position
