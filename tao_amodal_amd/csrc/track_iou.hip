@@ -352,8 +352,10 @@ __device__ __forceinline__ void tt_stager(
     }
 }
 
+// (six wavefronts per SIMD: 78 instead of 84 VGPRs, no spill, and seven tasks
+// of 21.5 KB LDS per CU instead of six: 0.329 -> 0.314 ms at 2000 videos)
 template <int MODE>
-__global__ __launch_bounds__(192) void track_iou_task_kernel(
+__global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(MODE == 2 ? 4 : 6, MODE == 2 ? 4 : 6))) void track_iou_task_kernel(
     const int4 *__restrict__ tasks, const int32_t *__restrict__ task_rows,
     const int32_t *__restrict__ task_pairs, const int64_t *__restrict__ task_out,
     const double4 *__restrict__ padded, const int4 *__restrict__ trk_meta,
