@@ -343,7 +343,7 @@ __global__ __launch_bounds__(256) void match_kernel(MatchArgs a, IouThr thr)
 //     "ignored" / "taken" sets are 64-bit masks over the run's GTs, so moving
 //     from one cell to the next needs no reset at all.
 template <bool FUSED>
-__global__ __launch_bounds__(256) void match_group_kernel(MatchArgs a, IouThr thr)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void match_group_kernel(MatchArgs a, IouThr thr)
 {
     __shared__ double4 s_gt[4][WAVE];
     // IoU tile of the run: only where the IoUs come from memory.  The fused
