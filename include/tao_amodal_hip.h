@@ -109,6 +109,23 @@ int taoamd_kernel_timing_collect(char *names_host, size_t names_bytes,
  * (L/eval.py:560-565).  Host pointers. */
 int taoamd_thresholds_host(double *iou_thrs, double *rec_thrs);
 
+/* The evaluation constants a caller of the class API may edit before run()
+ * (`params.iou_thrs`, `rec_thrs`: L/eval.py:234,319-322,407, T/eval.py:385,
+ * 473-477,562; `visibility_rng`: L/eval.py:143,205; `area_rng` / `time_rng`:
+ * T/eval.py:272-275,348-368,432-441).  They reach the kernels as by-value
+ * arguments; these two calls replace the CALLING THREAD's tables for its later
+ * launches (NULL = the reference's default for that table).  The counts are
+ * the kernels': TAOAMD_N_THR thresholds, TAOAMD_N_REC recall thresholds -- both
+ * ASCENDING (equal neighbours allowed; a caller with fewer pads with copies of
+ * its last value, one with more or in another order runs blocks and permutes:
+ * evaluation/_core.py), else TAOAMD_ERR_ARG --, 5 visibility ranges (the sixth
+ * range of the image level is the out-of-frame one and has no bounds), 5 area
+ * ranges (the last one is the occlusion range: T/eval.py:272) and 4 duration
+ * ranges, each as {lo, hi} pairs, bounds inclusive.  Host pointers. */
+int taoamd_set_thresholds(const double *iou_thrs, const double *rec_thrs);
+int taoamd_set_ranges(const double *visibility_rng, const double *area_rng,
+                      const double *time_rng);
+
 /* ---- bbIou ---------------------------------------------------------------
  * o[g*m + d] = IoU(dt[d], gt[g]); boxes are x,y,w,h doubles.  iscrowd may be
  * NULL (all zero); a non-zero entry selects u = area(dt) as in bbIou. */
@@ -626,6 +643,13 @@ int taoamd_accumulate(int64_t n_dt, int32_t n_cat, int32_t n_rng,
  * workspace, _prepared is taoamd_accumulate without that launch.  Same
  * workspace, n_dt, n_cat, n_rng, cat_off and max_segment in both; nothing else
  * may use the workspace in between. */
+/* The one-pass sweep of long categories resolves the counts of a category's
+ * earlier rows by a decoupled look-back between workgroups; a wait that does
+ * not end within ~1 s of polling (never observed: it would mean workgroups do
+ * not start in order) gives up and sets a flag in the workspace instead of
+ * hanging the GPU.  *flag_host != 0: the tables of a pass on this workspace
+ * are not to be trusted.  Synchronises with `stream`. */
+int taoamd_accumulate_error(const void *workspace, void *stream, int32_t *flag_host);
 int taoamd_accumulate_prepare(int64_t n_dt, int32_t n_cat, int32_t n_rng,
                               const int32_t *cat_off, int32_t max_segment,
                               void *workspace, size_t workspace_bytes, void *stream);

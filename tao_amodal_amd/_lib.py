@@ -26,6 +26,8 @@ SIGNATURES = {
     "taoamd_last_error": (C.c_char_p, []),
     "taoamd_version": (C.c_int, []),
     "taoamd_thresholds_host": (C.c_int, [_vp, _vp]),
+    "taoamd_set_thresholds": (C.c_int, [_vp, _vp]),
+    "taoamd_set_ranges": (C.c_int, [_vp, _vp, _vp]),
     "taoamd_kernel_timing_enable": (C.c_int, [C.c_int]),
     "taoamd_kernel_timing_label": (C.c_int, [C.c_char_p]),
     "taoamd_kernel_timing_collect": (C.c_int, [_vp, _sz, _vp, _vp, _i32, _vp]),
@@ -132,6 +134,7 @@ SIGNATURES = {
     "taoamd_accumulate_workspace": (_sz, [_i64, _i32, _i32]),
     "taoamd_accumulate": (C.c_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _i32,
                                     _vp, _vp, _vp, _sz, _vp]),
+    "taoamd_accumulate_error": (C.c_int, [_vp, _vp, _vp]),
     "taoamd_accumulate_prepare": (C.c_int, [_i64, _i32, _i32, _vp, _i32, _vp, _sz, _vp]),
     "taoamd_accumulate_prepared": (C.c_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _i32,
                                     _vp, _vp, _vp, _sz, _vp]),
@@ -200,6 +203,27 @@ def kernel_timings():
     for k in range(n.value):
         out[raw[k].decode()] = (float(ms[k]), int(calls[k]))
     return out
+
+
+def set_constants(iou_thrs=None, rec_thrs=None, visibility_rng=None, area_rng=None,
+                  time_rng=None):
+    """Replace the calling thread's evaluation constants (taoamd_set_thresholds,
+    taoamd_set_ranges); None = the reference's default for that table."""
+    import numpy as np
+
+    def arr(a, shape):
+        if a is None:
+            return None, None
+        a = np.ascontiguousarray(a, dtype=np.float64).reshape(shape)
+        return a, a.ctypes.data
+    lib = load()
+    i, ip = arr(iou_thrs, (N_THR,))
+    r, rp = arr(rec_thrs, (N_REC,))
+    check(lib.taoamd_set_thresholds(ip, rp), "taoamd_set_thresholds")
+    v, vp = arr(visibility_rng, (5, 2))
+    a, ap = arr(area_rng, (5, 2))
+    t, tp = arr(time_rng, (4, 2))
+    check(lib.taoamd_set_ranges(vp, ap, tp), "taoamd_set_ranges")
 
 
 def check(status, what):

@@ -46,6 +46,10 @@
 //    c with fl(c / num_gt) >= rec_thrs[j] is tabulated per (category, range)
 //    (in acc_prefix_kernel / acc_fused_kernel) with the reference's fp64 comparison, and the sweep
 //    compares integers.
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
+
 #include "common.hpp"
 
 using namespace taoamd;
@@ -80,6 +84,14 @@ struct AccArgs {
     int32_t fused_rows;          // categories up to this many rows take acc_fused_kernel
     int32_t fused_lo;            // ... and more than this many (size class of the launch)
     int32_t inline_scans;        // short categories: no acc_prefix / acc_sufmax launches
+    // one-pass sweep (acc_sweep_kernel): the chunk table then is a table of
+    // super-chunks of sc_rows rows (cat_chunk_off / chunk_tab / cnt_* per SC)
+    int32_t sc_rows;             // 0: the chunked kernels
+    uint32_t sc_gen;             // generation of this call's status words
+    uint64_t *sc_stat;           // [SC][word][64][2] look-back status {tp, fp}
+    uint64_t *sc_max;            // [SC][word][64] largest precision record of the SC
+    uint8_t *sc_jhi;             // [SC][word][64] recall thresholds reached up to its end
+    uint32_t *sc_error;          // set when a look-back gave up (never observed)
 };
 
 __global__ __launch_bounds__(256) void acc_chunks_kernel(AccArgs a)
@@ -94,8 +106,9 @@ __global__ __launch_bounds__(256) void acc_chunks_kernel(AccArgs a)
         if (a.fused_rows > 0 && rows <= a.fused_rows) return 0;
         // without acc_prefix_kernel nobody visits a category that has no
         // chunk: one of no rows carries its recall 0 / precision 0
-        if (a.inline_scans && rows == 0) return 1;
-        return (rows + ACC_CH - 1) / ACC_CH;
+        if ((a.inline_scans || a.sc_rows) && rows == 0) return 1;
+        const int32_t per = a.sc_rows ? a.sc_rows : ACC_CH;
+        return (rows + per - 1) / per;
     };
     for (int k = lo; k < hi; k++) s += chunks_of(k);
     part[threadIdx.x] = s;
@@ -199,25 +212,70 @@ __device__ __forceinline__ uint32_t xor_lane(uint32_t x, int lane)
 
 // 64 x 64 bit-matrix transpose across the wavefront: in: lane i holds row i
 // (bit j = element (i, j)); out: lane j holds column j (bit i = element (i, j)).
-// Stage s swaps the off-diagonal s x s blocks between lanes i and i ^ s.
-template <int S>
-__device__ __forceinline__ uint64_t transpose_stage(uint64_t x, int lane, uint64_t lo_mask)
+// Stage S swaps the off-diagonal S x S blocks between lanes i and i ^ S.
+//
+// Round 4: ~30 VALU instructions instead of ~100 (the ternaries of the first
+// version compiled to exec-masked branches, both sides executed; the sweep is
+// bound by VALU issue -- a wave64 instruction occupies its SIMD for four
+// cycles -- and the transposes were 0.12 ms of chip time at 21 M rows):
+//   S = 32  the two words change places between the wave's halves: ONE
+//           v_permlane32_swap (lower lanes' hi <-> upper lanes' lo);
+//   S = 16, 8  whole bytes move: the partner's word (v_permlane16_swap /
+//           DPP row_ror:8) and ONE v_perm_b32 with a per-lane selector;
+//   S = 4, 2, 1  the partner's word rotated so that the bits it hands over
+//           sit where they go (v_alignbit, per-lane amount) and ONE v_bfi.
+struct TransposeConsts {
+    uint32_t sel16, sel8;          // v_perm_b32 selectors
+    uint32_t keep4, keep2, keep1;  // bits of my own word that stay
+    uint32_t rot4, rot2, rot1;     // right-rotation of the partner's word
+};
+__device__ __forceinline__ TransposeConsts transpose_consts(int lane)
 {
-    const uint32_t ylo = xor_lane<S>((uint32_t)x, lane);
-    const uint32_t yhi = xor_lane<S>((uint32_t)(x >> 32), lane);
-    const uint64_t y = ((uint64_t)yhi << 32) | ylo;
-    return (lane & S) ? ((x & ~lo_mask) | ((y & ~lo_mask) >> S))
-                      : ((x & lo_mask) | ((y & lo_mask) << S));
+    TransposeConsts c;
+    // lower lane of a pair keeps the low part and takes the partner's low part
+    // into its high part; the upper lane the other way round
+    c.sel16 = (lane & 16) ? 0x03020706u : 0x05040100u;
+    c.sel8 = (lane & 8) ? 0x03070105u : 0x06020400u;
+    c.keep4 = (lane & 4) ? 0xf0f0f0f0u : 0x0f0f0f0fu;
+    c.keep2 = (lane & 2) ? 0xccccccccu : 0x33333333u;
+    c.keep1 = (lane & 1) ? 0xaaaaaaaau : 0x55555555u;
+    c.rot4 = (lane & 4) ? 4 : 28;      // upper: partner >> S; lower: partner << S
+    c.rot2 = (lane & 2) ? 2 : 30;
+    c.rot1 = (lane & 1) ? 1 : 31;
+    return c;
+}
+template <int S>
+__device__ __forceinline__ uint32_t transpose_bits(uint32_t x, int lane, uint32_t keep,
+                                                   uint32_t rot)
+{
+    const uint32_t y = xor_lane<S>(x, lane);
+    const uint32_t r = __builtin_amdgcn_alignbit(y, y, rot);
+    return (x & keep) | (r & ~keep);                       // v_bfi_b32
+}
+__device__ __forceinline__ uint64_t transpose64(uint64_t x, int lane, const TransposeConsts &c)
+{
+    uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    {
+        // vdst lanes 32..63 <-> src lanes 0..31
+        auto r = __builtin_amdgcn_permlane32_swap(lo, hi, false, false);
+        lo = r[0];
+        hi = r[1];
+    }
+    lo = __builtin_amdgcn_perm(xor_lane<16>(lo, lane), lo, c.sel16);
+    hi = __builtin_amdgcn_perm(xor_lane<16>(hi, lane), hi, c.sel16);
+    lo = __builtin_amdgcn_perm(xor_lane<8>(lo, lane), lo, c.sel8);
+    hi = __builtin_amdgcn_perm(xor_lane<8>(hi, lane), hi, c.sel8);
+    lo = transpose_bits<4>(lo, lane, c.keep4, c.rot4);
+    hi = transpose_bits<4>(hi, lane, c.keep4, c.rot4);
+    lo = transpose_bits<2>(lo, lane, c.keep2, c.rot2);
+    hi = transpose_bits<2>(hi, lane, c.keep2, c.rot2);
+    lo = transpose_bits<1>(lo, lane, c.keep1, c.rot1);
+    hi = transpose_bits<1>(hi, lane, c.keep1, c.rot1);
+    return ((uint64_t)hi << 32) | lo;
 }
 __device__ __forceinline__ uint64_t transpose64(uint64_t x, int lane)
 {
-    x = transpose_stage<32>(x, lane, 0x00000000ffffffffull);
-    x = transpose_stage<16>(x, lane, 0x0000ffff0000ffffull);
-    x = transpose_stage<8>(x, lane, 0x00ff00ff00ff00ffull);
-    x = transpose_stage<4>(x, lane, 0x0f0f0f0f0f0f0f0full);
-    x = transpose_stage<2>(x, lane, 0x3333333333333333ull);
-    x = transpose_stage<1>(x, lane, 0x5555555555555555ull);
-    return x;
+    return transpose64(x, lane, transpose_consts(lane));
 }
 
 #define ACC_BLK (ACC_CH / WAVE)   // 64-row blocks per chunk
@@ -870,6 +928,338 @@ __global__ __launch_bounds__(FW * WAVE) void acc_fused_kernel(AccArgs a, RecThr 
     }
 }
 
+// ===========================================================================
+// One-pass sweep of long categories (round 4).
+//
+// The chunked kernels above read the rows three times (count, chunk maxima,
+// emission: the transposed copy written once and read twice) in six dependent
+// launches.  Here ONE kernel reads every row once:
+//
+//   super-chunk (SC) = SW consecutive chunks of a category = one workgroup of
+//   SW wavefronts, wavefront = chunk; the transposed words of a chunk never
+//   leave the wavefront's registers.
+//
+//   forward dependency (TP / FP counts of everything before the chunk): inside
+//   the workgroup through LDS, between the SCs of a category by a decoupled
+//   look-back over 8-byte status words {generation | flag | count}: an SC
+//   publishes its own totals (flag AGG) as soon as its rows are counted, then
+//   the prefix that includes it (flag PRE); a later SC adds up the words it
+//   finds until it meets a PRE.  SCs take their number from a ticket counter,
+//   so an SC only ever waits for SCs that started before it.
+//
+//   backward dependency (the precision envelope of everything AFTER a row)
+//   cannot be waited for -- the later SCs may not have started.  It is not
+//   needed while walking: the envelope is a maximum, so a chunk emits every
+//   threshold it reaches with the envelope of ITS OWN later rows, and the
+//   maxima of what lies behind are folded in afterwards, which cannot change
+//   a bit of the result (max of the same set of (tp, n) pairs under the total
+//   order of pr_better):
+//     * later chunks of the same SC: after a barrier, from LDS, by the
+//       wavefront that wrote the records (it re-reads its own stores);
+//     * later SCs: acc_raise_kernel, a wavefront per (category, range,
+//       threshold) row, from two small per-SC tables: sc_max (largest
+//       precision record of the SC) and sc_jhi (recall thresholds reached up
+//       to its end).
+//
+// The walk itself (emit_block) is the chunked path's, statement by statement.
+// ===========================================================================
+#define SC_SPIN_LIMIT (1 << 18)     // a fraction of a second of polling
+#define SC_FLAG_AGG 1ull
+#define SC_FLAG_PRE 2ull
+__device__ __forceinline__ uint64_t sc_status(uint32_t gen, uint64_t flag, uint32_t v)
+{
+    return ((uint64_t)gen << 34) | (flag << 32) | v;
+}
+__device__ __forceinline__ void sc_publish(uint64_t *p, uint64_t v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint64_t sc_peek(const uint64_t *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// records [jlo, jhi) of `out` raised to `later` where it is the better pair
+__device__ __forceinline__ void sc_raise(uint64_t *__restrict__ out, int jlo, int jhi,
+                                         uint64_t later)
+{
+    const uint32_t lt = (uint32_t)(later >> 32), ln = (uint32_t)later;
+    for (int j = jlo; j < jhi; j++) {
+        const uint64_t v = out[j];
+        if (pr_better(lt, ln, v)) out[j] = later;
+    }
+}
+
+// MODE 0: look-back (one pass); MODE 1: the SC totals come from
+// acc_sccount_kernel (two passes over the rows, no flags); MODE 2: that
+// counting pass itself (rows -> SC totals, nothing else)
+template <int SW, int MODE>
+__global__ __launch_bounds__(SW * WAVE) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void acc_sweep_kernel(AccArgs a, RecThr rec)
+{
+    __shared__ uint32_t s_tp[SW][WAVE], s_fp[SW][WAVE];
+    __shared__ uint64_t s_max[SW][WAVE];
+    __shared__ uint32_t s_pre[2][WAVE];
+    __shared__ int32_t s_cj[EMIT_RMAX][N_REC];
+    __shared__ uint16_t s_jr[SW][WAVE];          // thresholds a chunk emitted: jlo | jhi << 8
+    __shared__ int32_t s_done;
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (threadIdx.x == 0) s_done = 0;
+    // SC = workgroup number.  A workgroup only ever waits for LOWER-numbered
+    // ones, which the dispatcher has started before it (workgroups leave the
+    // queue of their XCD in order); should that ever not hold the wait below
+    // gives up after SC_SPIN_LIMIT polls and flags the pass instead of hanging.
+    const int32_t item = (int32_t)blockIdx.x;
+    const int32_t sc = item / a.n_words;
+    const int word = item - sc * a.n_words;
+    if (sc >= a.cat_chunk_off[a.n_cat]) return;
+    const int32_t k = a.chunk_tab ? a.chunk_tab[sc] : chunk_cat(a.cat_chunk_off, a.n_cat, sc);
+    const int32_t jsc = sc - a.cat_chunk_off[k];
+    const int64_t cat_begin = a.cat_off[k], cat_end = a.cat_off[k + 1];
+    const int64_t start = cat_begin + ((int64_t)jsc * SW + wave) * ACC_CH;
+    const int len = (int)max((int64_t)0, min((int64_t)ACC_CH, cat_end - start));
+    const bool swept = k >= a.k_begin && k < a.k_end;       // (uniform)
+    // ---- rows of my chunk: every load ahead of anything else
+    uint64_t tpw[ACC_BLK], fpw[ACC_BLK];
+#pragma unroll
+    for (int blk = 0; blk < ACC_BLK; blk++)
+        load_rows(a, start + blk * WAVE, word, max(0, min(WAVE, len - blk * WAVE)), lane,
+                  tpw[blk], fpw[blk]);
+    const int r_lo = (word * WAVE) / N_THR;
+    const int r_hi = min(a.n_rng - 1, (word * WAVE + WAVE - 1) / N_THR);
+    if (MODE != 2) {
+        // recall crossings of the ranges this word overlaps (num_gt alone)
+        for (int i = threadIdx.x; i < (r_hi - r_lo + 1) * N_REC; i += SW * WAVE) {
+            const int q = i / N_REC;
+            const int32_t ngq = a.num_gt[(int64_t)k * a.n_rng + r_lo + q];
+            s_cj[q][i - q * N_REC] = ngq > 0 ? recall_crossing(rec.v[i - q * N_REC], ngq) : 0;
+        }
+    }
+    uint64_t T[ACC_BLK], TF[ACC_BLK];
+    uint32_t tp_own = 0, fp_own = 0;
+#pragma unroll
+    for (int blk = 0; blk < ACC_BLK; blk++) {
+        uint64_t t_ = 0, f_ = 0;
+        if (blk * WAVE < len) {
+            t_ = transpose64(tpw[blk], lane);
+            f_ = transpose64(fpw[blk], lane);
+        }
+        T[blk] = t_;
+        TF[blk] = t_ | f_;
+        tp_own += (uint32_t)__popcll(t_);
+        fp_own += (uint32_t)__popcll(f_);
+    }
+    s_tp[wave][lane] = tp_own;
+    s_fp[wave][lane] = fp_own;
+    __syncthreads();
+    uint32_t tp0 = 0, fp0 = 0;
+    for (int w = 0; w < wave; w++) {
+        tp0 += s_tp[w][lane];
+        fp0 += s_fp[w][lane];
+    }
+    const int64_t so = ((int64_t)sc * a.n_words + word) * WAVE + lane;
+    if (MODE == 2) {
+        if (wave == SW - 1) {
+            a.cnt_tp[so] = tp0 + tp_own;
+            a.cnt_fp[so] = fp0 + fp_own;
+        }
+        return;
+    }
+    // ---- counts of the category's earlier SCs
+    if (wave == SW - 1) {
+        const uint32_t tot_t = tp0 + tp_own, tot_f = fp0 + fp_own;
+        uint32_t acc_t = 0, acc_f = 0;
+        if (MODE == 0) {
+            uint64_t *st = a.sc_stat + 2 * so;              // {tp word, fp word} per lane
+            const uint64_t mine = jsc == 0 ? SC_FLAG_PRE : SC_FLAG_AGG;
+            sc_publish(st, sc_status(a.sc_gen, mine, tot_t));
+            sc_publish(st + 1, sc_status(a.sc_gen, mine, tot_f));
+            // look back over the category's earlier SCs until one carries its
+            // prefix.  A pair is usable when both words are of this call and of
+            // one kind (the publisher replaces AGG by PRE word by word)
+            bool open = jsc > 0;
+            const int64_t stride = 2 * (int64_t)a.n_words * WAVE;
+            const uint64_t *p = st - stride;
+            for (int32_t jj = jsc - 1; jj >= 0 && __ballot(open) != 0; jj--, p -= stride) {
+                uint64_t vt, vf;
+                for (int spin = 0;; spin++) {
+                    vt = sc_peek(p);
+                    vf = sc_peek(p + 1);
+                    const uint32_t ft = (uint32_t)(vt >> 32) & 3, ff = (uint32_t)(vf >> 32) & 3;
+                    const bool ready = (uint32_t)(vt >> 34) == a.sc_gen &&
+                                       (uint32_t)(vf >> 34) == a.sc_gen && ft != 0 && ft == ff;
+                    if (__ballot(open && !ready) == 0) break;
+                    if (spin >= SC_SPIN_LIMIT) {
+                        if (lane == 0) atomicOr(a.sc_error, 1u);
+                        vt = vf = 0;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                if (open) {
+                    acc_t += (uint32_t)vt;
+                    acc_f += (uint32_t)vf;
+                    if (((vt >> 32) & 3) == SC_FLAG_PRE) open = false;
+                }
+            }
+            if (jsc > 0) {
+                sc_publish(st, sc_status(a.sc_gen, SC_FLAG_PRE, acc_t + tot_t));
+                sc_publish(st + 1, sc_status(a.sc_gen, SC_FLAG_PRE, acc_f + tot_f));
+            }
+        } else {
+            for (int32_t jj = 0; jj < jsc; jj++) {
+                const int64_t o = ((int64_t)(sc - jsc + jj) * a.n_words + word) * WAVE + lane;
+                acc_t += a.cnt_tp[o];
+                acc_f += a.cnt_fp[o];
+            }
+        }
+        s_pre[0][lane] = acc_t;
+        s_pre[1][lane] = acc_f;
+    }
+    __syncthreads();
+    tp0 += s_pre[0][lane];
+    fp0 += s_pre[1][lane];
+    // ---- my lane's combo
+    const int combo = word * WAVE + lane;
+    const bool active = combo < a.n_rng * N_THR;
+    const int r = active ? combo / N_THR : 0;
+    const int t = active ? combo - r * N_THR : 0;
+    const int64_t kr = (int64_t)k * a.n_rng + r;
+    const int32_t ng = active ? a.num_gt[kr] : 0;
+    const bool live = active && ng > 0 && swept;
+    const int32_t *__restrict__ cj = s_cj[active ? r - r_lo : 0];
+    uint64_t *__restrict__ out = a.val + (kr * N_THR + t) * N_REC;
+    uint32_t tp = tp0 + tp_own;
+    uint32_t n = tp + fp0 + fp_own;
+    // the chunk that holds the category's last row (a category without rows:
+    // the first wavefront of its one SC)
+    const bool is_last = len > 0 ? start + len == cat_end : (cat_end == cat_begin && wave == 0);
+    const bool is_first = jsc == 0 && wave == 0;
+    int jcur = 0;
+    if (live) {
+        int lo = 0, hi = N_REC;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (cj[mid] <= (int32_t)tp) lo = mid + 1; else hi = mid;
+        }
+        jcur = lo;
+    }
+    const int jhi = jcur;                      // thresholds reached up to my chunk's end
+    if (is_last) {
+        if (live) a.rec[kr * N_THR + t] = (double)tp / (double)ng;
+        // thresholds the category never reaches: precision 0 (acc_emit_kernel)
+        const int jz = live ? (len == 0 ? 0 : jcur) : N_REC;
+        for (uint64_t need = __ballot(jz < N_REC); need != 0; need &= need - 1) {
+            const int l = __builtin_ctzll(need);
+            const int jl = __builtin_amdgcn_readlane(jz, l);
+            uint64_t *__restrict__ row = (uint64_t *)readlane_u64((uint64_t)out, l);
+            for (int j = jl + lane; j < N_REC; j += WAVE) row[j] = PR_ZERO;
+        }
+    }
+    uint64_t run = PR_ZERO;
+    int32_t cnext = jcur > 0 ? cj[jcur - 1] : -1;
+#pragma unroll
+    for (int blk = ACC_BLK - 1; blk >= 0; blk--) {
+        if (blk * WAVE >= len) continue;
+        emit_block<1>(live ? T[blk] : 0, live ? TF[blk] : 0, tp, n, run, jcur, cnext, out, cj);
+    }
+    if (live && is_first && jcur > 0 && len > 0) {
+        const uint64_t v = run;
+        while (jcur > 0) {
+            out[jcur - 1] = v;
+            jcur--;
+        }
+    }
+    // ---- envelope of the SC's later chunks into the records of the earlier
+    // ones.  No barrier: the walks of an SC's chunks differ by a factor of
+    // five in length and a wavefront that is done leaves; the LAST one to
+    // finish folds the chunk maxima into the records of all (a few per chunk).
+    s_max[wave][lane] = run;
+    s_jr[wave][lane] = (uint16_t)((len > 0 ? jcur : jhi) | (jhi << 8));
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    int done = 0;
+    if (lane == 0) done = atomicAdd(&s_done, 1);
+    done = __builtin_amdgcn_readfirstlane(done);
+    if (done != SW - 1) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    uint64_t later = PR_ZERO;
+    for (int w = SW - 1; w >= 0; w--) {
+        const int jr = s_jr[w][lane];
+        if (live && later != PR_ZERO) sc_raise(out, jr & 0xff, jr >> 8, later);
+        const uint64_t v = s_max[w][lane];
+        if (pr_better((uint32_t)(v >> 32), (uint32_t)v, later)) later = v;
+    }
+    a.sc_max[so] = live ? later : PR_ZERO;
+    // thresholds reached up to the end of this SC (its last wavefront's)
+    a.sc_jhi[so] = (uint8_t)(live ? s_jr[SW - 1][lane] >> 8 : 0);
+}
+
+// The envelope of the later SCs folded into val: one wavefront per (category,
+// range, threshold) row.  Pass 1, lane = SC (64 at a time, from the category's
+// last SC backwards): the SCs' maxima become suffix maxima by a wave scan, and
+// SC s, which emitted the thresholds [jhi(s - 1), jhi(s)), notes for each of
+// them the maximum of the SCs behind it in LDS.  Pass 2, lane = threshold: the
+// row's records are raised with coalesced loads and stores.
+__device__ __forceinline__ uint64_t pr_max(uint64_t a, uint64_t b)
+{
+    return pr_better((uint32_t)(a >> 32), (uint32_t)a, b) ? a : b;
+}
+__global__ __launch_bounds__(256) void acc_raise_kernel(AccArgs a)
+{
+    __shared__ uint64_t s_env[4][N_REC + 3];
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t rows = (int64_t)(a.k_end - a.k_begin) * a.n_rng * N_THR;
+    if (row >= rows) return;
+    const int32_t k = a.k_begin + (int32_t)(row / (a.n_rng * N_THR));
+    const int combo = (int)(row % (a.n_rng * N_THR));
+    const int32_t s0 = a.cat_chunk_off[k], s1 = a.cat_chunk_off[k + 1];
+    if (s1 - s0 < 2) return;
+    if (a.num_gt[(int64_t)k * a.n_rng + combo / N_THR] <= 0) return;
+    uint64_t *env = s_env[wave];
+    for (int j = lane; j < N_REC; j += WAVE) env[j] = PR_ZERO;
+    const int64_t step = (int64_t)a.n_words * WAVE;
+    const int64_t o0 = ((int64_t)combo / WAVE) * WAVE + combo % WAVE;
+    uint64_t behind = PR_ZERO;            // maximum of the SCs of the later passes
+    for (int32_t top = s1; top > s0; top -= WAVE) {
+        // lane l holds SC top - 1 - l: the scan runs towards higher lanes
+        const int32_t sc = top - 1 - lane;
+        const bool have = sc >= s0;
+        const int64_t o = (int64_t)(have ? sc : s0) * step + o0;
+        uint64_t v = have ? a.sc_max[o] : PR_ZERO;
+        const int jh = have ? (int)a.sc_jhi[o] : 0;
+        const int jl = (have && sc > s0) ? (int)a.sc_jhi[o - step] : 0;
+        // inclusive prefix maximum over the lanes below (= the later SCs)
+#pragma unroll
+        for (int d = 1; d < WAVE; d <<= 1) {
+            const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)v, d, WAVE);
+            const uint32_t hi = (uint32_t)__shfl_up((int)(uint32_t)(v >> 32), d, WAVE);
+            const uint64_t u = ((uint64_t)hi << 32) | lo;
+            if (lane >= d) v = pr_max(u, v);
+        }
+        // exclusive: what lies behind SC `sc`
+        const uint32_t elo = (uint32_t)__shfl_up((int)(uint32_t)v, 1, WAVE);
+        const uint32_t ehi = (uint32_t)__shfl_up((int)(uint32_t)(v >> 32), 1, WAVE);
+        uint64_t after = lane > 0 ? (((uint64_t)ehi << 32) | elo) : PR_ZERO;
+        after = pr_max(after, behind);
+        if (have && after != PR_ZERO)
+            for (int j = jl; j < jh; j++) env[j] = after;
+        behind = pr_max(behind, readlane_u64(v, WAVE - 1));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    uint64_t *__restrict__ out = a.val + ((int64_t)k * a.n_rng * N_THR + combo) * N_REC;
+    for (int j = lane; j < N_REC; j += WAVE) {
+        const uint64_t e = env[j];
+        if (e != PR_ZERO) {
+            const uint64_t v = out[j];
+            if (pr_better((uint32_t)(e >> 32), (uint32_t)e, v)) out[j] = e;
+        }
+    }
+}
+
 // val[KR][T*R] -> precision[T*R][KR], rec[KR][T] -> recall[T][KR], -1 fill
 struct FinArgs {
     int32_t n_cat, n_rng;
@@ -912,7 +1302,8 @@ __global__ __launch_bounds__(256) void acc_finalize_kernel(FinArgs a)
     if (live_rows != 0) {
         uint64_t m = live_rows & (0x1111111111111111ull << wave);
         const int64_t col = col0 + lane;
-        const uint64_t *__restrict__ src = a.val + row0 * COLS + (col < COLS ? col : 0);
+        const uint64_t *__restrict__ src =
+            a.val + row0 * COLS + (lane < ncol ? col : col0);
         while (m != 0) {
             int idx[4];
 #pragma unroll
@@ -955,11 +1346,51 @@ static int32_t max_chunks(int64_t n_dt, int32_t n_cat)
     return (int32_t)((n_dt + ACC_CH - 1) / ACC_CH + n_cat);
 }
 
+// ---- which sweep long categories take (TAOAMD_SWEEP, read once):
+//   "chunked" (default) the six chunked kernels;  "lookback" acc_sweep_kernel
+//   in one pass;  "twopass" acc_sweep_kernel behind a counting pass
+//   TAOAMD_SWEEP_SW = 8 | 16: wavefronts (chunks) per super-chunk
+enum { SWEEP_CHUNKED = 0, SWEEP_LOOKBACK = 1, SWEEP_TWOPASS = 2 };
+static int sweep_mode()
+{
+    static const int m = [] {
+        const char *e = getenv("TAOAMD_SWEEP");
+        if (e && !strcmp(e, "lookback")) return (int)SWEEP_LOOKBACK;
+        if (e && !strcmp(e, "twopass")) return (int)SWEEP_TWOPASS;
+        return (int)SWEEP_CHUNKED;
+    }();
+    return m;
+}
+static int sweep_sw()
+{
+    static const int w = [] {
+        const char *e = getenv("TAOAMD_SWEEP_SW");
+        const int v = e ? atoi(e) : 4;
+        return v == 8 || v == 16 ? v : 4;
+    }();
+    return w;
+}
+#define SC_TICKETS 64           // header words of the SC tables (word 0: the error flag)
+static std::atomic<uint32_t> g_sc_gen{0};
+
+static size_t max_scs(int64_t n_dt, int32_t n_cat)
+{
+    return (size_t)(n_dt / (4 * ACC_CH) + n_cat + 1);
+}
+
+static size_t sc_workspace(int64_t n_dt, int32_t n_cat, size_t nw)
+{
+    const size_t ns = max_scs(n_dt, n_cat);
+    return align256(SC_TICKETS * 4) + align256(ns * nw * WAVE * 16) +
+           align256(ns * nw * WAVE * 8) + align256(ns * nw * WAVE);
+}
+
 static size_t base_workspace(int64_t n_dt, int32_t n_cat, int32_t n_rng)
 {
     const size_t nw = (size_t)(n_rng * N_THR + 63) / 64;
     const size_t nc = (size_t)max_chunks(n_dt, n_cat);
-    return align256(((size_t)n_cat + 1) * 4) + align256(nc * 4) +
+    return sc_workspace(n_dt, n_cat, nw) +
+           align256(((size_t)n_cat + 1) * 4) + align256(nc * 4) +
            4 * align256(nc * nw * WAVE * 4) +
            align256(nc * nw * WAVE * 8) +
            2 * align256(nc * nw * ACC_BLK * WAVE * 8) +
@@ -1012,6 +1443,8 @@ static int accumulate_compact(int64_t n_dt, int32_t n_cat, int32_t n_rng,
     a.num_gt = num_gt; a.val = (uint64_t *)val; a.rec = rec;
     a.k_begin = k_begin; a.k_end = k_end;
     a.inline_scans = 0;
+    a.sc_rows = 0; a.sc_gen = 0; a.sc_stat = a.sc_max = nullptr; a.sc_jhi = nullptr;
+    a.sc_error = nullptr;
     // every category fits one workgroup (the host says so): the fused sweep.
     // Mixing the two paths per category was measured slower than the chunked
     // path alone when long categories exist (image level, Config 2: 162 vs
@@ -1022,6 +1455,12 @@ static int accumulate_compact(int64_t n_dt, int32_t n_cat, int32_t n_rng,
     // 16-wave workgroup the other 12 only hold the CU's wave slots (2
     // workgroups per CU).  Track level, 2000 videos: 305 -> 104 us.
     // Workgroups of the other classes leave at once.
+    // (header of the workspace: word 0 = the one-pass sweep's error flag,
+    // taoamd_accumulate_error -- zero whenever a plan or an unprepared pass
+    // starts, whatever path it takes)
+    if (phase != ACC_SWEEP)
+        TAO_HIP(hipMemsetAsync((void *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255), 0,
+                               align256(SC_TICKETS * 4), s));
     const int32_t fused_cap = ACC_FUSED_WAVES / a.n_words * ACC_CH;
     const bool all_fused = max_segment > 0 && max_segment <= fused_cap;
     a.fused_rows = 0;
@@ -1054,6 +1493,16 @@ static int accumulate_compact(int64_t n_dt, int32_t n_cat, int32_t n_rng,
     a.inline_scans = max_segment > 0 && max_segment <= ACC_INLINE_CHUNKS * ACC_CH;
     unsigned char *w = (unsigned char *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     const size_t nc = (size_t)a.n_chunks_max, nw = (size_t)a.n_words;
+    const int mode = sweep_mode(), sw = sweep_sw();
+    const size_t ns = max_scs(n_dt, n_cat);
+    uint32_t *tickets = (uint32_t *)w;   w += align256(SC_TICKETS * 4);
+    a.sc_stat = (uint64_t *)w;           w += align256(ns * nw * WAVE * 16);
+    a.sc_max = (uint64_t *)w;            w += align256(ns * nw * WAVE * 8);
+    a.sc_jhi = (uint8_t *)w;             w += align256(ns * nw * WAVE);
+    if (mode != SWEEP_CHUNKED) {
+        a.sc_rows = sw * ACC_CH;
+        a.inline_scans = 0;
+    }
     a.cat_chunk_off = (int32_t *)w; w += align256(((size_t)n_cat + 1) * 4);
     int32_t *chunk_tab = (int32_t *)w; w += align256(nc * 4);
     a.chunk_tab = phase == ACC_SWEEP ? chunk_tab : nullptr;
@@ -1071,6 +1520,42 @@ static int accumulate_compact(int64_t n_dt, int32_t n_cat, int32_t n_rng,
         TAO_TIMED("acc_chunks_kernel", s, acc_chunks_kernel<<<1, 256, 0, s>>>(a));
     if (phase == ACC_PLAN) {
         TAO_TIMED("acc_chunktab_kernel", s, acc_chunktab_kernel<<<(unsigned)((nc + 255) / 256), 256, 0, s>>>(a, chunk_tab));
+        // (the look-back's ticket slots and status words start from zero)
+        if (mode != SWEEP_CHUNKED)
+            TAO_HIP(hipMemsetAsync(tickets, 0, align256(SC_TICKETS * 4) + align256(ns * nw * WAVE * 16), s));
+        TAO_LAUNCH_CHECK();
+        return TAOAMD_OK;
+    }
+    if (mode != SWEEP_CHUNKED) {
+        // (every category's last SC may be a partial one; an SC past the table leaves at once)
+        const unsigned grid = (unsigned)(((size_t)(n_dt / a.sc_rows) + (size_t)n_cat + 1) * nw);
+        if (mode == SWEEP_LOOKBACK) {
+            // an unprepared workspace may hold anything
+            if (phase == ACC_ALL)
+                TAO_HIP(hipMemsetAsync(tickets, 0, align256(SC_TICKETS * 4) + align256(ns * nw * WAVE * 16), s));
+            uint32_t g = ++g_sc_gen;
+            a.sc_gen = (g & 0x3fffffffu) ? (g & 0x3fffffffu) : (++g_sc_gen & 0x3fffffffu);
+            a.sc_error = tickets;
+            if (sw == 4) {
+                TAO_TIMED("acc_sweep_kernel", s, acc_sweep_kernel<4, 0><<<grid, 4 * WAVE, 0, s>>>(a, rec_thr()));
+            } else if (sw == 8) {
+                TAO_TIMED("acc_sweep_kernel", s, acc_sweep_kernel<8, 0><<<grid, 8 * WAVE, 0, s>>>(a, rec_thr()));
+            } else {
+                TAO_TIMED("acc_sweep_kernel", s, acc_sweep_kernel<16, 0><<<grid, 16 * WAVE, 0, s>>>(a, rec_thr()));
+            }
+        } else if (sw == 4) {
+            TAO_TIMED("acc_sccount_kernel", s, acc_sweep_kernel<4, 2><<<grid, 4 * WAVE, 0, s>>>(a, rec_thr()));
+            TAO_TIMED("acc_sweep_kernel", s, acc_sweep_kernel<4, 1><<<grid, 4 * WAVE, 0, s>>>(a, rec_thr()));
+        } else if (sw == 8) {
+            TAO_TIMED("acc_sccount_kernel", s, acc_sweep_kernel<8, 2><<<grid, 8 * WAVE, 0, s>>>(a, rec_thr()));
+            TAO_TIMED("acc_sweep_kernel", s, acc_sweep_kernel<8, 1><<<grid, 8 * WAVE, 0, s>>>(a, rec_thr()));
+        } else {
+            TAO_TIMED("acc_sccount_kernel", s, acc_sweep_kernel<16, 2><<<grid, 16 * WAVE, 0, s>>>(a, rec_thr()));
+            TAO_TIMED("acc_sweep_kernel", s, acc_sweep_kernel<16, 1><<<grid, 16 * WAVE, 0, s>>>(a, rec_thr()));
+        }
+        // the later SCs' envelope into the records (val final after this)
+        const int64_t rows = (int64_t)(k_end - k_begin) * n_rng * N_THR;
+        TAO_TIMED("acc_raise_kernel", s, acc_raise_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, s>>>(a));
         TAO_LAUNCH_CHECK();
         return TAOAMD_OK;
     }
@@ -1085,6 +1570,20 @@ static int accumulate_compact(int64_t n_dt, int32_t n_cat, int32_t n_rng,
         TAO_TIMED("acc_emit_kernel", s, acc_emit_kernel<false><<<chunk_blocks, 256, 0, s>>>(a));
     }
     TAO_LAUNCH_CHECK();
+    return TAOAMD_OK;
+}
+
+// 0 / 1: a look-back of the one-pass sweep gave up waiting (SC_SPIN_LIMIT) in
+// a pass on this workspace since it was prepared -- its tables are not to be
+// trusted.  Synchronises with `stream`.
+extern "C" int taoamd_accumulate_error(const void *workspace, void *stream, int32_t *flag_host)
+{
+    if (!workspace || !flag_host) return TAOAMD_ERR_ARG;
+    const unsigned char *w = (const unsigned char *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    uint32_t f = 0;
+    TAO_HIP(hipMemcpyAsync(&f, w, sizeof f, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    TAO_HIP(hipStreamSynchronize((hipStream_t)stream));
+    *flag_host = (int32_t)f;
     return TAOAMD_OK;
 }
 

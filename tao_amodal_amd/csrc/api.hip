@@ -28,17 +28,35 @@ static void fill(double *out, double start, double stop, int num)
     out[num - 1] = stop;
 }
 
-const IouThr &iou_thr()
+static IouThr default_iou()
 {
-    static IouThr t = [] { IouThr x; fill(x.v, 0.5, 0.95, N_THR); return x; }();
+    IouThr x;
+    fill(x.v, 0.5, 0.95, N_THR);
+    return x;
+}
+static RecThr default_rec()
+{
+    RecThr x;
+    fill(x.v, 0.0, 1.0, N_REC);
+    return x;
+}
+static RangeTab default_ranges()
+{
+    // L/eval.py:567-574 (the sixth, out-of-frame range has no bounds);
+    // T/eval.py:735-744
+    const RangeTab t = {{0, 0, 0.1, 0.8, 0}, {1.0, 0.1, 0.8, 1.0, 0.8},
+                        {0, 0, 1024, 9216, 0}, {1e10, 1024, 9216, 1e10, 1e10},
+                        {0, 0, 3, 10}, {1e5, 3, 10, 1e5}};
     return t;
 }
+// per thread: the drop-in CLI evaluates its two levels on two threads
+static thread_local IouThr g_iou = default_iou();
+static thread_local RecThr g_rec = default_rec();
+static thread_local RangeTab g_rng = default_ranges();
 
-const RecThr &rec_thr()
-{
-    static RecThr t = [] { RecThr x; fill(x.v, 0.0, 1.0, N_REC); return x; }();
-    return t;
-}
+const IouThr &iou_thr() { return g_iou; }
+const RecThr &rec_thr() { return g_rec; }
+const RangeTab &range_tab() { return g_rng; }
 
 // ---- per-kernel timing: event pairs on the launch streams, reduced on demand
 bool g_timing_on = false;
@@ -174,7 +192,55 @@ extern "C" int taoamd_version(void) { return 100; }
 extern "C" int taoamd_thresholds_host(double *iou_thrs, double *rec_thrs)
 {
     if (!iou_thrs || !rec_thrs) return TAOAMD_ERR_ARG;
-    memcpy(iou_thrs, taoamd::iou_thr().v, sizeof(double) * N_THR);
-    memcpy(rec_thrs, taoamd::rec_thr().v, sizeof(double) * N_REC);
+    const IouThr i = taoamd::default_iou();
+    const RecThr r = taoamd::default_rec();
+    memcpy(iou_thrs, i.v, sizeof(double) * N_THR);
+    memcpy(rec_thrs, r.v, sizeof(double) * N_REC);
+    return TAOAMD_OK;
+}
+
+extern "C" int taoamd_set_thresholds(const double *iou_thrs, const double *rec_thrs)
+{
+    using namespace taoamd;
+    IouThr i = default_iou();
+    RecThr r = default_rec();
+    if (iou_thrs) {
+        memcpy(i.v, iou_thrs, sizeof(double) * N_THR);
+        // the kernels' closed form of the greedy match and the sweeps' tables
+        // of recall crossings take the thresholds in ascending order
+        for (int k = 0; k < N_THR; k++)
+            if (!(i.v[k] == i.v[k]) || (k > 0 && i.v[k] < i.v[k - 1])) return TAOAMD_ERR_ARG;
+    }
+    if (rec_thrs) {
+        memcpy(r.v, rec_thrs, sizeof(double) * N_REC);
+        for (int k = 0; k < N_REC; k++)
+            if (!(r.v[k] == r.v[k]) || (k > 0 && r.v[k] < r.v[k - 1])) return TAOAMD_ERR_ARG;
+    }
+    g_iou = i;
+    g_rec = r;
+    return TAOAMD_OK;
+}
+
+extern "C" int taoamd_set_ranges(const double *visibility_rng, const double *area_rng,
+                                 const double *time_rng)
+{
+    using namespace taoamd;
+    RangeTab t = default_ranges();
+    if (visibility_rng)
+        for (int k = 0; k < 5; k++) {
+            t.vis_lo[k] = visibility_rng[2 * k];
+            t.vis_hi[k] = visibility_rng[2 * k + 1];
+        }
+    if (area_rng)
+        for (int k = 0; k < 5; k++) {
+            t.area_lo[k] = area_rng[2 * k];
+            t.area_hi[k] = area_rng[2 * k + 1];
+        }
+    if (time_rng)
+        for (int k = 0; k < 4; k++) {
+            t.time_lo[k] = time_rng[2 * k];
+            t.time_hi[k] = time_rng[2 * k + 1];
+        }
+    g_rng = t;
     return TAOAMD_OK;
 }

@@ -17,12 +17,25 @@ struct IouThr {
 struct RecThr {
     double v[N_REC];
 };
+// Range tables of the two Params classes (L/eval.py:567-574, T/eval.py:735-744):
+// by-value kernel arguments like the thresholds.  The COUNTS are the kernels'
+// (5 visibility ranges + the out-of-frame one; 5 areas x 4 durations, the last
+// area range being the occlusion one); the values are the caller's.
+struct RangeTab {
+    double vis_lo[5], vis_hi[5];
+    double area_lo[5], area_hi[5];
+    double time_lo[4], time_hi[4];
+};
 
 namespace taoamd {
 
 void set_error(hipError_t e, const char *what);
+// the calling thread's evaluation constants: the reference's defaults unless
+// taoamd_set_thresholds / taoamd_set_ranges replaced them (params edited by the
+// caller of the class API)
 const IouThr &iou_thr();
 const RecThr &rec_thr();
+const RangeTab &range_tab();
 
 #define TAO_HIP(call)                                     \
     do {                                                  \

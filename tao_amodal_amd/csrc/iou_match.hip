@@ -53,11 +53,11 @@ __global__ void lvis_ranges_kernel(int64_t n_gt, const double *__restrict__ vis,
                                    const uint8_t *__restrict__ dflags,
                                    uint32_t *__restrict__ gt_rng,
                                    uint32_t *__restrict__ dt_rng,
-                                   int32_t *__restrict__ num_gt)
+                                   int32_t *__restrict__ num_gt, RangeTab tab)
 {
-    // visibility ranges of reference lvis_amodal/eval.py:567-574
-    const double lo[5] = {0, 0, 0.1, 0.8, 0};
-    const double hi[5] = {1.0, 0.1, 0.8, 1.0, 0.8};
+    // visibility ranges of reference lvis_amodal/eval.py:567-574 (params.
+    // visibility_rng, read at run time: eval.py:205)
+    const double *lo = tab.vis_lo, *hi = tab.vis_hi;
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i < n_gt) {
         uint32_t m = 0;
@@ -86,13 +86,12 @@ __global__ void tao_ranges_kernel(
     int64_t n_dt, const double *__restrict__ darea,
     const int32_t *__restrict__ dlen, const uint8_t *__restrict__ dflags,
     uint32_t *__restrict__ gt_rng, uint32_t *__restrict__ dt_rng,
-    int32_t *__restrict__ num_gt)
+    int32_t *__restrict__ num_gt, RangeTab tab)
 {
-    // area / duration ranges of reference tao_amodal/eval.py:735-744
-    const double alo[5] = {0, 0, 1024, 9216, 0};
-    const double ahi[5] = {1e10, 1024, 9216, 1e10, 1e10};
-    const double tlo[4] = {0, 0, 3, 10};
-    const double thi[4] = {1e5, 3, 10, 1e5};
+    // area / duration ranges of reference tao_amodal/eval.py:735-744 (params.
+    // area_rng / time_rng, read at run time: eval.py:272-275)
+    const double *alo = tab.area_lo, *ahi = tab.area_hi;
+    const double *tlo = tab.time_lo, *thi = tab.time_hi;
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i < n_gt) {
         uint32_t m = 0;
@@ -712,7 +711,7 @@ extern "C" int taoamd_lvis_ranges(int64_t n_gt, const double *gt_vis,
     if (n > 0) {
         TAO_TIMED("lvis_ranges_kernel", s, lvis_ranges_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(
             n_gt, gt_vis, gt_flags, gt_cat, n_dt, dt_flags, gt_rng, dt_rng,
-            grouped ? nullptr : num_gt));
+            grouped ? nullptr : num_gt, range_tab()));
     }
     if (grouped)
         TAO_TIMED("count_gt_kernel", s, count_gt_kernel<<<(unsigned)n_cat, 256, 0, s>>>(
@@ -738,7 +737,7 @@ extern "C" int taoamd_tao_ranges(int64_t n_gt, const double *gt_area,
     if (n > 0) {
         TAO_TIMED("tao_ranges_kernel", s, tao_ranges_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(
             n_gt, gt_area, gt_len, gt_nhp, gt_flags, gt_cat, n_dt, dt_area,
-            dt_len, dt_flags, gt_rng, dt_rng, grouped ? nullptr : num_gt));
+            dt_len, dt_flags, gt_rng, dt_rng, grouped ? nullptr : num_gt, range_tab()));
     }
     if (grouped)
         TAO_TIMED("count_gt_kernel", s, count_gt_kernel<<<(unsigned)n_cat, 256, 0, s>>>(

@@ -631,8 +631,25 @@ def apply_iou_guard(dp, ws, flat=None):
     return n
 
 
+def sweep_ok(dp, ws):
+    """Raise if a look-back of the one-pass sweep gave up in a pass on this
+    workspace (taoamd_accumulate_error; synchronises)."""
+    import ctypes as C
+    if dp.device.type != "cuda":
+        return
+    flag = C.c_int32(0)
+    with torch.cuda.device(dp.device):
+        _lib.check(_lib.load().taoamd_accumulate_error(
+            _ptr(ws.acc_ws), _stream(), C.addressof(flag)), "taoamd_accumulate_error")
+    if flag.value:
+        raise _lib.TaoAmdError("the sweep's look-back between workgroups timed out: "
+                               "precision / recall of this pass are invalid")
+
+
 def guarded_pairs(dp, ws):
-    """Pairs the last pass listed and recomputed (synchronises)."""
+    """Pairs the last pass listed and recomputed (synchronises).  Also the
+    place where a pass is checked for the sweep's error flag."""
+    sweep_ok(dp, ws)
     if not dp.guard_active():
         return 0
     if dp.guard_on_device and int(ws.guard_status.item()):

@@ -47,9 +47,13 @@ class GpuRun:
     """One evaluator pass on the device, split like the reference's API:
     evaluate() = ranges + sort + [track IoU] + match, accumulate() = sweep."""
 
-    def __init__(self, flat, device=None, iou_3d_type="3d_iou"):
+    def __init__(self, flat, device=None, iou_3d_type="3d_iou", constants=None):
+        """``constants`` (EvalConstants): edited ``params`` thresholds / ranges;
+        None = the reference's defaults."""
         import torch
         from .. import engine
+        self.constants = constants if constants is not None and not constants.default \
+            else None
         if not torch.cuda.is_available():
             raise RuntimeError(
                 "tao_amodal_amd evaluates on an AMD GPU through its HIP "
@@ -69,7 +73,10 @@ class GpuRun:
 
     def evaluate(self):
         e = self.engine
-        with timed("kernels"):
+        c = self.constants
+        if c is not None and not c.single:
+            return         # several blocks of thresholds: every pass in accumulate()
+        with timed("kernels"), applied(c):
             # (frame-order guard of the 3D IoU applied before the match, on
             # the device: engine.stage_iou_guard; its count is read later)
             e.run_guarded(self.dp, self.ws, self.flat, upto="match",
@@ -79,6 +86,9 @@ class GpuRun:
                 self.torch.cuda.synchronize(self.device)
 
     def accumulate(self):
+        c = self.constants
+        if c is not None:
+            return self._accumulate_blocks(c)
         with timed("kernels"):
             self.engine.stage_accumulate(self.dp, self.ws)
             self.torch.cuda.synchronize(self.device)
@@ -87,15 +97,62 @@ class GpuRun:
             self.precision = self.ws.precision.cpu().numpy()
             self.recall = self.ws.recall.cpu().numpy()
 
+    def _accumulate_blocks(self, c):
+        """Edited thresholds: the kernels take N_THR IoU thresholds and N_REC
+        recall thresholds per pass, ascending -- the caller's arrays are cut
+        into such blocks (EvalConstants) and every block's slice of the tables
+        is put where the caller's order has it.  IoU thresholds are independent
+        of each other (L/eval.py:234-277), recall thresholds too (:406-410)."""
+        e, dp, ws = self.engine, self.dp, self.ws
+        K, A = dp.n_cat, dp.n_rng
+        self.precision = np.empty((c.T, c.R, K, A))
+        self.recall = np.empty((c.T, K, A))
+        for bi, (t_idx, t_val) in enumerate(c.thr_blocks):
+            for bj, (r_idx, r_val) in enumerate(c.rec_blocks):
+                with timed("kernels"), applied(c, bi, bj):
+                    if bj == 0 and not (c.single and bi == 0):
+                        e.run_guarded(dp, ws, self.flat, upto="match", read_count=False)
+                    e.stage_accumulate(dp, ws)
+                    self.torch.cuda.synchronize(self.device)
+                with timed("download"):
+                    p = ws.precision[:len(t_idx), :len(r_idx)].cpu().numpy()
+                    self.precision[np.ix_(t_idx, r_idx)] = p
+                    if bj == 0:
+                        self.recall[t_idx] = ws.recall[:len(t_idx)].cpu().numpy()
+        self.near_threshold_pairs = e.guarded_pairs(dp, ws)
+        if not c.rec_sorted:
+            # the reference fills a row's recall thresholds IN THE CALLER'S
+            # ORDER and stops at the first one the category never reaches (the
+            # bare `except` of L/eval.py:406-410): what follows stays 0
+            never = np.maximum.accumulate(self.precision == 0, axis=1)
+            self.precision[never] = 0
+
     # ------------------------------------------------------ lazy detail
     def detail(self):
         """Per-detection match indices / IoUs (a second, detail-mode pass,
         only when the per-cell views are actually inspected)."""
         if self._detail is None:
-            self._detail = self.engine.evaluate_flat(
-                self.flat, self.device, detail=True,
-                iou_3d_type=self.iou_3d_type)
+            c = self.constants
+            if c is not None and not c.single:
+                raise NotImplementedError(
+                    "the per-cell views (ious, eval_imgs / eval_vids, dt_pointers) "
+                    "are kept for up to %d IoU thresholds" % N_THR)
+            with applied(c):
+                self._detail = self.engine.evaluate_flat(
+                    self.flat, self.device, detail=True,
+                    iou_3d_type=self.iou_3d_type)
         return self._detail
+
+    def thr_slots(self):
+        """Place of the caller's i-th IoU threshold among the kernels' combos."""
+        c = self.constants
+        if c is None:
+            return list(range(N_THR))
+        if not c.single:
+            self.detail()        # raises
+        slot = np.empty(c.T, dtype=np.int64)
+        slot[c.thr_blocks[0][0]] = np.arange(c.T)
+        return slot.tolist()
 
     def sorted_rows(self):
         n = self.dp.n_dt
@@ -200,11 +257,12 @@ class CellView:
         gid = f.gt_id[g0:g1]
         ig = ((d["gt_rng"][g0:g1] >> np.uint32(r)) & np.uint32(1)).astype(np.int64)
         perm = np.argsort(ig, kind="mergesort")
-        dt_m = np.full((N_THR, D), float(self.sentinel))
-        gt_m = np.full((N_THR, G), float(self.sentinel))
-        dt_ig = np.zeros((N_THR, D), dtype=bool)
-        for t in range(N_THR):
-            combo = r * N_THR + t
+        slots = self.run.thr_slots()
+        dt_m = np.full((len(slots), D), float(self.sentinel))
+        gt_m = np.full((len(slots), G), float(self.sentinel))
+        dt_ig = np.zeros((len(slots), D), dtype=bool)
+        for t, slot in enumerate(slots):
+            combo = r * N_THR + slot
             m = d["match_gt"][d0:d1, combo]
             hit = m >= 0
             if G:
@@ -281,8 +339,9 @@ class LazyPointers(Mapping):
         if num_gt[k, r] == 0:
             return {}
         lo, hi = self.run.dp.cat_off_host[k], self.run.dp.cat_off_host[k + 1]
-        m = np.stack([_bit(matched[lo:hi], r * N_THR + t) for t in range(N_THR)])
-        i = np.stack([_bit(ignored[lo:hi], r * N_THR + t) for t in range(N_THR)])
+        slots = self.run.thr_slots()
+        m = np.stack([_bit(matched[lo:hi], r * N_THR + t) for t in slots])
+        i = np.stack([_bit(ignored[lo:hi], r * N_THR + t) for t in slots])
         return {"dt_ids": self.run.flat.dt_id[order[lo:hi]],
                 "tps": m & ~i, "fps": ~m & ~i}
 
@@ -308,24 +367,83 @@ def now():
     return datetime.datetime.now().strftime("%Y-%m-%d %H:%M:%S")
 
 
-def require_default_params(params, fresh, id_fields=None):
-    """The kernels evaluate at the reference's default thresholds and ranges
-    (compiled in).  The reference lets a caller edit ``params`` before
-    ``evaluate()``; ``img_ids`` / ``vid_ids`` / ``cat_ids`` subsets,
-    ``max_dets`` (a label), ``use_cats`` and ``iou_3d_type`` ARE honoured
-    (restrict_to_params); edits of the thresholds and ranges cannot be and must
-    not pass silently, so they raise.  ``fresh`` is a newly built Params of the
-    same kind."""
-    for name in ("iou_thrs", "rec_thrs"):
-        if not np.array_equal(np.asarray(getattr(params, name), dtype=np.float64),
-                              getattr(fresh, name)):
-            raise NotImplementedError(
-                "params.%s differs from the reference defaults, which are "
-                "compiled into the kernels" % name)
-    for name in ("visibility_rng", "area_rng", "time_rng"):
-        if hasattr(fresh, name) and \
-                np.asarray(getattr(params, name), dtype=np.float64).tolist() != \
-                np.asarray(getattr(fresh, name), dtype=np.float64).tolist():
-            raise NotImplementedError(
-                "params.%s differs from the reference defaults, which are "
-                "compiled into the kernels" % name)
+class EvalConstants:
+    """``params.iou_thrs`` / ``rec_thrs`` and the range tables as the kernels
+    take them.  The reference reads all of them when it runs (L/eval.py:143,
+    205,234,319-322,407; T/eval.py:272-275,385,473-477,562), so a caller may
+    edit them before ``run()``.
+
+    The kernels take N_THR IoU thresholds and N_REC recall thresholds per pass,
+    ascending, as by-value arguments, and the range VALUES likewise
+    (taoamd_set_thresholds / taoamd_set_ranges); the NUMBER of ranges is theirs
+    (6 visibility ranges, the last one the out-of-frame range; 5 areas x 4
+    durations, the last area range the occlusion one).  Thresholds in any
+    number and order are cut into ascending blocks, a short block padded with
+    copies of its last value; an edit that changes the number of ranges
+    raises."""
+
+    def __init__(self, params, fresh, kind):
+        iou = np.asarray(params.iou_thrs, dtype=np.float64).reshape(-1)
+        rec = np.asarray(params.rec_thrs, dtype=np.float64).reshape(-1)
+        self.T, self.R = len(iou), len(rec)
+        if self.T == 0 or self.R == 0:
+            raise NotImplementedError("empty params.iou_thrs / params.rec_thrs")
+        if np.isnan(iou).any() or np.isnan(rec).any():
+            raise ValueError("params.iou_thrs / params.rec_thrs hold a NaN")
+        self.ranges = {}
+        same = np.array_equal(iou, fresh.iou_thrs) and np.array_equal(rec, fresh.rec_thrs)
+        names = ("visibility_rng",) if kind == "lvis" else ("area_rng", "time_rng")
+        for name in names:
+            want = np.asarray(getattr(fresh, name), dtype=np.float64)
+            try:
+                got = np.asarray(getattr(params, name), dtype=np.float64)
+            except (TypeError, ValueError):
+                got = np.zeros(0)
+            if got.shape != want.shape:
+                raise NotImplementedError(
+                    "params.%s: the kernels evaluate %d ranges of [lo, hi]; an "
+                    "edit may change their values, not their number"
+                    % (name, len(want)))
+            # (image level: the sixth range is the out-of-frame one, its bounds
+            # are never read -- L/eval.py:209-217)
+            self.ranges[name] = got[:5] if name == "visibility_rng" else got
+            same = same and np.array_equal(
+                got[:5] if name == "visibility_rng" else got,
+                want[:5] if name == "visibility_rng" else want)
+        self.default = bool(same)
+        self.thr_blocks = self._blocks(iou, N_THR)
+        self.rec_blocks = self._blocks(rec, N_REC)
+        self.single = len(self.thr_blocks) == 1 and len(self.rec_blocks) == 1
+        self.rec_sorted = bool(np.all(np.diff(rec) >= 0))
+
+    @staticmethod
+    def _blocks(values, cap):
+        order = np.argsort(values, kind="stable")
+        out = []
+        for i in range(0, len(values), cap):
+            idx = order[i:i + cap]
+            v = values[idx]
+            out.append((idx, np.concatenate([v, np.full(cap - len(v), v[-1])])))
+        return out
+
+
+def applied(constants, thr_block=0, rec_block=0):
+    """Context manager: the calling thread's kernels launched inside take
+    ``constants`` (None: nothing to do); the reference's defaults come back on
+    the way out."""
+    import contextlib
+    from .. import _lib
+
+    @contextlib.contextmanager
+    def cm():
+        if constants is None or constants.default:
+            yield
+            return
+        _lib.set_constants(iou_thrs=constants.thr_blocks[thr_block][1],
+                           rec_thrs=constants.rec_blocks[rec_block][1],
+                           **constants.ranges)
+        try:
+            yield
+        finally:
+            _lib.set_constants()
+    return cm()

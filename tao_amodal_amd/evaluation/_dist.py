@@ -41,6 +41,10 @@ class Ctx:
     def __init__(self, rank, world, device, group=None, host_group=None, backend="nccl"):
         self.rank, self.world, self.device = rank, world, device
         self.group, self.host_group, self.backend = group, host_group, backend
+        # set by shard_inputs: every rank holds the WHOLE inputs and the ranks
+        # split the categories instead of the videos (annotation files in which
+        # two records share an id)
+        self.whole = False
 
 
 def init_from_env():
@@ -175,10 +179,11 @@ def unique_track_ids(dt, first, ctx):
 class Shares:
     """This rank's inputs of both levels."""
 
-    def __init__(self, gt_lvis, dt_lvis, gt_tao, dt_tao, n_changed, total):
+    def __init__(self, gt_lvis, dt_lvis, gt_tao, dt_tao, n_changed, total, whole=False):
         self.gt_lvis, self.dt_lvis = gt_lvis, dt_lvis
         self.gt_tao, self.dt_tao = gt_tao, dt_tao
         self.n_changed, self.total = n_changed, total
+        self.whole = whole
 
 
 def shard_inputs(gt, dt, first, ctx):
@@ -189,17 +194,15 @@ def shard_inputs(gt, dt, first, ctx):
     from ..columns import DTColumns
     # The reference keeps images, videos, tracks and annotations in dicts keyed
     # by id: of two entries with one id the last replaces the first -- also
-    # when they sit in different videos.  A split by video cannot reproduce
-    # that replacement across ranks, so such a file (every rank sees it whole
-    # and decides alike) is evaluated on one GPU only.
-    for what, ids in (("image", gt.img_id), ("video", gt.vid_id), ("track", gt.trk_id),
-                      ("annotation", gt.ann_id)):
-        if len(np.unique(ids)) != len(ids):
-            raise NotImplementedError(
-                "the annotation file holds two %ss with one id; the reference "
-                "lets the last replace the first wherever they are, which a "
-                "multi-GPU split by video does not reproduce -- run on one GPU"
-                % what)
+    # when they sit in different videos (T/tao.py:131-160, L/lvis.py:34-61).
+    # A split by video cannot reproduce that replacement across ranks.  Every
+    # rank sees the annotation file whole and decides alike: such a file is
+    # evaluated with every rank holding the WHOLE inputs (the table build of
+    # flatten.py knows the dicts' semantics) and the ranks splitting the
+    # CATEGORIES (dist.CategoryShardedEval: no record exchange; the match and
+    # the sweep are independent per category).
+    whole = any(len(np.unique(ids)) != len(ids)
+                for ids in (gt.img_id, gt.vid_id, gt.trk_id, gt.ann_id))
     img_sorted = np.unique(gt.img_id)
     vid_sorted = np.unique(gt.vid_id)
     own_img = block_owner(img_sorted, np.asarray(dt.image_id), ctx.world)
@@ -232,6 +235,11 @@ def shard_inputs(gt, dt, first, ctx):
                          track_id=m[:, 7].copy(), video_id=m[:, 8].copy())
     # (the image level never looks at track ids: it gets the renumbered ones too)
     mat = pack(new_tid)
+    if whole:
+        # the shares are consecutive pieces of the list in rank order
+        every = unpack(np.concatenate(_gather_arrays(mat, ctx)))
+        ctx.whole = True
+        return Shares(gt, every, gt, every, n_changed, int(bad[2]), whole=True)
     dt_l = unpack(_route_rows(mat, own_img, ctx))
     dt_t = unpack(_route_rows(mat, own_vid, ctx))
     gt_l = gt.select_images(block_mask(img_sorted, gt.img_id, ctx.rank, ctx.world))
@@ -249,26 +257,43 @@ class DistRun:
     and downloads the assembled tables, identical on every rank.  The lazy
     per-cell views show the rank's own cells."""
 
-    def __init__(self, flat, ctx, iou_3d_type="3d_iou"):
+    def __init__(self, flat, ctx, iou_3d_type="3d_iou", constants=None):
         import torch
         from .. import dist as tdist, engine
-        from ._core import timed
+        from ._core import applied, timed
         self.engine, self.torch = engine, torch
         self.flat, self.iou_3d_type, self.ctx = flat, iou_3d_type, ctx
         self.device = ctx.device
-        with timed("upload+plan"):
-            self.dp = engine.DeviceProblem(flat, self.device, iou_3d_type)
-            self.ws = engine.Workspace(self.dp)
-            self.sharded = tdist.ShardedEval(self.dp, self.ws, ctx.rank, ctx.world,
-                                             tdist.HipBackend(), ctx.group)
+        # edited params (EvalConstants): one block of thresholds per pass
+        self.constants = constants if constants is not None and not constants.default \
+            else None
+        if self.constants is not None and not self.constants.single:
+            raise NotImplementedError(
+                "a multi-GPU run takes up to %d IoU and %d recall thresholds"
+                % (engine.N_THR, engine.N_REC))
+        with timed("upload+plan"), applied(self.constants):
+            if ctx.whole:
+                # `flat` is the whole problem on every rank: this rank's
+                # category block of its cells
+                k0, k1, _ = tdist.category_block(len(flat.cat_ids), ctx.rank, ctx.world)
+                self.dp = engine.DeviceProblem(tdist.shard_by_category(flat, k0, k1),
+                                               self.device, iou_3d_type)
+                self.ws = engine.Workspace(self.dp)
+                self.sharded = tdist.CategoryShardedEval(
+                    self.dp, self.ws, ctx.rank, ctx.world, tdist.HipBackend(), ctx.group)
+            else:
+                self.dp = engine.DeviceProblem(flat, self.device, iou_3d_type)
+                self.ws = engine.Workspace(self.dp)
+                self.sharded = tdist.ShardedEval(self.dp, self.ws, ctx.rank, ctx.world,
+                                                 tdist.HipBackend(), ctx.group)
             torch.cuda.synchronize(self.device)
         self._detail = None
         self.near_threshold_pairs = 0
         self.precision = self.recall = None
 
     def evaluate(self):
-        from ._core import timed
-        with timed("kernels"):
+        from ._core import applied, timed
+        with timed("kernels"), applied(self.constants):
             self.sharded.step()
 
     def accumulate(self):
@@ -280,11 +305,32 @@ class DistRun:
         with timed("download"):
             self.precision = self.sharded.precision.cpu().numpy()
             self.recall = self.sharded.recall.cpu().numpy()
+        c = self.constants
+        if c is not None:
+            # the caller's thresholds, in the caller's order (GpuRun._accumulate_blocks)
+            t_idx, r_idx = c.thr_blocks[0][0], c.rec_blocks[0][0]
+            p = np.empty((c.T, c.R) + self.precision.shape[2:])
+            p[np.ix_(t_idx, r_idx)] = self.precision[:c.T, :c.R]
+            r = np.empty((c.T,) + self.recall.shape[1:])
+            r[t_idx] = self.recall[:c.T]
+            if not c.rec_sorted:
+                p[np.maximum.accumulate(p == 0, axis=1)] = 0
+            self.precision, self.recall = p, r
+
+    def thr_slots(self):
+        c = self.constants
+        if c is None:
+            return list(range(self.engine.N_THR))
+        slot = np.empty(c.T, dtype=np.int64)
+        slot[c.thr_blocks[0][0]] = np.arange(c.T)
+        return slot.tolist()
 
     def detail(self):
         if self._detail is None:
-            self._detail = self.engine.evaluate_flat(
-                self.flat, self.device, detail=True, iou_3d_type=self.iou_3d_type)
+            from ._core import applied
+            with applied(self.constants):
+                self._detail = self.engine.evaluate_flat(
+                    self.flat, self.device, detail=True, iou_3d_type=self.iou_3d_type)
         return self._detail
 
     def sorted_rows(self):

@@ -12,7 +12,7 @@ import numpy as np
 
 from ... import flatten
 from .._core import (N_REC, N_THR, CellView, GpuRun, LazyIous, LazyPointers,
-                     require_default_params, restrict_to_params,
+                     EvalConstants, restrict_to_params,
                      masked_mean, now, timed)
 from .lvis import LVIS
 from .results import LVISResults
@@ -104,7 +104,7 @@ class LVISEval:
         if self.params.iou_type not in ("bbox", "segm"):
             raise ValueError("Unknown iou_type for iou computation.")
         self.params.img_ids = list(np.unique(self.params.img_ids))
-        require_default_params(self.params, Params(self.params.iou_type))
+        constants = EvalConstants(self.params, Params(self.params.iou_type), "lvis")
         use_cats = bool(self.params.use_cats)
         with timed("flatten"):
             # params.img_ids / cat_ids subsets (reference eval.py:59-105)
@@ -120,7 +120,8 @@ class LVISEval:
             from ... import flatten_dev
             flat = flatten_dev.flatten_lvis(gt_cols, dt_cols,
                                             self.lvis_dt.max_dets,
-                                            use_cats=use_cats, device=self.device)
+                                            use_cats=use_cats, device=self.device,
+                                            share=self.dist is not None and not self.dist.whole)
         if self.params.iou_type == "segm":
             with timed("masks"):
                 flat.masks = self._masks(flat)
@@ -130,9 +131,9 @@ class LVISEval:
             if self.params.iou_type != "bbox":
                 raise NotImplementedError("multi-GPU runs evaluate iou_type='bbox'")
             from .._dist import DistRun
-            self._run = DistRun(flat, self.dist)
+            self._run = DistRun(flat, self.dist, constants=constants)
         else:
-            self._run = GpuRun(flat, self.device)
+            self._run = GpuRun(flat, self.device, constants=constants)
         self._run.evaluate()
         view = CellView(self._run, flat.img_ids, 0, "image_id", "visibility_rng",
                         self.params.visibility_rng)
@@ -207,7 +208,7 @@ class LVISEval:
             recall = np.ascontiguousarray(recall[:, self._cat_pos])
         self.eval = {
             "params": self.params,
-            "counts": [N_THR, N_REC,
+            "counts": [len(self.params.iou_thrs), len(self.params.rec_thrs),
                        len(self.params.cat_ids) if self.params.use_cats else 1,
                        n_rng],
             "date": now(),

@@ -10,7 +10,7 @@ from collections.abc import Mapping
 import numpy as np
 
 from .._core import (N_REC, N_THR, CellView, GpuRun, LazyIous, LazyPointers,
-                     require_default_params,
+                     EvalConstants,
                      masked_mean, now, timed)
 from .results import TaoResults
 from .tao import Tao
@@ -115,7 +115,7 @@ class TaoEval:
         if self.params.iou_3d_type not in ("3d_iou", "avg_iou", "imagenetvid"):
             raise ValueError("Unknown iou_3d_type %r" % self.params.iou_3d_type)
         self.params.vid_ids = list(np.unique(self.params.vid_ids))
-        require_default_params(self.params, Params(self.params.iou_type))
+        constants = EvalConstants(self.params, Params(self.params.iou_type), "tao")
         # params.vid_ids / cat_ids subsets (reference eval.py:178-233)
         from .._core import restrict_to_params
         gt_cols, dt_cols, self._cat_pos = restrict_to_params(
@@ -141,9 +141,11 @@ class TaoEval:
         flat = self.flat
         if self.dist is not None:
             from .._dist import DistRun
-            self._run = DistRun(flat, self.dist, self.params.iou_3d_type)
+            self._run = DistRun(flat, self.dist, self.params.iou_3d_type,
+                                constants=constants)
         else:
-            self._run = GpuRun(flat, self.device, self.params.iou_3d_type)
+            self._run = GpuRun(flat, self.device, self.params.iou_3d_type,
+                               constants=constants)
         self._run.evaluate()
         P = self.params
         rngs = [(a, t) for a in P.area_rng for t in P.time_rng]
@@ -179,10 +181,10 @@ class TaoEval:
             recall = np.ascontiguousarray(recall[:, self._cat_pos])
         self.eval = {
             "params": P,
-            "counts": [N_THR, N_REC, K, A, T],
+            "counts": [len(P.iou_thrs), len(P.rec_thrs), K, A, T],
             "date": now(),
-            "precision": precision.reshape(N_THR, N_REC, K, A, T),
-            "recall": recall.reshape(N_THR, K, A, T),
+            "precision": precision.reshape(len(P.iou_thrs), len(P.rec_thrs), K, A, T),
+            "recall": recall.reshape(len(P.iou_thrs), K, A, T),
             "dt_pointers": LazyPointers(self._run, A * T, (A, T), self._cat_pos),
         }
 

@@ -334,13 +334,16 @@ def lvis_gt_tables(f, gt, g_sel, keys_g, U):
 
 
 def flatten_lvis(gt: GTColumns, dt: DTColumns, max_dets=MAX_DETS,
-                 use_cats=True):
+                 use_cats=True, share=False):
     """Cell tables of LVISEval (L/eval.py:59-110).  ``use_cats=False`` builds
     the class-agnostic problem of ``params.use_cats = 0`` (L/eval.py:125-128,
     147-166): one cell per image holding every ground truth / every kept
     detection of the image, category-major (the federated filter and the
     not-exhaustive flags still use the real categories), one output category."""
-    if len(dt) == 0:
+    # (``share``: one rank's block of a multi-GPU run -- the reference's
+    # statements about an empty list are about the WHOLE list, which
+    # evaluation/_dist.shard_inputs has checked: a share may hold nothing)
+    if len(dt) == 0 and not share:
         raise IndexError("list index out of range")  # L/results.py:42
     G = lvis_gt_side(gt)
     img_ids, cat_ids, img_row = G.img_ids, G.cat_ids, G.img_row
@@ -619,7 +622,9 @@ def tao_gt_side(gt, visit_universe=None):
     a_img = _lookup(img_ids, gt.ann_img)
     g_sel = _tao_select(visit_rank, a_img, _lookup(cat_ids, ann_cat), gt.ann_area,
                         gt.ann_id)
-    if len(g_sel) == 0:
+    # (a rank's share -- it comes with the whole set's visiting universe -- may
+    # hold no ground truth: the statement is shard_inputs' about the whole set)
+    if len(g_sel) == 0 and visit_universe is None:
         raise ValueError("Found no groundtruth annotations for given params")
     g_ids, g_perm, g_aoff = _group_tracks(
         gt.ann_trk[g_sel], gt.img_frame[img_row[a_img[g_sel]]])
@@ -651,7 +656,8 @@ def flatten_tao(gt: GTColumns, dt: DTColumns, max_dets=MAX_DETS,
     ``params.use_cats = 0`` (T/eval.py:257-260,293-303): one cell per video
     holding the tracks of all categories (category-major, as the reference
     concatenates them), no federated filter, a single pseudo category -1."""
-    if len(dt) == 0:
+    share = visit_universe is not None       # one rank's block (see flatten_lvis)
+    if len(dt) == 0 and not share:
         raise IndexError("list index out of range")  # T/results.py:61
     T = tao_gt_side(gt, visit_universe)
     ms, md = T.ms, T.md
@@ -710,7 +716,7 @@ def flatten_tao(gt: GTColumns, dt: DTColumns, max_dets=MAX_DETS,
     a_img, g_sel = T.a_img, T.g_sel
     d_sel = _tao_select(visit_rank, d_img, _lookup(cat_ids, d_cat_id), d_area,
                         np.arange(1, len(keep) + 1, dtype=np.int64))
-    if len(d_sel) == 0:
+    if len(d_sel) == 0 and not share:
         raise ValueError("Found no predicted annotations for given params")
 
     # ---- group into tracks

@@ -708,17 +708,18 @@ def _cuda(device):
     return dev if dev.type == "cuda" and torch.cuda.is_available() else None
 
 
-def flatten_lvis(gt, dt, max_dets=MAX_DETS, use_cats=True, device=None):
+def flatten_lvis(gt, dt, max_dets=MAX_DETS, use_cats=True, device=None, share=False):
     """The image-level cell tables: built on the device when the input allows
     it, by flatten.py otherwise (class-agnostic cells, > 2^31 keys, no GPU for
-    host-side tooling)."""
+    host-side tooling).  ``share``: one rank's block of a multi-GPU run, which
+    may hold no prediction at all (flatten.flatten_lvis)."""
     dev = _cuda(device)
     if dev is not None and use_cats and len(dt):
         try:
             return flatten_lvis_device(gt, dt, dev, max_dets)
         except Unsupported:
             pass
-    return flatten.flatten_lvis(gt, dt, max_dets, use_cats=use_cats)
+    return flatten.flatten_lvis(gt, dt, max_dets, use_cats=use_cats, share=share)
 
 
 def flatten_tao(gt, dt, max_dets=MAX_DETS, use_cats=True, device=None,

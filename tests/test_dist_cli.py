@@ -53,19 +53,42 @@ def _share_worker(rank, world, port, gt_p, pr_p, out):
 
 
 def _dup_worker(rank, world, port, gt_p, pr_p, out):
-    try:
-        _share_worker(rank, world, port, gt_p, pr_p, out)
-    except NotImplementedError as e:
-        open(os.path.join(out, "err%d.txt" % rank), "w").write(str(e))
+    sys.path[:0] = [ROOT, HERE]
+    import torch
+    import torch.distributed as dist
+    from tao_amodal_amd.columns import DTColumns, GTColumns
+    from tao_amodal_amd.evaluation import _dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ctx = _dist.Ctx(rank, world, torch.device("cpu"), None, None, "gloo")
+    gt = GTColumns.from_file_native(gt_p)
+    dt = DTColumns.from_file_native(pr_p, rank, world)
+    sh = _dist.shard_inputs(gt, dt, dt.first, ctx)
+    np.savez(os.path.join(out, "w%d.npz" % rank), whole=[sh.whole, ctx.whole],
+             same=sh.dt_lvis is sh.dt_tao, n_gt=len(sh.gt_tao.ann_id),
+             **{f: getattr(sh.dt_tao, f) for f in DTColumns.FIELDS})
+    dist.destroy_process_group()
 
 
-def test_duplicate_ids_are_refused_on_every_rank(tmp_path):
+@pytest.mark.parametrize("world", [2, 3])
+def test_duplicate_ids_put_the_whole_set_on_every_rank(world, tmp_path):
     """F2 holds two annotations with one id in different images (the
-    reference's dict keeps the last): refused alike by all ranks, no hang."""
+    reference's dict keeps the last, wherever it sits: T/tao.py:131-160): no
+    split by video reproduces that, so every rank gets the WHOLE list (track
+    ids made unique over it) and the ranks split the categories instead
+    (VERDICT r3 #8; round 3 refused such files under a launcher)."""
+    from tao_amodal_amd import flatten
+    from tao_amodal_amd.columns import DTColumns, GTColumns
     gt_p, pr_p = input_paths("f2", tmp_path)
-    mp.spawn(_dup_worker, args=(2, _port(), gt_p, pr_p, str(tmp_path)), nprocs=2, join=True)
-    for r in range(2):
-        assert "one id" in open(os.path.join(str(tmp_path), "err%d.txt" % r)).read()
+    mp.spawn(_dup_worker, args=(world, _port(), gt_p, pr_p, str(tmp_path)),
+             nprocs=world, join=True)
+    gt, dt = GTColumns.from_file_native(gt_p), DTColumns.from_file_native(pr_p)
+    want_tid, _ = flatten.make_track_ids_unique(dt)
+    for r in range(world):
+        z = np.load(os.path.join(str(tmp_path), "w%d.npz" % r))
+        assert z["whole"].all() and bool(z["same"]) and int(z["n_gt"]) == len(gt.ann_id)
+        for f in DTColumns.FIELDS:
+            assert np.array_equal(z[f], want_tid if f == "track_id" else getattr(dt, f)), f
 
 
 @pytest.mark.parametrize("world", [2, 3])
@@ -102,13 +125,45 @@ def test_shares_are_the_file_cut_by_owner(name, world, tmp_path):
     assert at == len(dt)
 
 
-@pytest.mark.gpu
-@pytest.mark.timeout(900)
-@pytest.mark.parametrize("world", [2, 3])
-@pytest.mark.parametrize("name", [n for n in FIXTURES if n != "f2"] + ["f8"])
-def test_cli_under_a_launcher_prints_the_reference_text(name, world, tmp_path):
-    gt_p, pr_p = input_paths(name, tmp_path)
-    log = tmp_path / "out" / "eval.log"
+def _empty_share_worker(rank, world, port, gt_p, pr_p, out):
+    sys.path[:0] = [ROOT, HERE]
+    import torch
+    import torch.distributed as dist
+    from tao_amodal_amd import dist as tdist, flatten
+    from tao_amodal_amd.columns import DTColumns, GTColumns
+    from tao_amodal_amd.evaluation import _dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ctx = _dist.Ctx(rank, world, torch.device("cpu"), None, None, "gloo")
+    gt = GTColumns.from_file_native(gt_p)
+    dt = DTColumns.from_file_native(pr_p, rank, world)
+    sh = _dist.shard_inputs(gt, dt, dt.first, ctx)
+    fl = flatten.flatten_lvis(sh.gt_lvis, sh.dt_lvis, share=True)
+    universe = tdist.gather_visit_universe(sh.gt_tao, ctx.device, ctx.group)
+    ft = flatten.flatten_tao(sh.gt_tao, sh.dt_tao, visit_universe=universe)
+    np.savez(os.path.join(out, "e%d.npz" % rank),
+             n=[len(sh.dt_lvis), len(sh.dt_tao), int(fl.cell_dt_off[-1]),
+                int(ft.cell_dt_off[-1]), int(fl.cell_gt_off[-1]), int(ft.cell_gt_off[-1])])
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["f1", "f5"])
+def test_a_rank_whose_block_holds_no_prediction_builds_its_tables(name, tmp_path):
+    """the rank that owns the upper block of the image / video ids
+    gets no prediction from `lower_half/pred.json`; its cell tables are the
+    ground truth's alone (it used to die with the reference's IndexError for
+    an empty list, and the other ranks hung in the exchange)."""
+    gt_p, _ = input_paths(name, tmp_path)
+    pr_p = path(name, os.path.join("lower_half", "pred.json"))
+    mp.spawn(_empty_share_worker, args=(2, _port(), gt_p, pr_p, str(tmp_path)),
+             nprocs=2, join=True)
+    n0 = np.load(os.path.join(str(tmp_path), "e0.npz"))["n"]
+    n1 = np.load(os.path.join(str(tmp_path), "e1.npz"))["n"]
+    assert n0[0] > 0 and n0[1] > 0 and n0[2] > 0 and n0[3] > 0
+    assert list(n1[:4]) == [0, 0, 0, 0] and n1[4] > 0 and n1[5] > 0
+
+
+def _launch_cli(world, gt_p, pr_p, log):
     port = _port()
     procs = []
     for r in range(world):
@@ -122,6 +177,36 @@ def test_cli_under_a_launcher_prints_the_reference_text(name, world, tmp_path):
     outs = [p.communicate(timeout=800) for p in procs]
     for r, p in enumerate(procs):
         assert p.returncode == 0, (r, outs[r][1][-3000:])
+    return outs
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("name", ["f1", "f5"])
+def test_cli_with_a_rank_without_predictions(name, world, tmp_path):
+    """The command on 2 / 3 ranks when the last rank's block of images and
+    videos has no prediction: the reference's text on that prediction file."""
+    gt_p, _ = input_paths(name, tmp_path)
+    sub = os.path.join("lower_half", "")
+    pr_p = path(name, sub + "pred.json")
+    log = tmp_path / "out" / "eval.log"
+    outs = _launch_cli(world, gt_p, pr_p, log)
+    assert outs[0][0] == open(path(name, sub + "cli_stdout.txt")).read()
+    want = open(path(name, sub + "cli_log.txt")).read()
+    got = log.read_text().replace(os.path.dirname(pr_p) + os.sep, "<PRED>/") \
+        .replace(os.path.dirname(gt_p) + os.sep, "<DIR>/")
+    assert got == want
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("name", FIXTURES + ["f8"])      # f2: the whole-set mode
+def test_cli_under_a_launcher_prints_the_reference_text(name, world, tmp_path):
+    gt_p, pr_p = input_paths(name, tmp_path)
+    log = tmp_path / "out" / "eval.log"
+    outs = _launch_cli(world, gt_p, pr_p, log)
     assert outs[0][0] == open(path(name, "cli_stdout.txt")).read()
     for r in range(1, world):
         assert outs[r][0] == ""

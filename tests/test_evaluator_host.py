@@ -109,13 +109,13 @@ def test_product_path_refuses_to_run_without_gpu():
 
 
 @pytest.mark.parametrize("edit", [
-    ("iou_thrs", lambda v: v[:3]), ("rec_thrs", lambda v: v[::2]),
-    ("visibility_rng", lambda v: v[:2])])
+    ("visibility_rng", lambda v: v[:2]), ("visibility_rng", lambda v: v + [[0, 1.0]])])
 def test_lvis_params_edits_the_kernels_cannot_honour_raise(edit):
-    """The reference lets a caller change params before evaluate(); id subsets
-    are honoured (tests/test_gpu_cli.py, goldens from the reference), the
-    thresholds and ranges are compiled into the kernels, so such edits must
-    raise instead of silently giving default numbers."""
+    """The reference lets a caller change params before evaluate().  Id subsets,
+    thresholds in any number and order and the range VALUES are honoured
+    (tests/test_gpu_cli.py, tests/test_gpu_constants.py: goldens from the
+    reference); the NUMBER of ranges is the kernels', so such an edit must
+    raise instead of silently giving other numbers."""
     ev = LVISEval(path("f1", "gt.json"), path("f1", "pred.json"), "bbox")
     name, fn = edit
     setattr(ev.params, name, fn(getattr(ev.params, name)))
@@ -124,8 +124,7 @@ def test_lvis_params_edits_the_kernels_cannot_honour_raise(edit):
 
 
 @pytest.mark.parametrize("edit", [
-    ("iou_thrs", lambda v: v + 0.01), ("area_rng", lambda v: v[:1]),
-    ("time_rng", lambda v: [[0, 5]])])
+    ("area_rng", lambda v: v[:1]), ("time_rng", lambda v: [[0, 5]])])
 def test_tao_params_edits_the_kernels_cannot_honour_raise(edit):
     gtj, predj = load_inputs("f1")
     dt = DTColumns.from_json(predj)
@@ -136,6 +135,40 @@ def test_tao_params_edits_the_kernels_cannot_honour_raise(edit):
     setattr(ev.params, name, fn(getattr(ev.params, name)))
     with pytest.raises(NotImplementedError, match="params." + name):
         ev.evaluate()
+
+
+def test_edited_thresholds_are_cut_into_the_kernels_blocks():
+    """_core.EvalConstants: the caller's thresholds, any number and order, as
+    ascending blocks of the kernels' sizes (10 IoU / 101 recall thresholds), a
+    short block padded with copies of its last value; idx = where a block's
+    values go in the caller's arrays."""
+    import numpy as np
+    from tao_amodal_amd.evaluation._core import EvalConstants
+    from tao_amodal_amd.evaluation.lvis_amodal.eval import Params
+    P = Params("bbox")
+    c = EvalConstants(P, Params("bbox"), "lvis")
+    assert c.default and c.single
+    P.iou_thrs = np.array([0.75, 0.3, 0.9, 0.5])
+    P.rec_thrs = np.linspace(0, 1, 201)
+    c = EvalConstants(P, Params("bbox"), "lvis")
+    assert not c.default and not c.single and (c.T, c.R) == (4, 201)
+    (idx, val), = c.thr_blocks
+    assert idx.tolist() == [1, 3, 0, 2]
+    assert val.tolist() == [0.3, 0.5, 0.75, 0.9] + [0.9] * 6
+    assert [len(i) for i, _ in c.rec_blocks] == [101, 100]
+    assert all(len(v) == 101 and np.all(np.diff(v) >= 0) for _, v in c.rec_blocks)
+    assert np.array_equal(np.sort(np.concatenate([i for i, _ in c.rec_blocks])), np.arange(201))
+    assert c.rec_sorted
+    P.rec_thrs = np.array([0.9, 0.1])
+    assert not EvalConstants(P, Params("bbox"), "lvis").rec_sorted
+    # range values: five visibility ranges travel, the sixth has no bounds
+    P = Params("bbox")
+    P.visibility_rng = [[0, 1.0], [0, 0.3], [0.3, 0.6], [0.6, 1.0], [0.05, 0.9], [7, 7]]
+    c = EvalConstants(P, Params("bbox"), "lvis")
+    assert not c.default and c.single and c.ranges["visibility_rng"].shape == (5, 2)
+    P.iou_thrs = np.array([])
+    with pytest.raises(NotImplementedError):
+        EvalConstants(P, Params("bbox"), "lvis")
 
 
 def test_restrict_to_params_is_the_references_prepare_filter():

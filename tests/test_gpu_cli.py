@@ -144,7 +144,9 @@ def test_edited_params_subsets_match_the_reference(name):
 def test_edited_params_the_path_cannot_honour_still_raise():
     from tao_amodal_amd.evaluation.lvis_amodal import LVISEval
     ev = LVISEval(path("f1", "gt.json"), path("f1", "pred.json"), "bbox")
-    ev.params.iou_thrs = np.array([0.5, 0.6])
+    # (thresholds and range VALUES are honoured: tests/test_gpu_constants.py;
+    # an edit that changes the NUMBER of ranges is not)
+    ev.params.visibility_rng = [[0, 1.0], [0, 0.5], [0, 1.0]]
     with pytest.raises(NotImplementedError):
         ev.evaluate()
     ev = LVISEval(path("f1", "gt.json"), path("f1", "pred.json"), "bbox")

@@ -229,7 +229,9 @@ def main_distributed(args, annotation):
             logger.info("Done")
             logger.info("Building")
             with timed("flatten"):
-                universe = tdist.gather_visit_universe(sh.gt_tao, ctx.device, ctx.group)
+                # (a file with duplicate ids: every rank holds the whole set)
+                universe = None if sh.whole else \
+                    tdist.gather_visit_universe(sh.gt_tao, ctx.device, ctx.group)
                 flat = flatten_dev.flatten_tao(sh.gt_tao, sh.dt_tao, device=ctx.device,
                                                visit_universe=universe)
             tao_eval = TaoEval(tao_gt, TaoResults(tao_gt, sh.dt_tao, _flat=flat, _share=True),

@@ -25,6 +25,10 @@ import shutil
 import sys
 
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import sources_digest  # noqa: E402  (the kernels the passes were taken on)
+
+
 def mean_counter(path):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
@@ -53,7 +57,8 @@ def main(src, prefix, workload=None):
             json.dump({"note": "mean per launch, by kernel and grid size (work "
                                "items); traffic = (2*FETCH_SIZE + WRITE_SIZE) * "
                                "1024 (gfx950 correction)",
-                       "workload": workload, "kernels": out}, fh, indent=1)
+                       "workload": workload, "sources": sources_digest(),
+                       "kernels": out}, fh, indent=1)
     print("wrote", prefix + "_*")
 
 
