@@ -213,6 +213,9 @@ def kernel_models(dp, ws):
              "seg_split_kernel": K * 256,
              "seg_kmerge_kernel": (n_dt + 255) // 256 * 256,
              "acc_finalize_kernel": ((K * A + 63) // 64) * ((T * R + 63) // 64) * 256,
+             "acc_sweep_kernel": ((n_dt // 2048) + K + 1) * nw * 256,
+             "acc_raise_kernel": (K * A * T + 3) // 4 * 256,
+             "acc_cj_kernel": (K * A * R + 255) // 256 * 256,
              "ss_scatter_kernel": nt_ * 256,
              "ss_sort_kernel": (nb_ + 3) // 4 * 256,
              "ss_split_kernel": (ns_ + 3) // 4 * 256}

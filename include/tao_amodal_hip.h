@@ -342,6 +342,11 @@ int taoamd_track_iou_plan_host(int64_t n_cells, const int32_t *cell_dt_off_host,
  * where matched is 16-byte aligned and out_stride even, a pair is written with
  * one 16-byte store;
  * taoamd_accumulate* recognise the same layout by the same pointer relation.
+ * The pointer relation IS the layout flag of this ABI: `ignored == matched + 1`
+ * means interleaved pairs in taoamd_match and every taoamd_accumulate* entry;
+ * the entries that only know DENSE [n][n_words] tables -- taoamd_gather_rows
+ * (its destination) and taoamd_exchange_merge -- return TAOAMD_ERR_ARG when
+ * handed that relation instead of scrambling rows (tests/test_abi.py).
  * max_gt_per_cell must be >= the largest GT count of a cell (host knows it
  * from the CSR table); cells with more than 64 GTs take a slower kernel and
  * more than TAOAMD_MAX_GT_PER_CELL is an error.
@@ -589,7 +594,8 @@ int taoamd_sort_segments(int64_t n, int32_t n_cat, const int32_t *cat_off,
 
 /* ---- row gather -----------------------------------------------------------------
  * dst_*[p*n_words + w] = src_*[order[p]*src_stride + w]: brings exchanged
- * records (multi-GPU path) into sorted order. */
+ * records (multi-GPU path) into sorted order.  Destination tables dense (the
+ * pair layout of taoamd_match is refused: TAOAMD_ERR_ARG). */
 int taoamd_gather_rows(int64_t n, int32_t n_words, const uint64_t *src_matched,
                        const uint64_t *src_ignored, int64_t src_stride,
                        const int32_t *order, uint64_t *dst_matched,

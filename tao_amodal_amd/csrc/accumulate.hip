@@ -186,6 +186,42 @@ __device__ __forceinline__ void load_rows(const AccArgs &a, int64_t first, int w
     fpw = ~m & ~i;
 }
 
+// The ACC_BLK blocks of a chunk's rows, all loads issued before the first is
+// waited for.  Round 4: load_rows() block by block compiled to a chain -- every
+// block's loads sit behind the run-time layout branches (order / wide / paired)
+// and an `if (lane < n)`, and the compiler put an s_waitcnt vmcnt(0) between
+// them: eight dependent round trips to HBM per wavefront in the counting,
+// fused and one-pass kernels.  The common layout (pairs, 16-byte aligned, no
+// gather) gets ACC_BLK unconditional 16-byte loads -- a lane past the chunk's
+// rows re-reads the chunk's first row -- and the others keep load_rows().
+template <int ACC_BLK_N>
+__device__ __forceinline__ void load_chunk(const AccArgs &a, int64_t start, int word, int len,
+                                           int lane, uint64_t (&tpw)[ACC_BLK_N],
+                                           uint64_t (&fpw)[ACC_BLK_N])
+{
+    if (a.wide && a.order == nullptr && len > 0) {
+        ulonglong2 v[ACC_BLK_N];
+#pragma unroll
+        for (int blk = 0; blk < ACC_BLK_N; blk++) {
+            const int i = blk * WAVE + lane;
+            const int64_t r = start + (i < len ? i : 0);
+            v[blk] = *reinterpret_cast<const ulonglong2 *>(a.matched + 2 * (r * a.n_words + word));
+        }
+#pragma unroll
+        for (int blk = 0; blk < ACC_BLK_N; blk++) {
+            const bool in = blk * WAVE + lane < len;
+            const uint64_t m = in ? v[blk].x : 0, i_ = in ? v[blk].y : ~0ull;
+            tpw[blk] = m & ~i_;
+            fpw[blk] = ~m & ~i_;
+        }
+        return;
+    }
+#pragma unroll
+    for (int blk = 0; blk < ACC_BLK_N; blk++)
+        load_rows(a, start + blk * WAVE, word, max(0, min(WAVE, len - blk * WAVE)), lane,
+                  tpw[blk], fpw[blk]);
+}
+
 // value of lane (i ^ S): CDNA4 lane permutes that need neither an address VGPR
 // nor a round trip through the LDS crossbar queue (what __shfl_xor compiles to,
 // ds_bpermute_b32): v_permlane32_swap / v_permlane16_swap for the two widest
@@ -320,10 +356,7 @@ __global__ __launch_bounds__(256) void acc_count_kernel(AccArgs a)
     // stores in one in-order counter (vmcnt), so a load issued after a store
     // waits for that store's acknowledgement as well
     uint64_t tpw[ACC_BLK], fpw[ACC_BLK];
-#pragma unroll
-    for (int blk = 0; blk < ACC_BLK; blk++)
-        load_rows(a, ci.start + blk * WAVE, ci.word,
-                  max(0, min(WAVE, ci.len - blk * WAVE)), lane, tpw[blk], fpw[blk]);
+    load_chunk(a, ci.start, ci.word, ci.len, lane, tpw, fpw);
 #pragma unroll
     for (int blk = 0; blk < ACC_BLK; blk++) {
         uint64_t T = 0, F = 0;
@@ -469,6 +502,8 @@ __global__ __launch_bounds__(256) void acc_chunkmax_kernel(AccArgs a, RecThr rec
     if (INLINE) {
         uint32_t fp0 = 0;
         tp0 = 0;
+        // (one chunk per step: most chunks have a handful of predecessors, and a
+        // step of eight with clamped loads was 2.4 times slower at Config 2)
         for (int32_t c = a.cat_chunk_off[ci.k]; c < ci.c; c++) {
             const int64_t oc = ((int64_t)c * a.n_words + ci.word) * WAVE + lane;
             tp0 += a.cnt_tp[oc];
@@ -829,15 +864,15 @@ __global__ __launch_bounds__(FW * WAVE) void acc_fused_kernel(AccArgs a, RecThr 
     uint64_t T[ACC_BLK], TF[ACC_BLK];
     uint32_t tp_own = 0, fp_own = 0;
     {
+        uint64_t tpw[ACC_BLK], fpw[ACC_BLK];
+        load_chunk(a, (int64_t)start, word, len, lane, tpw, fpw);
 #pragma unroll
         for (int blk = 0; blk < ACC_BLK; blk++) {
             const int base = blk * WAVE;
             uint64_t t_ = 0, f_ = 0;
             if (base < len) {
-                uint64_t tpw, fpw;
-                load_rows(a, (int64_t)start + base, word, min(WAVE, len - base), lane, tpw, fpw);
-                t_ = transpose64(tpw, lane);
-                f_ = transpose64(fpw, lane);
+                t_ = transpose64(tpw[blk], lane);
+                f_ = transpose64(fpw[blk], lane);
             }
             T[blk] = t_;
             TF[blk] = t_ | f_;
@@ -964,6 +999,10 @@ __global__ __launch_bounds__(FW * WAVE) void acc_fused_kernel(AccArgs a, RecThr 
 // The walk itself (emit_block) is the chunked path's, statement by statement.
 // ===========================================================================
 #define SC_SPIN_LIMIT (1 << 18)     // a fraction of a second of polling
+#define SWEEP_NB 8                   // blocks of 64 rows per wavefront of the one-pass sweep
+#define SWEEP_SW 4                   // wavefronts (chunks) per super-chunk: 16 and 8 were
+                                     // measured slower (big workgroups hold their CU's wave
+                                     // slots until the slowest wavefront is done)
 #define SC_FLAG_AGG 1ull
 #define SC_FLAG_PRE 2ull
 __device__ __forceinline__ uint64_t sc_status(uint32_t gen, uint64_t flag, uint32_t v)
@@ -990,10 +1029,25 @@ __device__ __forceinline__ void sc_raise(uint64_t *__restrict__ out, int jlo, in
     }
 }
 
+// cj[k][r][j]: smallest TP count c with fl(c / num_gt) >= rec_thrs[j]
+// (np.searchsorted(rc, rec_thrs, side="left") on rc = tp / num_gt, reference
+// lvis_amodal/eval.py:386,406-408); 0 where the range has no ground truth
+__global__ void acc_cj_kernel(AccArgs a, RecThr rec)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)a.n_cat * a.n_rng * N_REC) return;
+    const int64_t kr = i / N_REC;
+    const int32_t ng = a.num_gt[kr];
+    a.cj[i] = ng > 0 ? recall_crossing(rec.v[i - kr * N_REC], ng) : 0;
+}
+
 // MODE 0: look-back (one pass); MODE 1: the SC totals come from
 // acc_sccount_kernel (two passes over the rows, no flags); MODE 2: that
 // counting pass itself (rows -> SC totals, nothing else)
-template <int SW, int MODE>
+// NB = 64-row blocks of a wavefront's chunk (8: 512 rows; the chunked kernels'
+// (NB * WAVE) = 256 rows would be 4 -- 512 is 0.281 against 0.297 ms at 21 M rows:
+// half the wavefronts, half the per-wavefront set-up, still 64 VGPRs)
+template <int SW, int MODE, int NB = SWEEP_NB>
 __global__ __launch_bounds__(SW * WAVE) __attribute__((amdgpu_waves_per_eu(8, 8)))
 void acc_sweep_kernel(AccArgs a, RecThr rec)
 {
@@ -1017,29 +1071,26 @@ void acc_sweep_kernel(AccArgs a, RecThr rec)
     const int32_t k = a.chunk_tab ? a.chunk_tab[sc] : chunk_cat(a.cat_chunk_off, a.n_cat, sc);
     const int32_t jsc = sc - a.cat_chunk_off[k];
     const int64_t cat_begin = a.cat_off[k], cat_end = a.cat_off[k + 1];
-    const int64_t start = cat_begin + ((int64_t)jsc * SW + wave) * ACC_CH;
-    const int len = (int)max((int64_t)0, min((int64_t)ACC_CH, cat_end - start));
+    const int64_t start = cat_begin + ((int64_t)jsc * SW + wave) * (NB * WAVE);
+    const int len = (int)max((int64_t)0, min((int64_t)(NB * WAVE), cat_end - start));
     const bool swept = k >= a.k_begin && k < a.k_end;       // (uniform)
     // ---- rows of my chunk: every load ahead of anything else
-    uint64_t tpw[ACC_BLK], fpw[ACC_BLK];
-#pragma unroll
-    for (int blk = 0; blk < ACC_BLK; blk++)
-        load_rows(a, start + blk * WAVE, word, max(0, min(WAVE, len - blk * WAVE)), lane,
-                  tpw[blk], fpw[blk]);
+    uint64_t tpw[NB], fpw[NB];
+    load_chunk(a, start, word, len, lane, tpw, fpw);
     const int r_lo = (word * WAVE) / N_THR;
     const int r_hi = min(a.n_rng - 1, (word * WAVE + WAVE - 1) / N_THR);
     if (MODE != 2) {
-        // recall crossings of the ranges this word overlaps (num_gt alone)
-        for (int i = threadIdx.x; i < (r_hi - r_lo + 1) * N_REC; i += SW * WAVE) {
-            const int q = i / N_REC;
-            const int32_t ngq = a.num_gt[(int64_t)k * a.n_rng + r_lo + q];
-            s_cj[q][i - q * N_REC] = ngq > 0 ? recall_crossing(rec.v[i - q * N_REC], ngq) : 0;
-        }
+        // recall crossings of the ranges this word overlaps: tabulated once per
+        // pass by acc_cj_kernel (they depend on num_gt alone; every workgroup
+        // working them out for itself was a tenth of this kernel's time)
+        const int32_t *__restrict__ src = a.cj + ((int64_t)k * a.n_rng + r_lo) * N_REC;
+        for (int i = threadIdx.x; i < (r_hi - r_lo + 1) * N_REC; i += SW * WAVE)
+            (&s_cj[0][0])[i] = src[i];
     }
-    uint64_t T[ACC_BLK], TF[ACC_BLK];
+    uint64_t T[NB], TF[NB];
     uint32_t tp_own = 0, fp_own = 0;
 #pragma unroll
-    for (int blk = 0; blk < ACC_BLK; blk++) {
+    for (int blk = 0; blk < NB; blk++) {
         uint64_t t_ = 0, f_ = 0;
         if (blk * WAVE < len) {
             t_ = transpose64(tpw[blk], lane);
@@ -1160,7 +1211,7 @@ void acc_sweep_kernel(AccArgs a, RecThr rec)
     uint64_t run = PR_ZERO;
     int32_t cnext = jcur > 0 ? cj[jcur - 1] : -1;
 #pragma unroll
-    for (int blk = ACC_BLK - 1; blk >= 0; blk--) {
+    for (int blk = NB - 1; blk >= 0; blk--) {
         if (blk * WAVE >= len) continue;
         emit_block<1>(live ? T[blk] : 0, live ? TF[blk] : 0, tp, n, run, jcur, cnext, out, cj);
     }
@@ -1347,35 +1398,35 @@ static int32_t max_chunks(int64_t n_dt, int32_t n_cat)
 }
 
 // ---- which sweep long categories take (TAOAMD_SWEEP, read once):
-//   "chunked" (default) the six chunked kernels;  "lookback" acc_sweep_kernel
-//   in one pass;  "twopass" acc_sweep_kernel behind a counting pass
-//   TAOAMD_SWEEP_SW = 8 | 16: wavefronts (chunks) per super-chunk
+//   "chunked"  the six chunked kernels;  "lookback"  acc_sweep_kernel in one
+//   pass;  "twopass"  acc_sweep_kernel behind a counting pass
 enum { SWEEP_CHUNKED = 0, SWEEP_LOOKBACK = 1, SWEEP_TWOPASS = 2 };
-static int sweep_mode()
+// Without TAOAMD_SWEEP: the one-pass sweep from SWEEP_ONEPASS_MIN (row, combo word)
+// pairs up.  At
+// 21 M rows (2000 videos) it takes 0.39 ms against 0.52 for the chunked kernels
+// (rows read once instead of three times plus a transposed copy); at 2 M rows
+// (Config 2) everything is latency and the chunked kernels' three short
+// launches win, 0.12 against 0.16 ms.
+#define SWEEP_ONEPASS_MIN 6000000
+static int sweep_mode(int64_t n_dt)
 {
     static const int m = [] {
         const char *e = getenv("TAOAMD_SWEEP");
         if (e && !strcmp(e, "lookback")) return (int)SWEEP_LOOKBACK;
         if (e && !strcmp(e, "twopass")) return (int)SWEEP_TWOPASS;
-        return (int)SWEEP_CHUNKED;
+        if (e && !strcmp(e, "chunked")) return (int)SWEEP_CHUNKED;
+        return -1;
     }();
-    return m;
+    if (m >= 0) return m;
+    return n_dt >= SWEEP_ONEPASS_MIN ? (int)SWEEP_LOOKBACK : (int)SWEEP_CHUNKED;
 }
-static int sweep_sw()
-{
-    static const int w = [] {
-        const char *e = getenv("TAOAMD_SWEEP_SW");
-        const int v = e ? atoi(e) : 4;
-        return v == 8 || v == 16 ? v : 4;
-    }();
-    return w;
-}
+// (n_dt here = rows x combo words: a track-level row is four words)
 #define SC_TICKETS 64           // header words of the SC tables (word 0: the error flag)
 static std::atomic<uint32_t> g_sc_gen{0};
 
 static size_t max_scs(int64_t n_dt, int32_t n_cat)
 {
-    return (size_t)(n_dt / (4 * ACC_CH) + n_cat + 1);
+    return (size_t)(n_dt / (SWEEP_SW * SWEEP_NB * WAVE) + n_cat + 1);
 }
 
 static size_t sc_workspace(int64_t n_dt, int32_t n_cat, size_t nw)
@@ -1493,14 +1544,14 @@ static int accumulate_compact(int64_t n_dt, int32_t n_cat, int32_t n_rng,
     a.inline_scans = max_segment > 0 && max_segment <= ACC_INLINE_CHUNKS * ACC_CH;
     unsigned char *w = (unsigned char *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     const size_t nc = (size_t)a.n_chunks_max, nw = (size_t)a.n_words;
-    const int mode = sweep_mode(), sw = sweep_sw();
+    const int mode = sweep_mode(n_dt * a.n_words);
     const size_t ns = max_scs(n_dt, n_cat);
     uint32_t *tickets = (uint32_t *)w;   w += align256(SC_TICKETS * 4);
     a.sc_stat = (uint64_t *)w;           w += align256(ns * nw * WAVE * 16);
     a.sc_max = (uint64_t *)w;            w += align256(ns * nw * WAVE * 8);
     a.sc_jhi = (uint8_t *)w;             w += align256(ns * nw * WAVE);
     if (mode != SWEEP_CHUNKED) {
-        a.sc_rows = sw * ACC_CH;
+        a.sc_rows = SWEEP_SW * SWEEP_NB * WAVE;
         a.inline_scans = 0;
     }
     a.cat_chunk_off = (int32_t *)w; w += align256(((size_t)n_cat + 1) * 4);
@@ -1527,6 +1578,10 @@ static int accumulate_compact(int64_t n_dt, int32_t n_cat, int32_t n_rng,
         return TAOAMD_OK;
     }
     if (mode != SWEEP_CHUNKED) {
+        {
+            const int64_t n_cj = (int64_t)n_cat * n_rng * N_REC;
+            TAO_TIMED("acc_cj_kernel", s, acc_cj_kernel<<<(unsigned)((n_cj + 255) / 256), 256, 0, s>>>(a, rec_thr()));
+        }
         // (every category's last SC may be a partial one; an SC past the table leaves at once)
         const unsigned grid = (unsigned)(((size_t)(n_dt / a.sc_rows) + (size_t)n_cat + 1) * nw);
         if (mode == SWEEP_LOOKBACK) {
@@ -1536,22 +1591,10 @@ static int accumulate_compact(int64_t n_dt, int32_t n_cat, int32_t n_rng,
             uint32_t g = ++g_sc_gen;
             a.sc_gen = (g & 0x3fffffffu) ? (g & 0x3fffffffu) : (++g_sc_gen & 0x3fffffffu);
             a.sc_error = tickets;
-            if (sw == 4) {
-                TAO_TIMED("acc_sweep_kernel", s, acc_sweep_kernel<4, 0><<<grid, 4 * WAVE, 0, s>>>(a, rec_thr()));
-            } else if (sw == 8) {
-                TAO_TIMED("acc_sweep_kernel", s, acc_sweep_kernel<8, 0><<<grid, 8 * WAVE, 0, s>>>(a, rec_thr()));
-            } else {
-                TAO_TIMED("acc_sweep_kernel", s, acc_sweep_kernel<16, 0><<<grid, 16 * WAVE, 0, s>>>(a, rec_thr()));
-            }
-        } else if (sw == 4) {
-            TAO_TIMED("acc_sccount_kernel", s, acc_sweep_kernel<4, 2><<<grid, 4 * WAVE, 0, s>>>(a, rec_thr()));
-            TAO_TIMED("acc_sweep_kernel", s, acc_sweep_kernel<4, 1><<<grid, 4 * WAVE, 0, s>>>(a, rec_thr()));
-        } else if (sw == 8) {
-            TAO_TIMED("acc_sccount_kernel", s, acc_sweep_kernel<8, 2><<<grid, 8 * WAVE, 0, s>>>(a, rec_thr()));
-            TAO_TIMED("acc_sweep_kernel", s, acc_sweep_kernel<8, 1><<<grid, 8 * WAVE, 0, s>>>(a, rec_thr()));
+            TAO_TIMED("acc_sweep_kernel", s, (acc_sweep_kernel<SWEEP_SW, 0><<<grid, SWEEP_SW * WAVE, 0, s>>>(a, rec_thr())));
         } else {
-            TAO_TIMED("acc_sccount_kernel", s, acc_sweep_kernel<16, 2><<<grid, 16 * WAVE, 0, s>>>(a, rec_thr()));
-            TAO_TIMED("acc_sweep_kernel", s, acc_sweep_kernel<16, 1><<<grid, 16 * WAVE, 0, s>>>(a, rec_thr()));
+            TAO_TIMED("acc_sccount_kernel", s, (acc_sweep_kernel<SWEEP_SW, 2><<<grid, SWEEP_SW * WAVE, 0, s>>>(a, rec_thr())));
+            TAO_TIMED("acc_sweep_kernel", s, (acc_sweep_kernel<SWEEP_SW, 1><<<grid, SWEEP_SW * WAVE, 0, s>>>(a, rec_thr())));
         }
         // the later SCs' envelope into the records (val final after this)
         const int64_t rows = (int64_t)(k_end - k_begin) * n_rng * N_THR;

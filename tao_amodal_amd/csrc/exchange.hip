@@ -471,6 +471,8 @@ extern "C" int taoamd_exchange_merge(int64_t n_recv, int32_t world, int32_t bloc
     if (n_recv == 0) return TAOAMD_OK;
     if (!records || !src_base || !run_off || !cat_base || !matched || !ignored)
         return TAOAMD_ERR_ARG;
+    // dense [n_recv][n_words] tables only (see taoamd_gather_rows)
+    if (ignored == matched + 1 && n_recv * n_words > 1) return TAOAMD_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     TAO_TIMED("ex_merge_kernel", s, ex_merge_kernel<<<(unsigned)((n_recv + 255) / 256), 256, 0, s>>>(
         n_recv, world, block_cats, k0, records, width, n_words, src_base, run_off,

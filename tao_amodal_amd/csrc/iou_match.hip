@@ -341,7 +341,13 @@ __global__ __launch_bounds__(256) void match_kernel(MatchArgs a, IouThr thr)
 //   * lane = combo: the sequential greedy over the run's detections; the
 //     "ignored" / "taken" sets are 64-bit masks over the run's GTs, so moving
 //     from one cell to the next needs no reset at all.
-template <bool FUSED>
+// FAST (round 4): the image level's production layout -- boxes fused, dt_meta,
+// dst, range masks from the flags, no IoU output -- known at compile time, so
+// that every load that depends on the run descriptor alone is issued in ONE
+// batch: with the layout decided by run-time (uniform) branches the compiler
+// put an s_waitcnt vmcnt(0) behind each of them, four HBM round trips in a
+// row where two are needed (descriptor, then everything).
+template <bool FUSED, bool FAST = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void match_group_kernel(MatchArgs a, IouThr thr)
 {
     __shared__ double4 s_gt[4][WAVE];
@@ -358,7 +364,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const uint32_t blk = a.xcd ? xcd_block(blockIdx.x, gridDim.x) : blockIdx.x;
     const int64_t item = (int64_t)blk * 4 + wave;
     if (item >= (int64_t)a.n_groups * a.n_words) return;
-    const int64_t grp = item / a.n_words;
+    // (n_words is 1 or 4: no 64-bit division in the prologue)
+    const int64_t grp = a.n_words == 1 ? item : a.n_words == 4 ? item >> 2 : item / a.n_words;
     const int word = (int)(item - grp * a.n_words);
     // Everything a wavefront needs is at most two dependent loads away: the
     // run descriptor, then the per-detection / per-GT rows (the host resolved
@@ -380,7 +387,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     int32_t t_flags = 0, t_rng = 0, gb = 0, dloc = 0, Gc = 0;
     int64_t t_row = 0, t_ioff = 0;
     double4 B = make_double4(0, 0, 0, 0);
-    if (lane < nD) {
+    uint32_t grng = 0xffffffffu;
+    bool ghid = false;
+    if (FAST) {
+        // lanes past the run's detections / GTs re-read its last one
+        const int32_t d = d0 + min(lane, nD - 1);
+        const int32_t g = g0 + min(lane, max(nG, 1) - 1);
+        const uint32_t mt = a.dt_meta[d];
+        const int32_t row = a.dst[d];
+        const double4 box = reinterpret_cast<const double4 *>(a.dt_box)[d];
+        uint32_t gr = 0xffffffffu;
+        uint8_t gf = 0;
+        double4 gbx = make_double4(0, 0, 0, 0);
+        if (nG > 0) {
+            gr = a.gt_rng[g];
+            gf = a.gt_flags[g];
+            gbx = reinterpret_cast<const double4 *>(a.gt_box)[g];
+        }
+        if (lane < nD) {
+            t_flags = (int32_t)(mt & 0xffu);
+            gb = (int32_t)((mt >> 8) & 63u);
+            Gc = (int32_t)((mt >> 14) & 15u);
+            dloc = (int32_t)(mt >> 18);
+            t_rng = (int32_t)((t_flags & TAOAMD_DT_IGNORE_UNMATCHED)
+                                  ? 0xffffffffu >> (32 - a.n_rng) : 0u);
+            t_row = row;
+            B = box;
+        }
+        if (lane < nG) {
+            grng = gr;
+            ghid = gf & TAOAMD_GT_ID_HIDDEN;
+            s_gt[wave][lane] = gbx;
+        }
+    } else if (lane < nD) {
         const int32_t d = d0 + lane;
         if (FUSED && a.dt_meta != nullptr) {
             // one word instead of the 16-byte row and the flag byte (the cell
@@ -404,9 +443,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         if (FUSED) B = reinterpret_cast<const double4 *>(a.dt_box)[d];
     }
     // ---- lane = GT of the run
-    uint32_t grng = 0xffffffffu;
-    bool ghid = false;
-    if (lane < nG) {
+    if (!FAST && lane < nG) {
         grng = a.gt_rng[g0 + lane];
         ghid = a.gt_flags[g0 + lane] & TAOAMD_GT_ID_HIDDEN;
         if (FUSED) s_gt[wave][lane] = reinterpret_cast<const double4 *>(a.gt_box)[g0 + lane];
@@ -424,6 +461,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const double tmin = fmin(thr.v[0], 1 - 1e-10);
     int cand = -1, ncand = 0;
     double vc = 0.0;
+    // (IoUs from memory: a detection's row of up to GRP_GCAP values in one batch
+    // of loads -- inside the loop below every load was waited for on its own)
+    double vmem[FUSED ? 1 : GRP_GCAP];
+    if (!FUSED) {
+        const int64_t base = t_ioff + (int64_t)dloc * Gc;
+#pragma unroll
+        for (int k = 0; k < GRP_GCAP; k++)
+            vmem[k] = a.iou[lane < nD && k < Gc ? base + k : 0];
+    }
+#pragma unroll
     for (int k = 0; k < GRP_GCAP; k++) {
         const bool has = lane < nD && k < Gc;
         if (__ballot(has) == 0) break;
@@ -435,7 +482,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 if (a.ious_out != nullptr && word == 0)
                     a.ious_out[t_ioff + (int64_t)dloc * Gc + k] = v;
             } else {
-                v = a.iou[t_ioff + (int64_t)dloc * Gc + k];
+                v = vmem[k];
                 s_iou[wave][lane * GRP_GCAP + k] = v;
             }
             if (!(v < tmin)) { ncand++; cand = k; vc = v; }
@@ -838,7 +885,9 @@ extern "C" int taoamd_match(int64_t n_cells, const int32_t *cell_dt_off,
     hipStream_t s = (hipStream_t)stream;
     if (planned && n_groups > 0) {
         const unsigned gb = (unsigned)(((int64_t)n_groups * a.n_words + 3) / 4);
-        if (fused) TAO_TIMED("match_group_kernel", s, match_group_kernel<true><<<gb, 256, 0, s>>>(a, iou_thr()));
+        const bool fast = fused && a.dt_meta && a.dst && !a.dt_rng && !a.ious_out && !a.match_gt;
+        if (fast) TAO_TIMED("match_group_kernel", s, (match_group_kernel<true, true><<<gb, 256, 0, s>>>(a, iou_thr())));
+        else if (fused) TAO_TIMED("match_group_kernel", s, match_group_kernel<true><<<gb, 256, 0, s>>>(a, iou_thr()));
         else TAO_TIMED("match_group_kernel", s, match_group_kernel<false><<<gb, 256, 0, s>>>(a, iou_thr()));
     }
     const int64_t cells = planned ? n_singles : n_cells;
@@ -889,6 +938,10 @@ extern "C" int taoamd_gather_rows(int64_t n, int32_t n_words,
 {
     if (n == 0) return TAOAMD_OK;
     if (n_words < 1 || src_stride < n_words) return TAOAMD_ERR_ARG;
+    // the destination tables are DENSE [n][n_words]; the interleaved pair
+    // layout of taoamd_match / taoamd_accumulate (ignored == matched + 1) is
+    // not written here: refused rather than silently scrambled
+    if (dst_ignored == dst_matched + 1 && n * n_words > 1) return TAOAMD_ERR_ARG;
     const int64_t total = n * n_words;
     unsigned blocks = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     TAO_TIMED("gather_rows_kernel", (hipStream_t)stream, gather_rows_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(

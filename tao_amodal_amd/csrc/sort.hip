@@ -1241,6 +1241,109 @@ __device__ __forceinline__ void ss_split_chunk(const SsArgs &a, const SsChunk &c
     }
 }
 
+// Round 4: the splitters of one chunk by a WORKGROUP.  One wavefront sorting a
+// chunk's 1000-2000 samples in 16-32 registers per lane was 0.09 ms of pure
+// latency at the head of the step's critical chain (1300 wavefronts on 1024
+// SIMDs, nothing to hide behind).  Here the four wavefronts of a workgroup each
+// sort a quarter of the samples (every fourth one: four runs of the same
+// distribution; 8 registers per lane, a fifth of the network), park their
+// sorted runs in LDS, and an element's rank among all samples is its place in
+// its own run plus, by binary search, the elements of the other three runs
+// below it -- the packed words are distinct (they end in the sample's position
+// in the chunk), so there are no ties to break.
+template <int R>
+__device__ __forceinline__ void ss_split_chunk4(const SsArgs &a, const SsChunk &c, int lane,
+                                                int wave, uint64_t (*runs)[WAVE * 8])
+{
+    const int32_t S = ss_over(c.n), B = c.n_buckets, m = S * B;
+    const int32_t stride = c.n / m;
+    double p[R];
+    // every lane loads R samples whether it needs them or not (a lane past the
+    // m-th sample reads element 0): the R loads are in flight together -- under
+    // `if (j < m)` the compiler gave each load its own branch and waited for it,
+    // R round trips to HBM in a row (what the one-wavefront kernel's 0.09 ms
+    // mostly were: 32 of them)
+    int32_t rel[R];
+    double sc[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int j = (lane * R + r) * 4 + wave;  // my quarter: samples j = wave (mod 4)
+        rel[r] = j < m ? j * stride + (int32_t)(ss_mix((uint32_t)j * 0x9e3779b9u ^
+                                                       (uint32_t)c.begin) % (uint32_t)stride)
+                       : 0;
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) sc[r] = a.score[c.begin + rel[r]];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int j = (lane * R + r) * 4 + wave;
+        p[r] = j < m ? ss_pack(desc_key(sc[r]), 0, 64 - SS_SPLIT_KEY_BITS, rel[r])
+                     : __longlong_as_double((long long)SS_PAD);
+    }
+    ss_bitonic_packed<R>(p, lane);
+#pragma unroll
+    for (int r = 0; r < R; r++) runs[wave][lane * R + r] = (uint64_t)__double_as_longlong(p[r]);
+    // (slots past R * 64 of a run are never read: every search is bounded by R * 64)
+    __syncthreads();
+    // ranks of my R elements: the searches of all of them step together
+    // (fixed depth log2(R * 64): R x 3 independent LDS reads per step)
+    int32_t rank[R];
+    uint64_t v[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        v[r] = (uint64_t)__double_as_longlong(p[r]);
+        rank[r] = lane * R + r;
+    }
+#pragma unroll
+    for (int o = 1; o < 4; o++) {
+        const uint64_t *__restrict__ run = runs[(wave + o) & 3];
+        int32_t lo[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) lo[r] = 0;
+#pragma unroll
+        for (int half = R * WAVE / 2; half > 0; half >>= 1) {
+#pragma unroll
+            for (int r = 0; r < R; r++)            // (lo + half - 1 < R * 64 always)
+                lo[r] += run[lo[r] + half - 1] < v[r] ? half : 0;
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) rank[r] += lo[r] + (run[lo[r]] < v[r] ? 1 : 0);
+    }
+    // splitter b = the sample of rank b * S - 1: its full key from the scores
+    // (all of a lane's candidate loads in flight together, as above)
+    int32_t at[R];
+    double ks[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        at[r] = c.begin + (int32_t)(v[r] & ((1u << SS_IDX_BITS) - 1));
+        const int q = rank[r] + 1;
+        if (v[r] == SS_PAD || q % S != 0 || q / S >= B) at[r] = -1;
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) ks[r] = a.score[at[r] >= 0 ? at[r] : c.begin];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        if (at[r] >= 0) {
+            const int q = rank[r] + 1;
+            a.spl_key[c.bucket0 + q / S] = desc_key(ks[r]);
+            a.spl_idx[c.bucket0 + q / S] = at[r];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void ss_split4_kernel(SsArgs a, int32_t n_split)
+{
+    __shared__ uint64_t runs[4][WAVE * 8];
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const SsChunk c = a.chunks[a.split_list[blockIdx.x]];
+    const int32_t m = ss_over(c.n) * c.n_buckets;  // <= 2048 samples, <= 512 a wavefront
+    if (m <= 256) ss_split_chunk4<1>(a, c, lane, wave, runs);
+    else if (m <= 512) ss_split_chunk4<2>(a, c, lane, wave, runs);
+    else if (m <= 1024) ss_split_chunk4<4>(a, c, lane, wave, runs);
+    else ss_split_chunk4<8>(a, c, lane, wave, runs);
+}
+
 __global__ __launch_bounds__(256) void ss_split_kernel(SsArgs a, int32_t n_split)
 {
     const int lane = lane_id();
@@ -1285,12 +1388,20 @@ __global__ __launch_bounds__(SEG_THREADS) void ss_scatter_kernel(SsArgs a)
     }
     uint64_t kr[SEG_ROUNDS];
     int32_t br[SEG_ROUNDS], rr[SEG_ROUNDS];
+    // all of a thread's scores first: the eleven loads in flight together
+    // (round 4: loaded inside `if (i < t1)` the compiler gave every load its
+    // own branch and s_waitcnt vmcnt(0) -- eleven round trips to HBM in a row)
+#pragma unroll
+    for (int r = 0; r < SEG_ROUNDS; r++) {
+        const int32_t i = t0 + r * SEG_THREADS + (int32_t)threadIdx.x;
+        kr[r] = desc_key(a.score[i < t1 ? i : t0]);
+    }
 #pragma unroll
     for (int r = 0; r < SEG_ROUNDS; r++) {
         const int32_t i = t0 + r * SEG_THREADS + (int32_t)threadIdx.x;
         br[r] = -1;
         if (i < t1) {
-            const uint64_t k = desc_key(a.score[i]);
+            const uint64_t k = kr[r];
             // splitters 1 .. B-1 that precede (k, i); an element equal to a
             // splitter closes the lower bucket.  (A fixed-depth search with all
             // rounds of a thread in step -- their LDS reads in flight together --
@@ -1302,7 +1413,6 @@ __global__ __launch_bounds__(SEG_THREADS) void ss_scatter_kernel(SsArgs a)
                 const bool before = sk < k || (sk == k && s_idx[mid] < i);
                 if (before) lo = mid + 1; else hi = mid;
             }
-            kr[r] = k;
             br[r] = lo - 1;
             rr[r] = SS_DBG(a, 32) ? (int32_t)threadIdx.x >> 4 : atomicAdd(&s_cnt[lo - 1], 1);
         }
@@ -1365,21 +1475,32 @@ __device__ __forceinline__ bool ss_sort_bucket(const SsArgs &a, const SsChunk &c
     uint64_t k[R];
     int32_t x[R];
     uint64_t kmin = ~0ull, kmax = 0;
+    // every slot's loads issued before the first is looked at (slots past the
+    // bucket's count read slot 0): see ss_scatter_kernel
+    if (sk == nullptr) {                 // a direct chunk: read from the scores
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int e = r * WAVE + lane;
+            k[r] = desc_key(a.score[c.begin + (e < count ? e : 0)]);
+            x[r] = c.begin + e;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int e = r * WAVE + lane;
+            k[r] = sk[e < count ? e : 0];
+            x[r] = si[e < count ? e : 0];
+        }
+    }
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const int e = r * WAVE + lane;
-        k[r] = ~0ull;
-        x[r] = INT32_MAX;
         if (e < count) {
-            if (sk == nullptr) {         // a direct chunk: read from the scores
-                k[r] = desc_key(a.score[c.begin + e]);
-                x[r] = c.begin + e;
-            } else {
-                k[r] = sk[e];
-                x[r] = si[e];
-            }
             kmin = k[r] < kmin ? k[r] : kmin;
             kmax = k[r] > kmax ? k[r] : kmax;
+        } else {
+            k[r] = ~0ull;
+            x[r] = INT32_MAX;
         }
         full[e] = k[r];
     }
@@ -1698,7 +1819,12 @@ extern "C" int taoamd_sort_sampled(int64_t n, int32_t n_cat, const int32_t *cat_
     }
     TAO_HIP(hipMemsetAsync(a.cursor, 0, align256((size_t)n_buckets * 4 + 256), s));
     if (n_split > 0) {
-        TAO_TIMED("ss_split_kernel", s, ss_split_kernel<<<(unsigned)((n_split + 3) / 4), 256, 0, s>>>(a, n_split));
+        // (TAOAMD_SS_SPLIT=1: one wavefront per chunk, the round-3 kernel, for A/B timing)
+        static const bool one_wave = getenv("TAOAMD_SS_SPLIT") && atoi(getenv("TAOAMD_SS_SPLIT")) == 1;
+        if (one_wave)
+            TAO_TIMED("ss_split_kernel", s, ss_split_kernel<<<(unsigned)((n_split + 3) / 4), 256, 0, s>>>(a, n_split));
+        else
+            TAO_TIMED("ss_split_kernel", s, ss_split4_kernel<<<(unsigned)n_split, 256, 0, s>>>(a, n_split));
         TAO_TIMED("ss_scatter_kernel", s, ss_scatter_kernel<<<(unsigned)n_stiles, SEG_THREADS, 0, s>>>(a));
     }
     TAO_TIMED("ss_sort_kernel", s, ss_sort_kernel<<<(unsigned)((n_buckets + 3) / 4), 256, 0, s>>>(a));

@@ -434,7 +434,26 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
         const double *__restrict__ gr = rows[b] + rowg * TT_RS;
         const uint32_t dm = rmask[b][rowd], gm = rmask[b][rowg];
         if (MODE == 0) {
-            if (anydt) {
+            // Round 4: the adder's LDS reads are what a chunk costs (ten 16-byte
+            // reads per lane and position pair: 40 KB per chunk and task, seven
+            // tasks on a CU's 128 B / clock), and two thirds of a task's
+            // (pair, chunk) steps find at most ONE of the pair's tracks in the
+            // chunk.  Such a step adds that track's areas alone -- against far
+            // boxes (x = 1e300, area 0) the general formula gives i_ = 0 and
+            // u_ = (a + 0) - 0 = a, the same bits -- and a step without either
+            // track adds zeros, i.e. nothing.  Lanes branch on the rows' frame
+            // masks of the chunk: fewer lanes, fewer LDS reads.
+            const bool both = dm != 0 && gm != 0;
+            if (anydt && !both && (dm | gm) != 0) {
+                const double2 *__restrict__ a2 =
+                    reinterpret_cast<const double2 *>((dm != 0 ? dr : gr) + 4 * TT_P);
+#pragma unroll
+                for (int pp = 0; pp < TT_P / 2; pp++) {
+                    const double2 ar = a2[pp];
+                    u += ar.x;
+                    u += ar.y;
+                }
+            } else if (anydt && both) {
                 // two positions per 16-byte LDS read of every field
                 const double2 *__restrict__ d2 = reinterpret_cast<const double2 *>(dr);
                 const double2 *__restrict__ g2 = reinterpret_cast<const double2 *>(gr);
@@ -462,7 +481,7 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
                         i += i_;
                     }
                 }
-            } else {
+            } else if (!anydt && gm != 0) {
 #pragma unroll
                 for (int pp = 0; pp < TT_P; pp++) u += gr[4 * TT_P + pp];
             }

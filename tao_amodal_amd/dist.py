@@ -53,11 +53,12 @@ standing in for the kernels.
 """
 import os
 
-# the by-video step keeps 4 compute streams + RCCL's busy: with the default of
-# 4 hardware queues per process they alias and serialise (1.25 -> 0.94 ms/step
-# with 8).  Read by the HIP runtime when it starts, i.e. this has to run before
-# the first device call of the process.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# (the by-video step keeps 4 compute streams + RCCL's busy: with the default of
+# 4 hardware queues per process they alias and serialise -- 1.25 -> 0.94 ms/step
+# with GPU_MAX_HW_QUEUES=8.  The HIP runtime reads it when it starts: whoever
+# starts a multi-GPU process sets it before the first device call --
+# evaluation/_dist.init_from_env, bench.py -- importing this module does not
+# touch the environment.)
 
 import numpy as np
 import torch
@@ -205,7 +206,7 @@ class ShardedEval:
         cnt[:K] = np.diff(dp.cat_off_host)
         send = torch.from_numpy(cnt).to(dev)                  # [world * Kb]
         recv = torch.empty_like(send)                         # [source][kb]
-        dist.all_to_all_single(recv, send, group=group)
+        all_to_all(recv, send, group=group)
         rc = recv.cpu().numpy().reshape(world, Kb)
         self.send_counts = cnt.reshape(world, Kb).sum(1).tolist()
         self.recv_counts = rc.sum(1).tolist()
@@ -272,10 +273,9 @@ class ShardedEval:
                                self.totals, self.xws)
 
     def _exchange(self):
-        dist.all_to_all_single(
-            self.recv[:self.n_recv], self.send[:self.dp.n_dt],
-            output_split_sizes=self.recv_counts,
-            input_split_sizes=self.send_counts, group=self.group)
+        all_to_all(self.recv[:self.n_recv], self.send[:self.dp.n_dt],
+                   output_split_sizes=self.recv_counts,
+                   input_split_sizes=self.send_counts, group=self.group)
 
     def step(self, aux=None):
         """`aux`: a second stream for the range masks and the num_gt
@@ -327,29 +327,48 @@ class ShardedEval:
             raise _lib.TaoAmdError("exchange chunk overflow: the ground truth "
                                    "changed after the plan was built")
 
+    def owner_rows(self, ids):
+        """After step(): the rows of this rank's category block as the sweep
+        saw them -- (ids, matched, ignored, cat_base) with `ids` (int64 device
+        tensor, one per detection of this rank) taken through the very exchange
+        and merge the records went through (a second all_to_all whose records
+        carry the id where the matched word was: same scores, same runs, same
+        places).  Collective.  The source of eval['dt_pointers'] in a multi-GPU
+        run (T/eval.py:575-584)."""
+        dp, ws = self.dp, self.ws
+        send = torch.zeros_like(self.send)
+        if dp.n_dt:
+            slot = ws.dst[:dp.n_dt].long()
+            send[slot, 0] = dp.t["dt_score"].view(torch.int64)
+            send[slot, REC_HEAD] = ids
+        recv = torch.zeros_like(self.recv)
+        all_to_all(recv[:self.n_recv], send[:dp.n_dt],
+                   output_split_sizes=self.recv_counts,
+                   input_split_sizes=self.send_counts, group=self.group)
+        tab = torch.zeros_like(self.matched)
+        ign = torch.zeros_like(self.ignored)
+        self.be.merge_runs(self.n_recv, self.world, self.Kb, self.k0, recv, self.W,
+                           dp.n_words, self.src_base, self.run_off, self.cat_base,
+                           tab, ign)
+        n = self.n_recv
+        return (tab[:n, 0].cpu().numpy(), self.matched[:n].cpu().numpy().view(np.uint64),
+                self.ignored[:n].cpu().numpy().view(np.uint64),
+                self.cat_base.cpu().numpy())
 
-_PLAIN_ALL_TO_ALL = None
 
-
-def stage_all_to_all_through_host():
-    """gloo moves no device tensors through all_to_all: when the ranks of a
-    job share one GPU (a development box, the 2-rank tests) and therefore talk
-    over gloo, the record exchange is staged on the host.  RCCL jobs -- one GPU
-    per rank -- never come here."""
-    global _PLAIN_ALL_TO_ALL
-    if _PLAIN_ALL_TO_ALL is not None:
-        return
-    _PLAIN_ALL_TO_ALL = plain = dist.all_to_all_single
-
-    def staged(output, input, output_split_sizes=None, input_split_sizes=None,
-               group=None):
-        if not output.is_cuda:
-            return plain(output, input, output_split_sizes, input_split_sizes,
-                         group=group)
+def all_to_all(output, input, output_split_sizes=None, input_split_sizes=None, group=None):
+    """``dist.all_to_all_single`` of the record exchange.  One GPU per rank:
+    RCCL, device buffers over xGMI.  When the ranks of a job share one GPU (a
+    development box, the multi-rank tests on a one-GPU box) they talk over
+    gloo, which moves no device tensors through all_to_all: staged on the host."""
+    if output.is_cuda and dist.get_backend(group) == "gloo":
         o = torch.empty(output.shape, dtype=output.dtype)
-        plain(o, input.cpu(), output_split_sizes, input_split_sizes, group=group)
+        dist.all_to_all_single(o, input.cpu(), output_split_sizes, input_split_sizes,
+                               group=group)
         output.copy_(o)
-    dist.all_to_all_single = staged
+        return
+    dist.all_to_all_single(output, input, output_split_sizes, input_split_sizes,
+                           group=group)
 
 
 def gather_visit_universe(gt, device, group=None):
@@ -483,6 +502,18 @@ class CategoryShardedEval:
     def step(self):
         self.compute()
         self.assemble()
+
+    def owner_rows(self, ids):
+        """ShardedEval.owner_rows for the category partition: the rows of this
+        rank's block are its own pass's (no exchange)."""
+        dp, ws = self.dp, self.ws
+        n = dp.n_dt
+        order = ws.order[:n].long()
+        hi = min(self.k0 + self.Kb, dp.n_cat)
+        base = np.asarray(dp.cat_off_host[self.k0:hi + 1], dtype=np.int64)
+        base = np.concatenate([base, np.full(self.Kb + 1 - len(base), base[-1] if len(base) else 0)])
+        return (ids[order].cpu().numpy(), ws.matched[:n].cpu().numpy().view(np.uint64),
+                ws.ignored[:n].cpu().numpy().view(np.uint64), base - (base[0] if len(base) else 0))
 
     def check(self):
         """Host-side guard (synchronises): the capacity held."""

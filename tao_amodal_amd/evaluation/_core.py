@@ -154,13 +154,18 @@ class GpuRun:
         slot[c.thr_blocks[0][0]] = np.arange(c.T)
         return slot.tolist()
 
-    def sorted_rows(self):
+    def pointer_tables(self):
+        """What eval['dt_pointers'] is read from: the detections' ids and
+        (matched, ignored) words in the sweep's order (category-major, stable
+        descending score), num_gt and the categories' row offsets."""
         n = self.dp.n_dt
         ws = self.ws
-        return (ws.order[:n].cpu().numpy().astype(np.int64),
-                ws.matched[:n].cpu().numpy().view(np.uint64),
-                ws.ignored[:n].cpu().numpy().view(np.uint64),
-                ws.num_gt.cpu().numpy())
+        order = ws.order[:n].cpu().numpy().astype(np.int64)
+        return {"ids": np.asarray(self.flat.dt_id)[order],
+                "matched": ws.matched[:n].cpu().numpy().view(np.uint64),
+                "ignored": ws.ignored[:n].cpu().numpy().view(np.uint64),
+                "num_gt": ws.num_gt.cpu().numpy(),
+                "cat_off": np.asarray(self.dp.cat_off_host, dtype=np.int64)}
 
 
 def _bit(words, combo):
@@ -331,19 +336,19 @@ class LazyPointers(Mapping):
 
     def _data(self):
         if self._rows is None:
-            self._rows = self.run.sorted_rows()
+            self._rows = self.run.pointer_tables()
         return self._rows
 
     def leaf(self, k, r):
-        order, matched, ignored, num_gt = self._data()
-        if num_gt[k, r] == 0:
+        d = self._data()
+        matched, ignored = d["matched"], d["ignored"]
+        if d["num_gt"][k, r] == 0:
             return {}
-        lo, hi = self.run.dp.cat_off_host[k], self.run.dp.cat_off_host[k + 1]
+        lo, hi = int(d["cat_off"][k]), int(d["cat_off"][k + 1])
         slots = self.run.thr_slots()
         m = np.stack([_bit(matched[lo:hi], r * N_THR + t) for t in slots])
         i = np.stack([_bit(ignored[lo:hi], r * N_THR + t) for t in slots])
-        return {"dt_ids": self.run.flat.dt_id[order[lo:hi]],
-                "tps": m & ~i, "fps": ~m & ~i}
+        return {"dt_ids": d["ids"][lo:hi], "tps": m & ~i, "fps": ~m & ~i}
 
     def __getitem__(self, k):
         if not 0 <= k < len(self):

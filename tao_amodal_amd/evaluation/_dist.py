@@ -45,12 +45,17 @@ class Ctx:
         # split the categories instead of the videos (annotation files in which
         # two records share an id)
         self.whole = False
+        # True: accumulate() also assembles eval['dt_pointers'] (collective: the
+        # rows of a category live on its owner rank and are gathered to all)
+        self.pointers = False
 
 
 def init_from_env():
     """Process group from the launcher's environment (torchrun).  One GPU per
     rank -> RCCL; fewer GPUs than ranks (a development box) -> the ranks share
     GPU 0 and talk over gloo, device tensors staged through the host."""
+    # (read by the HIP runtime when it starts: before the first device call)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     import torch.distributed as dist
     world = int(os.environ["WORLD_SIZE"])
@@ -71,9 +76,6 @@ def init_from_env():
             dist.init_process_group("gloo", rank=rank, world_size=world)
     backend = dist.get_backend()
     host = dist.new_group(backend="gloo") if backend != "gloo" else None
-    if backend == "gloo":
-        from .. import dist as tdist
-        tdist.stage_all_to_all_through_host()
     return Ctx(rank, world, dev, None, host, backend)
 
 
@@ -219,7 +221,8 @@ def shard_inputs(gt, dt, first, ctx):
     new_tid, n_changed = unique_track_ids(dt, first, ctx)
 
     def pack(track_id):
-        m = np.empty((len(dt), 9), dtype=np.int64)
+        m = np.empty((len(dt), 10), dtype=np.int64)
+        m[:, 9] = first + np.arange(len(dt))       # place in the file's list
         m[:, 0] = dt.image_id
         m[:, 1] = dt.category_id
         m[:, 2:6] = np.ascontiguousarray(dt.bbox, dtype=np.float64).view(np.int64)
@@ -229,10 +232,12 @@ def shard_inputs(gt, dt, first, ctx):
         return m
 
     def unpack(m):
-        return DTColumns(image_id=m[:, 0].copy(), category_id=m[:, 1].copy(),
-                         bbox=np.ascontiguousarray(m[:, 2:6]).view(np.float64),
-                         score=np.ascontiguousarray(m[:, 6]).view(np.float64),
-                         track_id=m[:, 7].copy(), video_id=m[:, 8].copy())
+        d = DTColumns(image_id=m[:, 0].copy(), category_id=m[:, 1].copy(),
+                      bbox=np.ascontiguousarray(m[:, 2:6]).view(np.float64),
+                      score=np.ascontiguousarray(m[:, 6]).view(np.float64),
+                      track_id=m[:, 7].copy(), video_id=m[:, 8].copy())
+        d.file_pos = m[:, 9].copy()
+        return d
     # (the image level never looks at track ids: it gets the renumbered ones too)
     mat = pack(new_tid)
     if whole:
@@ -257,8 +262,15 @@ class DistRun:
     and downloads the assembled tables, identical on every rank.  The lazy
     per-cell views show the rank's own cells."""
 
-    def __init__(self, flat, ctx, iou_3d_type="3d_iou", constants=None):
+    def __init__(self, flat, ctx, iou_3d_type="3d_iou", constants=None, dt=None,
+                 max_dets=300):
+        """``dt`` / ``max_dets`` (image level): the share's prediction columns
+        and the cut of LVISResults -- what the global ``id`` of a detection
+        (its place in the WHOLE post-truncation list, L/results.py:73-84) is
+        worked out from when ctx.pointers asks for eval['dt_pointers']."""
         import torch
+        self.dt, self.max_dets = dt, max_dets
+        self._pointers = None
         from .. import dist as tdist, engine
         from ._core import applied, timed
         self.engine, self.torch = engine, torch
@@ -276,8 +288,8 @@ class DistRun:
                 # `flat` is the whole problem on every rank: this rank's
                 # category block of its cells
                 k0, k1, _ = tdist.category_block(len(flat.cat_ids), ctx.rank, ctx.world)
-                self.dp = engine.DeviceProblem(tdist.shard_by_category(flat, k0, k1),
-                                               self.device, iou_3d_type)
+                self._shard = tdist.shard_by_category(flat, k0, k1)
+                self.dp = engine.DeviceProblem(self._shard, self.device, iou_3d_type)
                 self.ws = engine.Workspace(self.dp)
                 self.sharded = tdist.CategoryShardedEval(
                     self.dp, self.ws, ctx.rank, ctx.world, tdist.HipBackend(), ctx.group)
@@ -305,6 +317,8 @@ class DistRun:
         with timed("download"):
             self.precision = self.sharded.precision.cpu().numpy()
             self.recall = self.sharded.recall.cpu().numpy()
+        if self.ctx.pointers:
+            self._pointers = self._gather_pointers()
         c = self.constants
         if c is not None:
             # the caller's thresholds, in the caller's order (GpuRun._accumulate_blocks)
@@ -333,8 +347,69 @@ class DistRun:
                     self.flat, self.device, detail=True, iou_3d_type=self.iou_3d_type)
         return self._detail
 
-    def sorted_rows(self):
-        raise NotImplementedError(
-            "eval['dt_pointers'] is not assembled in a multi-GPU run: a "
-            "category's rows live on its owner rank (run on one GPU to inspect "
-            "them)")
+    # ------------------------------------------------ eval['dt_pointers']
+    def _global_ids(self):
+        """`id` of this rank's detections as the reference numbers them."""
+        from .. import flatten
+        flat = self._shard if self.ctx.whole else self.flat
+        local = np.asarray(flat.dt_id, dtype=np.int64)
+        if flat.kind == "tao" or self.ctx.whole or self.dt is None:
+            return local            # track ids; ids of the whole list
+        # image level: id = 1 + place in the post-truncation list, which groups
+        # the kept boxes by image in the order the images FIRST APPEAR in the
+        # file (L/results.py:75-84).  A share holds whole images in file order:
+        # its local list has the same groups in the same relative order, so an
+        # id moves by (global - local) first row of its image's group.
+        dt = self.dt
+        keep = flatten.limit_dets_per_image(dt, self.max_dets)
+        img = np.asarray(dt.image_id)[keep]
+        head = np.ones(len(keep), bool)
+        head[1:] = img[1:] != img[:-1]
+        starts = np.flatnonzero(head)
+        counts = np.diff(np.r_[starts, len(keep)])
+        first_row = np.asarray(dt.file_pos)[
+            np.unique(np.asarray(dt.image_id), return_index=True)[1]]
+        # (np.unique sorts by image id: bring the first rows into group order)
+        by_id = np.argsort(img[starts], kind="stable")
+        first_pos = np.empty(len(starts), dtype=np.int64)
+        first_pos[by_id] = first_row
+        mine = np.stack([first_pos, counts], 1) if len(starts) else np.zeros((0, 2), np.int64)
+        every = _gather_arrays(mine, self.ctx)
+        table = np.concatenate(every)
+        o = np.argsort(table[:, 0], kind="stable")
+        base = np.empty(len(table), dtype=np.int64)
+        base[o] = np.cumsum(table[o, 1]) - table[o, 1]
+        at = sum(len(e) for e in every[:self.ctx.rank])
+        gbase = base[at:at + len(starts)]
+        pos = local - 1
+        run = np.searchsorted(starts, pos, "right") - 1
+        return gbase[run] + (pos - starts[run]) + 1
+
+    def _gather_pointers(self):
+        """Collective: every rank ends with the whole sorted tables."""
+        ids = self.torch.from_numpy(np.ascontiguousarray(self._global_ids())).to(self.device)
+        rows = self.sharded.owner_rows(ids)
+        every = [None] * self.ctx.world
+        import torch.distributed as dist
+        dist.all_gather_object(every, rows, group=self.ctx.host_group)
+        K = self.dp.n_cat
+        cat_off = np.zeros(K + 1, dtype=np.int64)
+        at, k = 0, 0
+        for ids_r, _m, _i, base in every:
+            kb = min(len(base) - 1, K - k)
+            cat_off[k:k + kb + 1] = at + base[:kb + 1]
+            at += len(ids_r)
+            k += kb
+        cat_off[k:] = at
+        return {"ids": np.concatenate([e[0] for e in every]),
+                "matched": np.concatenate([e[1] for e in every]),
+                "ignored": np.concatenate([e[2] for e in every]),
+                "num_gt": self.sharded.num_gt.cpu().numpy(), "cat_off": cat_off}
+
+    def pointer_tables(self):
+        if self._pointers is None:
+            raise NotImplementedError(
+                "eval['dt_pointers'] in a multi-GPU run: a category's rows live "
+                "on its owner rank; set ctx.pointers = True before run() and "
+                "accumulate() gathers them on every rank (a collective)")
+        return self._pointers

@@ -131,7 +131,8 @@ class LVISEval:
             if self.params.iou_type != "bbox":
                 raise NotImplementedError("multi-GPU runs evaluate iou_type='bbox'")
             from .._dist import DistRun
-            self._run = DistRun(flat, self.dist, constants=constants)
+            self._run = DistRun(flat, self.dist, constants=constants, dt=dt_cols,
+                                max_dets=self.lvis_dt.max_dets)
         else:
             self._run = GpuRun(flat, self.device, constants=constants)
         self._run.evaluate()

@@ -171,6 +171,15 @@ class TaoEval:
             self.logger.warning("Please run evaluate first.")
             return
         self._run.accumulate()
+        # frame-order guard: the listed pairs are recomputed one per thread in
+        # the reference's set order -- rare on real data (an IoU within the
+        # reordering bound of a comparison); many of them (identical tracks,
+        # avg_iou on integer boxes with exact rival ties) make the pass slow
+        # without making it wrong: say so
+        near, n_iou = self._run.near_threshold_pairs, getattr(self._run.dp, "n_iou", 0)
+        if near > 4096 and near * 100 > n_iou:
+            logging.getLogger("taoamd.guard").warning(
+                "%d of %d track pairs went through the frame-order guard", near, n_iou)
         P = self.params
         A, T = len(P.area_rng), len(P.time_rng)
         K = len(P.cat_ids) if P.use_cats else 1

@@ -99,3 +99,24 @@ def test_all_in_sorted_is_the_membership_test():
         outside[77777] = missing[0]
         assert ask(keys, outside) == 0
     assert ask([], []) == 1 and ask([1], []) == 1 and ask([], [1]) == 0
+
+
+def test_dense_only_entry_points_refuse_the_pair_layout():
+    """`ignored == matched + 1` selects the interleaved (matched,
+    ignored) pair layout in taoamd_match / taoamd_accumulate*; the entry points
+    that only know dense tables must refuse that relation (before touching the
+    device: this runs without a GPU) instead of scrambling rows."""
+    import numpy as np
+    from tao_amodal_amd import _lib
+    lib = _lib.load()
+    buf = np.zeros(64, dtype=np.uint64)
+    base = buf.ctypes.data
+    order = np.zeros(4, dtype=np.int32)
+    # taoamd_gather_rows(n, n_words, src_m, src_i, stride, order, dst_m, dst_i, stream)
+    assert lib.taoamd_gather_rows(4, 1, base, base + 32, 1, order.ctypes.data,
+                                  base + 256, base + 256 + 8, None) == 2
+    i64 = np.zeros(16, dtype=np.int64)
+    p = i64.ctypes.data
+    # taoamd_exchange_merge(n_recv, world, block_cats, k0, records, width, n_words,
+    #                       src_base, run_off, cat_base, matched, ignored, stream)
+    assert lib.taoamd_exchange_merge(4, 1, 1, 0, p, 3, 1, p, p, p, base, base + 8, None) == 2

@@ -213,3 +213,74 @@ def test_cli_under_a_launcher_prints_the_reference_text(name, world, tmp_path):
     want = open(path(name, "cli_log.txt")).read()
     got = log.read_text().replace(os.path.dirname(gt_p) + os.sep, "<DIR>/")
     assert got == want
+
+
+def _pointer_worker(rank, world, port, name, gt_p, pr_p, out):
+    sys.path[:0] = [ROOT, HERE]
+    import pickle
+    import torch
+    import torch.distributed as dist
+    from tao_amodal_amd import dist as tdist, flatten_dev
+    from tao_amodal_amd.columns import DTColumns, GTColumns
+    from tao_amodal_amd.evaluation import _dist
+    from tao_amodal_amd.evaluation.lvis_amodal import LVIS, LVISEval, LVISResults
+    from tao_amodal_amd.evaluation.tao_amodal import Tao, TaoEval, TaoResults
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      LOCAL_WORLD_SIZE=str(world))
+    ctx = _dist.init_from_env()
+    ctx.pointers = True
+    gt = GTColumns.from_file_native(gt_p)
+    dt = DTColumns.from_file_native(pr_p, ctx.rank, ctx.world)
+    sh = _dist.shard_inputs(gt, dt, dt.first, ctx)
+    lvis_gt = LVIS(gt_p, columns=sh.gt_lvis)
+    le = LVISEval(lvis_gt, LVISResults(lvis_gt, sh.dt_lvis, _share=True), "bbox", dist=ctx)
+    le.run()
+    tao_gt = Tao(gt_p, columns=sh.gt_tao)
+    universe = None if sh.whole else tdist.gather_visit_universe(sh.gt_tao, ctx.device, ctx.group)
+    flat = flatten_dev.flatten_tao(sh.gt_tao, sh.dt_tao, device=ctx.device,
+                                   visit_universe=universe)
+    te = TaoEval(tao_gt, TaoResults(tao_gt, sh.dt_tao, _flat=flat, _share=True), dist=ctx)
+    te.run()
+    lp = {(k, a): {f: np.asarray(v) for f, v in le.eval["dt_pointers"][k][a].items()}
+          for k in range(len(le.params.cat_ids)) for a in range(6)}
+    tp = {(k, a, t): {f: np.asarray(v) for f, v in te.eval["dt_pointers"][k][a][t].items()}
+          for k in range(len(te.params.cat_ids)) for a in range(5) for t in range(4)}
+    with open(os.path.join(out, "p%d.pkl" % rank), "wb") as f:
+        pickle.dump({"lvis": lp, "tao": tp, "whole": sh.whole}, f)
+    dist.barrier(group=ctx.host_group)
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("name", ["f1", "f2", "f5"])
+def test_dt_pointers_are_assembled_on_every_rank(name, world, tmp_path):
+    """eval['dt_pointers'] in a multi-GPU run (T/eval.py:575-584):
+    with ctx.pointers the owners' rows are gathered -- ids as the reference
+    numbers them over the WHOLE list -- and every rank reads the reference's
+    dt_ids / tps / fps (f5: shuffled image ids; f2: the whole-set mode of files
+    with duplicate ids)."""
+    import pickle
+    from goldenio import load_json_gz
+    gt_p, pr_p = input_paths(name, tmp_path)
+    mp.spawn(_pointer_worker, args=(world, _port(), name, gt_p, pr_p, str(tmp_path)),
+             nprocs=world, join=True)
+    want = {"lvis": load_json_gz(name, "lvis.json.gz")["dt_pointers"],
+            "tao": load_json_gz(name, "tao.json.gz")["dt_pointers"]}
+    for r in range(world):
+        with open(os.path.join(str(tmp_path), "p%d.pkl" % r), "rb") as f:
+            got = pickle.load(f)
+        assert got["whole"] == (name == "f2")
+        for side in ("lvis", "tao"):
+            n = 0
+            for p_ in want[side]:
+                g = got[side][tuple(p_["idx"])]
+                assert list(g["dt_ids"]) == p_["dt_ids"], (r, side, p_["idx"])
+                assert np.array_equal(g["tps"].astype(int),
+                                      np.asarray(p_["tps"]).reshape(g["tps"].shape))
+                assert np.array_equal(g["fps"].astype(int),
+                                      np.asarray(p_["fps"]).reshape(g["fps"].shape))
+                n += 1
+            assert n > 0

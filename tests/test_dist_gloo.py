@@ -238,8 +238,7 @@ class OracleCategoryBackend(OracleBackend):
         order = np.lexsort((np.arange(n), -(f.dt_score + 0.0), f.dt_cat))
         dst = np.empty(n, np.int64)
         dst[order] = np.arange(n)
-        ws.order[:n] = torch.from_numpy(order.astype(np.int32))
-        ws.dst[:n] = torch.from_numpy(dst.astype(np.int32))
+        ws.dst[:n] = torch.from_numpy(dst.astype(np.int32))    # (order[] = its inverse: engine.Workspace.order)
 
     def match_local(self, dp, ws):
         f = self._f(dp)

@@ -2,9 +2,12 @@
 
     Config 3 (stand-in)  2000 videos x 300 frames x 50 dets, 1203 categories
                          (the real validation JSONs are not in the container)
-    Config 4             Config 2 split over 2 / 4 / 8 ranks, BOTH partitions
-                         (by category, by video); RCCL when the box has that
-                         many GPUs, else the ranks share GPU 0 and talk over gloo
+    Config 4             the full-validation-scale set (2000 videos) split BY VIDEO
+                         over 2 and 8 ranks, the partition BASELINE.json names;
+                         and, as the fast variant, Config 2 (200 videos) over
+                         2 / 4 / 8 ranks in BOTH partitions (by category, by
+                         video).  RCCL when the box has that many GPUs, else the
+                         ranks share GPU 0 and talk over gloo
     Config 5 (stand-in)  10 000 videos x 1 frame x 1000 dets: the top-300 cut
                          per image at scale (L/results.py:39-40, T/results.py:56-58)
 
@@ -132,16 +135,9 @@ def _worker(rank, world, port, mode, out):
     if rccl:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     else:
+        # (gloo moves no device tensors through all_to_all: the product stages
+        # the record exchange on the host then, tao_amodal_amd.dist.all_to_all)
         dist.init_process_group("gloo", rank=rank, world_size=world)
-        # gloo moves no device tensors through all_to_all: stage on the host
-        plain = dist.all_to_all_single
-
-        def staged(output, input, output_split_sizes=None, input_split_sizes=None,
-                   group=None):
-            o = torch.empty(output.shape, dtype=output.dtype)
-            plain(o, input.cpu(), output_split_sizes, input_split_sizes, group=group)
-            output.copy_(o)
-        dist.all_to_all_single = staged
     from tao_amodal_amd import dist as tdist, engine
     if mode == "category":
         f_l, f_t = _whole(world)
@@ -196,3 +192,98 @@ def test_config4_ranks_reproduce_the_whole_problem(tmp_path, world, mode):
         for k in ("lvis", "tao"):
             assert np.array_equal(got[k][0], want[k]["precision"]), (rank, k)
             assert np.array_equal(got[k][1], want[k]["recall"]), (rank, k)
+
+
+# --------------------------------------------------------------------------
+# Config 4 at its own size: ONE set of 2000 videos split by video (the
+# `--scaling strong` semantics of bench.py) -- VERDICT r3 configs_untested
+# --------------------------------------------------------------------------
+V_FULL = 2000
+
+
+def _full_worker(rank, world, port, src, out):
+    import pickle
+    sys.path[:0] = [os.path.dirname(HERE), HERE]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    rccl = torch.cuda.device_count() >= world
+    dev = torch.device("cuda", rank if rccl else 0)
+    torch.cuda.set_device(dev)
+    if rccl:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tao_amodal_amd import dist as tdist, engine, flatten_dev
+    with open(os.path.join(src, "w%d_r%d.pkl" % (world, rank)), "rb") as f:
+        gt, dt = pickle.load(f)
+    universe = tdist.gather_visit_universe(gt, dev)
+    f_l = flatten_dev.flatten_lvis(gt, dt, device=dev)
+    f_t = flatten_dev.flatten_tao(gt, dt, device=dev, visit_universe=universe)
+    plan = tdist.ExchangePlan(engine.DeviceProblem(f_l, dev), engine.DeviceProblem(f_t, dev),
+                              rank, world, dev)
+    plan.step()
+    plan.step()
+    torch.cuda.synchronize()
+    plan.lvis.check()
+    plan.tao.check()
+    # every rank holds the whole tables: a digest each, the tensors from rank 0
+    digest = [int(t.contiguous().view(torch.int64).sum().item())
+              for t in (plan.lvis.precision, plan.lvis.recall, plan.tao.precision,
+                        plan.tao.recall)]
+    got = {"digest": digest, "backend": dist.get_backend()}
+    if rank == 0:
+        got.update(lvis=(plan.lvis.precision.cpu().numpy(), plan.lvis.recall.cpu().numpy()),
+                   tao=(plan.tao.precision.cpu().numpy(), plan.tao.recall.cpu().numpy()))
+    torch.save(got, os.path.join(out, "r%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(3000)
+def test_config4_at_full_validation_scale_split_by_video(tmp_path):
+    """2000 videos x 300 frames x 50 detections, 1203 categories (the Config 3
+    stand-in) cut into contiguous blocks of videos over 2 and over 8 ranks;
+    every rank ends with the whole precision / recall tables, bit for bit the C
+    oracle's on the whole set."""
+    import pickle
+    gt, dt = synth(seed=20240807, V=V_FULL, F=300, C=1203, dets_per_frame=50)
+    dt.track_id, _ = fl.make_track_ids_unique(dt)       # (a statement about the whole list)
+    f_l = fl.flatten_lvis(gt, dt)
+    f_t = fl.flatten_tao(gt, dt)
+    orclib.set_threads(0)
+    try:
+        want = {"lvis": orclib.run_flat(f_l, detail=False),
+                "tao": orclib.run_flat(f_t, detail=False)}
+    finally:
+        orclib.set_threads(1)
+    del f_l, f_t
+    want_digest = [int(np.ascontiguousarray(want[k][f]).view(np.int64).sum())
+                   for k in ("lvis", "tao") for f in ("precision", "recall")]
+    import shutil
+    for world in (2, 8):
+        out = str(tmp_path / ("out%d" % world))
+        src = str(tmp_path / ("blocks%d" % world))
+        os.makedirs(out)
+        os.makedirs(src)
+        for r in range(world):
+            keep = np.zeros(V_FULL, dtype=bool)
+            keep[V_FULL * r // world:V_FULL * (r + 1) // world] = True   # (synth: ids ascending)
+            mine = gt.vid_id[keep]
+            part = (gt.select_videos(keep),
+                    dt.take(np.flatnonzero((dt.video_id >= mine[0]) & (dt.video_id <= mine[-1]))))
+            with open(os.path.join(src, "w%d_r%d.pkl" % (world, r)), "wb") as f:
+                pickle.dump(part, f, protocol=4)
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        mp.spawn(_full_worker, args=(world, port, src, out), nprocs=world, join=True)
+        shutil.rmtree(src)
+        for rank in range(world):
+            got = torch.load(os.path.join(out, "r%d.pt" % rank), weights_only=False)
+            assert [d & (2 ** 64 - 1) for d in got["digest"]] == \
+                [d & (2 ** 64 - 1) for d in want_digest], (world, rank)
+            if rank == 0:
+                for k in ("lvis", "tao"):
+                    assert np.array_equal(got[k][0], want[k]["precision"]), (world, k)
+                    assert np.array_equal(got[k][1], want[k]["recall"]), (world, k)

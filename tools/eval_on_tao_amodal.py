@@ -180,9 +180,28 @@ def main_distributed(args, annotation):
     # their banners to the C-level stdout, so descriptor 1 is pointed at stderr
     # for the run and Python's stdout at a copy of the real one
     sys.stdout.flush()
+    saved_fd, saved_stdout = os.dup(1), sys.stdout
     py_stdout = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
     sys.stdout = py_stdout
+    try:
+        return _main_distributed(args, annotation)
+    finally:
+        # (a caller that runs the command in-process gets its stdout back)
+        py_stdout.flush()
+        sys.stdout = saved_stdout
+        os.dup2(saved_fd, 1)
+        os.close(saved_fd)
+        py_stdout.close()
+
+
+def _main_distributed(args, annotation):
+    import contextlib
+    import io
+    from tao_amodal_amd.columns import GTColumns
+    from tao_amodal_amd.evaluation import _dist
+    from tao_amodal_amd.evaluation._core import timed
+    from tao_amodal_amd import dist as tdist, flatten_dev
     ctx = _dist.init_from_env()
     logger = logging.getLogger("__main__")
     logger.setLevel(logging.INFO if ctx.rank == 0 else logging.ERROR)
@@ -259,11 +278,49 @@ def main_distributed(args, annotation):
             {k: round(v, 3) for k, v in TIMING.items()}), file=sys.stderr)
 
 
+def _warm_device(pred_path=None):
+    """Everything a cold process pays once, on a helper thread beside the
+    parse: torch's import, the HIP context, the kernel library and its code
+    object (first launch), and device memory for the prediction columns and
+    the tables in torch's caching allocator (a fresh process would otherwise
+    meet ~50 hipMalloc calls between the parse and the first kernel)."""
+    try:
+        import torch
+        from tao_amodal_amd import _lib, flatten_dev  # noqa: F401
+        if not torch.cuda.is_available():
+            return
+        lib = _lib.load()
+        box = torch.tensor([[0.0, 0.0, 1.0, 1.0]], dtype=torch.float64, device="cuda")
+        out = torch.empty(1, dtype=torch.float64, device="cuda")
+        lib.taoamd_bb_iou(box.data_ptr(), box.data_ptr(), 1, 1, None, out.data_ptr(),
+                          torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        if pred_path and os.path.exists(pred_path):
+            free, _total = torch.cuda.mem_get_info()
+            want = min(int(os.path.getsize(pred_path) * 1.5), int(free * 0.5))
+            if want > (64 << 20):
+                del box, out
+                block = torch.empty(want, dtype=torch.uint8, device="cuda")
+                del block           # (stays in the allocator's cache: split on demand)
+    except Exception:       # (whoever needs the device raises at the usual place)
+        pass
+
+
 def main(argv=None):
     args = default_arg_parser(argv)
     annotation = args.annotation if args.annotation else DEFAULT_ANNOTATION
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    # one rank of `torchrun ... eval_on_tao_amodal.py`: the launcher's own
+    # variables (a WORLD_SIZE left in the environment by something else -- a
+    # SLURM job, a notebook -- does not switch the mode: ADVICE r3)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and "RANK" in os.environ \
+            and "LOCAL_RANK" in os.environ and os.environ.get("TAOAMD_SINGLE", "0") == "0":
         return main_distributed(args, annotation)
+    # ~1 s of a cold start -- importing torch, creating the HIP context,
+    # loading the kernel library -- beside the parse instead of in front of the
+    # first table (the readers are native code and the ground-truth halves of
+    # the tables numpy: neither needs torch)
+    import threading
+    threading.Thread(target=_warm_device, args=(args.track_result,), daemon=True).start()
     output_log = Path(args.output_log)
     logger = logging.getLogger("__main__")
     logger.setLevel(logging.INFO)
@@ -284,8 +341,8 @@ def main(argv=None):
             if not dt_future.done():
                 # the annotation file is the smaller one: its halves of the
                 # cell tables are built while the predictions are still read
-                from tao_amodal_amd import flatten_dev
-                flatten_dev.prepare_gt(lvis_gt.columns)
+                from tao_amodal_amd import prepare
+                prepare.prepare_gt(lvis_gt.columns)
             dt_columns = dt_future.result()
         if len(dt_columns) and not os.environ.get("TAOAMD_CLI_SERIAL"):
             # the track level runs beside the image level on the worker
