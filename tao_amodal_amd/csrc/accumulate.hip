@@ -1401,8 +1401,7 @@ static int32_t max_chunks(int64_t n_dt, int32_t n_cat)
 //   "chunked"  the six chunked kernels;  "lookback"  acc_sweep_kernel in one
 //   pass;  "twopass"  acc_sweep_kernel behind a counting pass
 enum { SWEEP_CHUNKED = 0, SWEEP_LOOKBACK = 1, SWEEP_TWOPASS = 2 };
-// Without TAOAMD_SWEEP: the one-pass sweep from SWEEP_ONEPASS_MIN (row, combo word)
-// pairs up.  At
+// Without TAOAMD_SWEEP: the one-pass sweep from SWEEP_ONEPASS_MIN rows up.  At
 // 21 M rows (2000 videos) it takes 0.39 ms against 0.52 for the chunked kernels
 // (rows read once instead of three times plus a transposed copy); at 2 M rows
 // (Config 2) everything is latency and the chunked kernels' three short
@@ -1420,7 +1419,8 @@ static int sweep_mode(int64_t n_dt)
     if (m >= 0) return m;
     return n_dt >= SWEEP_ONEPASS_MIN ? (int)SWEEP_LOOKBACK : (int)SWEEP_CHUNKED;
 }
-// (n_dt here = rows x combo words: a track-level row is four words)
+// (rows, whatever their width: at 2.9 M track-level rows of four words -- the
+// stress shape -- the chunked kernels are as fast, 0.275 against 0.32 ms)
 #define SC_TICKETS 64           // header words of the SC tables (word 0: the error flag)
 static std::atomic<uint32_t> g_sc_gen{0};
 
@@ -1544,7 +1544,7 @@ static int accumulate_compact(int64_t n_dt, int32_t n_cat, int32_t n_rng,
     a.inline_scans = max_segment > 0 && max_segment <= ACC_INLINE_CHUNKS * ACC_CH;
     unsigned char *w = (unsigned char *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     const size_t nc = (size_t)a.n_chunks_max, nw = (size_t)a.n_words;
-    const int mode = sweep_mode(n_dt * a.n_words);
+    const int mode = sweep_mode(n_dt);
     const size_t ns = max_scs(n_dt, n_cat);
     uint32_t *tickets = (uint32_t *)w;   w += align256(SC_TICKETS * 4);
     a.sc_stat = (uint64_t *)w;           w += align256(ns * nw * WAVE * 16);

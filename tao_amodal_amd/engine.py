@@ -801,6 +801,9 @@ import os as _os
 # instead of 84 us beside the sort -- the step is bound by the sum of its
 # kernels, not by the chain); TAOAMD_SORT_ASIDE=1 switches it on for A/B timing
 SORT_ASIDE = _os.environ.get("TAOAMD_SORT_ASIDE", "0") != "0"
+# A/B: the 3D IoU (the longest kernel) alone ahead of the image level instead of beside it
+TRACK_FIRST = _os.environ.get("TAOAMD_TRACK_FIRST", "0") != "0"
+TRACK_AFTER_SORT = _os.environ.get("TAOAMD_TRACK_AFTER_SORT", "0") != "0"
 
 
 class Overlap:
@@ -830,8 +833,27 @@ class Overlap:
         # pass is forked and joined.
         cur = torch.cuda.current_stream(self.device)
         s_aux_l, s_aux_t = self.streams[2], self.streams[3]   # forked by run_forked
+        if TRACK_FIRST and dpt.kind == "tao":
+            # A/B schedule: the track level's head (range masks, sort, 3D IoU)
+            # ahead of everything, the rest of it beside the image level
+            run_forked(dpt, wst, s_aux_t, head_only=True, no_match=True)
+            st = self._fork(1)
+            run_forked(dpl, wsl, s_aux_l, sort_aside=SORT_ASIDE)
+            with torch.cuda.stream(st):
+                _probed("match", stage_match, dpt, wst)
+                stage_accumulate(dpt, wst)
+            cur.wait_stream(st)
+            return
         st = self._fork(1)
-        run_forked(dpl, wsl, s_aux_l, sort_aside=SORT_ASIDE)
+        if TRACK_AFTER_SORT:
+            # A/B schedule: the track level starts when the image level's sort is
+            # done -- its 3D IoU then runs beside the match and the sweep instead
+            # of holding the wave slots the sort's short kernels wait for
+            ev = torch.cuda.Event()
+            run_forked(dpl, wsl, s_aux_l, sort_aside=SORT_ASIDE, sort_done=ev)
+            st.wait_event(ev)
+        else:
+            run_forked(dpl, wsl, s_aux_l, sort_aside=SORT_ASIDE)
         with torch.cuda.stream(st):
             run_forked(dpt, wst, s_aux_t)
         cur.wait_stream(st)
@@ -869,7 +891,8 @@ def _probed(name, fn, dp, ws):
         PROBE.wrap(dp.kind + ":" + name, fn, dp, ws)
 
 
-def run_forked(dp, ws, aux, head_only=False, sort_aside=False):
+def run_forked(dp, ws, aux, head_only=False, sort_aside=False, no_match=False,
+               sort_done=None):
     """One evaluator pass on the current stream, its independent head stages
     on the stream `aux` (forked from and joined to the current stream):
     image level  ranges || sort -> match -> accumulate,
@@ -895,6 +918,8 @@ def run_forked(dp, ws, aux, head_only=False, sort_aside=False):
             stage_ranges(dp, ws)
             stage_mask_iou(dp, ws)
         stage_sort(dp, ws)
+        if sort_done is not None:
+            sort_done.record(cur)
     else:
         with torch.cuda.stream(aux):
             stage_ranges(dp, ws)
@@ -905,6 +930,8 @@ def run_forked(dp, ws, aux, head_only=False, sort_aside=False):
             # one synchronisation, the listed pairs patched before the match
             ws.guarded_pairs = apply_iou_guard(dp, ws)
     cur.wait_stream(aux)
+    if no_match:
+        return
     _probed("match", stage_match, dp, ws)
     if not head_only:
         stage_accumulate(dp, ws)

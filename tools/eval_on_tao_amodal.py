@@ -24,6 +24,8 @@ import sys
 from pathlib import Path
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+# (idle OpenMP threads sleep instead of spinning: tao_amodal_amd/__init__.py)
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
 
 import json  # noqa: E402
 
@@ -294,6 +296,18 @@ def _warm_device(pred_path=None):
         out = torch.empty(1, dtype=torch.float64, device="cuda")
         lib.taoamd_bb_iou(box.data_ptr(), box.data_ptr(), 1, 1, None, out.data_ptr(),
                           torch.cuda.current_stream().cuda_stream)
+        # torch's own device code is loaded op by op on first use: the handful
+        # of primitives the table build uses (flatten_dev._cells_from_runs,
+        # engine.DeviceProblem), once, on tiny tensors
+        t = torch.arange(8, dtype=torch.int32, device="cuda")
+        u = torch.unique(torch.cat([t, t]))
+        i = torch.searchsorted(u, t)
+        c = torch.cumsum(torch.bincount(i, minlength=8), 0)
+        z = torch.zeros(9, dtype=torch.int64, device="cuda")
+        z[i.long() + 1] = c
+        w = torch.stack([t, t], dim=1).to(torch.int32).contiguous()
+        (w[:, 0].clamp(max=3) << 2 | (t & 3)).long().cpu()
+        torch.div(t, 2, rounding_mode="floor").index_select(0, t.long())
         torch.cuda.synchronize()
         if pred_path and os.path.exists(pred_path):
             free, _total = torch.cuda.mem_get_info()
@@ -320,6 +334,9 @@ def main(argv=None):
     # first table (the readers are native code and the ground-truth halves of
     # the tables numpy: neither needs torch)
     import threading
+    # (the main thread's numpy work -- hundreds of short calls -- must not wait
+    # a full 5 ms GIL interval for the importing thread after each of them)
+    sys.setswitchinterval(2e-4)
     threading.Thread(target=_warm_device, args=(args.track_result,), daemon=True).start()
     output_log = Path(args.output_log)
     logger = logging.getLogger("__main__")
@@ -335,15 +352,18 @@ def main(argv=None):
             # the native readers run outside the GIL: the two files are
             # parsed side by side
             dt_future = pool.submit(DTColumns.from_json, args.track_result)
-            lvis_gt = LVIS(annotation)      # native reader when built
-            lvis_gt.columns
+            with timed("parse:annotation"):
+                lvis_gt = LVIS(annotation)      # native reader when built
+                lvis_gt.columns
             gt_dataset = annotation          # the track level shares the columns
             if not dt_future.done():
                 # the annotation file is the smaller one: its halves of the
                 # cell tables are built while the predictions are still read
-                from tao_amodal_amd import prepare
-                prepare.prepare_gt(lvis_gt.columns)
-            dt_columns = dt_future.result()
+                with timed("parse:gt_halves"):
+                    from tao_amodal_amd import prepare
+                    prepare.prepare_gt(lvis_gt.columns)
+            with timed("parse:wait_predictions"):
+                dt_columns = dt_future.result()
         if len(dt_columns) and not os.environ.get("TAOAMD_CLI_SERIAL"):
             # the track level runs beside the image level on the worker
             # thread (most of either is numpy or the GPU: no GIL held); what
