@@ -17,5 +17,6 @@ rocprofv3 --output-format csv --pmc WRITE_SIZE -d $OUT/write -o write -- $CMD > 
 cd $R
 WL=$(python -c "import json,sys; print(json.load(open('$OUT/bench.json'))['config']['workload'])")
 python tools/prof_summary.py $OUT profiles/$PREFIX "$WL"
+python tools/step_timeline.py $OUT/ktr profiles/${PREFIX}_step_timeline.txt || true
 cp $OUT/bench.json profiles/${PREFIX}_bench.json
 mkdir -p gpurun_out/profiles_out && cp profiles/${PREFIX}_* gpurun_out/profiles_out/
