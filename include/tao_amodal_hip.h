@@ -569,6 +569,17 @@ int taoamd_sort_plan_host(int32_t n_cat, const int32_t *cat_off_host, int64_t *s
                           int32_t *bucket_chunk);
 size_t taoamd_sort_sampled_workspace(int64_t n, int64_t n_buckets, int32_t merge);
 int taoamd_sort_sampled_cap_limit(int32_t limit);
+/* Ordering other streams around the splitter kernel INSIDE taoamd_sort_sampled:
+ * `event` (from taoamd_event_create) is recorded on the sort's stream right
+ * behind the splitter kernel of the calling thread's NEXT taoamd_sort_sampled
+ * (NULL = none; the request is consumed by that call).  The image level's
+ * splitters are 0.06 ms of latency at the head of the step's critical chain;
+ * work started beside the sort (the track level's 3D IoU) waits for them with
+ * taoamd_stream_wait_event instead of starving their workgroups of wave slots. */
+int taoamd_sort_sampled_notify(void *event);
+int taoamd_event_create(void **event);
+int taoamd_event_destroy(void *event);
+int taoamd_stream_wait_event(void *stream, void *event);
 int taoamd_sort_sampled(int64_t n, int32_t n_cat, const int32_t *cat_off,
                         const int32_t *tile_off, int32_t n_tiles, int32_t max_segment,
                         const double *dt_score, int32_t n_chunks, const int32_t *chunks,
@@ -720,8 +731,12 @@ int taoamd_exchange_unpack(int32_t n_cat, int32_t n_rng, int32_t block_cats,
                            int32_t *overflow, void *workspace,
                            size_t workspace_bytes, int32_t maps_ready, void *stream);
 
-/* By-video partition, owner side.  `records` = what one all_to_all delivered:
- * for source s the rows [src_base[s], src_base[s + 1]), each `width` int64
+/* By-video partition, owner side.  The merged input is, for source s, the rows
+ * [src_base[s], src_base[s + 1]) -- `records` = what the all_to_all delivered,
+ * the sources' rows back to back WITHOUT those of `own_rank` (>= 0), which
+ * never travel: they are read at `own_records`, where the rank's own match
+ * wrote them (own_rank < 0: every source's rows are in `records`, own_records
+ * unused).  Each row is `width` int64
  * {score bits, n_words matched words, n_words ignored words} (24 bytes at the
  * image level), sorted by (category, -score) inside the source -- a record
  * carries no category, the run it lies in says it; run_off[s * (block_cats + 1) + kb] =
@@ -734,6 +749,7 @@ int taoamd_exchange_merge(int64_t n_recv, int32_t world, int32_t block_cats,
                           int32_t k0, const int64_t *records, int64_t width,
                           int32_t n_words, const int64_t *src_base,
                           const int64_t *run_off, const int64_t *cat_base,
+                          int32_t own_rank, const int64_t *own_records,
                           uint64_t *matched, uint64_t *ignored, void *stream);
 
 #ifdef __cplusplus

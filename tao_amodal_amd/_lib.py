@@ -43,6 +43,10 @@ SIGNATURES = {
     "taoamd_sort_plan_host": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "taoamd_sort_sampled_workspace": (_sz, [_i64, _i64, _i32]),
     "taoamd_sort_sampled_cap_limit": (C.c_int, [_i32]),
+    "taoamd_sort_sampled_notify": (C.c_int, [_vp]),
+    "taoamd_event_create": (C.c_int, [_vp]),
+    "taoamd_event_destroy": (C.c_int, [_vp]),
+    "taoamd_stream_wait_event": (C.c_int, [_vp, _vp]),
     "taoamd_sort_sampled": (C.c_int, [_i64, _i32, _vp, _vp, _i32, _i32, _vp, _i32, _vp,
                                       _i32, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp,
                                       _sz, _vp]),
@@ -127,7 +131,7 @@ SIGNATURES = {
     "taoamd_exchange_unpack": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _i64, _vp,
                                          _vp, _vp, _vp, _vp, _sz, _i32, _vp]),
     "taoamd_exchange_merge": (C.c_int, [_i64, _i32, _i32, _i32, _vp, _i64, _i32,
-                                        _vp, _vp, _vp, _vp, _vp, _vp]),
+                                        _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "taoamd_sort_workspace": (_sz, [_i64]),
     "taoamd_sort_by_cat_score": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _sz,
                                            _vp]),

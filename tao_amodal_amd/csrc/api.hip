@@ -173,6 +173,31 @@ extern "C" int taoamd_kernel_timing_collect(char *names, size_t names_bytes,
     return TAOAMD_OK;
 }
 
+// ---- events between the caller's streams (taoamd_sort_sampled_notify): plain
+// hipEvent_t handles, so that a host that only holds stream handles (ctypes)
+// can order its streams around a kernel INSIDE one of the batched calls
+extern "C" int taoamd_event_create(void **event)
+{
+    if (!event) return TAOAMD_ERR_ARG;
+    hipEvent_t e = nullptr;
+    TAO_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    *event = (void *)e;
+    return TAOAMD_OK;
+}
+
+extern "C" int taoamd_event_destroy(void *event)
+{
+    if (event) TAO_HIP(hipEventDestroy((hipEvent_t)event));
+    return TAOAMD_OK;
+}
+
+extern "C" int taoamd_stream_wait_event(void *stream, void *event)
+{
+    if (!event) return TAOAMD_ERR_ARG;
+    TAO_HIP(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0));
+    return TAOAMD_OK;
+}
+
 extern "C" const char *taoamd_strerror(int status)
 {
     switch (status) {

@@ -419,6 +419,7 @@ __global__ void ex_merge_kernel(int64_t n_recv, int32_t world, int32_t block_cat
                                 const int64_t *__restrict__ src_base,
                                 const int64_t *__restrict__ run_off,
                                 const int64_t *__restrict__ cat_base,
+                                int32_t own, const int64_t *__restrict__ own_records,
                                 uint64_t *__restrict__ matched,
                                 uint64_t *__restrict__ ignored)
 {
@@ -427,13 +428,21 @@ __global__ void ex_merge_kernel(int64_t n_recv, int32_t world, int32_t block_cat
     (void)k0;          // (the block's first category: part of the ABI, not needed here)
     int s = 0;
     while (s + 1 < world && src_base[s + 1] <= i) s++;
-    const int64_t *rec = records + i * width;
+    // the rows of source o: the rank's own records never travelled (they are
+    // read where the match wrote them), `records` holds the other sources'
+    // rows back to back
+    const int64_t own_rows = own >= 0 ? src_base[own + 1] - src_base[own] : 0;
+    auto rows_of = [&](int o) -> const int64_t * {
+        return o == own ? own_records
+                        : records + (src_base[o] - (o > own ? own_rows : 0)) * width;
+    };
+    const int64_t at = i - src_base[s];
+    const int64_t *rec = rows_of(s) + at * width;
     const uint64_t key = ex_desc_key(rec[0]);
     const int64_t *ro = run_off + (int64_t)s * (block_cats + 1);
     // the record's category is the run it lies in (a record carries none: the
     // sender lays its records out category by category): last kb with
     // ro[kb] <= place inside the source's rows
-    const int64_t at = i - src_base[s];
     int32_t kb = 0;
     for (int32_t lo = 0, hi = block_cats; lo < hi;) {
         const int32_t mid = (lo + hi + 1) >> 1;
@@ -443,12 +452,13 @@ __global__ void ex_merge_kernel(int64_t n_recv, int32_t world, int32_t block_cat
     for (int o = 0; o < world; o++) {
         if (o == s) continue;
         const int64_t *oo = run_off + (int64_t)o * (block_cats + 1);
-        const int64_t b = src_base[o] + oo[kb], e = src_base[o] + oo[kb + 1];
+        const int64_t *other = rows_of(o);
+        const int64_t b = oo[kb], e = oo[kb + 1];
         // records of run o that come first: key' < key, or key' == key from a lower rank
         int64_t lo = b, hi = e;
         while (lo < hi) {
             const int64_t mid = (lo + hi) >> 1;
-            const uint64_t km = ex_desc_key(records[mid * width]);
+            const uint64_t km = ex_desc_key(other[mid * width]);
             if (km < key || (km == key && o < s)) lo = mid + 1; else hi = mid;
         }
         pos += lo - b;
@@ -463,20 +473,25 @@ extern "C" int taoamd_exchange_merge(int64_t n_recv, int32_t world, int32_t bloc
                                      int32_t k0, const int64_t *records, int64_t width,
                                      int32_t n_words, const int64_t *src_base,
                                      const int64_t *run_off, const int64_t *cat_base,
+                                     int32_t own_rank, const int64_t *own_records,
                                      uint64_t *matched, uint64_t *ignored, void *stream)
 {
     if (n_recv < 0 || world < 1 || block_cats < 1 || n_words < 1 ||
-        width < 1 + 2 * (int64_t)n_words)
+        width < 1 + 2 * (int64_t)n_words || own_rank >= world)
         return TAOAMD_ERR_ARG;
     if (n_recv == 0) return TAOAMD_OK;
-    if (!records || !src_base || !run_off || !cat_base || !matched || !ignored)
+    if (!src_base || !run_off || !cat_base || !matched || !ignored)
         return TAOAMD_ERR_ARG;
+    if (own_rank < 0) own_rank = -1;
+    // (`records` may be null when every row is the rank's own: world == 1)
+    if ((own_rank < 0 || world > 1) && !records) return TAOAMD_ERR_ARG;
+    if (own_rank >= 0 && !own_records) return TAOAMD_ERR_ARG;
     // dense [n_recv][n_words] tables only (see taoamd_gather_rows)
     if (ignored == matched + 1 && n_recv * n_words > 1) return TAOAMD_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     TAO_TIMED("ex_merge_kernel", s, ex_merge_kernel<<<(unsigned)((n_recv + 255) / 256), 256, 0, s>>>(
         n_recv, world, block_cats, k0, records, width, n_words, src_base, run_off,
-        cat_base, matched, ignored));
+        cat_base, own_rank, own_records, matched, ignored));
     TAO_LAUNCH_CHECK();
     return TAOAMD_OK;
 }

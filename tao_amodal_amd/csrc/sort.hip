@@ -1759,6 +1759,21 @@ extern "C" size_t taoamd_sort_sampled_workspace(int64_t n, int64_t n_buckets, in
     return b + 4096;
 }
 
+// The splitter kernel is 0.06 ms of latency at the head of the image level's
+// chain; a caller that starts other work beside the sort (the track level's 3D
+// IoU: 11 k workgroups that take every wave slot they find) wants that work to
+// wait for the splitters, not for the whole sort -- in a kernel trace of the
+// step the splitters' workgroups, 139 VGPRs each, took 347 us to get their turn
+// beside it.  `event` (a hipEvent_t) is recorded on the sort's stream right
+// behind the splitter kernel of the calling thread's NEXT taoamd_sort_sampled;
+// NULL = none.
+static thread_local hipEvent_t g_ss_notify = nullptr;
+extern "C" int taoamd_sort_sampled_notify(void *event)
+{
+    g_ss_notify = (hipEvent_t)event;
+    return TAOAMD_OK;
+}
+
 extern "C" int taoamd_sort_sampled_cap_limit(int32_t limit)
 {
     g_ss_cap_limit = limit > 0 && limit < SS_CAP ? limit : SS_CAP;
@@ -1825,8 +1840,12 @@ extern "C" int taoamd_sort_sampled(int64_t n, int32_t n_cat, const int32_t *cat_
             TAO_TIMED("ss_split_kernel", s, ss_split_kernel<<<(unsigned)((n_split + 3) / 4), 256, 0, s>>>(a, n_split));
         else
             TAO_TIMED("ss_split_kernel", s, ss_split4_kernel<<<(unsigned)n_split, 256, 0, s>>>(a, n_split));
+        if (g_ss_notify) TAO_HIP(hipEventRecord(g_ss_notify, s));
         TAO_TIMED("ss_scatter_kernel", s, ss_scatter_kernel<<<(unsigned)n_stiles, SEG_THREADS, 0, s>>>(a));
+    } else if (g_ss_notify) {
+        TAO_HIP(hipEventRecord(g_ss_notify, s));
     }
+    g_ss_notify = nullptr;
     TAO_TIMED("ss_sort_kernel", s, ss_sort_kernel<<<(unsigned)((n_buckets + 3) / 4), 256, 0, s>>>(a));
     TAO_TIMED("ss_redo_kernel", s, ss_redo_kernel<<<(unsigned)std::min<int64_t>(1024, (n_buckets + 3) / 4), 256, 0, s>>>(a));
     if (merge) {

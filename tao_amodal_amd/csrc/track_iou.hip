@@ -297,7 +297,11 @@ __device__ __forceinline__ void tt_stager(
 #pragma unroll
         for (int i = 0; i < NR; i++) {
             const bool in = p >= F[i] && p <= L[i];
+#ifdef TT_ABLATE_LOADS     // (timing experiment: every load hits slot 0)
+            Bx[i] = padded[in ? 0 : 0];
+#else
             Bx[i] = padded[in ? M[i] + p : 0];      // slot 0: the far box
+#endif
         }
     };
     auto stage = [&](const double4 *Bx, int32_t pc, int b) {
@@ -427,6 +431,9 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
     double u = 0.0, i = 0.0;
     unsigned long long common = 0;
     auto add = [&](int b) {
+#ifdef TT_ABLATE_ADDER     // (timing experiment: the adder only keeps the barriers)
+        return;
+#endif
         const bool any = flags[b][0][0] | flags[b][1][0];
         const bool anydt = flags[b][0][1] | flags[b][1][1];
         if (!any || lane >= n_pairs) return;

@@ -133,10 +133,12 @@ class HipBackend:
             ws_bytes, self._s()), "taoamd_sort_by_cat_score")
 
     def merge_runs(self, n_recv, world, block_cats, k0, records, width, n_words,
-                   src_base, run_off, cat_base, matched, ignored):
+                   src_base, run_off, cat_base, matched, ignored, own=-1,
+                   own_records=None):
         _lib.check(self.lib.taoamd_exchange_merge(
             n_recv, world, block_cats, k0, _ptr(records), width, n_words,
-            _ptr(src_base), _ptr(run_off), _ptr(cat_base), _ptr(matched),
+            _ptr(src_base), _ptr(run_off), _ptr(cat_base), own,
+            None if own_records is None else _ptr(own_records), _ptr(matched),
             _ptr(ignored), self._s()), "taoamd_exchange_merge")
 
     def gather_rows(self, n, n_words, records, width, order, matched, ignored):
@@ -211,6 +213,9 @@ class ShardedEval:
         self.send_counts = cnt.reshape(world, Kb).sum(1).tolist()
         self.recv_counts = rc.sum(1).tolist()
         self.n_recv = int(rc.sum())
+        # the rank's own block never travels: the merge reads it in `send`
+        self.own_at = sum(self.send_counts[:rank])
+        self.n_wire = self.n_recv - self.recv_counts[rank]
         src_base = np.zeros(world + 1, dtype=np.int64)
         np.cumsum(rc.sum(1), out=src_base[1:])
         run_off = np.zeros((world, Kb + 1), dtype=np.int64)
@@ -228,7 +233,7 @@ class ShardedEval:
         self.cat_off = torch.from_numpy(cat_off.astype(np.int32)).to(dev)
         self.send = torch.zeros((max(dp.n_dt, 1), self.W), dtype=torch.int64,
                                 device=dev)
-        self.recv = torch.zeros((max(self.n_recv, 1), self.W), dtype=torch.int64,
+        self.recv = torch.zeros((max(self.n_wire, 1), self.W), dtype=torch.int64,
                                 device=dev)
         self._static = False          # score / category columns of `send`
         n = max(self.n_recv, 1)
@@ -272,10 +277,30 @@ class ShardedEval:
         self.be.exchange_sizes(self.Kb, self.dp.n_rng, self.world, self.table,
                                self.totals, self.xws)
 
-    def _exchange(self):
-        all_to_all(self.recv[:self.n_recv], self.send[:self.dp.n_dt],
-                   output_split_sizes=self.recv_counts,
-                   input_split_sizes=self.send_counts, group=self.group)
+    def _exchange(self, send=None, recv=None):
+        """The records of the other owners' categories leave, those of this
+        rank's block arrive (`recv`: the sources' rows back to back, without
+        this rank's own).  Two calls, because the block that stays lies in the
+        middle of `send`: to the lower ranks / from the higher ones, then the
+        other way round."""
+        send = self.send if send is None else send
+        recv = self.recv if recv is None else recv
+        if self.world == 1:
+            return
+        r, w = self.rank, self.world
+        sc, rc = self.send_counts, self.recv_counts
+        below = sum(rc[:r])
+        own_end = self.own_at + sc[r]
+        all_to_all(recv[below:self.n_wire], send[:self.own_at],
+                   output_split_sizes=[0] * (r + 1) + rc[r + 1:],
+                   input_split_sizes=sc[:r] + [0] * (w - r), group=self.group)
+        all_to_all(recv[:below], send[own_end:self.dp.n_dt],
+                   output_split_sizes=rc[:r] + [0] * (w - r),
+                   input_split_sizes=[0] * (r + 1) + sc[r + 1:], group=self.group)
+
+    def _own(self, send=None):
+        send = self.send if send is None else send
+        return send[self.own_at:] if self.own_at < send.shape[0] else send
 
     def step(self, aux=None):
         """`aux`: a second stream for the range masks and the num_gt
@@ -306,7 +331,7 @@ class ShardedEval:
         self._exchange()
         be.merge_runs(self.n_recv, self.world, self.Kb, self.k0, self.recv, self.W,
                       dp.n_words, self.src_base, self.run_off, self.cat_base,
-                      self.matched, self.ignored)
+                      self.matched, self.ignored, self.rank, self._own())
         be.accumulate_compact(self.n_recv, dp.n_cat, dp.n_rng, self.cat_off,
                               self.matched, self.ignored, self.num_gt, self.k0,
                               self.k1, self.val, self.rec, self.acc_ws,
@@ -342,14 +367,12 @@ class ShardedEval:
             send[slot, 0] = dp.t["dt_score"].view(torch.int64)
             send[slot, REC_HEAD] = ids
         recv = torch.zeros_like(self.recv)
-        all_to_all(recv[:self.n_recv], send[:dp.n_dt],
-                   output_split_sizes=self.recv_counts,
-                   input_split_sizes=self.send_counts, group=self.group)
+        self._exchange(send, recv)
         tab = torch.zeros_like(self.matched)
         ign = torch.zeros_like(self.ignored)
         self.be.merge_runs(self.n_recv, self.world, self.Kb, self.k0, recv, self.W,
                            dp.n_words, self.src_base, self.run_off, self.cat_base,
-                           tab, ign)
+                           tab, ign, self.rank, self._own(send))
         n = self.n_recv
         return (tab[:n, 0].cpu().numpy(), self.matched[:n].cpu().numpy().view(np.uint64),
                 self.ignored[:n].cpu().numpy().view(np.uint64),

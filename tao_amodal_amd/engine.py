@@ -804,6 +804,11 @@ SORT_ASIDE = _os.environ.get("TAOAMD_SORT_ASIDE", "0") != "0"
 # A/B: the 3D IoU (the longest kernel) alone ahead of the image level instead of beside it
 TRACK_FIRST = _os.environ.get("TAOAMD_TRACK_FIRST", "0") != "0"
 TRACK_AFTER_SORT = _os.environ.get("TAOAMD_TRACK_AFTER_SORT", "0") != "0"
+# ... or when its splitter kernel is done (taoamd_sort_sampled_notify): the
+# splitters then take 0.08 instead of 0.35 ms, but the 3D IoU runs beside the
+# scatter and the bucket sort instead and slows those down: 1.54 against 1.52
+# ms.  The step is bound by the sum of its kernels' work, not by the chain.
+TRACK_AFTER_SPLIT = _os.environ.get("TAOAMD_TRACK_AFTER_SPLIT", "0") != "0"
 
 
 class Overlap:
@@ -817,8 +822,22 @@ class Overlap:
     events, so the caller's barrier + synchronize bracketing stays valid."""
 
     def __init__(self, device, n=4):
+        import ctypes as C
         self.device = torch.device(device)
         self.streams = [torch.cuda.Stream(self.device) for _ in range(n)]
+        # recorded behind the image level's splitter kernel: what the track
+        # level waits for (run_pair)
+        self.split_done = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().taoamd_event_create(C.byref(self.split_done)),
+                       "taoamd_event_create")
+
+    def __del__(self):
+        try:
+            if self.split_done:
+                _lib.load().taoamd_event_destroy(self.split_done)
+        except Exception:
+            pass
 
     def _fork(self, k):
         s = self.streams[k]
@@ -845,7 +864,21 @@ class Overlap:
             cur.wait_stream(st)
             return
         st = self._fork(1)
-        if TRACK_AFTER_SORT:
+        if TRACK_AFTER_SPLIT and dpl.kind == "lvis" and sort_is_sampled(dpl) and dpl.grouped \
+                and dpl.n_dt and not SORT_ASIDE:
+            # The track level starts when the image level's SPLITTERS are done.
+            # Those are 0.06 ms of latency at the head of the step's critical
+            # chain, 1200 workgroups of 139 VGPRs; started together, the 3D
+            # IoU's 11 k small workgroups took every wave slot that came free
+            # and the splitters ran for 0.35 ms (kernel trace of round 4).
+            lib = _lib.load()
+            lib.taoamd_sort_sampled_notify(self.split_done)
+            run_forked(dpl, wsl, s_aux_l)
+            _lib.check(lib.taoamd_stream_wait_event(st.cuda_stream, self.split_done),
+                       "taoamd_stream_wait_event")
+            _lib.check(lib.taoamd_stream_wait_event(s_aux_t.cuda_stream, self.split_done),
+                       "taoamd_stream_wait_event")
+        elif TRACK_AFTER_SORT:
             # A/B schedule: the track level starts when the image level's sort is
             # done -- its 3D IoU then runs beside the match and the sweep instead
             # of holding the wave slots the sort's short kernels wait for

@@ -118,5 +118,7 @@ def test_dense_only_entry_points_refuse_the_pair_layout():
     i64 = np.zeros(16, dtype=np.int64)
     p = i64.ctypes.data
     # taoamd_exchange_merge(n_recv, world, block_cats, k0, records, width, n_words,
-    #                       src_base, run_off, cat_base, matched, ignored, stream)
-    assert lib.taoamd_exchange_merge(4, 1, 1, 0, p, 3, 1, p, p, p, base, base + 8, None) == 2
+    #                       src_base, run_off, cat_base, own_rank, own_records,
+    #                       matched, ignored, stream)
+    assert lib.taoamd_exchange_merge(4, 1, 1, 0, p, 3, 1, p, p, p, -1, None,
+                                     base, base + 8, None) == 2

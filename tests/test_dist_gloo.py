@@ -67,9 +67,19 @@ class OracleBackend:
             np.lexsort((np.arange(n), -(s + 0.0), c)).astype(np.int32))
 
     def merge_runs(self, n_recv, world, block_cats, k0, records, width, n_words,
-                   src_base, run_off, cat_base, matched, ignored):
-        rec, sb = records.numpy(), src_base.numpy()
+                   src_base, run_off, cat_base, matched, ignored, own=-1,
+                   own_records=None):
+        sb = src_base.numpy()
         ro, cb = run_off.numpy(), cat_base.numpy()
+        # the logical input: every source's rows, the rank's own taken where
+        # the match wrote them (they do not travel)
+        wire = records.numpy()
+        if own >= 0:
+            n_own = int(sb[own + 1] - sb[own])
+            rec = np.concatenate([wire[:sb[own]], own_records.numpy()[:n_own],
+                                  wire[sb[own]:]])
+        else:
+            rec = wire
         for kb in range(block_cats):
             idx = np.concatenate([np.arange(sb[s] + ro[s, kb], sb[s] + ro[s, kb + 1])
                                   for s in range(world)]).astype(np.int64)
