@@ -98,6 +98,29 @@ int taoamd_gt_write(const char *path, const void *const *arrays,
 int taoamd_host_sort_key_score(int64_t n, const int64_t *key, const double *score,
                                int64_t *order);
 
+/* ---- vector primitives of the ground-truth halves of the cell tables
+ * (tao_amodal_amd/flatten.py: the id -> row resolutions of lvis_amodal/lvis.py:
+ * 34-61 and tao_amodal/tao.py:108-160 over 3 M annotations), on all threads.
+ * lookup: out[i] = index of values[i] in keys (ascending, unique) or -1.
+ * take:   out[i] = src[idx[i]], elements of 1 / 4 / 8 / 32 bytes; returns 2
+ *         when an index lies outside [0, n_src).
+ * seq_mean: Python's left-to-right sum(...) / len(...) of each CSR segment
+ *         (tao_amodal/tao.py:186-187).  All return 0 on success, 1 on bad
+ *         arguments. */
+int taoamd_host_lookup(int64_t n_keys, const int64_t *keys, int64_t n,
+                       const int64_t *values, int64_t *out);
+int taoamd_host_take(int32_t elem, int64_t n_src, const void *src, int64_t n,
+                     const int64_t *idx, void *out);
+int taoamd_host_seq_mean(int64_t n_seg, const int64_t *off, const double *vals,
+                         double *out);
+
+/* out[0 .. *n_out) = list(set(ids) & set(ids)) as CPython 3.7 - 3.12 iterates
+ * it (ints 0 <= k < 2^61 - 1): the visiting order of the images of the
+ * evaluated videos, tao_amodal/tao.py:224-230.  `out` holds n entries.  Returns
+ * 0; 3 when a key is outside that range (the caller asks the interpreter). */
+int taoamd_host_pyset_self_and(int64_t n, const int64_t *ids, int64_t *out,
+                               int64_t *n_out);
+
 /* OpenMP threads the host-side entry points of this library start: the
  * logical CPUs of the process capped by its affinity mask and by the control
  * group's CPU quota (csrc/host_threads.hpp; TAOAMD_HOST_THREADS overrides). */

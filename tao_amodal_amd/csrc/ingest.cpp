@@ -1223,4 +1223,179 @@ int taoamd_host_sort_key_score(int64_t n, const int64_t *key, const double *scor
     return 0;
 }
 
+// out[i] = index of values[i] in `keys` (ascending, unique), -1 when absent --
+// flatten._lookup on all threads (ids in a modest range through a dense table,
+// else a binary search each).  The ground-truth halves of the cell tables look
+// up 3 M image / category / track ids a dozen times.
+int taoamd_host_lookup(int64_t n_keys, const int64_t *keys, int64_t n,
+                       const int64_t *values, int64_t *out)
+{
+    taoamd::ThreadScope threads;
+    if (n_keys < 0 || n < 0 || (n_keys && !keys) || (n && (!values || !out))) return 1;
+    const int T = std::max(1, std::min(32, taoamd::host_threads()));
+    if (n_keys == 0) {
+#pragma omp parallel for schedule(static) num_threads(T)
+        for (int64_t i = 0; i < n; i++) out[i] = -1;
+        return 0;
+    }
+    const int64_t lo = keys[0], hi = keys[n_keys - 1];
+    const uint64_t span = (uint64_t)hi - (uint64_t)lo;
+    if (span < (uint64_t)std::max<int64_t>(8 * n, (int64_t)1 << 22)) {
+        std::vector<int32_t, NoInit<int32_t>> table((size_t)span + 1);
+        int32_t *t = table.data();
+        const bool small = n_keys < ((int64_t)1 << 31);
+        if (small) {
+#pragma omp parallel for schedule(static) num_threads(T)
+            for (int64_t j = 0; j <= (int64_t)span; j++) t[j] = -1;
+#pragma omp parallel for schedule(static) num_threads(T)
+            for (int64_t j = 0; j < n_keys; j++) t[keys[j] - lo] = (int32_t)j;
+#pragma omp parallel for schedule(static) num_threads(T)
+            for (int64_t i = 0; i < n; i++) {
+                const int64_t v = values[i];
+                out[i] = (v < lo || v > hi) ? -1 : t[v - lo];
+            }
+            return 0;
+        }
+    }
+#pragma omp parallel for schedule(static) num_threads(T)
+    for (int64_t i = 0; i < n; i++) {
+        const int64_t v = values[i];
+        const int64_t *p = std::lower_bound(keys, keys + n_keys, v);
+        out[i] = (p != keys + n_keys && *p == v) ? (int64_t)(p - keys) : -1;
+    }
+    return 0;
+}
+
+// out[i] = src[idx[i]] for elements of `elem` bytes (1, 4, 8 or 32): numpy's
+// fancy-index gather on all threads.  Every idx[i] must lie in [0, n_src).
+int taoamd_host_take(int32_t elem, int64_t n_src, const void *src, int64_t n,
+                     const int64_t *idx, void *out)
+{
+    taoamd::ThreadScope threads;
+    if (n < 0 || n_src < 0 || (n && (!src || !idx || !out))) return 1;
+    const int T = std::max(1, std::min(32, taoamd::host_threads()));
+    int bad = 0;
+#define TAKE_LOOP(TYPE)                                                          \
+    {                                                                             \
+        const TYPE *s_ = (const TYPE *)src;                                       \
+        TYPE *o_ = (TYPE *)out;                                                   \
+        _Pragma("omp parallel for schedule(static) num_threads(T) reduction(| : bad)") \
+        for (int64_t i = 0; i < n; i++) {                                         \
+            const int64_t j = idx[i];                                             \
+            if (j < 0 || j >= n_src) { bad |= 1; continue; }                      \
+            o_[i] = s_[j];                                                        \
+        }                                                                         \
+    }
+    struct B32 { uint64_t w[4]; };
+    switch (elem) {
+    case 1: TAKE_LOOP(uint8_t) break;
+    case 4: TAKE_LOOP(uint32_t) break;
+    case 8: TAKE_LOOP(uint64_t) break;
+    case 32: TAKE_LOOP(B32) break;
+    default: return 1;
+    }
+#undef TAKE_LOOP
+    return bad ? 2 : 0;
+}
+
+// out[s] = (((0.0 + v[off[s]]) + v[off[s] + 1]) + ...) / len(s): Python's
+// left-to-right ``sum(x['area'] for x in track) / len(track)`` per track
+// (reference tao_amodal/tao.py:186-187); an empty segment gives 0.0 / 0 = NaN
+// as numpy does.
+int taoamd_host_seq_mean(int64_t n_seg, const int64_t *off, const double *vals,
+                         double *out)
+{
+    taoamd::ThreadScope threads;
+    if (n_seg < 0 || (n_seg && (!off || !out))) return 1;
+    const int T = std::max(1, std::min(32, taoamd::host_threads()));
+#pragma omp parallel for schedule(static, 256) num_threads(T)
+    for (int64_t s = 0; s < n_seg; s++) {
+        double acc = 0.0;
+        for (int64_t i = off[s]; i < off[s + 1]; i++) acc = acc + vals[i];
+        out[s] = acc / (double)(off[s + 1] - off[s]);
+    }
+    return 0;
+}
+
+// ``list(set(ids) & set(ids))`` of CPython 3.7 - 3.12 for ints 0 <= k < 2^61 - 1
+// (hash(k) == k): the order in which the reference visits the images of the
+// evaluated videos (tao_amodal/tao.py:224-230, img_ids = video_images).
+// Objects/setobject.c: set(iterable) adds key by key (set_add_entry: linear
+// probes of 9 neighbours, then i = 5 i + 1 + perturb; growth when
+// fill * 5 >= mask * 3 to used * 4, used * 2 above 50000 entries, re-inserting
+// in slot order); set_intersection() of two equally large sets walks the second
+// operand in slot order and adds what the first contains to a NEW set the same
+// way; list() walks that one in slot order.  (csrc/pyset.hpp restates the same
+// text for the device; here on int64 keys, -1 = unused slot.)  Returns 0, or 3
+// when a key lies outside the supported range (the caller uses the interpreter).
+namespace {
+struct IdSet {
+    std::vector<int64_t, NoInit<int64_t>> t;
+    uint64_t mask = 7, used = 0;
+    IdSet() : t(8) { std::fill(t.begin(), t.end(), (int64_t)-1); }
+    static void insert_clean(int64_t *t, uint64_t mask, int64_t key)
+    {
+        uint64_t perturb = (uint64_t)key, i = (uint64_t)key & mask;
+        for (;;) {
+            if (t[i] < 0) { t[i] = key; return; }
+            if (i + 9 <= mask)
+                for (int j = 1; j <= 9; j++)
+                    if (t[i + j] < 0) { t[i + j] = key; return; }
+            perturb >>= 5;
+            i = (i * 5 + 1 + perturb) & mask;
+        }
+    }
+    void resize(uint64_t minused)
+    {
+        uint64_t size = 8;
+        while (size <= minused) size <<= 1;
+        std::vector<int64_t, NoInit<int64_t>> n(size);
+        std::fill(n.begin(), n.end(), (int64_t)-1);
+        for (uint64_t i = 0; i <= mask; i++)
+            if (t[i] >= 0) insert_clean(n.data(), size - 1, t[i]);
+        t.swap(n);
+        mask = size - 1;
+    }
+    void add(int64_t key)
+    {
+        uint64_t perturb = (uint64_t)key, i = (uint64_t)key & mask;
+        for (;;) {
+            uint64_t e = i;
+            int probes = (i + 9 <= mask) ? 9 : 0;
+            do {
+                const int64_t c = t[e];
+                if (c < 0) {
+                    t[e] = key;
+                    used++;
+                    if (used * 5 >= mask * 3) resize(used > 50000 ? used * 2 : used * 4);
+                    return;
+                }
+                if (c == key) return;
+                e++;
+            } while (probes--);
+            perturb >>= 5;
+            i = (i * 5 + 1 + perturb) & mask;
+        }
+    }
+};
+}  // namespace
+
+int taoamd_host_pyset_self_and(int64_t n, const int64_t *ids, int64_t *out, int64_t *n_out)
+{
+    if (n < 0 || (n && (!ids || !out)) || !n_out) return 1;
+    const int64_t limit = ((int64_t)1 << 61) - 1;
+    for (int64_t i = 0; i < n; i++)
+        if (ids[i] < 0 || ids[i] >= limit) return 3;
+    IdSet b;
+    for (int64_t i = 0; i < n; i++) b.add(ids[i]);
+    IdSet r;
+    for (uint64_t i = 0; i <= b.mask; i++)
+        if (b.t[i] >= 0) r.add(b.t[i]);
+    int64_t m = 0;
+    for (uint64_t i = 0; i <= r.mask; i++)
+        if (r.t[i] >= 0) out[m++] = r.t[i];
+    *n_out = m;
+    return 0;
+}
+
 }  // extern "C"

@@ -36,6 +36,8 @@ tao_amodal/evaluation/tao_amodal/):
 * track area = left-to-right ``sum(area)/len`` over annotations sorted by
   frame_index (T/tao.py:181-187)
 """
+import sys
+
 import numpy as np
 
 from .columns import DTColumns, GTColumns
@@ -68,8 +70,38 @@ def _host_lib():
             if hasattr(lib, "taoamd_host_sort_key_score"):
                 lib.taoamd_host_sort_key_score.argtypes = [
                     C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+                lib.taoamd_host_lookup.argtypes = [
+                    C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+                lib.taoamd_host_take.argtypes = [
+                    C.c_int32, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+                lib.taoamd_host_seq_mean.argtypes = [
+                    C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+                lib.taoamd_host_pyset_self_and.argtypes = [
+                    C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
                 _HOST_LIB = lib
     return _HOST_LIB
+
+
+_NATIVE_MIN = 50000       # elements from which a call into the host library pays
+
+
+def take(src, idx):
+    """``src[idx]`` (1-D index array into the first axis) on all threads of the
+    host library for the large gathers of the ground-truth halves; numpy for
+    small inputs, unsupported element sizes or without the library.  Negative
+    (wrapping) indices go through numpy as well."""
+    n = len(idx)
+    lib = _host_lib() if n >= _NATIVE_MIN else False
+    if lib and isinstance(src, np.ndarray) and src.flags.c_contiguous:
+        elem = src.dtype.itemsize * int(np.prod(src.shape[1:], dtype=np.int64))
+        if elem in (1, 4, 8, 32) and len(src):
+            ix = np.ascontiguousarray(idx, dtype=np.int64)
+            out = np.empty((n,) + src.shape[1:], dtype=src.dtype)
+            rc = lib.taoamd_host_take(elem, len(src), src.ctypes.data, n,
+                                      ix.ctypes.data, out.ctypes.data)
+            if rc == 0:
+                return out
+    return src[idx]
 
 
 def sort_key_score(key, score=None):
@@ -77,7 +109,7 @@ def sort_key_score(key, score=None):
     of key) through the parallel native sort when the host library is built
     and the input is large enough to pay for the call."""
     n = len(key)
-    lib = _host_lib() if n >= 50000 else False
+    lib = _host_lib() if n >= _NATIVE_MIN else False
     if not lib:
         if score is None:
             return np.argsort(key, kind="stable")
@@ -96,6 +128,16 @@ def _lookup(sorted_keys, values):
     """index of each value in sorted_keys (ascending, unique), -1 when absent"""
     if len(sorted_keys) == 0:
         return np.full(len(values), -1, dtype=np.int64)
+    lib = _host_lib() if len(values) >= _NATIVE_MIN else False
+    if lib and np.asarray(sorted_keys).dtype.kind in "iu" and \
+            np.asarray(values).dtype.kind in "iu":
+        k = np.ascontiguousarray(sorted_keys, dtype=np.int64)
+        v = np.ascontiguousarray(values, dtype=np.int64)
+        out = np.empty(len(v), dtype=np.int64)
+        rc = lib.taoamd_host_lookup(len(k), k.ctypes.data, len(v), v.ctypes.data,
+                                    out.ctypes.data)
+        assert rc == 0
+        return out
     lo, hi = int(sorted_keys[0]), int(sorted_keys[-1])
     if len(values) > 4096 and hi - lo < max(8 * len(values), 1 << 22):
         # ids in a modest range (image / category / track ids): one gather
@@ -309,13 +351,13 @@ def lvis_gt_side(gt):
     a_cat = _lookup(cat_ids, gt.ann_cat)
     alias = _last_with_same_id(gt.ann_id)
     g_sel = np.flatnonzero(a_img >= 0)
-    g_sel = g_sel[np.argsort(a_img[g_sel], kind="stable")]
-    g_sel = g_sel[(a_cat[g_sel] >= 0) & (gt.ann_area[g_sel] > 0)
-                  & (gt.ann_area[g_sel] < np.inf)]
-    g_sel = alias[g_sel]
+    g_sel = g_sel[sort_key_score(take(a_img, g_sel))]       # (stable)
+    area = take(gt.ann_area, g_sel)
+    g_sel = g_sel[(take(a_cat, g_sel) >= 0) & (area > 0) & (area < np.inf)]
+    g_sel = take(alias, g_sel)
     G = Flat()
     G.img_ids, G.cat_ids, G.img_row = img_ids, cat_ids, img_row
-    G.g_sel, G.g_img, G.g_cat = g_sel, a_img[g_sel], a_cat[g_sel]
+    G.g_sel, G.g_img, G.g_cat = g_sel, take(a_img, g_sel), take(a_cat, g_sel)
     return G
 
 
@@ -323,13 +365,12 @@ def lvis_gt_tables(f, gt, g_sel, keys_g, U):
     """Ground-truth columns of a flattened image-level problem (rows g_sel,
     already in final order)."""
     f.gt_row = g_sel                # row of dataset["annotations"]
-    f.gt_box = np.ascontiguousarray(gt.ann_bbox[g_sel])
-    f.gt_vis = np.ascontiguousarray(gt.ann_vis[g_sel])
-    f.gt_flags = (np.where(gt.ann_ignore[g_sel] != 0, GT_IGNORE, 0)
-                  | np.where(gt.ann_oof[g_sel] != 0, GT_OOF, 0)
-                  | np.where(gt.ann_id[g_sel] == 0, GT_ID_HIDDEN, 0)
-                  ).astype(np.uint8)
-    f.gt_id = gt.ann_id[g_sel]
+    f.gt_box = np.ascontiguousarray(take(gt.ann_bbox, g_sel))
+    f.gt_vis = np.ascontiguousarray(take(gt.ann_vis, g_sel))
+    f.gt_id = take(gt.ann_id, g_sel)
+    f.gt_flags = ((take(gt.ann_ignore, g_sel) != 0) * np.uint8(GT_IGNORE)
+                  | (take(gt.ann_oof, g_sel) != 0) * np.uint8(GT_OOF)
+                  | (f.gt_id == 0) * np.uint8(GT_ID_HIDDEN)).astype(np.uint8)
     f.gt_cat = (keys_g // U).astype(I32)
 
 
@@ -453,6 +494,15 @@ def _seq_track_mean(vals, off):
     acc = np.zeros(len(lens))
     if len(lens) == 0:
         return acc
+    lib = _host_lib() if len(vals) >= _NATIVE_MIN else False
+    if lib:
+        o = np.ascontiguousarray(off, dtype=np.int64)
+        v = np.ascontiguousarray(vals, dtype=np.float64)
+        with np.errstate(all="ignore"):
+            rc = lib.taoamd_host_seq_mean(len(lens), o.ctypes.data, v.ctypes.data,
+                                          acc.ctypes.data)
+        assert rc == 0
+        return acc
     for s in range(int(lens.max())):
         live = np.flatnonzero(lens > s)
         acc[live] = acc[live] + vals[off[live] + s]
@@ -469,7 +519,20 @@ def _group_tracks(sel_trk, sel_frame_index):
     t_rank = np.empty(len(uniq), dtype=np.int64)
     t_rank[np.argsort(first, kind="stable")] = np.arange(len(uniq))
     trk_of_ann = t_rank[inv]
-    perm = sort_key_score(trk_of_ann, -np.asarray(sel_frame_index, dtype=np.float64))
+    fi = np.asarray(sel_frame_index)
+    span = 0
+    if len(fi) and fi.dtype.kind in "iuf":
+        # frame indices that are whole numbers (the usual case; a JSON number
+        # parses as a double): (track, frame_index) is one integer key
+        with np.errstate(invalid="ignore"):
+            whole = fi.astype(np.int64)
+        if fi.dtype.kind != "f" or np.array_equal(whole.astype(np.float64), fi):
+            base = int(whole.min())
+            span = int(whole.max()) - base + 1
+    if span and len(uniq) * span < (1 << 32):
+        perm = sort_key_score(trk_of_ann * span + (whole - base))   # (radix sort)
+    else:
+        perm = sort_key_score(trk_of_ann, -np.asarray(fi, dtype=np.float64))
     off = np.zeros(len(uniq) + 1, dtype=np.int64)
     np.cumsum(np.bincount(trk_of_ann, minlength=len(uniq)), out=off[1:])
     ids = np.empty(len(uniq), dtype=np.int64)
@@ -497,7 +560,7 @@ def track_frames(tl_pos, trk_order, trk_of_ann, aoff, ann_rows, img_idx_of_ann,
                  boxes):
     """Frame lists of the tracks `trk_order` (final, cell order).  The
     annotations are grouped by track (CSR `aoff`) in frame_index order."""
-    pos = tl_pos[img_idx_of_ann]
+    pos = take(tl_pos, img_idx_of_ann)
     if len(pos) > 1:
         rising = pos[1:] > pos[:-1]
         rising[aoff[1:-1][aoff[1:-1] < len(pos)] - 1] = True   # track boundaries
@@ -519,18 +582,38 @@ def track_frames(tl_pos, trk_order, trk_of_ann, aoff, ann_rows, img_idx_of_ann,
         live = np.flatnonzero(nt >= 0)
         sel, off = _unique_frames(nt[live], pos[live], len(trk_order))
         rows = live[sel]
-    return (pos[rows].astype(I32), LazyRows(boxes, ann_rows[rows]),
+    return (take(pos, rows).astype(I32), LazyRows(boxes, take(ann_rows, rows)),
             off.astype(I32))
 
 
 def _tao_select(visit_rank, a_img_idx, a_cat_idx, a_area, a_ids):
     """get_ann_ids(vid_ids, cat_ids) + load_anns (T/tao.py:203-254)"""
     sel = np.flatnonzero(a_img_idx >= 0)
-    sel = sel[visit_rank[a_img_idx[sel]] >= 0]
-    sel = sel[sort_key_score(visit_rank[a_img_idx[sel]])]
-    sel = sel[(a_cat_idx[sel] >= 0) & (a_area[sel] > 0)
-              & (a_area[sel] < np.inf)]
-    return _last_with_same_id(a_ids)[sel]
+    rank = take(visit_rank, take(a_img_idx, sel))
+    sel, rank = sel[rank >= 0], rank[rank >= 0]
+    sel = sel[sort_key_score(rank)]
+    area = take(a_area, sel)
+    sel = sel[(take(a_cat_idx, sel) >= 0) & (area > 0) & (area < np.inf)]
+    return take(_last_with_same_id(a_ids), sel)
+
+
+def visiting_order(image_ids):
+    """``list(set(ids) & set(ids))``: the order the reference walks the images
+    of the evaluated videos in (T/tao.py:224-230 with img_ids = video_images)
+    -- CPython's set iteration order, from the interpreter itself or, for large
+    inputs, from the host library's restatement of setobject.c (pinned to the
+    interpreter in tests/test_host_primitives.py)."""
+    import ctypes as C
+    ids = np.ascontiguousarray(image_ids, dtype=np.int64)
+    lib = _host_lib() if len(ids) >= _NATIVE_MIN else False
+    if lib and sys.version_info[:2] <= (3, 12):
+        out = np.empty(len(ids), dtype=np.int64)
+        m = C.c_int64(0)
+        if lib.taoamd_host_pyset_self_and(len(ids), ids.ctypes.data, out.ctypes.data,
+                                          C.addressof(m)) == 0:
+            return out[:m.value]
+    lst = ids.tolist()
+    return np.asarray(list(set(lst) & set(lst)), dtype=np.int64)
 
 
 def video_images(gt):
@@ -609,9 +692,8 @@ def tao_gt_side(gt, visit_universe=None):
 
     # ---- visiting order of images: CPython set iteration (T/tao.py:224-230)
     own_images = video_images(gt)
-    vis_list = (own_images if visit_universe is None
-                else np.asarray(visit_universe, dtype=np.int64)).tolist()
-    visit = np.asarray(list(set(vis_list) & set(vis_list)), dtype=np.int64)
+    visit = visiting_order(own_images if visit_universe is None
+                           else np.asarray(visit_universe, dtype=np.int64))
     # (images of other ranks' videos drop out of the ranking)
     at = _lookup(img_ids, visit)
     visit_rank = np.full(len(img_ids), -1, dtype=np.int64)
@@ -627,13 +709,16 @@ def tao_gt_side(gt, visit_universe=None):
     if len(g_sel) == 0 and visit_universe is None:
         raise ValueError("Found no groundtruth annotations for given params")
     g_ids, g_perm, g_aoff = _group_tracks(
-        gt.ann_trk[g_sel], gt.img_frame[img_row[a_img[g_sel]]])
-    g_ann = g_sel[g_perm]                          # annotations, track-major
+        take(gt.ann_trk, g_sel),
+        take(gt.img_frame, take(img_row, take(a_img, g_sel))))
+    g_ann = take(g_sel, g_perm)                    # annotations, track-major
     g_trk_of_ann = np.repeat(np.arange(len(g_ids)), np.diff(g_aoff))
-    g_area = _seq_track_mean(gt.ann_area[g_ann], g_aoff)
+    g_area = _seq_track_mean(take(gt.ann_area, g_ann), g_aoff)
     g_len = np.diff(g_aoff)
-    g_nhp = np.bincount(g_trk_of_ann, weights=(gt.ann_vis[g_ann] < 0.8),
-                        minlength=len(g_ids)).astype(np.int64)
+    # annotations below 0.8 visibility per track (every track lists >= 1)
+    _low = np.zeros(len(g_ann) + 1, dtype=np.int64)
+    np.cumsum(take(gt.ann_vis, g_ann) < 0.8, out=_low[1:])
+    g_nhp = _low[g_aoff[1:]] - _low[g_aoff[:-1]]
     g_row = t_rows_u[_lookup(t_keys_u, g_ids)]
     g_vid = _lookup(vid_ids, gt.trk_vid[g_row])
     g_cat = _lookup(cat_ids, trk_cat[g_row])

@@ -19,6 +19,13 @@ def _gt_key(gt):
                  for k, v in sorted(vars(gt).items()) if isinstance(v, np.ndarray))
 
 
+def _sorted_unique(keys):
+    """np.unique of an ascending array (no second sort)."""
+    if len(keys) < 2:
+        return keys.copy()
+    return keys[np.r_[True, keys[1:] != keys[:-1]]]
+
+
 def _lvis_gt_ready(gt):
     """Everything of the image-level tables that depends on the annotation
     file alone: lvis_gt_side, the cell order of the ground truths and their
@@ -27,10 +34,10 @@ def _lvis_gt_ready(gt):
     U = len(G.img_ids)
     keys_g = G.g_cat * U + G.g_img
     og = flatten.sort_key_score(keys_g)
-    g_sel, keys_g = G.g_sel[og], keys_g[og]
+    g_sel, keys_g = flatten.take(G.g_sel, og), flatten.take(keys_g, og)
     R = Flat()
     R.G, R.g_sel, R.keys_g = G, g_sel, keys_g
-    R.gkeys = np.unique(keys_g).astype(np.int32)
+    R.gkeys = _sorted_unique(keys_g).astype(np.int32)
     R.tables = Flat()
     flatten.lvis_gt_tables(R.tables, gt, g_sel, keys_g, max(U, 1))
     return R
@@ -45,10 +52,10 @@ def _tao_gt_ready(gt, visit_universe=None):
     keys_g = keys_g[og]
     R = Flat()
     R.T, R.og, R.keys_g = T, og, keys_g
-    R.gkeys = np.unique(keys_g).astype(np.int32)
+    R.gkeys = _sorted_unique(keys_g).astype(np.int32)
     R.img_frame = gt.img_frame[T.img_row]
     R.frames = flatten.track_frames(T.tl_pos, og, T.g_trk_of_ann, T.g_aoff, T.g_ann,
-                                    T.a_img[T.g_ann], gt.ann_bbox)
+                                    flatten.take(T.a_img, T.g_ann), gt.ann_bbox)
     t = R.tables = Flat()
     t.gt_area = np.ascontiguousarray(T.g_area[og])
     t.gt_len = T.g_len[og].astype(I32)

@@ -1,0 +1,111 @@
+"""The native vector primitives behind the ground-truth halves of the cell
+tables (libtao_amodal_ingest.so: taoamd_host_lookup / _take / _seq_mean and the
+radix path of taoamd_host_sort_key_score) against the numpy statements they
+replace above flatten._NATIVE_MIN elements -- the reference goldens are far
+smaller than that threshold, so the two paths are compared here directly."""
+import numpy as np
+import pytest
+
+from tao_amodal_amd import flatten
+
+
+@pytest.fixture
+def both_paths(monkeypatch):
+    if not flatten._host_lib():
+        pytest.skip("libtao_amodal_ingest.so not built")
+
+    def run(fn, *args):
+        monkeypatch.setattr(flatten, "_NATIVE_MIN", 1 << 62)
+        ref = fn(*args)
+        monkeypatch.setattr(flatten, "_NATIVE_MIN", 1)
+        return ref, fn(*args)
+    return run
+
+
+def _same(a, b):
+    assert a.dtype == b.dtype and a.shape == b.shape
+    assert np.array_equal(a, b, equal_nan=a.dtype.kind == "f")
+
+
+@pytest.mark.parametrize("spread", [3, 1 << 40])
+def test_lookup(both_paths, spread):
+    rng = np.random.default_rng(1)
+    keys = np.unique(rng.integers(-50, 70000, 40000) * spread)
+    vals = np.concatenate([rng.choice(keys, 90000), rng.integers(-10**6, 10**6, 5000),
+                           [keys[0] - 1, keys[-1] + 1, keys[0], keys[-1]]])
+    _same(*both_paths(flatten._lookup, keys, vals))
+    _same(*both_paths(flatten._lookup, keys, vals.astype(np.int32) if spread == 3 else vals))
+    _same(*both_paths(flatten._lookup, keys[:0], vals))
+    _same(*both_paths(flatten._lookup, keys, vals[:0]))
+
+
+@pytest.mark.parametrize("dtype,tail", [(np.uint8, ()), (np.int32, ()), (np.int64, ()),
+                                        (np.float64, ()), (np.float64, (4,)),
+                                        (np.float32, (3,))])
+def test_take(both_paths, dtype, tail):
+    rng = np.random.default_rng(2)
+    src = rng.integers(0, 250, (7000,) + tail).astype(dtype)
+    idx = rng.integers(0, len(src), 60000)
+    _same(*both_paths(flatten.take, src, idx))
+    _same(*both_paths(flatten.take, src, idx.astype(np.int32)))
+    neg = idx.copy()
+    neg[::7] -= len(src)                       # numpy's wrapping indices
+    _same(*both_paths(flatten.take, src, neg))
+    with pytest.raises(IndexError):
+        flatten.take(src, np.r_[idx, len(src)])
+    _same(*both_paths(flatten.take, src[::2], idx // 2))   # (a view: numpy's path)
+
+
+def test_seq_track_mean(both_paths):
+    rng = np.random.default_rng(3)
+    lens = rng.integers(0, 40, 5000)
+    lens[10] = 300
+    off = np.r_[0, np.cumsum(lens)]
+    vals = rng.random(int(off[-1])) * 1e6
+    vals[5] = np.inf
+    with np.errstate(all="ignore"):
+        ref, out = both_paths(flatten._seq_track_mean, vals, off)
+    _same(ref, out)
+    assert np.isnan(out[lens == 0]).all()
+
+
+def test_group_tracks_and_sorts(both_paths):
+    rng = np.random.default_rng(4)
+    trk = rng.integers(5, 4000, 80000) * 17
+    frame = rng.integers(0, 900, 80000)
+    for a, b in zip(*both_paths(flatten._group_tracks, trk, frame)):
+        _same(a, b)
+    for a, b in zip(*both_paths(flatten._group_tracks, trk, frame.astype(np.float64))):
+        _same(a, b)
+    odd = frame.astype(np.float64)
+    odd[3], odd[9], odd[11] = 0.5, np.nan, -0.0      # fractions / NaN: the merge sort
+    for a, b in zip(*both_paths(flatten._group_tracks, trk, odd)):
+        _same(a, b)
+    # the composite key does not fit 32 bits: the (key, score) merge sort
+    for a, b in zip(*both_paths(flatten._group_tracks, trk, frame * (1 << 21))):
+        _same(a, b)
+    key = rng.integers(0, 1 << 31, 70000)
+    _same(*both_paths(flatten.sort_key_score, key))
+    _same(*both_paths(flatten.sort_key_score, key // (1 << 20)))     # many ties: stable
+
+
+@pytest.mark.parametrize("seed,n,hi", [(0, 60000, 10**6), (1, 70001, 80000), (2, 300000, 1 << 40),
+                                       (3, 52000, 53000), (4, 200000, 10**9)])
+def test_visiting_order_is_the_interpreters(both_paths, seed, n, hi):
+    """set(ids) & set(ids), listed: CPython's own answer (below the threshold
+    the function asks the interpreter) against the host library's restatement
+    of setobject.c -- past the 50000-entry change of the growth factor, with
+    duplicates, dense and sparse ids."""
+    rng = np.random.default_rng(seed)
+    ids = rng.integers(0, hi, n)
+    ref, out = both_paths(flatten.visiting_order, ids)
+    _same(ref, out)
+    lst = ids.tolist()
+    assert out.tolist() == list(set(lst) & set(lst))
+    # ids in dataset order (ascending runs per video), as video_images() lists them
+    runs = np.concatenate([np.arange(s, s + 300) for s in rng.permutation(2500) * 300])
+    _same(*both_paths(flatten.visiting_order, runs))
+    # out of the supported range: the interpreter answers
+    odd = ids.copy()
+    odd[5] = -3
+    _same(*both_paths(flatten.visiting_order, odd))
