@@ -1007,13 +1007,16 @@ extern "C" int taoamd_sort_segments(int64_t n, int32_t n_cat,
 // ===========================================================================
 #define SS_CAP 1024
 #define SS_FAST 512                    // most elements the one-word network takes
+#ifndef SS_TARGET                      // (build.sh -DSS_TARGET=.. -DSS_CHUNK_TILES=..: experiments)
 #define SS_TARGET 352
+#define SS_CHUNK_TILES 16
+#define SS_FIRST_MERGE_PASS 4          // log2(SS_CHUNK / SEG_TILE)
+#endif
 #define SS_OVER 32
 #define SS_DIRECT 1024
-#define SS_CHUNK (16 * SEG_TILE)       // 45056 = SS_MAXB * SS_TARGET
+#define SS_CHUNK (SS_CHUNK_TILES * SEG_TILE)   // 45056 = SS_MAXB * SS_TARGET
 #define SS_MAXB 128
-#define SS_HALF_CHUNK (8 * SEG_TILE)   // chunks up to here: SS_OVER samples per bucket, beyond: half
-#define SS_FIRST_MERGE_PASS 4          // log2(SS_CHUNK / SEG_TILE)
+#define SS_HALF_CHUNK (SS_CHUNK / 2)   // chunks up to here: SS_OVER samples per bucket, beyond: half
 
 struct SsChunk {                       // 32 bytes
     int32_t begin, n;                  // elements [begin, begin + n)

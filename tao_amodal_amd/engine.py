@@ -676,7 +676,17 @@ def guarded_pairs(dp, ws):
     if dp.guard_on_device and int(ws.guard_status.item()):
         raise _lib.TaoAmdError("frame-order guard: a track pair outgrew the set "
                                "tables sized for the longest tracks")
-    return int(ws.near_count.item())
+    n = int(ws.near_count.item())
+    if n > max(dp.n_iou // 8, 1024):
+        # every listed pair is recomputed serially by one thread (the CPython
+        # set emulation): a large share of the pairs -- avg_iou on integer
+        # boxes with many exact ties, duplicated tracks -- turns a 0.3 ms pass
+        # into a much longer one without changing any result; say so
+        import logging
+        logging.getLogger("tao_amodal_amd").warning(
+            "frame-order guard: %d of %d track pairs were recomputed in the "
+            "reference's frame order (slow path)", n, dp.n_iou)
+    return n
 
 
 def set_order_iou(flat, pairs, mode=0):
