@@ -121,6 +121,13 @@ int taoamd_host_seq_mean(int64_t n_seg, const int64_t *off, const double *vals,
 int taoamd_host_pyset_self_and(int64_t n, const int64_t *ids, int64_t *out,
                                int64_t *n_out);
 
+/* *n_clash = how many track ids the predictions use in more than one video
+ * (tools/eval_on_tao_amodal.py:44-58, len(track_ids_to_update)); 0 = nothing
+ * to renumber, the usual case.  Returns 0; 3 when the ids span too wide a
+ * range for a dense table (the caller's general statement takes over). */
+int taoamd_host_track_clash(int64_t n, const int64_t *track_id, const int64_t *video_id,
+                            int64_t *n_clash);
+
 /* OpenMP threads the host-side entry points of this library start: the
  * logical CPUs of the process capped by its affinity mask and by the control
  * group's CPU quota (csrc/host_threads.hpp; TAOAMD_HOST_THREADS overrides). */

@@ -1398,4 +1398,46 @@ int taoamd_host_pyset_self_and(int64_t n, const int64_t *ids, int64_t *out, int6
     return 0;
 }
 
+// How many track ids occur with more than one video id (reference
+// tools/eval_on_tao_amodal.py:44-58: the size of track_ids_to_update -- a track
+// is in it iff some prediction's video differs from the FIRST one's, i.e. iff
+// the id has two different videos, whatever the order).  Ids in a modest range
+// through a dense table on all threads: a video per id from any of its rows
+// (racing plain stores of equal-sized words: one of the stored values wins),
+// then every row against it.  Returns 0; 3 when the ids span too wide a range
+// (the caller's numpy statement takes over).
+int taoamd_host_track_clash(int64_t n, const int64_t *tid, const int64_t *vid, int64_t *n_clash)
+{
+    taoamd::ThreadScope threads;
+    if (n < 0 || (n && (!tid || !vid)) || !n_clash) return 1;
+    *n_clash = 0;
+    if (n == 0) return 0;
+    const int T = std::max(1, std::min(32, taoamd::host_threads()));
+    int64_t lo = INT64_MAX, hi = INT64_MIN;
+#pragma omp parallel for schedule(static) num_threads(T) reduction(min : lo) reduction(max : hi)
+    for (int64_t i = 0; i < n; i++) {
+        lo = std::min(lo, tid[i]);
+        hi = std::max(hi, tid[i]);
+    }
+    const uint64_t span = (uint64_t)hi - (uint64_t)lo;
+    if (span >= (uint64_t)std::max<int64_t>(8 * n, (int64_t)1 << 22)) return 3;
+    std::vector<int64_t, NoInit<int64_t>> of((size_t)span + 1);
+    std::vector<uint8_t, NoInit<uint8_t>> bad((size_t)span + 1);
+    int64_t *o = of.data();
+    uint8_t *b = bad.data();
+#pragma omp parallel for schedule(static) num_threads(T)
+    for (int64_t j = 0; j <= (int64_t)span; j++) b[j] = 0;
+#pragma omp parallel for schedule(static) num_threads(T)
+    for (int64_t i = 0; i < n; i++) __atomic_store_n(&o[tid[i] - lo], vid[i], __ATOMIC_RELAXED);
+#pragma omp parallel for schedule(static) num_threads(T)
+    for (int64_t i = 0; i < n; i++)
+        if (__atomic_load_n(&o[tid[i] - lo], __ATOMIC_RELAXED) != vid[i])
+            __atomic_store_n(&b[tid[i] - lo], (uint8_t)1, __ATOMIC_RELAXED);
+    int64_t c = 0;
+#pragma omp parallel for schedule(static) num_threads(T) reduction(+ : c)
+    for (int64_t j = 0; j <= (int64_t)span; j++) c += b[j];
+    *n_clash = c;
+    return 0;
+}
+
 }  // extern "C"

@@ -78,6 +78,8 @@ def _host_lib():
                     C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
                 lib.taoamd_host_pyset_self_and.argtypes = [
                     C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+                lib.taoamd_host_track_clash.argtypes = [
+                    C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
                 _HOST_LIB = lib
     return _HOST_LIB
 
@@ -226,6 +228,17 @@ def make_track_ids_unique(dt):
     tid, vid = dt.track_id, dt.video_id
     if n == 0:
         return tid.copy(), 0
+    lib = _host_lib() if n >= _NATIVE_MIN else False
+    if lib and tid.dtype == np.int64 and vid.dtype == np.int64 \
+            and tid.flags.c_contiguous and vid.flags.c_contiguous:
+        # the usual answer -- no id is shared between videos -- on all threads
+        # (the statement below: 0.26 s of numpy at 30 M predictions); the
+        # column is then returned as it is, not copied
+        import ctypes as C
+        clash = C.c_int64(0)
+        if lib.taoamd_host_track_clash(n, tid.ctypes.data, vid.ctypes.data,
+                                       C.addressof(clash)) == 0 and clash.value == 0:
+            return tid, 0
     uniq, first, inv = first_inverse(tid)
     clash_t = np.bincount(inv, weights=(vid != vid[first][inv]),
                           minlength=len(uniq)) > 0

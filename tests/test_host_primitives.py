@@ -109,3 +109,30 @@ def test_visiting_order_is_the_interpreters(both_paths, seed, n, hi):
     odd = ids.copy()
     odd[5] = -3
     _same(*both_paths(flatten.visiting_order, odd))
+
+
+def test_track_clash_detection(both_paths):
+    """make_track_ids_unique: the native 'nothing to renumber' answer against
+    the numpy statement, with and without ids shared between videos."""
+    from tao_amodal_amd.columns import DTColumns
+    rng = np.random.default_rng(5)
+    n = 90000
+    tid = rng.integers(0, 7000, n)
+    vid = tid // 10                               # a track lives in one video
+    z = np.zeros(n, dtype=np.int64)
+
+    def cols(t, v):
+        return DTColumns(image_id=z, category_id=z, bbox=np.zeros((n, 4)), score=np.zeros(n),
+                         track_id=t.copy(), video_id=v.copy())
+    (a, na), (b, nb) = both_paths(lambda: flatten.make_track_ids_unique(cols(tid, vid)))
+    assert na == nb == 0 and np.array_equal(a, b) and np.array_equal(a, tid)
+    v2 = vid.copy()
+    v2[rng.integers(0, n, 40)] += 1000            # some ids now span two videos
+    (a, na), (b, nb) = both_paths(lambda: flatten.make_track_ids_unique(cols(tid, v2)))
+    assert na == nb > 0 and np.array_equal(a, b)
+    wide = tid * (1 << 40)                        # ids too sparse for a table
+    (a, na), (b, nb) = both_paths(lambda: flatten.make_track_ids_unique(cols(wide, vid)))
+    assert na == nb == 0 and np.array_equal(a, b)
+    neg = tid - 3500
+    (a, na), (b, nb) = both_paths(lambda: flatten.make_track_ids_unique(cols(neg, v2)))
+    assert na == nb > 0 and np.array_equal(a, b)

@@ -79,8 +79,12 @@ def make_track_ids_unique(dt):
 def evaluate_predictions_on_lvis(lvis_gt, track_result, dt_columns, iou_type,
                                  logger):
     logger.info("Evaluating {} on LVIS...".format(track_result))
-    lvis_eval = LVISEval(lvis_gt, LVISResults(lvis_gt, dt_columns), iou_type)
-    lvis_eval.run()
+    from tao_amodal_amd.evaluation._core import timed
+    with timed("image:results"):
+        lvis_dt = LVISResults(lvis_gt, dt_columns)
+    with timed("image:eval"):
+        lvis_eval = LVISEval(lvis_gt, lvis_dt, iou_type)
+        lvis_eval.run()
     lvis_eval.print_results()
     results = lvis_eval.get_results()
     results = {m: float(results[m] * 100) for m in LVIS_METRICS}
@@ -98,13 +102,18 @@ def eval_tao_track(ann_path, gt_dataset, gt_columns, dt_columns, logger):
     logger.info("Loading gt {}...".format(ann_path))
     tao_gt = Tao(gt_dataset, columns=gt_columns)
     logger.info("Done")
+    from tao_amodal_amd.evaluation._core import timed
     logger.info("Loading results...")
-    make_track_ids_unique(dt_columns)
+    with timed("track:unique_ids"):
+        make_track_ids_unique(dt_columns)
     logger.info("Done")
     logger.info("Building")
-    tao_eval = TaoEval(tao_gt, TaoResults(tao_gt, dt_columns), logger=logger)
-    logger.info("Done")
-    tao_eval.run()
+    with timed("track:results"):
+        tao_dt = TaoResults(tao_gt, dt_columns)
+    with timed("track:eval"):
+        tao_eval = TaoEval(tao_gt, tao_dt, logger=logger)
+        logger.info("Done")
+        tao_eval.run()
     tao_eval.print_results()
     res = tao_eval.get_results()
     results["TAO 3DmAP50"] = res["AP50"] * 100
