@@ -133,6 +133,12 @@ int taoamd_host_track_clash(int64_t n, const int64_t *track_id, const int64_t *v
  * group's CPU quota (csrc/host_threads.hpp; TAOAMD_HOST_THREADS overrides). */
 int taoamd_host_threads(void);
 
+/* Caps the OpenMP teams that entry points called FROM THIS host thread start
+ * (n <= 0: no cap); returns the previous cap.  For callers that run several
+ * entry points side by side under a CPU quota (tools/eval_on_tao_amodal.py: the
+ * two readers beside the thread that imports torch in a fresh process). */
+int taoamd_host_thread_cap(int n);
+
 /* 1 if every one of values[0..n) occurs in keys[0..n_keys) (ascending), 0 if
  * one does not, -1 on a bad argument: the membership test behind "Results do
  * not correspond to current LVIS set." (reference lvis_amodal/results.py:62-65). */

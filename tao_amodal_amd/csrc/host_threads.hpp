@@ -65,10 +65,26 @@ inline int host_threads()
     return n;
 }
 
+// A caller's cap on the teams THIS host thread starts (taoamd_host_thread_cap;
+// 0 = none): when several entry points run side by side -- the two readers of
+// the CLI, beside an interpreter thread that imports torch -- more runnable
+// threads than the control group's quota are all frozen together for the rest
+// of every scheduler period, the serial thread on the critical path included.
+inline thread_local int g_thread_cap = 0;
+
+inline int team_threads()
+{
+    const int n = host_threads();
+    return g_thread_cap > 0 && g_thread_cap < n ? g_thread_cap : n;
+}
+
 // the calling thread's OpenMP team size for the lifetime of the object
 struct ThreadScope {
     int before;
-    ThreadScope() : before(omp_get_max_threads()) { omp_set_num_threads(host_threads()); }
+    ThreadScope() : before(omp_get_max_threads())
+    {
+        omp_set_num_threads(team_threads());
+    }
     ~ThreadScope() { omp_set_num_threads(before); }
     ThreadScope(const ThreadScope &) = delete;
     ThreadScope &operator=(const ThreadScope &) = delete;

@@ -1110,6 +1110,13 @@ void taoamd_gt_free(void *h) { delete (GT *)h; }
 
 int taoamd_host_threads(void) { return taoamd::host_threads(); }
 
+int taoamd_host_thread_cap(int n)
+{
+    const int before = taoamd::g_thread_cap;
+    taoamd::g_thread_cap = n > 0 ? n : 0;
+    return before;
+}
+
 // 1 if every value occurs in `keys` (ascending), 0 if one does not: the
 // "Results do not correspond to current LVIS set." test of LVISResults
 // (reference lvis_amodal/results.py:62-65) over 30 M image ids on all threads.
@@ -1157,7 +1164,7 @@ int taoamd_host_sort_key_score(int64_t n, const int64_t *key, const double *scor
         // keys in ~15 ms where the merge sort of 24-byte records takes ~100
         // (round 4: it was the largest single item of the ground-truth halves
         // of the cell tables, which sit on the CLI's critical path).
-        const int T = std::max(1, std::min(32, taoamd::host_threads()));
+        const int T = std::max(1, std::min(32, taoamd::team_threads()));
         int64_t lo = INT64_MAX, hi = INT64_MIN;
 #pragma omp parallel for schedule(static) num_threads(T) reduction(min : lo) reduction(max : hi)
         for (int64_t i = 0; i < n; i++) {
@@ -1202,7 +1209,7 @@ int taoamd_host_sort_key_score(int64_t n, const int64_t *key, const double *scor
     }
     struct Rec { int64_t key; double neg; int64_t idx; };
     std::vector<Rec> r((size_t)n);
-#pragma omp parallel for schedule(static) num_threads(std::min(32, taoamd::host_threads()))
+#pragma omp parallel for schedule(static) num_threads(std::min(32, taoamd::team_threads()))
     for (int64_t i = 0; i < n; i++) r[i] = Rec{key[i], score ? -score[i] : 0.0, i};
     // a team sized to the input: on a 256-core host the full team costs more
     // in start-up and merge steps than it saves below a few million records
@@ -1218,7 +1225,7 @@ int taoamd_host_sort_key_score(int64_t n, const int64_t *key, const double *scor
         __gnu_parallel::stable_sort(r.begin(), r.end(),
                                     [](const Rec &a, const Rec &b) { return a.key < b.key; },
                                     tag);
-#pragma omp parallel for schedule(static) num_threads(std::min(32, taoamd::host_threads()))
+#pragma omp parallel for schedule(static) num_threads(std::min(32, taoamd::team_threads()))
     for (int64_t i = 0; i < n; i++) order[i] = r[i].idx;
     return 0;
 }
@@ -1232,7 +1239,7 @@ int taoamd_host_lookup(int64_t n_keys, const int64_t *keys, int64_t n,
 {
     taoamd::ThreadScope threads;
     if (n_keys < 0 || n < 0 || (n_keys && !keys) || (n && (!values || !out))) return 1;
-    const int T = std::max(1, std::min(32, taoamd::host_threads()));
+    const int T = std::max(1, std::min(32, taoamd::team_threads()));
     if (n_keys == 0) {
 #pragma omp parallel for schedule(static) num_threads(T)
         for (int64_t i = 0; i < n; i++) out[i] = -1;
@@ -1273,7 +1280,7 @@ int taoamd_host_take(int32_t elem, int64_t n_src, const void *src, int64_t n,
 {
     taoamd::ThreadScope threads;
     if (n < 0 || n_src < 0 || (n && (!src || !idx || !out))) return 1;
-    const int T = std::max(1, std::min(32, taoamd::host_threads()));
+    const int T = std::max(1, std::min(32, taoamd::team_threads()));
     int bad = 0;
 #define TAKE_LOOP(TYPE)                                                          \
     {                                                                             \
@@ -1307,7 +1314,7 @@ int taoamd_host_seq_mean(int64_t n_seg, const int64_t *off, const double *vals,
 {
     taoamd::ThreadScope threads;
     if (n_seg < 0 || (n_seg && (!off || !out))) return 1;
-    const int T = std::max(1, std::min(32, taoamd::host_threads()));
+    const int T = std::max(1, std::min(32, taoamd::team_threads()));
 #pragma omp parallel for schedule(static, 256) num_threads(T)
     for (int64_t s = 0; s < n_seg; s++) {
         double acc = 0.0;
@@ -1412,7 +1419,7 @@ int taoamd_host_track_clash(int64_t n, const int64_t *tid, const int64_t *vid, i
     if (n < 0 || (n && (!tid || !vid)) || !n_clash) return 1;
     *n_clash = 0;
     if (n == 0) return 0;
-    const int T = std::max(1, std::min(32, taoamd::host_threads()));
+    const int T = std::max(1, std::min(32, taoamd::team_threads()));
     int64_t lo = INT64_MAX, hi = INT64_MIN;
 #pragma omp parallel for schedule(static) num_threads(T) reduction(min : lo) reduction(max : hi)
     for (int64_t i = 0; i < n; i++) {
