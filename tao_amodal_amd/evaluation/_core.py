@@ -24,6 +24,10 @@ def masked_mean(s):
 TIMING = {}   # wall-clock seconds per stage, filled when TAOAMD_TIMING is set
 
 
+import threading as _threading
+_TIMING_LOCK = _threading.Lock()
+
+
 def timed(name):
     """Context manager adding the elapsed wall-clock to TIMING[name]."""
     import contextlib
@@ -39,7 +43,8 @@ def timed(name):
         try:
             yield
         finally:
-            TIMING[name] = TIMING.get(name, 0.0) + time.perf_counter() - t0
+            with _TIMING_LOCK:      # (the CLI's two levels time the same keys)
+                TIMING[name] = TIMING.get(name, 0.0) + time.perf_counter() - t0
     return cm()
 
 
