@@ -394,7 +394,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         const int32_t d = d0 + min(lane, nD - 1);
         const int32_t g = g0 + min(lane, max(nG, 1) - 1);
         const uint32_t mt = a.dt_meta[d];
+#ifdef TAOAMD_ABLATE_SCATTER     // (timing experiment: rows stored in detection order)
+        const int32_t row = d + (a.dst[d] & 0);
+#else
         const int32_t row = a.dst[d];
+#endif
         const double4 box = reinterpret_cast<const double4 *>(a.dt_box)[d];
         uint32_t gr = 0xffffffffu;
         uint8_t gf = 0;
