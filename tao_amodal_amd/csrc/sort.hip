@@ -1099,8 +1099,33 @@ __device__ __forceinline__ double ss_fmax(double a, double b)
     asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+// The partner lane's word.  Exchanges inside a row of 16 lanes are DPP moves
+// (VALU: no LDS crossbar, no s_waitcnt) -- xor 1 / 2 / 3 are quad permutations,
+// xor 7 / 15 the half-row / row mirrors, xor 8 a row rotation, xor 4 the two
+// mirrors 7 and 3 in a row; the masks that cross rows (16, 31, 32, 63) go
+// through ds_bpermute.  `m` is a compile-time constant wherever the unrolled
+// network calls this.
+template <int CTRL>
+__device__ __forceinline__ double ss_dpp_f64(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double ss_shfl_xor_f64(double v, int m)
 {
+#ifndef SS_NO_DPP
+    switch (m) {
+    case 1: return ss_dpp_f64<0xB1>(v);           // quad_perm [1, 0, 3, 2]
+    case 2: return ss_dpp_f64<0x4E>(v);           // quad_perm [2, 3, 0, 1]
+    case 3: return ss_dpp_f64<0x1B>(v);           // quad_perm [3, 2, 1, 0]
+    case 4: return ss_dpp_f64<0x1B>(ss_dpp_f64<0x141>(v));
+    case 7: return ss_dpp_f64<0x141>(v);          // row_half_mirror
+    case 8: return ss_dpp_f64<0x128>(v);          // row_ror:8
+    case 15: return ss_dpp_f64<0x140>(v);         // row_mirror
+    default: break;
+    }
+#endif
     const int lo = __shfl_xor(__double2loint(v), m, WAVE);
     const int hi = __shfl_xor(__double2hiint(v), m, WAVE);
     return __hiloint2double(hi, lo);
