@@ -216,6 +216,29 @@ __device__ __forceinline__ void load_chunk(const AccArgs &a, int64_t start, int 
         }
         return;
     }
+    if (a.wide && a.order != nullptr && len > 0) {
+        // rows in cell order, gathered through the sort's order[]: the places
+        // first (coalesced), then all the 16-byte gathers in flight together
+        int32_t at[ACC_BLK_N];
+#pragma unroll
+        for (int blk = 0; blk < ACC_BLK_N; blk++) {
+            const int i = blk * WAVE + lane;
+            at[blk] = a.order[start + (i < len ? i : 0)];
+        }
+        ulonglong2 v[ACC_BLK_N];
+#pragma unroll
+        for (int blk = 0; blk < ACC_BLK_N; blk++)
+            v[blk] = *reinterpret_cast<const ulonglong2 *>(
+                a.matched + 2 * ((int64_t)at[blk] * a.n_words + word));
+#pragma unroll
+        for (int blk = 0; blk < ACC_BLK_N; blk++) {
+            const bool in = blk * WAVE + lane < len;
+            const uint64_t m = in ? v[blk].x : 0, i_ = in ? v[blk].y : ~0ull;
+            tpw[blk] = m & ~i_;
+            fpw[blk] = ~m & ~i_;
+        }
+        return;
+    }
 #pragma unroll
     for (int blk = 0; blk < ACC_BLK_N; blk++)
         load_rows(a, start + blk * WAVE, word, max(0, min(WAVE, len - blk * WAVE)), lane,

@@ -417,7 +417,7 @@ class Workspace:
         # demand (the `order` property) unless a caller wants the sort to store
         # it: 86 MB of stores less per pass at 21 M detections
         self.order_buf = torch.empty(max(dp.n_dt, 1), dtype=torch.int32, device=dev) \
-            if (detail or keep_order) else None
+            if (detail or keep_order or _os0.environ.get("TAOAMD_SORT_ASIDE", "0") != "0") else None
         self._n_dt = dp.n_dt
         self.dst = torch.empty(max(dp.n_dt, 1), dtype=torch.int32, device=dev)
         self.sort_bytes = max(lib.taoamd_sort_workspace(dp.n_dt),
@@ -536,7 +536,7 @@ def sort_is_sampled(dp):
     return dp.n_dt >= SORT_SAMPLED_MIN
 
 
-def stage_sort(dp, ws):
+def stage_sort(dp, ws, order_only=False):
     lib, t, s = _lib.load(), dp.t, _stream()
     if dp.grouped and dp.n_dt and sort_is_sampled(dp):
         nc, ns, nt, nb = dp.ss_sizes
@@ -544,7 +544,8 @@ def stage_sort(dp, ws):
             dp.n_dt, dp.n_cat, _ptr(t["cat_off"]), _ptr(t["tile_off"]), dp.n_tiles,
             dp.max_segment, _ptr(t["dt_score"]), nc, _ptr(t["ss_chunks"]), ns,
             _ptr(t["ss_split"]), nt, _ptr(t["ss_stile"]), nb, _ptr(t["ss_bucket"]),
-            _ptr(ws.order_buf), _ptr(ws.dst), _ptr(ws.sort_ws), ws.sort_bytes, s),
+            _ptr(ws.order_buf), None if order_only else _ptr(ws.dst), _ptr(ws.sort_ws),
+            ws.sort_bytes, s),
             "taoamd_sort_sampled")
         return
     if dp.grouped:
@@ -950,7 +951,7 @@ def run_forked(dp, ws, aux, head_only=False, sort_aside=False, no_match=False,
     if sort_aside and dp.kind == "lvis" and not dp.mask_iou and not head_only \
             and dp.grouped and dp.n_dt:
         with torch.cuda.stream(aux):
-            stage_sort(dp, ws)
+            stage_sort(dp, ws, order_only=sort_is_sampled(dp) and ws.order_buf is not None)
         stage_ranges(dp, ws)
         _probed("match", lambda d, w: stage_match(d, w, scatter=False), dp, ws)
         cur.wait_stream(aux)
