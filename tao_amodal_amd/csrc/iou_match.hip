@@ -543,16 +543,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         }
         const int val = consumes ? qpass : 0;
         int M = 0;
+        // The scan in DPP moves (round 4): a cell's number in the bits above the
+        // value makes the segmented maximum an ordinary one -- a later cell's
+        // entries outrank every earlier cell's, so the running maximum at a lane
+        // is that of its own cell's lanes up to it -- and an ordinary inclusive
+        // maximum over the wavefront is four row shifts and two row broadcasts
+        // on the VALU (v_max_u32 with a DPP operand) instead of six ds_bpermute
+        // round trips through the LDS crossbar with a compare and a select each.
+        const uint32_t cell_no = (uint32_t)__popcll(starts & (lane >= 63 ? ~0ull : ((2ull << lane) - 1)));
         for (int c = 0; c < GRP_GCAP; c++) {
             if (__ballot(simple && cand >= c) == 0) break;          // wave-uniform
-            int x = cand == c ? val : 0;
-#pragma unroll
-            for (int d = 1; d < WAVE; d <<= 1) {
-                const int y = __shfl_up(x, d, WAVE);
-                if (lane - d >= ca) x = max(x, y);
-            }
-            const int before = __shfl_up(x, 1, WAVE);
-            if (cand == c) M = lane - 1 >= ca ? before : 0;
+            static_assert(N_THR < 16, "value bits of the keyed scan");
+            uint32_t x = (lane < nD ? cell_no << 4 : 0u) | (uint32_t)(cand == c ? val : 0);
+#define TAOAMD_SCAN_STEP(CTRL, ROWS)                                                         \
+            x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROWS, 0xF, false))
+            TAOAMD_SCAN_STEP(0x111, 0xF);        // row_shr:1 (a lane without a source keeps 0)
+            TAOAMD_SCAN_STEP(0x112, 0xF);        // row_shr:2
+            TAOAMD_SCAN_STEP(0x114, 0xF);        // row_shr:4
+            TAOAMD_SCAN_STEP(0x118, 0xF);        // row_shr:8
+            TAOAMD_SCAN_STEP(0x142, 0xA);        // row_bcast:15 into rows 1 and 3
+            TAOAMD_SCAN_STEP(0x143, 0xC);        // row_bcast:31 into rows 2 and 3
+#undef TAOAMD_SCAN_STEP
+            // the lane before me (wave_shr:1; lane 0 has none): in my cell iff it
+            // carries my cell's number
+            const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138, 0xF, 0xF, true);
+            if (cand == c) M = (prev >> 4) == cell_no ? (int)(prev & 15u) : 0;
         }
         const uint32_t m10 = qpass > M ? ((1u << qpass) - 1) & ~((1u << M) - 1) : 0u;
         if (simple) {
