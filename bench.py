@@ -276,7 +276,9 @@ def pmc_traffic(kernel, variant, grid, workload):
         ents = []
         for name, ee in d["kernels"].items():
             mm = re.match(r"(?:void )?%s(<[^(]*>)?\(" % re.escape(kernel), name)
-            if not mm or (variant and mm.group(1) != variant):
+            # (the variant names the FIRST template argument: "<true>" is
+            # match_group_kernel<true, ...>, whatever switches follow it)
+            if not mm or (variant and not (mm.group(1) or "").startswith(variant.rstrip(">"))):
                 continue
             ents += [e for e in ee if e.get("hbm_bytes_corrected") is not None]
         if grid is not None:

@@ -28,6 +28,15 @@ def main(src, out):
     grid = lambda r: int(r.get("Grid_Size") or r["Grid_Size_X"])  # noqa: E731
     big = max(grid(rows[i]) for i in marks)
     marks = [i for i in marks if grid(rows[i]) == big]
+    # (both evaluators may launch the anchor with the same grid: the image level's
+    # is the one on the busiest stream -- the caller's, which carries its chain)
+    sid = lambda r: r.get("Stream_Id") or r["Queue_Id"]  # noqa: E731
+    busy = {}
+    for r in rows:
+        busy[sid(r)] = busy.get(sid(r), 0) + int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    main = max(busy, key=busy.get)
+    if any(sid(rows[i]) == main for i in marks):
+        marks = [i for i in marks if sid(rows[i]) == main]
     k = len(marks) // 2
     t0 = int(rows[marks[k]]["Start_Timestamp"])
     t1 = int(rows[marks[k + 1]]["Start_Timestamp"])
