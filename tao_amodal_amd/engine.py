@@ -524,9 +524,12 @@ import os as _os0
 # scatter pass + one register sort per bucket) wins where categories span many
 # LDS tiles -- 2000 videos, 21 M detections: 0.62 against 0.79 ms -- but is four
 # dependent launches; below SORT_SAMPLED_MIN detections the tile sort + one
-# rank-merge pass (taoamd_sort_segments) is the shorter chain (Config 2, 2.1 M
-# detections: 107 against 130 us).  TAOAMD_SORT=sampled / segments forces one.
-SORT_SAMPLED_MIN = 6_000_000
+# rank-merge pass (taoamd_sort_segments) is the shorter chain.  (Until the
+# bucket sort's exchanges became DPP moves the threshold was 6 M -- Config 2,
+# 2.1 M detections: 107 against 130 us; since then the sample sort takes 80 us
+# there against 102, and 67 against 77 at the 3 M rows of the stress stand-in.)
+# TAOAMD_SORT=sampled / segments forces one.
+SORT_SAMPLED_MIN = 1_500_000
 _SORT_FORCE = _os0.environ.get("TAOAMD_SORT", "")
 
 
