@@ -20,6 +20,17 @@
 
 using namespace taoamd;
 
+// The IoU thresholds as the match kernels compare with them: min(thr, 1 - 1e-10)
+// (reference lvis_amodal/eval.py:250 / tao_amodal/eval.py:401), clamped once on
+// the host instead of by every wavefront.
+static IouThr match_thr()
+{
+    IouThr t = iou_thr();
+    for (int q = 0; q < N_THR; q++) t.v[q] = t.v[q] < 1 - 1e-10 ? t.v[q] : 1 - 1e-10;
+    return t;
+}
+
+
 // --------------------------------------------------------------------- bbIou
 __global__ void bb_iou_kernel(const double *__restrict__ dt,
                               const double *__restrict__ gt, size_t m,
@@ -35,8 +46,8 @@ __global__ void bb_iou_kernel(const double *__restrict__ dt,
         double v;
         if (crowd != nullptr && crowd[g]) {
             double da = D.z * D.w;
-            double w = fmin(D.z + D.x, G.z + G.x) - fmax(D.x, G.x);
-            double h = fmin(D.w + D.y, G.w + G.y) - fmax(D.y, G.y);
+            double w = raw_fmin(D.z + D.x, G.z + G.x) - raw_fmax(D.x, G.x);
+            double h = raw_fmin(D.w + D.y, G.w + G.y) - raw_fmax(D.y, G.y);
             v = (w <= 0 || h <= 0) ? 0.0 : (w * h) / da;
         } else {
             v = box_iou(D.x, D.y, D.z, D.w, G.x, G.y, G.z, G.w);
@@ -250,7 +261,7 @@ __global__ __launch_bounds__(256) void match_kernel(MatchArgs a, IouThr thr)
     const bool active = combo < n_combo;
     const int r = active ? combo / N_THR : 0;
     const int t = active ? combo - r * N_THR : 0;
-    const double thr0 = fmin(thr.v[t], 1 - 1e-10);
+    const double thr0 = thr.v[t];
     const int64_t ioff = (FUSED && a.ious_out == nullptr && a.iou == nullptr)
                              ? 0 : a.cell_iou_off[cell];
 
@@ -381,7 +392,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const bool active = combo < n_combo;
     const int r = active ? combo / N_THR : 0;
     const int t = active ? combo - r * N_THR : 0;
-    const double thr0 = fmin(thr.v[t], 1 - 1e-10);
+    const double thr0 = thr.v[t];
 
     // ---- lane = detection of the run
     int32_t t_flags = 0, t_rng = 0, gb = 0, dloc = 0, Gc = 0;
@@ -462,7 +473,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     __builtin_amdgcn_wave_barrier();
     // ---- IoU of every detection against the GTs of its own cell, and its
     // CANDIDATES on the way (see below)
-    const double tmin = fmin(thr.v[0], 1 - 1e-10);
+    const double tmin = thr.v[0];
     int cand = -1, ncand = 0;
     double vc = 0.0;
     // (IoUs from memory: a detection's row of up to GRP_GCAP values in one batch
@@ -539,7 +550,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         int qpass = 0;
         if (simple && cand >= 0) {
 #pragma unroll
-            for (int q = 0; q < N_THR; q++) qpass += !(vc < fmin(thr.v[q], 1 - 1e-10)) ? 1 : 0;
+            for (int q = 0; q < N_THR; q++) qpass += !(vc < thr.v[q]) ? 1 : 0;
         }
         const int val = consumes ? qpass : 0;
         int M = 0;
@@ -667,7 +678,7 @@ __global__ __launch_bounds__(64) void match_big_kernel(MatchArgs a, IouThr thr,
     const bool active = combo < n_combo;
     const int r = active ? combo / N_THR : 0;
     const int t = active ? combo - r * N_THR : 0;
-    const double thr0 = fmin(thr.v[t], 1 - 1e-10);
+    const double thr0 = thr.v[t];
     const int64_t ioff = a.cell_iou_off != nullptr ? a.cell_iou_off[cell] : 0;
     const int n_tw = (G + 31) / 32;
     for (int w = 0; w < n_tw; w++) takenw[w * WAVE + lane] = 0;
@@ -905,23 +916,23 @@ extern "C" int taoamd_match(int64_t n_cells, const int32_t *cell_dt_off,
     if (planned && n_groups > 0) {
         const unsigned gb = (unsigned)(((int64_t)n_groups * a.n_words + 3) / 4);
         const bool fast = fused && a.dt_meta && a.dst && !a.dt_rng && !a.ious_out && !a.match_gt;
-        if (fast) TAO_TIMED("match_group_kernel", s, (match_group_kernel<true, true><<<gb, 256, 0, s>>>(a, iou_thr())));
-        else if (fused) TAO_TIMED("match_group_kernel", s, match_group_kernel<true><<<gb, 256, 0, s>>>(a, iou_thr()));
-        else TAO_TIMED("match_group_kernel", s, match_group_kernel<false><<<gb, 256, 0, s>>>(a, iou_thr()));
+        if (fast) TAO_TIMED("match_group_kernel", s, (match_group_kernel<true, true><<<gb, 256, 0, s>>>(a, match_thr())));
+        else if (fused) TAO_TIMED("match_group_kernel", s, match_group_kernel<true><<<gb, 256, 0, s>>>(a, match_thr()));
+        else TAO_TIMED("match_group_kernel", s, match_group_kernel<false><<<gb, 256, 0, s>>>(a, match_thr()));
     }
     const int64_t cells = planned ? n_singles : n_cells;
     const int64_t items = cells * a.n_words;
     if (items > 0) {
         const unsigned blocks = (unsigned)((items + 3) / 4);
-        if (fused) TAO_TIMED("match_kernel", s, match_kernel<true><<<blocks, 256, 0, s>>>(a, iou_thr()));
-        else TAO_TIMED("match_kernel", s, match_kernel<false><<<blocks, 256, 0, s>>>(a, iou_thr()));
+        if (fused) TAO_TIMED("match_kernel", s, match_kernel<true><<<blocks, 256, 0, s>>>(a, match_thr()));
+        else TAO_TIMED("match_kernel", s, match_kernel<false><<<blocks, 256, 0, s>>>(a, match_thr()));
         if (max_gt_per_cell > WAVE) {
             const int32_t cap = (max_gt_per_cell + 31) / 32 * 32;
             const size_t lds = (size_t)cap * 8 + (size_t)(cap / 32) * WAVE * 4;
             if (fused)
-                TAO_TIMED("match_big_kernel", s, match_big_kernel<true><<<(unsigned)items, 64, lds, s>>>(a, iou_thr(), cap));
+                TAO_TIMED("match_big_kernel", s, match_big_kernel<true><<<(unsigned)items, 64, lds, s>>>(a, match_thr(), cap));
             else
-                TAO_TIMED("match_big_kernel", s, match_big_kernel<false><<<(unsigned)items, 64, lds, s>>>(a, iou_thr(), cap));
+                TAO_TIMED("match_big_kernel", s, match_big_kernel<false><<<(unsigned)items, 64, lds, s>>>(a, match_thr(), cap));
         }
     }
     TAO_LAUNCH_CHECK();
