@@ -536,6 +536,17 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     in_step = _lib.kernel_timings() if rank == 0 else {}
+    # ---- the one-pass sweep's look-back: a wait that gave up anywhere in the
+    # timed region left its (sticky) flag in the workspace that was swept; the
+    # last pass is then swept again with the chunked kernels (what the CLI
+    # does) and the line says so
+    if use_dist:
+        plan.lvis.check()
+        plan.tao.check()
+        look_back_timeouts = int(getattr(plan.lvis, "sweep_recovered", 0) +
+                                 getattr(plan.tao, "sweep_recovered", 0))
+    else:
+        look_back_timeouts = int(engine.sweep_ok(dpl, wsl)) + int(engine.sweep_ok(dpt, wst))
     # ---- every kernel alone: a few serial steps, one stream, events on
     alone = {}
     if rank == 0 and not use_dist:
@@ -798,6 +809,7 @@ def main():
             "host_launch_ms_per_step": round(host_ms, 4),
             "wall_clock_s": wall,
             "bit_exact_vs_oracle": verified,
+            "look_back_timeouts": look_back_timeouts,
             "frame_order_guard": {
                 "exact_terms": bool(dpt.exact_terms),
                 "active": bool(dpt.guard_active()),

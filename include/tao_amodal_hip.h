@@ -662,11 +662,44 @@ int taoamd_accumulate(int64_t n_dt, int32_t n_cat, int32_t n_rng,
  * may use the workspace in between. */
 /* The one-pass sweep of long categories resolves the counts of a category's
  * earlier rows by a decoupled look-back between workgroups; a wait that does
- * not end within ~1 s of polling (never observed: it would mean workgroups do
- * not start in order) gives up and sets a flag in the workspace instead of
- * hanging the GPU.  *flag_host != 0: the tables of a pass on this workspace
- * are not to be trusted.  Synchronises with `stream`. */
+ * not end within the poll limit (never observed: it would mean workgroups do
+ * not start in order, which an idle GPU does and a shared one need not) gives
+ * up and sets a flag in the workspace instead of hanging the GPU.
+ * *flag_host != 0: the tables of a pass on this workspace are not to be
+ * trusted -- run the pass's sweep again with taoamd_accumulate_chunked /
+ * taoamd_accumulate_compact_chunked (same arguments as taoamd_accumulate /
+ * _compact; the chunked kernels whatever the mode; the rows of the pass are
+ * still in place; a prepared plan in the workspace does not survive it, so
+ * taoamd_accumulate_prepare again).  Synchronises with `stream`. */
 int taoamd_accumulate_error(const void *workspace, void *stream, int32_t *flag_host);
+int taoamd_accumulate_chunked(int64_t n_dt, int32_t n_cat, int32_t n_rng,
+                      const int32_t *cat_off, const uint64_t *matched,
+                      const uint64_t *ignored,
+                      const int32_t *num_gt, int32_t max_segment, double *precision,
+                      double *recall, void *workspace, size_t workspace_bytes,
+                      void *stream);
+int taoamd_accumulate_compact_chunked(int64_t n_dt, int32_t n_cat, int32_t n_rng,
+                              const int32_t *cat_off, const uint64_t *matched,
+                              const uint64_t *ignored, const int32_t *num_gt,
+                              int32_t k_begin, int32_t k_end, int32_t max_segment,
+                              double *val, double *rec, void *workspace,
+                              size_t workspace_bytes, void *stream);
+/* Which sweep long categories take, for the process: -1 automatic (the
+ * environment's TAOAMD_SWEEP=chunked|lookback|twopass if set, else the
+ * one-pass look-back sweep from 6 M rows up), 0 the chunked kernels, 1 the
+ * one-pass sweep with the look-back, 2 the one-pass sweep behind a counting
+ * pass.  An explicit 1 / 2 also takes the short categories the fused
+ * single-workgroup sweep would have taken (every case of the parity suite runs
+ * under each mode that way).  _plan_kind: the kind of plan
+ * taoamd_accumulate_prepare builds for these sizes under the current mode (0
+ * none, 1 chunk table, 2 / 3 super-chunk table): a prepared workspace serves
+ * taoamd_accumulate_prepared while this is the value it was built under.
+ * _spin_limit: polls a look-back waits for one predecessor (0: the default,
+ * 2^18; < 0: every look-back gives up at once -- fault injection for the
+ * caller's recovery path). */
+int taoamd_accumulate_sweep_mode(int32_t mode);
+int taoamd_accumulate_plan_kind(int64_t n_dt, int32_t n_rng, int32_t max_segment);
+int taoamd_accumulate_spin_limit(int32_t polls);
 int taoamd_accumulate_prepare(int64_t n_dt, int32_t n_cat, int32_t n_rng,
                               const int32_t *cat_off, int32_t max_segment,
                               void *workspace, size_t workspace_bytes, void *stream);

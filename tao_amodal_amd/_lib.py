@@ -139,6 +139,14 @@ SIGNATURES = {
     "taoamd_accumulate": (C.c_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _i32,
                                     _vp, _vp, _vp, _sz, _vp]),
     "taoamd_accumulate_error": (C.c_int, [_vp, _vp, _vp]),
+    "taoamd_accumulate_chunked": (C.c_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _i32,
+                                            _vp, _vp, _vp, _sz, _vp]),
+    "taoamd_accumulate_compact_chunked": (C.c_int, [_i64, _i32, _i32, _vp, _vp, _vp,
+                                                    _vp, _i32, _i32, _i32, _vp, _vp,
+                                                    _vp, _sz, _vp]),
+    "taoamd_accumulate_sweep_mode": (C.c_int, [_i32]),
+    "taoamd_accumulate_plan_kind": (C.c_int, [_i64, _i32, _i32]),
+    "taoamd_accumulate_spin_limit": (C.c_int, [_i32]),
     "taoamd_accumulate_prepare": (C.c_int, [_i64, _i32, _i32, _vp, _i32, _vp, _sz, _vp]),
     "taoamd_accumulate_prepared": (C.c_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _i32,
                                     _vp, _vp, _vp, _sz, _vp]),
@@ -228,6 +236,19 @@ def set_constants(iou_thrs=None, rec_thrs=None, visibility_rng=None, area_rng=No
     a, ap = arr(area_rng, (5, 2))
     t, tp = arr(time_rng, (4, 2))
     check(lib.taoamd_set_ranges(vp, ap, tp), "taoamd_set_ranges")
+
+
+SWEEP_MODES = {"auto": -1, "chunked": 0, "lookback": 1, "twopass": 2}
+
+
+def sweep_mode(mode="auto", spin_limit=0):
+    """Which sweep long categories take, for the process
+    (taoamd_accumulate_sweep_mode: "auto" | "chunked" | "lookback" | "twopass"),
+    and the look-back's poll limit (taoamd_accumulate_spin_limit; 0 default,
+    < 0 every look-back gives up at once)."""
+    lib = load()
+    check(lib.taoamd_accumulate_sweep_mode(SWEEP_MODES[mode]), "taoamd_accumulate_sweep_mode")
+    check(lib.taoamd_accumulate_spin_limit(int(spin_limit)), "taoamd_accumulate_spin_limit")
 
 
 def check(status, what):

@@ -92,6 +92,8 @@ struct AccArgs {
     uint64_t *sc_max;            // [SC][word][64] largest precision record of the SC
     uint8_t *sc_jhi;             // [SC][word][64] recall thresholds reached up to its end
     uint32_t *sc_error;          // set when a look-back gave up (never observed)
+    int32_t sc_spin;             // polls a look-back waits for one predecessor; < 0: it gives
+                                 // up at once (fault injection, taoamd_accumulate_spin_limit)
 };
 
 __global__ __launch_bounds__(256) void acc_chunks_kernel(AccArgs a)
@@ -1002,8 +1004,12 @@ __global__ __launch_bounds__(FW * WAVE) void acc_fused_kernel(AccArgs a, RecThr 
 //   look-back over 8-byte status words {generation | flag | count}: an SC
 //   publishes its own totals (flag AGG) as soon as its rows are counted, then
 //   the prefix that includes it (flag PRE); a later SC adds up the words it
-//   finds until it meets a PRE.  SCs take their number from a ticket counter,
-//   so an SC only ever waits for SCs that started before it.
+//   finds until it meets a PRE.  An SC's number is its workgroup number (a
+//   ticket atomic ahead of the first load was measured slower): an SC waits
+//   for lower-numbered workgroups, which the dispatcher starts first on an idle
+//   GPU.  That is a matter of speed, not of correctness: a wait that exceeds
+//   the poll limit flags the pass (taoamd_accumulate_error) and the caller
+//   sweeps it again with the chunked kernels (taoamd_accumulate_chunked).
 //
 //   backward dependency (the precision envelope of everything AFTER a row)
 //   cannot be waited for -- the later SCs may not have started.  It is not
@@ -1163,8 +1169,8 @@ void acc_sweep_kernel(AccArgs a, RecThr rec)
                     const uint32_t ft = (uint32_t)(vt >> 32) & 3, ff = (uint32_t)(vf >> 32) & 3;
                     const bool ready = (uint32_t)(vt >> 34) == a.sc_gen &&
                                        (uint32_t)(vf >> 34) == a.sc_gen && ft != 0 && ft == ff;
-                    if (__ballot(open && !ready) == 0) break;
-                    if (spin >= SC_SPIN_LIMIT) {
+                    if (a.sc_spin >= 0 && __ballot(open && !ready) == 0) break;
+                    if (spin >= a.sc_spin) {
                         if (lane == 0) atomicOr(a.sc_error, 1u);
                         vt = vf = 0;
                         break;
@@ -1420,27 +1426,70 @@ static int32_t max_chunks(int64_t n_dt, int32_t n_cat)
     return (int32_t)((n_dt + ACC_CH - 1) / ACC_CH + n_cat);
 }
 
-// ---- which sweep long categories take (TAOAMD_SWEEP, read once):
+// ---- which sweep long categories take:
 //   "chunked"  the six chunked kernels;  "lookback"  acc_sweep_kernel in one
-//   pass;  "twopass"  acc_sweep_kernel behind a counting pass
-enum { SWEEP_CHUNKED = 0, SWEEP_LOOKBACK = 1, SWEEP_TWOPASS = 2 };
-// Without TAOAMD_SWEEP: the one-pass sweep from SWEEP_ONEPASS_MIN rows up.  At
+//   pass;  "twopass"  acc_sweep_kernel behind a counting pass.
+// taoamd_accumulate_sweep_mode() sets it for the process (the tests run every
+// parity case under each); unset, the environment's TAOAMD_SWEEP (read once);
+// without either: the one-pass sweep from SWEEP_ONEPASS_MIN rows up.  At
 // 21 M rows (2000 videos) it takes 0.39 ms against 0.52 for the chunked kernels
 // (rows read once instead of three times plus a transposed copy); at 2 M rows
 // (Config 2) everything is latency and the chunked kernels' three short
 // launches win, 0.12 against 0.16 ms.
+enum { SWEEP_AUTO = -1, SWEEP_CHUNKED = 0, SWEEP_LOOKBACK = 1, SWEEP_TWOPASS = 2 };
 #define SWEEP_ONEPASS_MIN 6000000
+static std::atomic<int> g_sweep_set{SWEEP_AUTO};
+static std::atomic<int> g_sweep_spin{0};       // 0: SC_SPIN_LIMIT
 static int sweep_mode(int64_t n_dt)
 {
-    static const int m = [] {
+    static const int env = [] {
         const char *e = getenv("TAOAMD_SWEEP");
         if (e && !strcmp(e, "lookback")) return (int)SWEEP_LOOKBACK;
         if (e && !strcmp(e, "twopass")) return (int)SWEEP_TWOPASS;
         if (e && !strcmp(e, "chunked")) return (int)SWEEP_CHUNKED;
-        return -1;
+        return (int)SWEEP_AUTO;
     }();
-    if (m >= 0) return m;
+    const int set = g_sweep_set.load(std::memory_order_relaxed);
+    const int m = set != SWEEP_AUTO ? set : env;
+    if (m != SWEEP_AUTO) return m;
     return n_dt >= SWEEP_ONEPASS_MIN ? (int)SWEEP_LOOKBACK : (int)SWEEP_CHUNKED;
+}
+
+extern "C" int taoamd_accumulate_sweep_mode(int32_t mode)
+{
+    if (mode < SWEEP_AUTO || mode > SWEEP_TWOPASS) return TAOAMD_ERR_ARG;
+    g_sweep_set.store(mode, std::memory_order_relaxed);
+    return TAOAMD_OK;
+}
+
+// an explicit one-pass mode (setter or environment) also takes the categories
+// the fused single-workgroup sweep would have taken: the parity tests drive the
+// small reference fixtures through the look-back that way
+static bool sweep_mode_explicit_onepass()
+{
+    const int set = g_sweep_set.load(std::memory_order_relaxed);
+    const char *e = set == SWEEP_AUTO ? getenv("TAOAMD_SWEEP") : nullptr;
+    return set == SWEEP_LOOKBACK || set == SWEEP_TWOPASS ||
+           (e && (!strcmp(e, "lookback") || !strcmp(e, "twopass")));
+}
+
+// Which kind of plan taoamd_accumulate_prepare builds for these sizes under
+// the current mode: 0 none (fused sweep), 1 chunk table, 2 / 3 super-chunk
+// table (look-back / two passes).  A prepared workspace serves
+// taoamd_accumulate_prepared while this value is the one it was built under.
+extern "C" int taoamd_accumulate_plan_kind(int64_t n_dt, int32_t n_rng, int32_t max_segment)
+{
+    if (n_rng < 1 || n_rng > 32) return -1;
+    const int32_t n_words = (n_rng * N_THR + 63) / 64;
+    const int32_t fused_cap = ACC_FUSED_WAVES / n_words * ACC_CH;
+    if (max_segment > 0 && max_segment <= fused_cap && !sweep_mode_explicit_onepass()) return 0;
+    return 1 + sweep_mode(n_dt);
+}
+
+extern "C" int taoamd_accumulate_spin_limit(int32_t polls)
+{
+    g_sweep_spin.store(polls, std::memory_order_relaxed);
+    return TAOAMD_OK;
 }
 // (rows, whatever their width: at 2.9 M track-level rows of four words -- the
 // stress shape -- the chunked kernels are as fast, 0.275 against 0.32 ms)
@@ -1495,7 +1544,7 @@ static int accumulate_compact(int64_t n_dt, int32_t n_cat, int32_t n_rng,
                               const int32_t *num_gt, int32_t k_begin, int32_t k_end,
                               int32_t max_segment, double *val, double *rec,
                               void *workspace, size_t workspace_bytes, void *stream,
-                              int phase = ACC_ALL)
+                              int phase = ACC_ALL, int force_mode = SWEEP_AUTO)
 {
     if (n_cat <= 0 || n_rng < 1 || n_rng > 32) return TAOAMD_ERR_ARG;
     if (k_begin < 0 || k_end > n_cat || k_begin > k_end) return TAOAMD_ERR_ARG;
@@ -1519,6 +1568,10 @@ static int accumulate_compact(int64_t n_dt, int32_t n_cat, int32_t n_rng,
     a.inline_scans = 0;
     a.sc_rows = 0; a.sc_gen = 0; a.sc_stat = a.sc_max = nullptr; a.sc_jhi = nullptr;
     a.sc_error = nullptr;
+    {
+        const int sp = g_sweep_spin.load(std::memory_order_relaxed);
+        a.sc_spin = sp == 0 ? SC_SPIN_LIMIT : sp;
+    }
     // every category fits one workgroup (the host says so): the fused sweep.
     // Mixing the two paths per category was measured slower than the chunked
     // path alone when long categories exist (image level, Config 2: 162 vs
@@ -1536,7 +1589,8 @@ static int accumulate_compact(int64_t n_dt, int32_t n_cat, int32_t n_rng,
         TAO_HIP(hipMemsetAsync((void *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255), 0,
                                align256(SC_TICKETS * 4), s));
     const int32_t fused_cap = ACC_FUSED_WAVES / a.n_words * ACC_CH;
-    const bool all_fused = max_segment > 0 && max_segment <= fused_cap;
+    const bool all_fused = max_segment > 0 && max_segment <= fused_cap &&
+                           (force_mode == SWEEP_CHUNKED || !sweep_mode_explicit_onepass());
     a.fused_rows = 0;
     a.fused_lo = -1;
     if (all_fused && phase == ACC_PLAN) return TAOAMD_OK;     // no chunk table
@@ -1567,7 +1621,7 @@ static int accumulate_compact(int64_t n_dt, int32_t n_cat, int32_t n_rng,
     a.inline_scans = max_segment > 0 && max_segment <= ACC_INLINE_CHUNKS * ACC_CH;
     unsigned char *w = (unsigned char *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     const size_t nc = (size_t)a.n_chunks_max, nw = (size_t)a.n_words;
-    const int mode = sweep_mode(n_dt);
+    const int mode = force_mode != SWEEP_AUTO ? force_mode : sweep_mode(n_dt);
     const size_t ns = max_scs(n_dt, n_cat);
     uint32_t *tickets = (uint32_t *)w;   w += align256(SC_TICKETS * 4);
     a.sc_stat = (uint64_t *)w;           w += align256(ns * nw * WAVE * 16);
@@ -1691,7 +1745,8 @@ static int accumulate_all(int64_t n_dt, int32_t n_cat, int32_t n_rng,
                           const uint64_t *matched, const uint64_t *ignored,
                           const int32_t *num_gt, int32_t max_segment,
                           double *precision, double *recall, void *workspace,
-                          size_t workspace_bytes, void *stream, int phase = ACC_ALL)
+                          size_t workspace_bytes, void *stream, int phase = ACC_ALL,
+                          int force_mode = SWEEP_AUTO)
 {
     if (n_cat <= 0 || n_rng < 1 || n_rng > 32) return TAOAMD_ERR_ARG;
     if (!workspace) return TAOAMD_ERR_ARG;
@@ -1703,7 +1758,7 @@ static int accumulate_all(int64_t n_dt, int32_t n_cat, int32_t n_rng,
     double *rec = val + (align256(taoamd_compact_elems(n_cat, n_rng) * 8) / 8);
     int st = accumulate_compact(n_dt, n_cat, n_rng, cat_off, order, matched, ignored,
                                 num_gt, 0, n_cat, max_segment, val, rec, w, base,
-                                stream, phase);
+                                stream, phase, force_mode);
     if (st != TAOAMD_OK || phase == ACC_PLAN) return st;
     return taoamd_finalize(n_cat, n_rng, num_gt, val, rec, precision, recall, stream);
 }
@@ -1719,6 +1774,39 @@ extern "C" int taoamd_accumulate(int64_t n_dt, int32_t n_cat, int32_t n_rng,
     return accumulate_all(n_dt, n_cat, n_rng, cat_off, nullptr, matched, ignored,
                           num_gt, max_segment, precision, recall, workspace,
                           workspace_bytes, stream);
+}
+
+// The same tables from the chunked kernels whatever the sweep mode: what a
+// caller runs again when taoamd_accumulate_error reports that a look-back of
+// the one-pass sweep gave up (the rows of the pass are still in place).  The
+// workspace's prepared plan does not survive it (taoamd_accumulate_prepare
+// again before the next taoamd_accumulate_prepared).
+extern "C" int taoamd_accumulate_chunked(int64_t n_dt, int32_t n_cat, int32_t n_rng,
+                                         const int32_t *cat_off,
+                                         const uint64_t *matched,
+                                         const uint64_t *ignored, const int32_t *num_gt,
+                                         int32_t max_segment, double *precision,
+                                         double *recall, void *workspace,
+                                         size_t workspace_bytes, void *stream)
+{
+    return accumulate_all(n_dt, n_cat, n_rng, cat_off, nullptr, matched, ignored,
+                          num_gt, max_segment, precision, recall, workspace,
+                          workspace_bytes, stream, ACC_ALL, SWEEP_CHUNKED);
+}
+
+extern "C" int taoamd_accumulate_compact_chunked(int64_t n_dt, int32_t n_cat,
+                                                 int32_t n_rng, const int32_t *cat_off,
+                                                 const uint64_t *matched,
+                                                 const uint64_t *ignored,
+                                                 const int32_t *num_gt, int32_t k_begin,
+                                                 int32_t k_end, int32_t max_segment,
+                                                 double *val, double *rec,
+                                                 void *workspace, size_t workspace_bytes,
+                                                 void *stream)
+{
+    return accumulate_compact(n_dt, n_cat, n_rng, cat_off, nullptr, matched, ignored,
+                              num_gt, k_begin, k_end, max_segment, val, rec,
+                              workspace, workspace_bytes, stream, ACC_ALL, SWEEP_CHUNKED);
 }
 
 extern "C" int taoamd_accumulate_by_order(int64_t n_dt, int32_t n_cat, int32_t n_rng,

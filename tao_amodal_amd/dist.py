@@ -150,11 +150,20 @@ class HipBackend:
 
     def accumulate_compact(self, n, n_cat, n_rng, cat_off, matched, ignored,
                            num_gt, k0, k1, val, rec, ws_buf, ws_bytes,
-                           max_segment=0):
-        _lib.check(self.lib.taoamd_accumulate_compact(
+                           max_segment=0, chunked=False):
+        """`chunked`: the chunked kernels whatever the sweep mode (a pass whose
+        look-back gave up is swept again, ShardedEval.check)."""
+        fn = self.lib.taoamd_accumulate_compact_chunked if chunked \
+            else self.lib.taoamd_accumulate_compact
+        _lib.check(fn(
             n, n_cat, n_rng, _ptr(cat_off), _ptr(matched), _ptr(ignored),
             _ptr(num_gt), k0, k1, max_segment, _ptr(val), _ptr(rec),
             _ptr(ws_buf), ws_bytes, self._s()), "taoamd_accumulate_compact")
+
+    def sweep_flag(self, ws_buf):
+        """The one-pass sweep's error flag of the workspace a pass swept on
+        (synchronises)."""
+        return self.engine.sweep_flag(ws_buf, ws_buf.device)
 
     def finalize(self, n_cat, n_rng, num_gt, val, rec, precision, recall):
         _lib.check(self.lib.taoamd_finalize(
@@ -332,10 +341,20 @@ class ShardedEval:
         be.merge_runs(self.n_recv, self.world, self.Kb, self.k0, self.recv, self.W,
                       dp.n_words, self.src_base, self.run_off, self.cat_base,
                       self.matched, self.ignored, self.rank, self._own())
-        be.accumulate_compact(self.n_recv, dp.n_cat, dp.n_rng, self.cat_off,
-                              self.matched, self.ignored, self.num_gt, self.k0,
-                              self.k1, self.val, self.rec, self.acc_ws,
-                              self.acc_bytes, self.max_segment)
+        self._sweep()
+        self._publish()
+
+    def _sweep(self, chunked=False):
+        """The owner's sweep of the merged rows of its category block."""
+        dp = self.dp
+        self.be.accumulate_compact(self.n_recv, dp.n_cat, dp.n_rng, self.cat_off,
+                                   self.matched, self.ignored, self.num_gt, self.k0,
+                                   self.k1, self.val, self.rec, self.acc_ws,
+                                   self.acc_bytes, self.max_segment, chunked=chunked)
+
+    def _publish(self):
+        """Result exchange: pack the own block, all_gather, expand."""
+        dp, be = self.dp, self.be
         lo, hi = self.rank * self.chunk_bytes, (self.rank + 1) * self.chunk_bytes
         be.exchange_pack(dp.n_cat, dp.n_rng, self.Kb, self.world, self.rank,
                          self.num_gt, self.val, self.rec, self.chunks[lo:hi],
@@ -347,10 +366,24 @@ class ShardedEval:
                            self.recall, self.overflow, self.xws, maps_ready=True)
 
     def check(self):
-        """Host-side guard (synchronises): the capacity held."""
+        """Host-side guard of the last step (synchronises; COLLECTIVE): the
+        exchange capacity held, and no rank's sweep gave up a look-back -- if
+        one did, every rank sweeps its block again with the chunked kernels
+        (the merged rows are still in place) and the result exchange is
+        repeated, so the tables are right when this returns.  Under the
+        evaluation constants of the step."""
         if int(self.overflow.item()):
             raise _lib.TaoAmdError("exchange chunk overflow: the ground truth "
                                    "changed after the plan was built")
+        if any_rank(self.be.sweep_flag(self.acc_ws), self.dp.device, self.group):
+            _warn_sweep()
+            self._sweep(chunked=True)
+            self._publish()
+            if self.dp.device.type == "cuda":
+                torch.cuda.synchronize(self.dp.device)
+            self.sweep_recovered = getattr(self, "sweep_recovered", 0) + 1
+            if int(self.overflow.item()):
+                raise _lib.TaoAmdError("exchange chunk overflow")
 
     def owner_rows(self, ids):
         """After step(): the rows of this rank's category block as the sweep
@@ -377,6 +410,22 @@ class ShardedEval:
         return (tab[:n, 0].cpu().numpy(), self.matched[:n].cpu().numpy().view(np.uint64),
                 self.ignored[:n].cpu().numpy().view(np.uint64),
                 self.cat_base.cpu().numpy())
+
+
+def any_rank(flag, device, group=None):
+    """True on every rank if `flag` is set on any (one all-reduce)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return bool(flag)
+    t = torch.tensor([int(bool(flag))], dtype=torch.int32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return bool(t.item())
+
+
+def _warn_sweep():
+    import logging
+    logging.getLogger("tao_amodal_amd").warning(
+        "the one-pass sweep's look-back between workgroups timed out on a rank: "
+        "the pass is swept again with the chunked kernels")
 
 
 def all_to_all(output, input, output_split_sizes=None, input_split_sizes=None, group=None):
@@ -492,13 +541,13 @@ class CategoryShardedEval:
             be.match_local(dp, ws)
         self.sweep()
 
-    def sweep(self):
+    def sweep(self, chunked=False):
         """AP sweep of the own categories + pack into the own chunk."""
         dp, ws, be = self.dp, self.ws, self.be
         be.accumulate_compact(dp.n_dt, dp.n_cat, dp.n_rng, dp.t["cat_off"],
                               ws.matched, ws.ignored, ws.num_gt, self.k0,
                               self.k1, self.val, self.rec, ws.acc_ws,
-                              ws.acc_bytes, dp.acc_hint)
+                              ws.acc_bytes, dp.acc_hint, chunked=chunked)
         lo, hi = self.rank * self.chunk_bytes, (self.rank + 1) * self.chunk_bytes
         be.exchange_pack(dp.n_cat, dp.n_rng, self.Kb, self.world, self.rank,
                          ws.num_gt, self.val, self.rec, self.chunks[lo:hi],
@@ -539,10 +588,25 @@ class CategoryShardedEval:
                 ws.ignored[:n].cpu().numpy().view(np.uint64), base - (base[0] if len(base) else 0))
 
     def check(self):
-        """Host-side guard (synchronises): the capacity held."""
+        """Host-side guard of the last step (synchronises; COLLECTIVE): the
+        capacity held and no rank's look-back gave up (ShardedEval.check: the
+        block is swept again with the chunked kernels and exchanged again)."""
         if int(self.overflow.item()):
             raise _lib.TaoAmdError("exchange chunk overflow: the ground truth "
                                    "changed after the plan was built")
+        if any_rank(self.be.sweep_flag(self.ws.acc_ws), self.dp.device, self.group):
+            _warn_sweep()
+            self.sweep(chunked=True)
+            self.assemble()
+            if self.dp.device.type == "cuda":
+                torch.cuda.synchronize(self.dp.device)
+                self.engine_prepare()
+            self.sweep_recovered = getattr(self, "sweep_recovered", 0) + 1
+
+    def engine_prepare(self):
+        # (the unprepared chunked pass overwrote the workspace's plan)
+        from . import engine
+        engine.prepare_sweep(self.dp, self.ws)
 
 
 class CategoryPlan:

@@ -436,14 +436,10 @@ class Workspace:
         self.acc_ws = buf(self.acc_bytes)
         # the chunk table of the sweep depends on cat_off alone: built once here,
         # one launch less on the chain of every pass
-        self.acc_prepared = None          # the max_segment hint it was built for
+        self.acc_prepared = None          # (max_segment hint, plan kind) it was built for
+        self.sweep_recovered = 0          # passes swept again after a look-back gave up
         if torch.device(dev).type == "cuda":
-            with torch.cuda.device(dev):
-                _lib.check(lib.taoamd_accumulate_prepare(
-                    dp.n_dt, dp.n_cat, dp.n_rng, _ptr(dp.t["cat_off"]), dp.acc_hint,
-                    _ptr(self.acc_ws), self.acc_bytes, _stream()),
-                    "taoamd_accumulate_prepare")
-            self.acc_prepared = dp.acc_hint
+            prepare_sweep(dp, self)
         self.precision = torch.empty((N_THR, N_REC, dp.n_cat, dp.n_rng),
                                      dtype=torch.float64, device=dev)
         self.recall = torch.empty((N_THR, dp.n_cat, dp.n_rng),
@@ -656,25 +652,65 @@ def apply_iou_guard(dp, ws, flat=None):
     return n
 
 
-def sweep_ok(dp, ws):
-    """Raise if a look-back of the one-pass sweep gave up in a pass on this
-    workspace (taoamd_accumulate_error; synchronises)."""
-    import ctypes as C
-    if dp.device.type != "cuda":
-        return
-    flag = C.c_int32(0)
+def _plan_key(dp):
+    return (dp.acc_hint, int(_lib.load().taoamd_accumulate_plan_kind(
+        dp.n_dt, dp.n_rng, dp.acc_hint)))
+
+
+def prepare_sweep(dp, ws):
+    """(Re)build the sweep's plan in the workspace (taoamd_accumulate_prepare):
+    the table that cuts the categories into chunks / super-chunks under the
+    current sweep mode."""
     with torch.cuda.device(dp.device):
+        _lib.check(_lib.load().taoamd_accumulate_prepare(
+            dp.n_dt, dp.n_cat, dp.n_rng, _ptr(dp.t["cat_off"]), dp.acc_hint,
+            _ptr(ws.acc_ws), ws.acc_bytes, _stream()), "taoamd_accumulate_prepare")
+    ws.acc_prepared = _plan_key(dp)
+
+
+def sweep_flag(acc_ws, device):
+    """The one-pass sweep's error flag of a workspace (taoamd_accumulate_error;
+    synchronises with the current stream)."""
+    import ctypes as C
+    flag = C.c_int32(0)
+    with torch.cuda.device(device):
         _lib.check(_lib.load().taoamd_accumulate_error(
-            _ptr(ws.acc_ws), _stream(), C.addressof(flag)), "taoamd_accumulate_error")
-    if flag.value:
-        raise _lib.TaoAmdError("the sweep's look-back between workgroups timed out: "
-                               "precision / recall of this pass are invalid")
+            _ptr(acc_ws), _stream(), C.addressof(flag)), "taoamd_accumulate_error")
+    return int(flag.value)
 
 
-def guarded_pairs(dp, ws):
+def sweep_ok(dp, ws):
+    """Check the last pass on this workspace for the one-pass sweep's error flag
+    (a look-back between workgroups gave up waiting; synchronises).  Such a
+    pass is swept AGAIN with the chunked kernels -- its rows are still in the
+    workspace -- so precision / recall are the right tables when this returns;
+    the plan is rebuilt for the passes to come.  Returns True if it had to."""
+    if dp.device.type != "cuda" or not sweep_flag(ws.acc_ws, dp.device):
+        return False
+    import logging
+    logging.getLogger("tao_amodal_amd").warning(
+        "the one-pass sweep's look-back between workgroups timed out (a busy or "
+        "shared GPU?): this pass is swept again with the chunked kernels")
+    lib, t = _lib.load(), dp.t
+    with torch.cuda.device(dp.device):
+        _lib.check(lib.taoamd_accumulate_chunked(
+            dp.n_dt, dp.n_cat, dp.n_rng, _ptr(t["cat_off"]), _ptr(ws.matched),
+            _ptr(ws.ignored), _ptr(ws.num_gt), dp.acc_hint, _ptr(ws.precision),
+            _ptr(ws.recall), _ptr(ws.acc_ws), ws.acc_bytes, _stream()),
+            "taoamd_accumulate_chunked")
+    prepare_sweep(dp, ws)
+    torch.cuda.synchronize(dp.device)
+    ws.sweep_recovered += 1
+    return True
+
+
+def guarded_pairs(dp, ws, check_sweep=True):
     """Pairs the last pass listed and recomputed (synchronises).  Also the
-    place where a pass is checked for the sweep's error flag."""
-    sweep_ok(dp, ws)
+    place where a pass is checked for the sweep's error flag (and swept again
+    if it is set: sweep_ok; the multi-GPU plans check the workspace they swept
+    on themselves, collectively: dist.ShardedEval.check)."""
+    if check_sweep:
+        sweep_ok(dp, ws)
     if not dp.guard_active():
         return 0
     if dp.guard_on_device and int(ws.guard_status.item()):
@@ -779,7 +815,8 @@ def stage_accumulate_by_order(dp, ws):
 
 def stage_accumulate(dp, ws):
     lib, t, s = _lib.load(), dp.t, _stream()
-    fn = lib.taoamd_accumulate_prepared if ws.acc_prepared == dp.acc_hint \
+    # (a plan built under another sweep mode or hint does not serve this pass)
+    fn = lib.taoamd_accumulate_prepared if ws.acc_prepared == _plan_key(dp) \
         else lib.taoamd_accumulate
     _lib.check(fn(
         dp.n_dt, dp.n_cat, dp.n_rng, _ptr(t["cat_off"]), _ptr(ws.matched),

@@ -119,6 +119,9 @@ class GpuRun:
                         e.run_guarded(dp, ws, self.flat, upto="match", read_count=False)
                     e.stage_accumulate(dp, ws)
                     self.torch.cuda.synchronize(self.device)
+                    # (per block, under the block's constants: an unprepared
+                    # pass clears the flag of the pass before it)
+                    e.sweep_ok(dp, ws)
                 with timed("download"):
                     p = ws.precision[:len(t_idx), :len(r_idx)].cpu().numpy()
                     self.precision[np.ix_(t_idx, r_idx)] = p

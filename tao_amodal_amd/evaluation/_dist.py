@@ -309,11 +309,15 @@ class DistRun:
             self.sharded.step()
 
     def accumulate(self):
-        from ._core import timed
+        from ._core import applied, timed
         with timed("kernels"):
             self.torch.cuda.synchronize(self.device)
-            self.sharded.check()
-            self.near_threshold_pairs = self.engine.guarded_pairs(self.dp, self.ws)
+            # (collective; the flag of the workspace that was actually swept:
+            # a rank whose look-back gave up makes every rank sweep again)
+            with applied(self.constants):
+                self.sharded.check()
+            self.near_threshold_pairs = self.engine.guarded_pairs(
+                self.dp, self.ws, check_sweep=False)
         with timed("download"):
             self.precision = self.sharded.precision.cpu().numpy()
             self.recall = self.sharded.recall.cpu().numpy()

@@ -31,6 +31,14 @@ class OracleBackend:
     def _f(self, dp):
         return self.flats[id(dp)]
 
+    inject_sweep_flags = 0      # how many checks report "a look-back gave up"
+
+    def sweep_flag(self, ws_buf):
+        if self.inject_sweep_flags > 0:
+            self.inject_sweep_flags -= 1
+            return 1
+        return 0
+
     def ranges(self, dp, ws):
         f = self._f(dp)
         g, d = orclib.ranges(f)
@@ -99,7 +107,7 @@ class OracleBackend:
 
     def accumulate_compact(self, n, n_cat, n_rng, cat_off, matched, ignored,
                            num_gt, k0, k1, val, rec, ws_buf, ws_bytes,
-                           max_segment=0):
+                           max_segment=0, chunked=False):
         import ctypes as C
         co = cat_off.numpy().astype(np.int64)
         cat = np.repeat(np.arange(n_cat, dtype=np.int32), np.diff(co))
@@ -170,7 +178,14 @@ def _worker(rank, world, port, out):
         ev = tdist.ShardedEval(dp, ws, rank, world, be)
         ev.step()
         ev.step()          # a second step must reproduce the first
+        # the last rank reports that its sweep gave up a look-back: check() is
+        # collective, every rank sweeps again (chunked) and exchanges again
+        be.inject_sweep_flags = int(rank == world - 1)
+        ev.precision.fill_(7.0)
         ev.check()
+        assert getattr(ev, "sweep_recovered", 0) == 1 and be.inject_sweep_flags == 0
+        ev.check()
+        assert ev.sweep_recovered == 1
         res[name] = (ev.precision.numpy().copy(), ev.recall.numpy().copy(),
                      ev.num_gt.numpy().copy(), flat.n_pairs)
     torch.save(res, os.path.join(out, "rank%d.pt" % rank))
@@ -308,10 +323,14 @@ def _worker_cat(rank, world, port, out):
         shard = tdist.shard_by_category(flat, k0, k1)
         dp = engine.DeviceProblem(shard, "cpu")
         ws = engine.Workspace(dp)
-        ev = tdist.CategoryShardedEval(dp, ws, rank, world,
-                                       OracleCategoryBackend({id(dp): shard}))
+        be = OracleCategoryBackend({id(dp): shard})
+        ev = tdist.CategoryShardedEval(dp, ws, rank, world, be)
         ev.step()
         ev.step()
+        be.inject_sweep_flags = int(rank == 0)     # (see _worker)
+        ev.precision.fill_(7.0)
+        ev.check()
+        assert ev.sweep_recovered == 1
         res[name] = (ev.precision.numpy().copy(), ev.recall.numpy().copy(),
                      shard.n_pairs)
     torch.save(res, os.path.join(out, "cat_rank%d.pt" % rank))
