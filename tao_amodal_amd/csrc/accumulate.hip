@@ -693,6 +693,46 @@ __device__ __forceinline__ void emit_block(uint64_t T, uint64_t TF, uint32_t &tp
     const uint32_t Th[2] = {(uint32_t)T, (uint32_t)(T >> 32)};
     const uint32_t TFh[2] = {(uint32_t)TF, (uint32_t)(TF >> 32)};
     const uint32_t mh[2] = {Th[0] & ~((Th[0] >> 1) | (Th[1] << 31)), Th[1] & ~(Th[1] >> 1)};
+    if (W == 1) {
+        // The walk of the long categories' sweeps, bound by VALU issue (round 5:
+        // 24 -> 17 VALU instructions per visited row).  The envelope lives in
+        // two registers; a row's counts come from the counts BEFORE the half
+        // plus a popcount (v_bcnt with its addend); `run` only ever holds a
+        // LATER row, whose n is larger, so on equal rationals it stays
+        // (pr_better's tie rule can never favour the earlier row) and the
+        // comparison is one 64-bit compare of the cross products.
+        uint32_t rt = (uint32_t)(run >> 32), rn = (uint32_t)run;
+#pragma unroll
+        for (int h = 1; h >= 0; h--) {
+            const uint32_t tps = tp - (uint32_t)__popc(Th[h]);     // counts before the half
+            const uint32_t ns = n - (uint32_t)__popc(TFh[h]);
+            for (uint32_t m = mh[h]; m != 0;) {
+                const uint32_t le = 0xffffffffu >> __builtin_clz(m);       // rows <= q
+                const uint32_t tpq = tps + (uint32_t)__popc(Th[h] & le);   // incl. row q
+                const uint32_t nq = ns + (uint32_t)__popc(TFh[h] & le);
+                const bool better = (uint64_t)tpq * rn > (uint64_t)rt * nq;
+                if (cnext >= (int32_t)tpq) {
+                    // thresholds reached above row q (crossing count > tpq) take
+                    // the envelope before this row, those reached exactly at it
+                    // (== tpq) the envelope including it
+                    const uint64_t above = pr_pack(rt, rn);
+                    const uint64_t at = better ? pr_pack(tpq, nq) : above;
+                    do {
+                        out[--jcur] = cnext > (int32_t)tpq ? above : at;
+                        cnext = jcur > 0 ? cj[jcur - 1] : -1;
+                    } while (cnext >= (int32_t)tpq);
+                }
+                rt = better ? tpq : rt;
+                rn = better ? nq : rn;
+                m &= le >> 1;
+            }
+            tp = tps;
+            n = ns;
+        }
+        run = pr_pack(rt, rn);
+        if (cnext > (int32_t)tp) emit_burst<true, W>(out, cj, jcur, cnext, (int32_t)tp, run);
+        return;
+    }
 #pragma unroll
     for (int h = 1; h >= 0; h--) {
         for (uint32_t m = mh[h]; m != 0;) {
@@ -700,27 +740,11 @@ __device__ __forceinline__ void emit_block(uint64_t T, uint64_t TF, uint32_t &tp
             const uint32_t gt = 0xfffffffeu << q;              // rows > q (q = 31: none)
             const uint32_t tpq = tp - (uint32_t)__popc(Th[h] & gt);    // incl. row q
             const uint32_t nq = n - (uint32_t)__popc(TFh[h] & gt);
-            if (W == 1) {
-                // one loop for both kinds of threshold reached here: above row
-                // q (crossing count > tpq: the envelope before this row) and
-                // exactly at it (== tpq: the envelope including it) -- the
-                // heaviest wavefronts of the chunked sweep, the first chunks of
-                // their categories, take this branch at nearly every row
-                const uint64_t above = run;
-                if (pr_better(tpq, nq, run)) run = pr_pack(tpq, nq);
-                if (cnext >= (int32_t)tpq) {
-                    do {
-                        out[--jcur] = cnext > (int32_t)tpq ? above : run;
-                        cnext = jcur > 0 ? cj[jcur - 1] : -1;
-                    } while (cnext >= (int32_t)tpq);
-                }
-            } else {
-                if (cnext > (int32_t)tpq)          // reached above row q
-                    emit_burst<true, W>(out, cj, jcur, cnext, (int32_t)tpq, run);
-                if (pr_better(tpq, nq, run)) run = pr_pack(tpq, nq);
-                if (cnext == (int32_t)tpq)         // reached exactly at row q
-                    emit_burst<false, W>(out, cj, jcur, cnext, (int32_t)tpq, run);
-            }
+            if (cnext > (int32_t)tpq)          // reached above row q
+                emit_burst<true, W>(out, cj, jcur, cnext, (int32_t)tpq, run);
+            if (pr_better(tpq, nq, run)) run = pr_pack(tpq, nq);
+            if (cnext == (int32_t)tpq)         // reached exactly at row q
+                emit_burst<false, W>(out, cj, jcur, cnext, (int32_t)tpq, run);
             m &= ~(1u << q);
         }
         tp -= (uint32_t)__popc(Th[h]);
