@@ -103,30 +103,37 @@ class GpuRun:
             self.recall = self.ws.recall.cpu().numpy()
 
     def _accumulate_blocks(self, c):
-        """Edited thresholds: the kernels take N_THR IoU thresholds and N_REC
-        recall thresholds per pass, ascending -- the caller's arrays are cut
-        into such blocks (EvalConstants) and every block's slice of the tables
-        is put where the caller's order has it.  IoU thresholds are independent
-        of each other (L/eval.py:234-277), recall thresholds too (:406-410)."""
+        """Edited constants: the kernels take N_THR IoU thresholds, N_REC
+        recall thresholds and their own number of ranges per pass -- the
+        caller's arrays are cut into such blocks (EvalConstants) and every
+        block's slice of the tables is put where the caller's order has it.
+        IoU thresholds are independent of each other (L/eval.py:234-277), recall
+        thresholds (:406-410) and ranges (:140-145, T/eval.py:271-276) too."""
         e, dp, ws = self.engine, self.dp, self.ws
-        K, A = dp.n_cat, dp.n_rng
-        self.precision = np.empty((c.T, c.R, K, A))
-        self.recall = np.empty((c.T, K, A))
+        K = dp.n_cat
+        self.precision = np.empty((c.T, c.R, K, c.n_rng))
+        self.recall = np.empty((c.T, K, c.n_rng))
+        first = True
         for bi, (t_idx, t_val) in enumerate(c.thr_blocks):
-            for bj, (r_idx, r_val) in enumerate(c.rec_blocks):
-                with timed("kernels"), applied(c, bi, bj):
-                    if bj == 0 and not (c.single and bi == 0):
-                        e.run_guarded(dp, ws, self.flat, upto="match", read_count=False)
-                    e.stage_accumulate(dp, ws)
-                    self.torch.cuda.synchronize(self.device)
-                    # (per block, under the block's constants: an unprepared
-                    # pass clears the flag of the pass before it)
-                    e.sweep_ok(dp, ws)
-                with timed("download"):
-                    p = ws.precision[:len(t_idx), :len(r_idx)].cpu().numpy()
-                    self.precision[np.ix_(t_idx, r_idx)] = p
-                    if bj == 0:
-                        self.recall[t_idx] = ws.recall[:len(t_idx)].cpu().numpy()
+            for bk, (_, slots) in enumerate(c.rng_blocks):
+                ks = np.array([k for k, _ in slots], dtype=np.int64)
+                out = np.array([i for _, i in slots], dtype=np.int64)
+                for bj, (r_idx, r_val) in enumerate(c.rec_blocks):
+                    with timed("kernels"), applied(c, bi, bj, bk):
+                        if bj == 0 and not (c.single and first):
+                            e.run_guarded(dp, ws, self.flat, upto="match", read_count=False)
+                        first = False
+                        e.stage_accumulate(dp, ws)
+                        self.torch.cuda.synchronize(self.device)
+                        # (per block, under the block's constants: an unprepared
+                        # pass clears the flag of the pass before it)
+                        e.sweep_ok(dp, ws)
+                    with timed("download"):
+                        p = ws.precision[:len(t_idx), :len(r_idx)].cpu().numpy()
+                        self.precision[np.ix_(t_idx, r_idx, np.arange(K), out)] = p[..., ks]
+                        if bj == 0:
+                            rc = ws.recall[:len(t_idx)].cpu().numpy()
+                            self.recall[np.ix_(t_idx, np.arange(K), out)] = rc[..., ks]
         self.near_threshold_pairs = e.guarded_pairs(dp, ws)
         if not c.rec_sorted:
             # the reference fills a row's recall thresholds IN THE CALLER'S
@@ -144,7 +151,8 @@ class GpuRun:
             if c is not None and not c.single:
                 raise NotImplementedError(
                     "the per-cell views (ious, eval_imgs / eval_vids, dt_pointers) "
-                    "are kept for up to %d IoU thresholds" % N_THR)
+                    "are kept for up to %d IoU thresholds and the reference's "
+                    "number of ranges" % N_THR)
             with applied(c):
                 self._detail = self.engine.evaluate_flat(
                     self.flat, self.device, detail=True,
@@ -382,18 +390,22 @@ def now():
 
 class EvalConstants:
     """``params.iou_thrs`` / ``rec_thrs`` and the range tables as the kernels
-    take them.  The reference reads all of them when it runs (L/eval.py:143,
-    205,234,319-322,407; T/eval.py:272-275,385,473-477,562), so a caller may
-    edit them before ``run()``.
+    take them.  The reference reads all of them when it runs (L/eval.py:140-145,
+    205,234,319-329,407; T/eval.py:271-276,385,473-477,562), so a caller may
+    edit them before ``run()`` -- values, order AND number.
 
     The kernels take N_THR IoU thresholds and N_REC recall thresholds per pass,
     ascending, as by-value arguments, and the range VALUES likewise
-    (taoamd_set_thresholds / taoamd_set_ranges); the NUMBER of ranges is theirs
-    (6 visibility ranges, the last one the out-of-frame range; 5 areas x 4
-    durations, the last area range the occlusion one).  Thresholds in any
-    number and order are cut into ascending blocks, a short block padded with
-    copies of its last value; an edit that changes the number of ranges
-    raises."""
+    (taoamd_set_thresholds / taoamd_set_ranges); the NUMBER of ranges per pass
+    is theirs (5 visibility ranges + the out-of-frame one -- the reference's
+    LAST range, whatever its bounds, L/eval.py:143 --; 4 areas + the occlusion
+    one -- the LAST area range, T/eval.py:272 -- x 4 durations).  Every
+    threshold and every range is evaluated independently of the others, so
+    the caller's arrays -- any number, any order -- are cut into blocks, a
+    short block padded with copies of its last value, a pass runs per block
+    and every block's slice of the tables goes where the caller's order has
+    it (``rng_blocks``: the tables of a pass and, per kernel range slot, the
+    caller's range index)."""
 
     def __init__(self, params, fresh, kind):
         iou = np.asarray(params.iou_thrs, dtype=np.float64).reshape(-1)
@@ -403,31 +415,72 @@ class EvalConstants:
             raise NotImplementedError("empty params.iou_thrs / params.rec_thrs")
         if np.isnan(iou).any() or np.isnan(rec).any():
             raise ValueError("params.iou_thrs / params.rec_thrs hold a NaN")
-        self.ranges = {}
         same = np.array_equal(iou, fresh.iou_thrs) and np.array_equal(rec, fresh.rec_thrs)
-        names = ("visibility_rng",) if kind == "lvis" else ("area_rng", "time_rng")
-        for name in names:
-            want = np.asarray(getattr(fresh, name), dtype=np.float64)
+
+        def table(name):
             try:
                 got = np.asarray(getattr(params, name), dtype=np.float64)
             except (TypeError, ValueError):
                 got = np.zeros(0)
-            if got.shape != want.shape:
+            if got.ndim != 2 or got.shape[1] != 2 or len(got) == 0:
                 raise NotImplementedError(
-                    "params.%s: the kernels evaluate %d ranges of [lo, hi]; an "
-                    "edit may change their values, not their number"
-                    % (name, len(want)))
-            # (image level: the sixth range is the out-of-frame one, its bounds
-            # are never read -- L/eval.py:209-217)
-            self.ranges[name] = got[:5] if name == "visibility_rng" else got
-            same = same and np.array_equal(
-                got[:5] if name == "visibility_rng" else got,
-                want[:5] if name == "visibility_rng" else want)
+                    "params.%s: a non-empty list of [lo, hi] pairs is evaluated" % name)
+            return got, np.asarray(getattr(fresh, name), dtype=np.float64)
+
+        def cut(idx, cap, values, filler):
+            """Blocks of <= cap of the ranges `idx`: (indices, (cap, 2) values
+            padded with the block's last range)."""
+            out = []
+            for i in range(0, max(len(idx), 1), cap):
+                sel = idx[i:i + cap]
+                v = values[sel] if len(sel) else np.zeros((0, 2))
+                pad = v[-1:] if len(sel) else filler[None]
+                out.append((list(sel), np.concatenate([v] + [pad] * (cap - len(sel)))))
+            return out
+
+        self.rng_blocks = []
+        if kind == "lvis":
+            got, want = table("visibility_rng")
+            self.n_rng = len(got)
+            # (the last range is the out-of-frame one, its bounds are never
+            # read -- L/eval.py:143,209-217)
+            same = same and got.shape == want.shape and np.array_equal(got[:-1], want[:-1])
+            for b, (sel, vals) in enumerate(cut(np.arange(len(got) - 1), 5, got,
+                                                 np.array([0.0, 1.0]))):
+                slots = [(k, int(i)) for k, i in enumerate(sel)]
+                if b == 0:
+                    slots.append((5, len(got) - 1))
+                self.rng_blocks.append(({"visibility_rng": vals}, slots))
+            identity = len(got) == 6
+        else:
+            area, want_a = table("area_rng")
+            time_, want_t = table("time_rng")
+            A, Tm = len(area), len(time_)
+            self.n_rng = A * Tm
+            same = same and area.shape == want_a.shape and time_.shape == want_t.shape \
+                and np.array_equal(area, want_a) and np.array_equal(time_, want_t)
+            a_blocks = cut(np.arange(A - 1), 4, area, area[-1])
+            t_blocks = cut(np.arange(Tm), 4, time_, time_[-1])
+            for ab, (asel, avals) in enumerate(a_blocks):
+                # slot 4 of the kernels' area table: the occlusion range
+                atab = np.concatenate([avals, area[-1:]])
+                aslots = [(k, int(i)) for k, i in enumerate(asel)]
+                if ab == 0:
+                    aslots.append((4, A - 1))
+                for tsel, tvals in t_blocks:
+                    slots = [(ka * 4 + kt, ia * Tm + int(it)) for ka, ia in aslots
+                             for kt, it in enumerate(tsel)]
+                    self.rng_blocks.append(({"area_rng": atab, "time_rng": tvals}, slots))
+            identity = A == 5 and Tm == 4
         self.default = bool(same)
         self.thr_blocks = self._blocks(iou, N_THR)
         self.rec_blocks = self._blocks(rec, N_REC)
-        self.single = len(self.thr_blocks) == 1 and len(self.rec_blocks) == 1
+        # one pass whose tables are the caller's, slot for slot: the per-cell
+        # views (ious, eval_imgs / eval_vids, dt_pointers) read such a pass
+        self.single = len(self.thr_blocks) == 1 and len(self.rec_blocks) == 1 \
+            and len(self.rng_blocks) == 1 and identity
         self.rec_sorted = bool(np.all(np.diff(rec) >= 0))
+        self.ranges = self.rng_blocks[0][0]
 
     @staticmethod
     def _blocks(values, cap):
@@ -440,7 +493,7 @@ class EvalConstants:
         return out
 
 
-def applied(constants, thr_block=0, rec_block=0):
+def applied(constants, thr_block=0, rec_block=0, rng_block=0):
     """Context manager: the calling thread's kernels launched inside take
     ``constants`` (None: nothing to do); the reference's defaults come back on
     the way out."""
@@ -454,7 +507,7 @@ def applied(constants, thr_block=0, rec_block=0):
             return
         _lib.set_constants(iou_thrs=constants.thr_blocks[thr_block][1],
                            rec_thrs=constants.rec_blocks[rec_block][1],
-                           **constants.ranges)
+                           **constants.rng_blocks[rng_block][0])
         try:
             yield
         finally:

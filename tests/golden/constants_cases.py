@@ -23,6 +23,21 @@ def cases():
                    "tao:area_rng": [[0, 1e10], [0, 2000.0], [2000.0, 20000.0],
                                     [20000.0, 1e10], [500.0, 1e10]],
                    "tao:time_rng": [[0, 1e5], [0, 5], [5, 12], [12, 1e5]]},
+        # another NUMBER of ranges: the reference loops over whatever the lists
+        # hold, the last visibility range is the out-of-frame one, the last
+        # area range the occlusion one (L/eval.py:140-145, T/eval.py:271-276).
+        # Fewer than the labels name: summarize() raises IndexError there
+        "ranges3": {"lvis:visibility_rng": [[0, 1.0], [0.2, 0.7], [0, 1.0]],
+                    "tao:area_rng": [[0, 1e10], [1500.0, 30000.0], [0, 1e10]],
+                    "tao:time_rng": [[0, 1e5], [4, 11]]},
+        # ... and more than one block of the kernels' range slots
+        "ranges8": {"lvis:visibility_rng": [[0, 1.0], [0, 0.1], [0.1, 0.8], [0.8, 1.0],
+                                            [0, 0.8], [0.05, 0.3], [0.3, 0.9], [0, 1.0]],
+                    "tao:area_rng": [[0, 1e10], [0, 1024.0], [1024.0, 9216.0],
+                                     [9216.0, 1e10], [0, 5000.0], [5000.0, 1e10],
+                                     [100.0, 1e10]],
+                    "tao:time_rng": [[0, 1e5], [0, 3], [3, 10], [10, 1e5], [2, 6],
+                                     [6, 1e5]]},
     }
 
 

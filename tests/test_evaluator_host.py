@@ -108,33 +108,62 @@ def test_product_path_refuses_to_run_without_gpu():
         ev.run()
 
 
-@pytest.mark.parametrize("edit", [
-    ("visibility_rng", lambda v: v[:2]), ("visibility_rng", lambda v: v + [[0, 1.0]])])
-def test_lvis_params_edits_the_kernels_cannot_honour_raise(edit):
-    """The reference lets a caller change params before evaluate().  Id subsets,
-    thresholds in any number and order and the range VALUES are honoured
-    (tests/test_gpu_cli.py, tests/test_gpu_constants.py: goldens from the
-    reference); the NUMBER of ranges is the kernels', so such an edit must
-    raise instead of silently giving other numbers."""
-    ev = LVISEval(path("f1", "gt.json"), path("f1", "pred.json"), "bbox")
-    name, fn = edit
-    setattr(ev.params, name, fn(getattr(ev.params, name)))
-    with pytest.raises(NotImplementedError, match="params." + name):
-        ev.evaluate()
-
-
-@pytest.mark.parametrize("edit", [
-    ("area_rng", lambda v: v[:1]), ("time_rng", lambda v: [[0, 5]])])
-def test_tao_params_edits_the_kernels_cannot_honour_raise(edit):
-    gtj, predj = load_inputs("f1")
-    dt = DTColumns.from_json(predj)
-    dt.track_id, _ = flatten.make_track_ids_unique(dt)
-    gt = Tao(gtj)
-    ev = TaoEval(gt, TaoResults(gt, dt))
-    name, fn = edit
-    setattr(ev.params, name, fn(getattr(ev.params, name)))
-    with pytest.raises(NotImplementedError, match="params." + name):
-        ev.evaluate()
+def test_range_tables_of_any_length_are_cut_into_the_kernels_slots():
+    """The reference loops over whatever params.visibility_rng / area_rng /
+    time_rng hold (L/eval.py:140-145, T/eval.py:271-276); the kernels evaluate
+    5 visibility ranges + the out-of-frame one (the LAST of the caller's), 4
+    areas + the occlusion one (the LAST area range) x 4 durations per pass:
+    EvalConstants cuts the caller's tables into such blocks and says, per
+    kernel slot, which of the caller's ranges it holds (goldens from the
+    reference: tests/test_gpu_constants.py, cases ranges3 / ranges8)."""
+    import numpy as np
+    from tao_amodal_amd.evaluation._core import EvalConstants
+    from tao_amodal_amd.evaluation.lvis_amodal.eval import Params as LP
+    from tao_amodal_amd.evaluation.tao_amodal.eval import Params as TP
+    P = LP("bbox")
+    P.visibility_rng = P.visibility_rng[:2]              # one range + out-of-frame
+    c = EvalConstants(P, LP("bbox"), "lvis")
+    assert not c.default and not c.single and c.n_rng == 2
+    (tab, slots), = c.rng_blocks
+    assert tab["visibility_rng"].shape == (5, 2) and slots == [(0, 0), (5, 1)]
+    assert (tab["visibility_rng"] == [0, 1.0]).all()
+    P.visibility_rng = [[0, 0.1 * k] for k in range(1, 13)] + [[0, 1.0]]   # 12 + oof
+    c = EvalConstants(P, LP("bbox"), "lvis")
+    assert c.n_rng == 13 and len(c.rng_blocks) == 3
+    seen = sorted(i for _, sl in c.rng_blocks for _, i in sl)
+    assert seen == list(range(13))                        # every range once
+    assert c.rng_blocks[0][1][-1] == (5, 12)              # the last one in the oof slot
+    assert np.array_equal(c.rng_blocks[2][0]["visibility_rng"],
+                          [[0, 0.1 * 11], [0, 0.1 * 12]] + [[0, 0.1 * 12]] * 3)   # padded
+    P.visibility_rng = [[0, 1.0]]                         # the out-of-frame range alone
+    c = EvalConstants(P, LP("bbox"), "lvis")
+    assert c.n_rng == 1 and c.rng_blocks[0][1] == [(5, 0)]
+    for bad in ([], [[0, 1.0, 2.0]], "all"):
+        P.visibility_rng = bad
+        with pytest.raises(NotImplementedError, match="params.visibility_rng"):
+            EvalConstants(P, LP("bbox"), "lvis")
+    # track level: areas x durations
+    Q = TP("bbox")
+    c = EvalConstants(Q, TP("bbox"), "tao")
+    assert c.default and c.single and c.n_rng == 20
+    assert c.rng_blocks[0][1] == [(k, k) for k in range(20)]
+    Q.area_rng = Q.area_rng[:1]                           # the occlusion range alone
+    Q.time_rng = [[0, 5]]
+    c = EvalConstants(Q, TP("bbox"), "tao")
+    assert c.n_rng == 1 and c.rng_blocks[0][1] == [(16, 0)] and not c.single
+    Q.area_rng = [[0, 10.0 * k] for k in range(1, 7)] + [[0, 1e10]]   # 6 + occlusion
+    Q.time_rng = [[0, k] for k in range(1, 6)]                        # 5 durations
+    c = EvalConstants(Q, TP("bbox"), "tao")
+    assert c.n_rng == 35 and len(c.rng_blocks) == 2 * 2
+    seen = sorted(i for _, sl in c.rng_blocks for _, i in sl)
+    assert seen == list(range(35))
+    # the occlusion range (area index 6) sits in area slot 4 of the first area block
+    occ = [(k, i) for _, sl in c.rng_blocks[:2] for k, i in sl if i // 5 == 6]
+    assert sorted(i for _, i in occ) == [30, 31, 32, 33, 34] and all(k // 4 == 4 for k, _ in occ)
+    assert all(np.array_equal(t["area_rng"][4], [0, 1e10]) for t, _ in c.rng_blocks)
+    Q.time_rng = []
+    with pytest.raises(NotImplementedError, match="params.time_rng"):
+        EvalConstants(Q, TP("bbox"), "tao")
 
 
 def test_edited_thresholds_are_cut_into_the_kernels_blocks():

@@ -144,11 +144,20 @@ def test_edited_params_subsets_match_the_reference(name):
 def test_edited_params_the_path_cannot_honour_still_raise():
     from tao_amodal_amd.evaluation.lvis_amodal import LVISEval
     ev = LVISEval(path("f1", "gt.json"), path("f1", "pred.json"), "bbox")
-    # (thresholds and range VALUES are honoured: tests/test_gpu_constants.py;
-    # an edit that changes the NUMBER of ranges is not)
-    ev.params.visibility_rng = [[0, 1.0], [0, 0.5], [0, 1.0]]
+    # (thresholds and range tables of any values, order and length are
+    # honoured: tests/test_gpu_constants.py; a table that is no list of
+    # [lo, hi] pairs is not)
+    ev.params.visibility_rng = [[0, 1.0, 2.0], [0, 0.5, 1.0]]
     with pytest.raises(NotImplementedError):
         ev.evaluate()
+    # with another number of ranges the per-cell views are not kept
+    ev = LVISEval(path("f1", "gt.json"), path("f1", "pred.json"), "bbox")
+    ev.params.visibility_rng = [[0, 1.0], [0, 0.5], [0, 1.0]]
+    ev.evaluate()
+    ev.accumulate()
+    assert ev.eval["precision"].shape[-1] == 3
+    with pytest.raises(NotImplementedError):
+        ev.eval_imgs[0]
     ev = LVISEval(path("f1", "gt.json"), path("f1", "pred.json"), "bbox")
     ev.params.img_ids = [10 ** 9]
     with pytest.raises(KeyError):

@@ -29,9 +29,24 @@ def test_edited_constants_match_the_reference(name, case):
     from tao_amodal_amd.evaluation.lvis_amodal import LVISEval
     from tao_amodal_amd.evaluation.tao_amodal import Tao, TaoEval, TaoResults
     z = _golden(name)
+
+    def run_all(e, side):
+        """run(); a summarize() that raises in the reference (fewer ranges than
+        its labels name: IndexError) must raise the same here, after the same
+        partial results."""
+        e.evaluate()
+        e.accumulate()
+        err = str(z[case + "_%s_summarize_error" % side]) \
+            if case + "_%s_summarize_error" % side in z else ""
+        if err:
+            with pytest.raises(Exception) as info:
+                e.summarize()
+            assert type(info.value).__name__ == err
+        else:
+            e.summarize()
     ev = LVISEval(path(name, "gt.json"), path(name, "pred.json"), "bbox")
     edit(ev.params, cases()[case], "lvis")
-    ev.run()
+    run_all(ev, "lvis")
     assert ev.eval["precision"].shape == z[case + "_lvis_precision"].shape
     assert np.array_equal(ev.eval["precision"], z[case + "_lvis_precision"])
     assert np.array_equal(ev.eval["recall"], z[case + "_lvis_recall"])
@@ -42,7 +57,7 @@ def test_edited_constants_match_the_reference(name, case):
     gt = Tao(path(name, "gt.json"))
     te = TaoEval(gt, TaoResults(gt, dt))
     edit(te.params, cases()[case], "tao")
-    te.run()
+    run_all(te, "tao")
     want_p, want_r = z[case + "_tao_precision"], z[case + "_tao_recall"]
     assert te.eval["precision"].shape == want_p.shape
     assert np.array_equal(te.eval["precision"], want_p)
