@@ -344,8 +344,8 @@ int taoamd_track_iou_plan_host(int64_t n_cells, const int32_t *cell_dt_off_host,
  * taoamd_accumulate* recognise the same layout by the same pointer relation.
  * The pointer relation IS the layout flag of this ABI: `ignored == matched + 1`
  * means interleaved pairs in taoamd_match and every taoamd_accumulate* entry;
- * the entries that only know DENSE [n][n_words] tables -- taoamd_gather_rows
- * (its destination) and taoamd_exchange_merge -- return TAOAMD_ERR_ARG when
+ * the entry that only knows DENSE [n][n_words] tables -- taoamd_gather_rows
+ * (its destination) -- returns TAOAMD_ERR_ARG when
  * handed that relation instead of scrambling rows (tests/test_abi.py).
  * max_gt_per_cell must be >= the largest GT count of a cell (host knows it
  * from the CSR table); cells with more than 64 GTs take a slower kernel and
@@ -764,26 +764,38 @@ int taoamd_exchange_unpack(int32_t n_cat, int32_t n_rng, int32_t block_cats,
                            int32_t *overflow, void *workspace,
                            size_t workspace_bytes, int32_t maps_ready, void *stream);
 
-/* By-video partition, owner side.  The merged input is, for source s, the rows
- * [src_base[s], src_base[s + 1]) -- `records` = what the all_to_all delivered,
- * the sources' rows back to back WITHOUT those of `own_rank` (>= 0), which
- * never travel: they are read at `own_records`, where the rank's own match
- * wrote them (own_rank < 0: every source's rows are in `records`, own_records
- * unused).  Each row is `width` int64
- * {score bits, n_words matched words, n_words ignored words} (24 bytes at the
- * image level), sorted by (category, -score) inside the source -- a record
- * carries no category, the run it lies in says it; run_off[s * (block_cats + 1) + kb] =
- * offset of the run of category k0 + kb inside source s's rows; cat_base[kb] =
- * first row of that category in the merged layout.  Writes every record's
- * words at its place in the reference's order (stable -score sort of the
- * sources' concatenation in rank order, L/eval.py:353-361): one binary search
- * per other source instead of a radix sort and a gather. */
-int taoamd_exchange_merge(int64_t n_recv, int32_t world, int32_t block_cats,
-                          int32_t k0, const int64_t *records, int64_t width,
-                          int32_t n_words, const int64_t *src_base,
-                          const int64_t *run_off, const int64_t *cat_base,
-                          int32_t own_rank, const int64_t *own_records,
-                          uint64_t *matched, uint64_t *ignored, void *stream);
+/* By-video partition, owner side (round 5: in two messages).  A rank's records
+ * lie at their sorted place (category, -score): the sort gives the place, the
+ * match writes a detection's (matched, ignored) pairs there.  The merged input
+ * of an owner is, for source s, the rows [src_base[s], src_base[s + 1]) -- the
+ * wire buffer = what the all_to_all delivered, the sources' rows back to back
+ * WITHOUT those of `own_rank` (>= 0), which never travel: they are read where
+ * the rank's own sort / match wrote them (own_rank < 0: every source's rows
+ * are in the wire buffer).  A record carries no category, the run it lies in
+ * says it: run_off[s * (block_cats + 1) + kb] = offset of the run of the
+ * block's category kb inside source s's rows; cat_base[kb] = first row of that
+ * category in the merged layout.
+ *  _scores     out[dst[i]] = score[i] (bit patterns): the first message, ready
+ *              when the local sort is;
+ *  _positions  pos[i] = row of record i in the reference's order (stable -score
+ *              sort of the sources' concatenation in rank order,
+ *              L/eval.py:353-361): one binary search per other source over the
+ *              exchanged scores instead of a radix sort -- needs the scores
+ *              alone, so it runs beside the match;
+ *  _place      the second message's 16-byte (matched, ignored) pairs scattered
+ *              to out[pos[i] * n_words + w]: the paired table the sweep reads
+ *              (out, out + 1 as taoamd_accumulate*'s matched / ignored). */
+int taoamd_exchange_scores(int64_t n, const int32_t *dst, const double *score,
+                           int64_t *out, void *stream);
+int taoamd_exchange_positions(int64_t n_recv, int32_t world, int32_t block_cats,
+                              const int64_t *scores, const int64_t *own_scores,
+                              int32_t own_rank, const int64_t *src_base,
+                              const int64_t *run_off, const int64_t *cat_base,
+                              int32_t *pos, void *stream);
+int taoamd_exchange_place(int64_t n_recv, int32_t world, int32_t n_words,
+                          const uint64_t *rows, const uint64_t *own_rows,
+                          int32_t own_rank, const int64_t *src_base,
+                          const int32_t *pos, uint64_t *out, void *stream);
 
 #ifdef __cplusplus
 }

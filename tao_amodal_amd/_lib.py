@@ -130,8 +130,11 @@ SIGNATURES = {
                                        _vp, _vp, _i64, _vp, _vp, _sz, _i32, _vp]),
     "taoamd_exchange_unpack": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _i64, _vp,
                                          _vp, _vp, _vp, _vp, _sz, _i32, _vp]),
-    "taoamd_exchange_merge": (C.c_int, [_i64, _i32, _i32, _i32, _vp, _i64, _i32,
-                                        _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "taoamd_exchange_scores": (C.c_int, [_i64, _vp, _vp, _vp, _vp]),
+    "taoamd_exchange_positions": (C.c_int, [_i64, _i32, _i32, _vp, _vp, _i32, _vp, _vp,
+                                            _vp, _vp, _vp]),
+    "taoamd_exchange_place": (C.c_int, [_i64, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp,
+                                        _vp]),
     "taoamd_sort_workspace": (_sz, [_i64]),
     "taoamd_sort_by_cat_score": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _sz,
                                            _vp]),

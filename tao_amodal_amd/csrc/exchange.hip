@@ -391,19 +391,27 @@ extern "C" int taoamd_exchange_unpack(int32_t n_cat, int32_t n_rng,
 }
 
 // ---------------------------------------------------------------------------
-// By-video partition, owner side: k-way merge of the received runs.
+// By-video partition, owner side: k-way merge of the received runs -- in two
+// messages (round 5).
 //
-// Every source rank sends its records sorted by (category, -score) (the match
-// kernel writes them at their sorted place).  What an owner receives is, per
-// source, one block holding the runs of the owner's categories back to back.
-// The reference's order of a category = stable sort by -score of the
+// Every source rank holds its records sorted by (category, -score): the sort
+// gives a detection's place, the match writes its (matched, ignored) pairs
+// there.  The reference's order of a category = stable sort by -score of the
 // concatenation of the sources in rank order (tao_amodal/eval.py:508-518,
-// lvis_amodal/eval.py:353-361); inside a run that order is already there, so
-// a record's final row = its place in its own run + the number of records of
-// the OTHER sources' runs of the category that precede it (better score; on a
-// tie the lower rank) -- one binary search per other source.  The rows are
-// written straight into the sorted layout the sweep reads: no radix sort, no
-// gather pass.
+// lvis_amodal/eval.py:353-361); inside a source's run that order is already
+// there, so a record's final row = its place in its own run + the number of
+// records of the OTHER sources' runs of the category that precede it (better
+// score; on a tie the lower rank) -- one binary search per other source.
+//
+// That row depends on the SCORES alone, which a rank knows as soon as its
+// local sort is done.  So the scores travel first (8 bytes a record, while the
+// 3D IoU and the match still run), the owner works out every record's row
+// beside the match (ex_positions_kernel), and what is left behind the match
+// is the exchange of the rows themselves (16 bytes a record and combo word, in
+// category blocks: dist.ShardedEval) and one scatter of 16-byte pairs
+// (ex_place_kernel) straight into the paired layout the sweep streams.
+// Round 4 shipped {score, matched, ignored} records after the match and
+// searched, read and placed them in one kernel on the critical chain.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t ex_desc_key(int64_t score_bits)
 {
@@ -413,32 +421,58 @@ __device__ __forceinline__ uint64_t ex_desc_key(int64_t score_bits)
     return ~asc;                                          // ascending = score descending
 }
 
-__global__ void ex_merge_kernel(int64_t n_recv, int32_t world, int32_t block_cats,
-                                int32_t k0, const int64_t *__restrict__ records,
-                                int64_t width, int32_t n_words,
-                                const int64_t *__restrict__ src_base,
-                                const int64_t *__restrict__ run_off,
-                                const int64_t *__restrict__ cat_base,
-                                int32_t own, const int64_t *__restrict__ own_records,
-                                uint64_t *__restrict__ matched,
-                                uint64_t *__restrict__ ignored)
+// scores at their sorted place: the first message of the exchange
+__global__ void ex_scores_kernel(int64_t n, const int32_t *__restrict__ dst,
+                                 const int64_t *__restrict__ score,
+                                 int64_t *__restrict__ out)
 {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i >= n_recv) return;
-    (void)k0;          // (the block's first category: part of the ABI, not needed here)
+    if (i < n) out[dst[i]] = score[i];
+}
+
+extern "C" int taoamd_exchange_scores(int64_t n, const int32_t *dst, const double *score,
+                                      int64_t *out, void *stream)
+{
+    if (n < 0) return TAOAMD_ERR_ARG;
+    if (n == 0) return TAOAMD_OK;
+    if (!dst || !score || !out) return TAOAMD_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    TAO_TIMED("ex_scores_kernel", s, ex_scores_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(
+        n, dst, (const int64_t *)score, out));
+    TAO_LAUNCH_CHECK();
+    return TAOAMD_OK;
+}
+
+struct ExSources {           // record i of the merged input -> where it lies
+    int64_t n_recv;
+    int32_t world, own;
+    const int64_t *src_base; // [world + 1] rows of source s: [src_base[s], src_base[s + 1])
+};
+
+// element index (in units of one record) of record `at` of source o inside
+// the wire buffer / the own buffer
+__device__ __forceinline__ int64_t ex_wire_at(const ExSources &x, int o, int64_t at)
+{
+    const int64_t own_rows = x.own >= 0 ? x.src_base[x.own + 1] - x.src_base[x.own] : 0;
+    return x.src_base[o] - (o > x.own ? own_rows : 0) + at;
+}
+
+__global__ void ex_positions_kernel(ExSources x, int32_t block_cats,
+                                    const int64_t *__restrict__ wire,
+                                    const int64_t *__restrict__ own_scores,
+                                    const int64_t *__restrict__ run_off,
+                                    const int64_t *__restrict__ cat_base,
+                                    int32_t *__restrict__ pos_out)
+{
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= x.n_recv) return;
     int s = 0;
-    while (s + 1 < world && src_base[s + 1] <= i) s++;
-    // the rows of source o: the rank's own records never travelled (they are
-    // read where the match wrote them), `records` holds the other sources'
-    // rows back to back
-    const int64_t own_rows = own >= 0 ? src_base[own + 1] - src_base[own] : 0;
-    auto rows_of = [&](int o) -> const int64_t * {
-        return o == own ? own_records
-                        : records + (src_base[o] - (o > own ? own_rows : 0)) * width;
+    while (s + 1 < x.world && x.src_base[s + 1] <= i) s++;
+    const int64_t at = i - x.src_base[s];
+    auto score_of = [&](int o, int64_t a) -> int64_t {
+        return o == x.own ? own_scores[a] : wire[ex_wire_at(x, o, a)];
     };
-    const int64_t at = i - src_base[s];
-    const int64_t *rec = rows_of(s) + at * width;
-    const uint64_t key = ex_desc_key(rec[0]);
+    const uint64_t key = ex_desc_key(score_of(s, at));
     const int64_t *ro = run_off + (int64_t)s * (block_cats + 1);
     // the record's category is the run it lies in (a record carries none: the
     // sender lays its records out category by category): last kb with
@@ -449,49 +483,93 @@ __global__ void ex_merge_kernel(int64_t n_recv, int32_t world, int32_t block_cat
         if (ro[mid] <= at) { lo = mid; kb = mid; } else hi = mid - 1;
     }
     int64_t pos = cat_base[kb] + (at - ro[kb]);
-    for (int o = 0; o < world; o++) {
+    for (int o = 0; o < x.world; o++) {
         if (o == s) continue;
         const int64_t *oo = run_off + (int64_t)o * (block_cats + 1);
-        const int64_t *other = rows_of(o);
         const int64_t b = oo[kb], e = oo[kb + 1];
         // records of run o that come first: key' < key, or key' == key from a lower rank
         int64_t lo = b, hi = e;
         while (lo < hi) {
             const int64_t mid = (lo + hi) >> 1;
-            const uint64_t km = ex_desc_key(other[mid * width]);
+            const uint64_t km = ex_desc_key(score_of(o, mid));
             if (km < key || (km == key && o < s)) lo = mid + 1; else hi = mid;
         }
         pos += lo - b;
     }
-    for (int w = 0; w < n_words; w++) {
-        matched[pos * n_words + w] = (uint64_t)rec[1 + w];
-        ignored[pos * n_words + w] = (uint64_t)rec[1 + n_words + w];
-    }
+    pos_out[i] = (int32_t)pos;
 }
 
-extern "C" int taoamd_exchange_merge(int64_t n_recv, int32_t world, int32_t block_cats,
-                                     int32_t k0, const int64_t *records, int64_t width,
-                                     int32_t n_words, const int64_t *src_base,
-                                     const int64_t *run_off, const int64_t *cat_base,
-                                     int32_t own_rank, const int64_t *own_records,
-                                     uint64_t *matched, uint64_t *ignored, void *stream)
+// one 16-byte (matched, ignored) pair per thread, at its row of the paired table
+__global__ void ex_place_kernel(ExSources x, int32_t n_words,
+                                const ulonglong2 *__restrict__ wire,
+                                const ulonglong2 *__restrict__ own_rows,
+                                const int32_t *__restrict__ pos,
+                                ulonglong2 *__restrict__ out)
 {
-    if (n_recv < 0 || world < 1 || block_cats < 1 || n_words < 1 ||
-        width < 1 + 2 * (int64_t)n_words || own_rank >= world)
+    // consecutive records lie in one category's segment of the output: the
+    // blocks of a category behind one L2 (xcd_block, common.hpp)
+    const int64_t t = (int64_t)xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+    const int64_t i = t / n_words;
+    if (i >= x.n_recv) return;
+    const int w = (int)(t - i * n_words);
+    int s = 0;
+    while (s + 1 < x.world && x.src_base[s + 1] <= i) s++;
+    const int64_t at = i - x.src_base[s];
+    const ulonglong2 v = s == x.own ? own_rows[at * n_words + w]
+                                    : wire[ex_wire_at(x, s, at) * n_words + w];
+    out[(int64_t)pos[i] * n_words + w] = v;
+}
+
+static int ex_sources(ExSources &x, int64_t n_recv, int32_t world, const int64_t *src_base,
+                      int32_t own_rank)
+{
+    if (n_recv < 0 || world < 1 || own_rank >= world || !src_base) return TAOAMD_ERR_ARG;
+    x.n_recv = n_recv; x.world = world; x.own = own_rank < 0 ? -1 : own_rank;
+    x.src_base = src_base;
+    return TAOAMD_OK;
+}
+
+extern "C" int taoamd_exchange_positions(int64_t n_recv, int32_t world, int32_t block_cats,
+                                         const int64_t *scores, const int64_t *own_scores,
+                                         int32_t own_rank, const int64_t *src_base,
+                                         const int64_t *run_off, const int64_t *cat_base,
+                                         int32_t *pos, void *stream)
+{
+    ExSources x;
+    if (ex_sources(x, n_recv, world, src_base, own_rank) != TAOAMD_OK || block_cats < 1)
         return TAOAMD_ERR_ARG;
     if (n_recv == 0) return TAOAMD_OK;
-    if (!src_base || !run_off || !cat_base || !matched || !ignored)
-        return TAOAMD_ERR_ARG;
-    if (own_rank < 0) own_rank = -1;
-    // (`records` may be null when every row is the rank's own: world == 1)
-    if ((own_rank < 0 || world > 1) && !records) return TAOAMD_ERR_ARG;
-    if (own_rank >= 0 && !own_records) return TAOAMD_ERR_ARG;
-    // dense [n_recv][n_words] tables only (see taoamd_gather_rows)
-    if (ignored == matched + 1 && n_recv * n_words > 1) return TAOAMD_ERR_ARG;
+    if (!run_off || !cat_base || !pos) return TAOAMD_ERR_ARG;
+    // (`scores` may be null when every row is the rank's own: world == 1)
+    if ((x.own < 0 || world > 1) && !scores) return TAOAMD_ERR_ARG;
+    if (x.own >= 0 && !own_scores) return TAOAMD_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    TAO_TIMED("ex_merge_kernel", s, ex_merge_kernel<<<(unsigned)((n_recv + 255) / 256), 256, 0, s>>>(
-        n_recv, world, block_cats, k0, records, width, n_words, src_base, run_off,
-        cat_base, own_rank, own_records, matched, ignored));
+    TAO_TIMED("ex_positions_kernel", s, ex_positions_kernel<<<(unsigned)((n_recv + 255) / 256), 256, 0, s>>>(
+        x, block_cats, scores, own_scores, run_off, cat_base, pos));
+    TAO_LAUNCH_CHECK();
+    return TAOAMD_OK;
+}
+
+extern "C" int taoamd_exchange_place(int64_t n_recv, int32_t world, int32_t n_words,
+                                     const uint64_t *rows, const uint64_t *own_rows,
+                                     int32_t own_rank, const int64_t *src_base,
+                                     const int32_t *pos, uint64_t *out, void *stream)
+{
+    ExSources x;
+    if (ex_sources(x, n_recv, world, src_base, own_rank) != TAOAMD_OK || n_words < 1)
+        return TAOAMD_ERR_ARG;
+    if (n_recv == 0) return TAOAMD_OK;
+    if (!pos || !out) return TAOAMD_ERR_ARG;
+    if ((x.own < 0 || world > 1) && !rows) return TAOAMD_ERR_ARG;
+    if (x.own >= 0 && !own_rows) return TAOAMD_ERR_ARG;
+    // tables of 16-byte pairs
+    if ((((uintptr_t)rows | (uintptr_t)own_rows | (uintptr_t)out) & 15) != 0)
+        return TAOAMD_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t threads = n_recv * n_words;
+    TAO_TIMED("ex_place_kernel", s, ex_place_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>(
+        x, n_words, (const ulonglong2 *)rows, (const ulonglong2 *)own_rows, pos,
+        (ulonglong2 *)out));
     TAO_LAUNCH_CHECK();
     return TAOAMD_OK;
 }

@@ -19,33 +19,40 @@ independent per cell, but AP needs every category's detections in ONE global
 score order (reference lvis_amodal/eval.py:353-361).  A histogram all-reduce
 is not enough for exact AP; the per-detection TP/ignore words have to meet.
 
-Per evaluator pass and rank:
+Per evaluator pass and rank (round 5: the exchange in two messages, the
+second in category blocks -- nothing of it waits behind the match that could
+run beside it):
 
-  1. range masks; ``all_reduce(sum)`` of num_gt[K, n_rng]        (tiny)
-  2. local segment sort (the rank's tables are category-major) || [3D track
-     IoU]; the match kernel writes each detection's words straight into the
-     send buffer AT ITS SORTED PLACE, so what a rank sends to an owner is the
-     runs of the owner's categories, each in (-score, concatenation) order
-  3. ONE ``all_to_all_single`` of the records
-         [score | matched words | ignored words]   (int64 cols; 24 bytes at
-         the image level -- the category is the run a record lies in)
-     Category k is owned by rank k // ceil(K / world): contiguous blocks.
-  4. owner: k-way merge of the received runs (taoamd_exchange_merge): a
-     record's row = its place in its run + the records of the other sources'
-     runs that precede it -- one binary search per other source.  Ranks hold
-     ascending, disjoint unit ranges and all_to_all delivers sources in rank
-     order, so "lower rank first on ties" == the reference's concatenation
-     order and its stable sort is reproduced exactly.  The rows land in the
-     sorted layout the sweep reads: no radix sort, no gather pass.
-  5. owner: sweep of its categories (taoamd_accumulate_compact), result rows
-     run-length packed (taoamd_exchange_pack)
+  1. range masks; ``all_reduce(sum)`` of num_gt[K, n_rng]        (tiny; side stream)
+  2. local segment sort (the rank's tables are category-major): a detection's
+     sorted place -- where its record lies in everything that follows, so what
+     a rank sends to an owner is the runs of the owner's categories, each in
+     (-score, concatenation) order.  Category k is owned by rank
+     k // ceil(K / world): contiguous blocks.
+  3. the SCORES at their sorted place -> ``all_to_all`` #1 (8 bytes a record),
+     on the communication stream while the 3D IoU and the match run; from the
+     scores alone the owner works out every record's row in the reference's
+     order (taoamd_exchange_positions: a record's row = its place in its run +
+     the records of the other sources' runs that precede it, one binary search
+     per other source; ranks hold ascending, disjoint unit ranges and the
+     sources are taken in rank order, so "lower rank first on ties" == the
+     reference's concatenation order and its stable sort is reproduced
+     exactly) -- on a side stream, beside the match.
+  4. the match, in B phases: phase j matches the cells of the j-th sub-block
+     of EVERY owner's category block and writes the (matched, ignored) pairs at
+     their sorted place; ``all_to_all`` #2.j ships exactly those rows (16 bytes
+     a record and combo word; every link busy in every phase) while phase
+     j + 1 is matched.  A rank's own block never travels.
+  5. owner: one scatter of the received pairs to their rows
+     (taoamd_exchange_place) -- the paired table the sweep streams --, sweep
+     of its categories (taoamd_accumulate_compact), result rows run-length
+     packed (taoamd_exchange_pack)
   6. ONE in-place ``all_gather_into_tensor`` of the packed chunks, expanded
      straight into the reference layout (taoamd_exchange_unpack) -- the same
      tail as the category partition.
 
-Volumes at Config 2 per rank: step 3 ~ 32 B x 2.1 M records, step 6 a few MB
--- far below the 7 x ~153 GB/s xGMI links, so the design minimises the NUMBER
-of collectives (2 + one tiny all-reduce per evaluator).
+With one rank there is nothing to exchange or merge: the sweep reads the rows
+where the match wrote them.
 
 The collective plumbing is backend-agnostic: ``tests/test_dist_gloo.py`` runs
 this very module with world_size 2 on CPU tensors over gloo, with the oracle
@@ -69,7 +76,6 @@ from . import _lib
 N_THR, N_REC = _lib.N_THR, _lib.N_REC
 
 
-REC_HEAD = 1        # int64 columns ahead of a record's words: the score
 
 
 def _ptr(t):
@@ -98,24 +104,23 @@ class HipBackend:
         if dp.guard_flat is not None:
             ws.guarded_pairs = self.engine.apply_iou_guard(dp, ws)
 
-    def match_into(self, dp, ws, dst, records, width):
-        if dp.n_dt == 0:
-            return
-        t, lib = dp.t, self.lib
-        fused = dp.kind == "lvis" and not dp.mask_iou
-        base = records.data_ptr()
-        _lib.check(lib.taoamd_match(
-            dp.n_cells, _ptr(t["cell_dt_off"]), _ptr(t["cell_gt_off"]),
-            _ptr(t["cell_iou_off"]), dp.max_g,
-            _ptr(t["dt_box"]) if fused else None,
-            _ptr(t["gt_box"]) if fused else None,
-            None if fused else _ptr(ws.iou), dp.n_rng, _ptr(ws.gt_rng),
-            None if dp.kind == "lvis" else _ptr(ws.dt_rng),   # (image level: from the flags)
-            _ptr(t["gt_flags"]), _ptr(t["dt_flags"]),
-            _ptr(dst), width, base + 8 * REC_HEAD,
-            base + 8 * REC_HEAD + 8 * dp.n_words, None, None,
-            _ptr(t["dt_group"]), _ptr(t["dt_meta"]), _ptr(t["groups"]), dp.n_groups,
-            _ptr(t["singles"]), dp.n_singles, self._s()), "taoamd_match")
+    def scores_at_place(self, dp, ws, out):
+        """out[sorted place of detection i] = bits of its score: the first
+        message of the exchange (after sort_local)."""
+        if dp.n_dt:
+            _lib.check(self.lib.taoamd_exchange_scores(
+                dp.n_dt, _ptr(ws.dst), _ptr(dp.t["dt_score"]), _ptr(out), self._s()),
+                "taoamd_exchange_scores")
+
+    def match_rows(self, dp, ws, phase=None):
+        """The match of one phase's cells (None: all), rows at their sorted
+        place in ws.rows.  `phase`: {"groups": (first, count) in
+        phase["groups_dev"], "singles": ... in phase["singles_dev"]}."""
+        if phase is None:
+            return self.engine.stage_match(dp, ws)
+        self.engine.stage_match(
+            dp, ws, groups=(phase["groups_dev"], phase["groups"][0], phase["groups"][1]),
+            singles=(phase["singles_dev"], phase["singles"][0], phase["singles"][1]))
 
     def sort_local(self, dp, ws):
         self.engine.stage_sort(dp, ws)
@@ -132,21 +137,17 @@ class HipBackend:
             n, _ptr(cat), _ptr(score), _ptr(order), None, _ptr(ws_buf),
             ws_bytes, self._s()), "taoamd_sort_by_cat_score")
 
-    def merge_runs(self, n_recv, world, block_cats, k0, records, width, n_words,
-                   src_base, run_off, cat_base, matched, ignored, own=-1,
-                   own_records=None):
-        _lib.check(self.lib.taoamd_exchange_merge(
-            n_recv, world, block_cats, k0, _ptr(records), width, n_words,
-            _ptr(src_base), _ptr(run_off), _ptr(cat_base), own,
-            None if own_records is None else _ptr(own_records), _ptr(matched),
-            _ptr(ignored), self._s()), "taoamd_exchange_merge")
+    def positions(self, n_recv, world, block_cats, scores, own_scores, own, src_base,
+                  run_off, cat_base, pos):
+        _lib.check(self.lib.taoamd_exchange_positions(
+            n_recv, world, block_cats, _ptr(scores), _ptr(own_scores), own,
+            _ptr(src_base), _ptr(run_off), _ptr(cat_base), _ptr(pos), self._s()),
+            "taoamd_exchange_positions")
 
-    def gather_rows(self, n, n_words, records, width, order, matched, ignored):
-        base = records.data_ptr()
-        _lib.check(self.lib.taoamd_gather_rows(
-            n, n_words, base + 8 * REC_HEAD, base + 8 * REC_HEAD + 8 * n_words, width,
-            _ptr(order),
-            _ptr(matched), _ptr(ignored), self._s()), "taoamd_gather_rows")
+    def place(self, n_recv, world, n_words, rows, own_rows, own, src_base, pos, out):
+        _lib.check(self.lib.taoamd_exchange_place(
+            n_recv, world, n_words, _ptr(rows), _ptr(own_rows), own, _ptr(src_base),
+            _ptr(pos), _ptr(out), self._s()), "taoamd_exchange_place")
 
     def accumulate_compact(self, n, n_cat, n_rng, cat_off, matched, ignored,
                            num_gt, k0, k1, val, rec, ws_buf, ws_bytes,
@@ -198,18 +199,49 @@ class HipBackend:
             "taoamd_exchange_unpack")
 
 
+PHASES = 4      # category sub-blocks per owner of the rows exchange (message #2)
+
+
+class _Done:
+    """A finished exchange (the synchronous, host-staged form)."""
+
+    def wait(self):
+        return True
+
+
+def exchange_pieces(out_list, in_list, group=None):
+    """``all_to_all`` of per-rank pieces (piece r of `in_list` goes to rank r,
+    piece s of `out_list` comes from rank s; views into larger buffers, empty
+    where nothing travels).  One GPU per rank: RCCL, asynchronous -- returns
+    the work handle, ``wait()`` makes the CURRENT STREAM wait, the host never
+    blocks.  gloo has no list form and moves no device tensors: the pieces are
+    packed, staged on the host and exchanged with ``all_to_all_single``
+    (ranks of a job sharing one GPU, the CPU tests)."""
+    if dist.get_backend(group) != "gloo":
+        return dist.all_to_all(out_list, in_list, group=group, async_op=True)
+    inp = torch.cat([t.reshape(-1) for t in in_list]).cpu() if in_list else torch.empty(0)
+    out = torch.empty(sum(t.numel() for t in out_list), dtype=inp.dtype)
+    dist.all_to_all_single(out, inp, [t.numel() for t in out_list],
+                           [t.numel() for t in in_list], group=group)
+    at = 0
+    for t in out_list:
+        if t.numel():
+            t.copy_(out[at:at + t.numel()].view(t.shape))
+        at += t.numel()
+    return _Done()
+
+
 class ShardedEval:
     """One evaluator (LVIS or TAO side) of one rank when the problem is
     partitioned BY UNIT: the rank holds the cell tables of its own images /
     videos (category-major, flatten.py) and owns a contiguous category block
     of the result."""
 
-    def __init__(self, dp, ws, rank, world, backend, group=None):
+    def __init__(self, dp, ws, rank, world, backend, group=None, phases=None):
         self.dp, self.ws, self.rank, self.world = dp, ws, rank, world
         self.be, self.group = backend, group
         dev = dp.device
         K, nw, R = dp.n_cat, dp.n_words, dp.n_rng
-        self.W = REC_HEAD + 2 * nw                # int64 columns of a record
         self.k0, self.k1, self.Kb = category_block(K, rank, world)
         Kb = self.Kb
         # ---- who sends what: records per (owner, category of its block)
@@ -222,7 +254,8 @@ class ShardedEval:
         self.send_counts = cnt.reshape(world, Kb).sum(1).tolist()
         self.recv_counts = rc.sum(1).tolist()
         self.n_recv = int(rc.sum())
-        # the rank's own block never travels: the merge reads it in `send`
+        # the rank's own block never travels: it is read where the sort / the
+        # match wrote it
         self.own_at = sum(self.send_counts[:rank])
         self.n_wire = self.n_recv - self.recv_counts[rank]
         src_base = np.zeros(world + 1, dtype=np.int64)
@@ -240,14 +273,43 @@ class ShardedEval:
         self.run_off = torch.from_numpy(run_off).to(dev)
         self.cat_base = torch.from_numpy(cat_base).to(dev)
         self.cat_off = torch.from_numpy(cat_off.astype(np.int32)).to(dev)
-        self.send = torch.zeros((max(dp.n_dt, 1), self.W), dtype=torch.int64,
-                                device=dev)
-        self.recv = torch.zeros((max(self.n_wire, 1), self.W), dtype=torch.int64,
-                                device=dev)
-        self._static = False          # score / category columns of `send`
-        n = max(self.n_recv, 1)
-        self.matched = torch.empty((n, nw), dtype=torch.int64, device=dev)
-        self.ignored = torch.empty((n, nw), dtype=torch.int64, device=dev)
+        # ---- buffers.  Message #1: scores at their sorted place; message #2:
+        # the rows of ws.rows (where the match writes them: the send buffer IS
+        # the plain pass's row table).  `pos`: row of a received record,
+        # `rows`: the paired table the sweep reads -- with one rank the match's.
+        i64 = torch.int64
+        self.send_score = torch.zeros(max(dp.n_dt, 1), dtype=i64, device=dev)
+        self.recv_score = torch.zeros(max(self.n_wire, 1), dtype=i64, device=dev)
+        self.recv_rows = torch.zeros((max(self.n_wire, 1), nw, 2), dtype=i64, device=dev)
+        self.pos = torch.zeros(max(self.n_recv, 1), dtype=torch.int32, device=dev)
+        self.rows = ws.rows if world == 1 else \
+            torch.zeros((max(self.n_recv, 1), nw, 2), dtype=i64, device=dev)
+        self.matched, self.ignored = self.rows[..., 0], self.rows[..., 1]
+        # ---- the pieces of both messages (element ranges of the buffers)
+        wire_base = src_base[:-1] - np.where(np.arange(world) > rank,
+                                             self.recv_counts[rank], 0)
+        cs = np.zeros(Kb * world + 1, dtype=np.int64)
+        np.cumsum(cnt, out=cs[1:])
+        self._score_pieces = (
+            [(int(cs[r * Kb]), int(cs[(r + 1) * Kb])) if r != rank else (0, 0)
+             for r in range(world)],
+            [(int(wire_base[s_]), int(wire_base[s_] + rc[s_].sum())) if s_ != rank else (0, 0)
+             for s_ in range(world)])
+        B = phases if phases is not None else (1 if world == 1 else PHASES)
+        B = max(1, min(B, Kb))
+        edges = [Kb * j // B for j in range(B + 1)]
+        self.phases = []
+        for j in range(B):
+            e0, e1 = edges[j], edges[j + 1]
+            self.phases.append({
+                # the phase's categories: sub-block j of every owner's block
+                "cat_ranges": [(min(r * Kb + e0, K), min(r * Kb + e1, K)) for r in range(world)],
+                "send": [(int(cs[r * Kb + e0]), int(cs[r * Kb + e1])) if r != rank else (0, 0)
+                         for r in range(world)],
+                "recv": [(int(wire_base[s_] + run_off[s_, e0]), int(wire_base[s_] + run_off[s_, e1]))
+                         if s_ != rank else (0, 0) for s_ in range(world)]})
+        self._plan_match_phases(edges)
+        self._side = torch.cuda.Stream(dev) if dev.type == "cuda" and world > 1 else None
         lib = _lib.load()
         self.acc_bytes = lib.taoamd_accumulate_workspace(self.n_recv, K, R)
         self.acc_ws = torch.empty(max(self.acc_bytes, 256), dtype=torch.uint8,
@@ -276,6 +338,45 @@ class ShardedEval:
         self.chunks = torch.zeros(world * self.chunk_bytes, dtype=torch.uint8,
                                   device=dev)
 
+    def _plan_match_phases(self, edges):
+        """The match's launch plan cut into the phases: the run descriptors
+        (groups) and single cells permuted phase-major, a phase = one slice of
+        each.  A run belongs to the EARLIEST phase among its cells' categories:
+        its rows are then ready early, never late.  (The tables are
+        category-major and a phase's categories are sub-block j of every
+        owner's block, so inside one owner's block the phase follows from the
+        run's first category; a run that straddles two owners' blocks holds
+        categories of the next owner's FIRST sub-block: phase 0.)"""
+        dp = self.dp
+        if len(self.phases) == 1 or dp.n_dt == 0:
+            for ph in self.phases:
+                ph["groups"] = ph["singles"] = None
+            return
+        Kb = self.Kb
+        edges = np.asarray(edges)
+
+        def phase_of(first_dt, last_dt):
+            c0 = np.searchsorted(dp.cat_off_host, first_dt, "right") - 1
+            c1 = np.searchsorted(dp.cat_off_host, np.maximum(last_dt, first_dt), "right") - 1
+            ph = np.searchsorted(edges, c0 % Kb, "right") - 1
+            return np.where(c0 // Kb != c1 // Kb, 0, ph)
+        dev = dp.device
+        gh, sh = dp.groups_host, dp.singles_host
+        pg = phase_of(gh[:, 0], gh[:, 0] + gh[:, 1] - 1) if len(gh) else np.zeros(0, np.int64)
+        ps = phase_of(dp.singles_first_dt, dp.singles_first_dt) if len(sh) \
+            else np.zeros(0, np.int64)
+        og, os_ = np.argsort(pg, kind="stable"), np.argsort(ps, kind="stable")
+        g_dev = torch.from_numpy(np.ascontiguousarray(gh[og]) if len(gh)
+                                 else np.zeros((1, 4), np.int32)).to(dev)
+        s_dev = torch.from_numpy(np.ascontiguousarray(sh[os_]) if len(sh)
+                                 else np.zeros(1, np.int32)).to(dev)
+        gb = np.searchsorted(pg[og], np.arange(len(self.phases) + 1))
+        sb = np.searchsorted(ps[os_], np.arange(len(self.phases) + 1))
+        for j, ph in enumerate(self.phases):
+            ph["groups_dev"], ph["singles_dev"] = g_dev, s_dev
+            ph["groups"] = (int(gb[j]), int(gb[j + 1] - gb[j]))
+            ph["singles"] = (int(sb[j]), int(sb[j + 1] - sb[j]))
+
     def _global_num_gt(self):
         """num_gt of all rows (one all-reduce) and, from it, the run maps and
         level offsets the result exchange needs -- known at the head of the
@@ -286,30 +387,16 @@ class ShardedEval:
         self.be.exchange_sizes(self.Kb, self.dp.n_rng, self.world, self.table,
                                self.totals, self.xws)
 
-    def _exchange(self, send=None, recv=None):
-        """The records of the other owners' categories leave, those of this
-        rank's block arrive (`recv`: the sources' rows back to back, without
-        this rank's own).  Two calls, because the block that stays lies in the
-        middle of `send`: to the lower ranks / from the higher ones, then the
-        other way round."""
-        send = self.send if send is None else send
-        recv = self.recv if recv is None else recv
-        if self.world == 1:
-            return
-        r, w = self.rank, self.world
-        sc, rc = self.send_counts, self.recv_counts
-        below = sum(rc[:r])
-        own_end = self.own_at + sc[r]
-        all_to_all(recv[below:self.n_wire], send[:self.own_at],
-                   output_split_sizes=[0] * (r + 1) + rc[r + 1:],
-                   input_split_sizes=sc[:r] + [0] * (w - r), group=self.group)
-        all_to_all(recv[:below], send[own_end:self.dp.n_dt],
-                   output_split_sizes=rc[:r] + [0] * (w - r),
-                   input_split_sizes=[0] * (r + 1) + sc[r + 1:], group=self.group)
+    def _pieces(self, buf, ranges):
+        return [buf[a:b] for a, b in ranges]
 
-    def _own(self, send=None):
-        send = self.send if send is None else send
-        return send[self.own_at:] if self.own_at < send.shape[0] else send
+    def _exchange_scores(self, send=None, recv=None):
+        """Message #1 (also what carries the detections' ids for
+        eval['dt_pointers']: owner_rows)."""
+        send = self.send_score if send is None else send
+        recv = self.recv_score if recv is None else recv
+        return exchange_pieces(self._pieces(recv, self._score_pieces[1]),
+                               self._pieces(send, self._score_pieces[0]), self.group)
 
     def step(self, aux=None):
         """`aux`: a second stream for the range masks and the num_gt
@@ -327,20 +414,38 @@ class ShardedEval:
             be.ranges(dp, ws)
             self._global_num_gt()
         be.sort_local(dp, ws)
-        if not self._static and dp.n_dt:
-            # the input of the exchange that no pass changes: a record's score,
-            # at the record's sorted place
-            slot = ws.dst[:dp.n_dt].long()
-            self.send[slot, 0] = dp.t["dt_score"].view(torch.int64)
-            self._static = True
+        lone = self.world == 1
+        if not lone:
+            # message #1 leaves as soon as the places are known; the rows of
+            # the records are worked out from it beside the 3D IoU / the match
+            be.scores_at_place(dp, ws, self.send_score)
+            scores_in = self._exchange_scores()
+            side = self._side
+            if side is not None:
+                side.wait_stream(torch.cuda.current_stream(dp.device))
+            with (torch.cuda.stream(side) if side is not None else _null()):
+                scores_in.wait()
+                be.positions(self.n_recv, self.world, self.Kb, self.recv_score,
+                             self.send_score[self.own_at:], self.rank, self.src_base,
+                             self.run_off, self.cat_base, self.pos)
         be.track_iou(dp, ws)
         if cur is not None:
             cur.wait_stream(aux)         # the match reads the range masks
-        be.match_into(dp, ws, ws.dst, self.send, self.W)
-        self._exchange()
-        be.merge_runs(self.n_recv, self.world, self.Kb, self.k0, self.recv, self.W,
-                      dp.n_words, self.src_base, self.run_off, self.cat_base,
-                      self.matched, self.ignored, self.rank, self._own())
+        arrivals = []
+        for ph in self.phases:
+            be.match_rows(dp, ws, ph if ph["groups"] is not None else None)
+            if not lone:
+                # message #2.j: this phase's rows, while the next phase is matched
+                arrivals.append(exchange_pieces(self._pieces(self.recv_rows, ph["recv"]),
+                                                self._pieces(ws.rows, ph["send"]),
+                                                self.group))
+        if not lone:
+            for w in arrivals:
+                w.wait()
+            if self._side is not None:
+                torch.cuda.current_stream(dp.device).wait_stream(self._side)
+            be.place(self.n_recv, self.world, dp.n_words, self.recv_rows,
+                     ws.rows[self.own_at:], self.rank, self.src_base, self.pos, self.rows)
         self._sweep()
         self._publish()
 
@@ -389,27 +494,37 @@ class ShardedEval:
         """After step(): the rows of this rank's category block as the sweep
         saw them -- (ids, matched, ignored, cat_base) with `ids` (int64 device
         tensor, one per detection of this rank) taken through the very exchange
-        and merge the records went through (a second all_to_all whose records
-        carry the id where the matched word was: same scores, same runs, same
-        places).  Collective.  The source of eval['dt_pointers'] in a multi-GPU
+        the scores went through (message #1's pieces, the ids at the sorted
+        places) and put at the rows the pass worked out for the records
+        (`pos`).  Collective.  The source of eval['dt_pointers'] in a multi-GPU
         run (T/eval.py:575-584)."""
         dp, ws = self.dp, self.ws
-        send = torch.zeros_like(self.send)
-        if dp.n_dt:
-            slot = ws.dst[:dp.n_dt].long()
-            send[slot, 0] = dp.t["dt_score"].view(torch.int64)
-            send[slot, REC_HEAD] = ids
-        recv = torch.zeros_like(self.recv)
-        self._exchange(send, recv)
-        tab = torch.zeros_like(self.matched)
-        ign = torch.zeros_like(self.ignored)
-        self.be.merge_runs(self.n_recv, self.world, self.Kb, self.k0, recv, self.W,
-                           dp.n_words, self.src_base, self.run_off, self.cat_base,
-                           tab, ign, self.rank, self._own(send))
         n = self.n_recv
-        return (tab[:n, 0].cpu().numpy(), self.matched[:n].cpu().numpy().view(np.uint64),
-                self.ignored[:n].cpu().numpy().view(np.uint64),
+        send = torch.zeros_like(self.send_score)
+        if dp.n_dt:
+            send[ws.dst[:dp.n_dt].long()] = ids
+        if self.world == 1:
+            out = send[:n]
+        else:
+            recv = torch.zeros_like(self.recv_score)
+            self._exchange_scores(send, recv).wait()
+            below = int(sum(self.recv_counts[:self.rank]))
+            own = send[self.own_at:self.own_at + self.recv_counts[self.rank]]
+            rec = torch.cat([recv[:below], own, recv[below:self.n_wire]])
+            out = torch.zeros(max(n, 1), dtype=torch.int64, device=send.device)
+            out[self.pos[:n].long()] = rec[:n]
+        return (out[:n].cpu().numpy(),
+                self.matched[:n].contiguous().cpu().numpy().view(np.uint64),
+                self.ignored[:n].contiguous().cpu().numpy().view(np.uint64),
                 self.cat_base.cpu().numpy())
+
+
+class _null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
 
 
 def any_rank(flag, device, group=None):

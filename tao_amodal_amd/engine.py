@@ -254,6 +254,11 @@ class DeviceProblem:
             runs[:, 2] = flat.cell_gt_off[c0]
             runs[:, 3] = flat.cell_gt_off[c1] - flat.cell_gt_off[c0]
         self.t["groups"] = torch.from_numpy(runs).to(self.device)
+        # (host copies: the multi-GPU plan cuts the launch plan into phases)
+        self.groups_host = runs[:len(groups)]
+        self.singles_host = np.asarray(singles, dtype=np.int32)
+        self.singles_first_dt = np.asarray(flat.cell_dt_off)[self.singles_host] \
+            if len(singles) else np.zeros(0, np.int32)
         self.n_tasks = 0
         self.single_frame = False
         self.exact_terms = False
@@ -783,10 +788,20 @@ def set_order_iou(flat, pairs, mode=0):
     return out
 
 
-def stage_match(dp, ws, scatter=True):
+def stage_match(dp, ws, scatter=True, groups=None, singles=None):
+    """`groups` / `singles`: (device table, first, count) -- a slice of a
+    launch plan instead of the problem's whole plan (the phases of the
+    multi-GPU exchange, dist.ShardedEval)."""
     if dp.n_dt == 0:        # nothing was detected: every cell is GT-only
         return
     lib, t, s = _lib.load(), dp.t, _stream()
+    g_ptr, n_g = _ptr(t["groups"]), dp.n_groups
+    s_ptr, n_s = _ptr(t["singles"]), dp.n_singles
+    if groups is not None:
+        g_ptr, n_g = groups[0].data_ptr() + 16 * groups[1], groups[2]
+        s_ptr, n_s = singles[0].data_ptr() + 4 * singles[1], singles[2]
+        if n_g == 0 and n_s == 0:
+            return
     fused = dp.kind == "lvis" and not dp.mask_iou
     _lib.check(lib.taoamd_match(
         dp.n_cells, _ptr(t["cell_dt_off"]), _ptr(t["cell_gt_off"]),
@@ -798,8 +813,8 @@ def stage_match(dp, ws, scatter=True):
         _ptr(t["gt_flags"]), _ptr(t["dt_flags"]),
         _ptr(ws.dst) if scatter else None, 0, _ptr(ws.matched),
         _ptr(ws.ignored), _ptr(ws.match_gt), _ptr(ws.ious_out),
-        _ptr(t["dt_group"]), _ptr(t["dt_meta"]), _ptr(t["groups"]), dp.n_groups,
-        _ptr(t["singles"]), dp.n_singles, s), "taoamd_match")
+        _ptr(t["dt_group"]), _ptr(t["dt_meta"]), g_ptr, n_g,
+        s_ptr, n_s, s), "taoamd_match")
 
 
 def stage_accumulate_by_order(dp, ws):

@@ -115,10 +115,9 @@ def test_dense_only_entry_points_refuse_the_pair_layout():
     # taoamd_gather_rows(n, n_words, src_m, src_i, stride, order, dst_m, dst_i, stream)
     assert lib.taoamd_gather_rows(4, 1, base, base + 32, 1, order.ctypes.data,
                                   base + 256, base + 256 + 8, None) == 2
+    # taoamd_exchange_place(n_recv, world, n_words, rows, own_rows, own_rank, src_base,
+    #                       pos, out, stream): tables of 16-byte pairs only
     i64 = np.zeros(16, dtype=np.int64)
     p = i64.ctypes.data
-    # taoamd_exchange_merge(n_recv, world, block_cats, k0, records, width, n_words,
-    #                       src_base, run_off, cat_base, own_rank, own_records,
-    #                       matched, ignored, stream)
-    assert lib.taoamd_exchange_merge(4, 1, 1, 0, p, 3, 1, p, p, p, -1, None,
-                                     base, base + 8, None) == 2
+    assert lib.taoamd_exchange_place(4, 1, 1, base + 8, base + 8, 0, p, p, base + 256,
+                                     None) == 2

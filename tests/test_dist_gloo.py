@@ -18,8 +18,6 @@ import torch.multiprocessing as mp
 import exchange_ref
 import orclib
 
-from tao_amodal_amd.dist import REC_HEAD as H    # int64 columns ahead of a record's words
-
 N_THR, N_REC = 10, 101
 
 
@@ -27,6 +25,7 @@ class OracleBackend:
     def __init__(self, flats):
         self.flats = flats          # id(dp) -> Flat
         self.dt_rng = {}            # id(dp) -> range masks of the detections
+        self._matched = {}          # id(dp) -> the pass's (matched, ignored) words
 
     def _f(self, dp):
         return self.flats[id(dp)]
@@ -41,6 +40,7 @@ class OracleBackend:
 
     def ranges(self, dp, ws):
         f = self._f(dp)
+        self._matched.pop(id(dp), None)          # a new pass
         g, d = orclib.ranges(f)
         ws.gt_rng[:len(g)] = torch.from_numpy(g.view(np.int32))
         # (the image-level workspace keeps no table: the HIP match derives
@@ -57,53 +57,73 @@ class OracleBackend:
             ws.iou[:len(iou)] = torch.from_numpy(iou)
             ws.pair_frames[0] = pairs
 
-    def match_into(self, dp, ws, dst, records, width):
-        f = self._f(dp)
-        g = ws.gt_rng[:dp.n_gt].numpy().view(np.uint32)
-        d = self.dt_rng[id(dp)]
-        iou = ws.iou[:dp.n_iou].numpy() if dp.kind == "tao" else None
-        m, i, _, _ = orclib.match(f, g, d, iou, detail=False)
-        nw = dp.n_words
-        slot = dst.numpy().astype(np.int64)
-        rec = records.numpy()
-        rec[slot, H:H + nw] = m.view(np.int64)
-        rec[slot, H + nw:H + 2 * nw] = i.view(np.int64)
+    def scores_at_place(self, dp, ws, out):
+        f, n = self._f(dp), dp.n_dt
+        dst = ws.dst[:n].numpy().astype(np.int64)
+        out.numpy()[dst] = np.ascontiguousarray(f.dt_score).view(np.int64)
+
+    def match_rows(self, dp, ws, phase=None):
+        """The oracle's match of the whole share (once per pass: ranges() starts
+        one); a phase writes the rows of ITS categories only -- what the rows
+        message of that phase then ships."""
+        f, n = self._f(dp), dp.n_dt
+        if n == 0:
+            return
+        if id(dp) not in self._matched:
+            g = ws.gt_rng[:dp.n_gt].numpy().view(np.uint32)
+            d = self.dt_rng[id(dp)]
+            iou = ws.iou[:dp.n_iou].numpy() if dp.kind == "tao" else None
+            m, i, _, _ = orclib.match(f, g, d, iou, detail=False)
+            self._matched[id(dp)] = (m.view(np.int64), i.view(np.int64))
+        m, i = self._matched[id(dp)]
+        sel = np.ones(n, bool)
+        if phase is not None:
+            # exactly the detections the product's launch plan of the phase
+            # covers: its slice of the run descriptors {first detection, count,
+            # ..} and of the single cells
+            sel[:] = False
+            g0, ng = phase["groups"]
+            for d0, cnt in phase["groups_dev"].numpy()[g0:g0 + ng, :2].tolist():
+                sel[d0:d0 + cnt] = True
+            s0, ns = phase["singles"]
+            for c in phase["singles_dev"].numpy()[s0:s0 + ns].tolist():
+                sel[f.cell_dt_off[c]:f.cell_dt_off[c + 1]] = True
+        dst = ws.dst[:n].numpy().astype(np.int64)[sel]
+        rows = ws.rows.numpy()
+        rows[dst, :, 0] = m[sel]
+        rows[dst, :, 1] = i[sel]
 
     def sort(self, n, cat, score, order, ws_buf, ws_bytes):
         c, s = cat[:n].numpy(), score[:n].numpy()
         order[:n] = torch.from_numpy(
             np.lexsort((np.arange(n), -(s + 0.0), c)).astype(np.int32))
 
-    def merge_runs(self, n_recv, world, block_cats, k0, records, width, n_words,
-                   src_base, run_off, cat_base, matched, ignored, own=-1,
-                   own_records=None):
-        sb = src_base.numpy()
-        ro, cb = run_off.numpy(), cat_base.numpy()
-        # the logical input: every source's rows, the rank's own taken where
-        # the match wrote them (they do not travel)
-        wire = records.numpy()
-        if own >= 0:
-            n_own = int(sb[own + 1] - sb[own])
-            rec = np.concatenate([wire[:sb[own]], own_records.numpy()[:n_own],
-                                  wire[sb[own]:]])
-        else:
-            rec = wire
+    @staticmethod
+    def _records(sb, own, wire, own_part):
+        """Records of all sources in rank order: the rank's own never travelled."""
+        wire = wire.numpy()
+        if own < 0:
+            return wire
+        n_own = int(sb[own + 1] - sb[own])
+        return np.concatenate([wire[:sb[own]], own_part.numpy()[:n_own], wire[sb[own]:]])
+
+    def positions(self, n_recv, world, block_cats, scores, own_scores, own, src_base,
+                  run_off, cat_base, pos):
+        sb, ro, cb = src_base.numpy(), run_off.numpy(), cat_base.numpy()
+        rec = self._records(sb, own, scores, own_scores)
+        out = pos.numpy()
         for kb in range(block_cats):
             idx = np.concatenate([np.arange(sb[s] + ro[s, kb], sb[s] + ro[s, kb + 1])
                                   for s in range(world)]).astype(np.int64)
             if len(idx) == 0:
                 continue
-            sc = np.ascontiguousarray(rec[idx, 0]).view(np.float64)
-            rows = idx[np.argsort(-(sc + 0.0), kind="stable")]
-            at = cb[kb] + np.arange(len(rows))
-            matched[at] = torch.from_numpy(rec[rows, H:H + n_words].copy())
-            ignored[at] = torch.from_numpy(rec[rows, H + n_words:H + 2 * n_words].copy())
+            sc = np.ascontiguousarray(rec[idx]).view(np.float64)
+            # stable -score sort of the sources' concatenation in rank order
+            out[idx[np.argsort(-(sc + 0.0), kind="stable")]] = cb[kb] + np.arange(len(idx))
 
-    def gather_rows(self, n, n_words, records, width, order, matched, ignored):
-        o = order[:n].numpy().astype(np.int64)
-        rec = records.numpy()
-        matched[:n] = torch.from_numpy(rec[o, H:H + n_words].copy())
-        ignored[:n] = torch.from_numpy(rec[o, H + n_words:H + 2 * n_words].copy())
+    def place(self, n_recv, world, n_words, rows, own_rows, own, src_base, pos, out):
+        rec = self._records(src_base.numpy(), own, rows, own_rows)
+        out.numpy()[pos.numpy()[:n_recv].astype(np.int64)] = rec[:n_recv]
 
     def accumulate_compact(self, n, n_cat, n_rng, cat_off, matched, ignored,
                            num_gt, k0, k1, val, rec, ws_buf, ws_bytes,
@@ -153,30 +173,52 @@ def _free_port():
     return port
 
 
-def _unit_parts(world):
+def _unit_parts(world, empty=None):
+    """One share per rank (ascending video ids); `empty`: that rank's share
+    holds ground truth and NO prediction."""
     from tao_amodal_amd.synth import synth
-    return [synth(seed=17 + r, V=3, F=12, C=23, dets_per_frame=30, n_present=4,
-                  video_id_base=r * 3) for r in range(world)]
+    parts = [synth(seed=17 + r, V=3, F=12, C=23, dets_per_frame=30, n_present=4,
+                   video_id_base=r * 3) for r in range(world)]
+    if empty is not None:
+        gt, dt = parts[empty]
+        parts[empty] = (gt, dt.take(np.zeros(0, dtype=np.int64)))
+    return parts
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, empty=None):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path[:0] = [root, os.path.join(root, "tests")]
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from tao_amodal_amd import dist as tdist, engine, flatten
-    gt, dt = _unit_parts(world)[rank]          # the rank's own videos
-    fl = flatten.flatten_lvis(gt, dt)
+    parts = _unit_parts(world, empty)
+    gt, dt = parts[rank]                       # the rank's own videos
+    fl = flatten.flatten_lvis(gt, dt, share=True)
     dt.track_id, _ = flatten.make_track_ids_unique(dt)
-    ft = flatten.flatten_tao(gt, dt)
+    # (the CPython-set visiting order of the track level is ranked inside the
+    # image ids of ALL ranks: dist.gather_visit_universe)
+    universe = np.concatenate([flatten.video_images(p[0]) for p in parts])
+    ft = flatten.flatten_tao(gt, dt, visit_universe=universe)
     res = {}
     for name, flat in (("lvis", fl), ("tao", ft)):
         dp = engine.DeviceProblem(flat, "cpu")
         ws = engine.Workspace(dp)
         be = OracleCategoryBackend({id(dp): flat})
         ev = tdist.ShardedEval(dp, ws, rank, world, be)
+        covered = np.zeros(dp.n_dt, int)
+        for ph in ev.phases:            # the phases' launch plans cover every detection once
+            if ph["groups"] is not None:
+                g0, ng = ph["groups"]
+                for d0, cnt in ph["groups_dev"].numpy()[g0:g0 + ng, :2].tolist():
+                    covered[d0:d0 + cnt] += 1
+                s0, ns = ph["singles"]
+                for c in ph["singles_dev"].numpy()[s0:s0 + ns].tolist():
+                    covered[flat.cell_dt_off[c]:flat.cell_dt_off[c + 1]] += 1
+        assert ev.phases[0]["groups"] is None or (covered == 1).all()
+        ws.rows.fill_(-1)  # (rows a phase ships before they are matched show up)
         ev.step()
+        ws.rows.fill_(-1)
         ev.step()          # a second step must reproduce the first
         # the last rank reports that its sweep gave up a look-back: check() is
         # collective, every rank sweeps again (chunked) and exchanges again
@@ -192,17 +234,21 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(600)
-@pytest.mark.parametrize("world", [2, 3])
-def test_unit_partition_ranks_reproduce_the_whole_problem(tmp_path, world):
-    """Every rank holds its own videos; the records meet at the category owners
-    (one all_to_all), are merged run by run and swept; every rank ends with the
-    tables a single process computes on the union."""
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world,
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world,empty", [(2, None), (3, None), (3, 1), (8, None), (8, 7)])
+def test_unit_partition_ranks_reproduce_the_whole_problem(tmp_path, world, empty):
+    """Every rank holds its own videos; the scores, then -- in category phases
+    -- the rows meet at the category owners, every record's row is worked out
+    from the scores alone, the rows are placed and swept; every rank ends with
+    the tables a single process computes on the union.  World sizes 2, 3 and 8
+    (8 owners of 3 categories each: one phase per category), also with a rank
+    whose share holds no prediction (it takes part in every collective with
+    zero records)."""
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), empty), nprocs=world,
              join=True)
     from tao_amodal_amd import flatten
     from tao_amodal_amd.columns import DTColumns, GTColumns
-    parts = _unit_parts(world)
+    parts = _unit_parts(world, empty)
     gt = GTColumns.concat([p[0] for p in parts])
     dt = DTColumns.concat([p[1] for p in parts])
     fl = flatten.flatten_lvis(gt, dt)
@@ -215,7 +261,7 @@ def test_unit_partition_ranks_reproduce_the_whole_problem(tmp_path, world):
                          weights_only=False)
         for name in ("lvis", "tao"):
             p, r, ng, n_pairs = got[name]
-            assert n_pairs > 0, "every rank must hold cells"
+            assert n_pairs > 0 or rank == empty, "every other rank must hold cells"
             assert np.array_equal(ng, want[name]["num_gt"])
             assert np.array_equal(p, want[name]["precision"]), (rank, name)
             assert np.array_equal(r, want[name]["recall"]), (rank, name)

@@ -9,7 +9,8 @@
                          video).  RCCL when the box has that many GPUs, else the
                          ranks share GPU 0 and talk over gloo
     Config 5 (stand-in)  10 000 videos x 1 frame x 1000 dets: the top-300 cut
-                         per image at scale (L/results.py:39-40, T/results.py:56-58)
+                         per image at scale (L/results.py:39-40, T/results.py:56-58),
+                         on one GPU and split by video over 8 ranks
 
 Every one is compared bit for bit with the C oracle (all host cores) on the
 WHOLE problem, plus idempotence of a second pass."""
@@ -159,6 +160,8 @@ def _worker(rank, world, port, mode, out):
         plan = tdist.ExchangePlan(engine.DeviceProblem(f_l, dev),
                                   engine.DeviceProblem(f_t, dev), rank, world, dev)
     plan.step()
+    for ev in (plan.lvis, plan.tao):       # (rows shipped before they are matched would show)
+        ev.ws.rows.fill_(-1)
     plan.step()
     torch.cuda.synchronize()
     if mode == "category":
@@ -223,6 +226,8 @@ def _full_worker(rank, world, port, src, out):
     plan = tdist.ExchangePlan(engine.DeviceProblem(f_l, dev), engine.DeviceProblem(f_t, dev),
                               rank, world, dev)
     plan.step()
+    for ev in (plan.lvis, plan.tao):       # (rows shipped before they are matched would show)
+        ev.ws.rows.fill_(-1)
     plan.step()
     torch.cuda.synchronize()
     plan.lvis.check()
@@ -239,14 +244,12 @@ def _full_worker(rank, world, port, src, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(3000)
-def test_config4_at_full_validation_scale_split_by_video(tmp_path):
-    """2000 videos x 300 frames x 50 detections, 1203 categories (the Config 3
-    stand-in) cut into contiguous blocks of videos over 2 and over 8 ranks;
-    every rank ends with the whole precision / recall tables, bit for bit the C
-    oracle's on the whole set."""
+def _split_by_video_vs_oracle(tmp_path, gt, dt, n_videos, worlds):
+    """ONE set cut into contiguous blocks of videos over `worlds` ranks (the
+    by-video plan); every rank must end with the whole precision / recall
+    tables, bit for bit the C oracle's on the whole set."""
     import pickle
-    gt, dt = synth(seed=20240807, V=V_FULL, F=300, C=1203, dets_per_frame=50)
+    import shutil
     dt.track_id, _ = fl.make_track_ids_unique(dt)       # (a statement about the whole list)
     f_l = fl.flatten_lvis(gt, dt)
     f_t = fl.flatten_tao(gt, dt)
@@ -259,15 +262,14 @@ def test_config4_at_full_validation_scale_split_by_video(tmp_path):
     del f_l, f_t
     want_digest = [int(np.ascontiguousarray(want[k][f]).view(np.int64).sum())
                    for k in ("lvis", "tao") for f in ("precision", "recall")]
-    import shutil
-    for world in (2, 8):
+    for world in worlds:
         out = str(tmp_path / ("out%d" % world))
         src = str(tmp_path / ("blocks%d" % world))
         os.makedirs(out)
         os.makedirs(src)
         for r in range(world):
-            keep = np.zeros(V_FULL, dtype=bool)
-            keep[V_FULL * r // world:V_FULL * (r + 1) // world] = True   # (synth: ids ascending)
+            keep = np.zeros(n_videos, dtype=bool)
+            keep[n_videos * r // world:n_videos * (r + 1) // world] = True   # (synth: ids ascending)
             mine = gt.vid_id[keep]
             part = (gt.select_videos(keep),
                     dt.take(np.flatnonzero((dt.video_id >= mine[0]) & (dt.video_id <= mine[-1]))))
@@ -287,3 +289,24 @@ def test_config4_at_full_validation_scale_split_by_video(tmp_path):
                 for k in ("lvis", "tao"):
                     assert np.array_equal(got[k][0], want[k]["precision"]), (world, k)
                     assert np.array_equal(got[k][1], want[k]["recall"]), (world, k)
+
+
+@pytest.mark.timeout(3000)
+def test_config4_at_full_validation_scale_split_by_video(tmp_path):
+    """2000 videos x 300 frames x 50 detections, 1203 categories (the Config 3
+    stand-in) cut into contiguous blocks of videos over 2 and over 8 ranks;
+    every rank ends with the whole precision / recall tables, bit for bit the C
+    oracle's on the whole set."""
+    gt, dt = synth(seed=20240807, V=V_FULL, F=300, C=1203, dets_per_frame=50)
+    _split_by_video_vs_oracle(tmp_path, gt, dt, V_FULL, (2, 8))
+
+
+@pytest.mark.timeout(3000)
+def test_config5_stress_set_split_over_8_ranks(tmp_path):
+    """BASELINE Config 5 as written ("10k synthetic videos, 1k dets/frame, 8
+    GPUs"): the stress stand-in (10 000 one-frame videos x 1000 detections, the
+    top-300 cut per image) cut by video over 8 ranks -- every rank cuts its own
+    images' lists (L/results.py:39-40 is per image), one-frame tracks take the
+    single-frame 3D IoU kernel, the exchange runs in its category phases."""
+    gt, dt = synth(seed=5, V=10000, F=1, C=1203, dets_per_frame=1000)
+    _split_by_video_vs_oracle(tmp_path, gt, dt, 10000, (8,))
