@@ -1,12 +1,9 @@
-"""MI355X-native TAO-Amodal evaluation hot path."""
-import os as _os
+"""MI355X-native TAO-Amodal evaluation hot path.
 
-# libgomp's idle threads SPIN by default.  The host side of this package runs
-# several OpenMP teams side by side (the two native readers, the sorts of the
-# table build) on boxes whose CPU quota is far below their core count: spinning
-# teams starve each other -- one 3 M-key sort took 0.64 s instead of 0.016 s
-# behind another team's region.  Read by libgomp when it is loaded, so this must
-# run before the first library that brings it in (ours, or torch).
-_os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+(libgomp's idle threads SPIN by default, and the host side of this package
+runs several OpenMP teams side by side on boxes whose CPU quota is far below
+their core count: the ENTRY POINTS -- tools/eval_on_tao_amodal.py, bench.py --
+set OMP_WAIT_POLICY=PASSIVE before the first library that loads libgomp;
+importing the package does not touch the environment.)"""
 
 __all__ = ["columns", "synth"]

@@ -449,7 +449,12 @@ class DTColumns:
                 for k in range(len(self.image_id))]
 
     def take(self, idx):
-        return DTColumns(**{f: getattr(self, f)[idx] for f in self.FIELDS})
+        out = DTColumns(**{f: getattr(self, f)[idx] for f in self.FIELDS})
+        # (per-row extras ride along: a share's place in the file's list,
+        # evaluation/_dist.shard_inputs)
+        if getattr(self, "file_pos", None) is not None:
+            out.file_pos = np.asarray(self.file_pos)[idx]
+        return out
 
     def write_json(self, path):
         """The prediction list written by the native writer (csrc/

@@ -263,7 +263,7 @@ class DistRun:
     per-cell views show the rank's own cells."""
 
     def __init__(self, flat, ctx, iou_3d_type="3d_iou", constants=None, dt=None,
-                 max_dets=300):
+                 max_dets=300, subset=False):
         """``dt`` / ``max_dets`` (image level): the share's prediction columns
         and the cut of LVISResults -- what the global ``id`` of a detection
         (its place in the WHOLE post-truncation list, L/results.py:73-84) is
@@ -271,6 +271,13 @@ class DistRun:
         import torch
         self.dt, self.max_dets = dt, max_dets
         self._pointers = None
+        if subset and ctx.pointers and flat.kind == "lvis" and not ctx.whole:
+            # the reference numbers the detections over the WHOLE list before
+            # any subset is taken (L/results.py:75-84, eval.py:59-105); a rank
+            # only sees the subset's part of its share (alike on every rank)
+            raise NotImplementedError(
+                "eval['dt_pointers'] of a multi-GPU run with params.img_ids "
+                "restricted to a subset")
         from .. import dist as tdist, engine
         from ._core import applied, timed
         self.engine, self.torch = engine, torch

@@ -132,7 +132,8 @@ class LVISEval:
                 raise NotImplementedError("multi-GPU runs evaluate iou_type='bbox'")
             from .._dist import DistRun
             self._run = DistRun(flat, self.dist, constants=constants, dt=dt_cols,
-                                max_dets=self.lvis_dt.max_dets)
+                                max_dets=self.lvis_dt.max_dets,
+                                subset=gt_cols is not self.lvis_gt.columns)
         else:
             self._run = GpuRun(flat, self.device, constants=constants)
         self._run.evaluate()

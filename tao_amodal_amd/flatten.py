@@ -67,19 +67,23 @@ def _host_lib():
         _HOST_LIB = False
         if os.path.exists(so):
             lib = C.CDLL(so)
-            if hasattr(lib, "taoamd_host_sort_key_score"):
-                lib.taoamd_host_sort_key_score.argtypes = [
-                    C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
-                lib.taoamd_host_lookup.argtypes = [
-                    C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
-                lib.taoamd_host_take.argtypes = [
-                    C.c_int32, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
-                lib.taoamd_host_seq_mean.argtypes = [
-                    C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
-                lib.taoamd_host_pyset_self_and.argtypes = [
-                    C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
-                lib.taoamd_host_track_clash.argtypes = [
-                    C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+            vp, i64 = C.c_void_p, C.c_int64
+            sigs = {
+                "taoamd_host_sort_key_score": [i64, vp, vp, vp],
+                "taoamd_host_lookup": [i64, vp, i64, vp, vp],
+                "taoamd_host_take": [C.c_int32, i64, vp, i64, vp, vp],
+                "taoamd_host_seq_mean": [i64, vp, vp, vp],
+                "taoamd_host_pyset_self_and": [i64, vp, vp, vp],
+                "taoamd_host_track_clash": [i64, vp, vp, vp],
+                "taoamd_host_threads": [],
+                "taoamd_host_thread_cap": [C.c_int32],
+            }
+            # (a library of another build -- a symbol missing -- is not used at
+            # all: the numpy statements of these helpers are the fallback)
+            if all(hasattr(lib, name) for name in sigs):
+                for name, args in sigs.items():
+                    getattr(lib, name).argtypes = args
+                    getattr(lib, name).restype = C.c_int
                 _HOST_LIB = lib
     return _HOST_LIB
 
