@@ -34,6 +34,60 @@ def _all_known(sorted_ids, values):
     return rc == 1
 
 
+def merge_categories_like_reference(results, merge):
+    """tao_amodal/results.py:47-50: merged categories mapped on EVERY dict of
+    the caller's list, before anything is checked."""
+    for x in results:
+        if x["category_id"] in merge:
+            x["category_id"] = merge[x["category_id"]]
+
+
+def rewrite_like_reference(results, columns, max_dets, tao=False):
+    """A LIST of prediction dicts handed to the constructor is the caller's:
+    the reference rewrites it in place (results.py:39-65; tao_amodal/
+    results.py:47-98) -- every box that survives the per-image cut gets
+    ``segmentation`` (the box's polygon, where absent), ``area`` and ``id`` (1 +
+    its place in the post-truncation list); the track level first maps merged
+    categories on EVERY dict and, where a track's kept boxes carry different
+    scores, replaces them by their np.mean -- and a caller may look at its
+    dicts afterwards.  The evaluation itself runs on the columns; this loop is
+    the reference's, on the dicts, for list inputs only.  ``tao``: the track
+    level's form (its category map is merge_categories_like_reference)."""
+    if not results:
+        return
+    keep = limit_dets_per_image(columns, max_dets) if max_dets >= 0 \
+        else np.arange(len(results))
+    kept = [results[k] for k in keep.tolist()]
+    if "bbox" in kept[0]:
+        for id_, ann in enumerate(kept):
+            x1, y1, w, h = ann["bbox"]
+            x2 = x1 + w
+            y2 = y1 + h
+            if "segmentation" not in ann:
+                ann["segmentation"] = [[x1, y1, x1, y2, x2, y2, x2, y1]]
+            ann["area"] = w * h
+            ann["id"] = id_ + 1
+    elif not tao and "segmentation" in kept[0]:
+        # results given as compressed RLE (results.py:54-60): area and, where
+        # absent, the tight box come from the mask
+        area = np.asarray(columns.area)[keep]
+        for id_, (k, ann) in enumerate(zip(keep.tolist(), kept)):
+            ann["area"] = np.uint32(area[id_])
+            if "bbox" not in ann:
+                ann["bbox"] = np.array(columns.bbox[k], dtype=np.float64)
+            ann["id"] = id_ + 1
+    if tao:
+        by_track = {}
+        for ann in kept:
+            by_track.setdefault(ann["track_id"], []).append(ann)
+        for anns in by_track.values():
+            scores = [float(x["score"]) for x in anns]
+            if len(set(scores)) > 1:
+                avg = np.mean(scores)
+                for x in anns:
+                    x["score"] = avg
+
+
 class LVISResults(LVIS):
     def __init__(self, lvis_gt, results, max_dets=300, _share=False):
         """``_share``: the columns are one rank's share of a multi-GPU run (it
@@ -71,6 +125,8 @@ class LVISResults(LVIS):
         self.max_dets = max_dets
         if len(self.columns_dt) == 0 and not _share:
             raise IndexError("list index out of range")  # results.py:42
+        if self._raw is not None and self._raw_path is None:
+            rewrite_like_reference(self._raw, self.columns_dt, max_dets)
         assert _all_known(np.unique(self.gt.columns.img_id), self.columns_dt.image_id), \
             "Results do not correspond to current LVIS set."
         self._index = None

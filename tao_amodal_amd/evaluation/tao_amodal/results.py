@@ -26,6 +26,7 @@ class TaoResults(Tao):
             raise TypeError("Unsupported type {} of tao_gt.".format(type(tao_gt)))
         self.logger = logging.getLogger("tao.results")
         self.logger.info("Loading and preparing results.")
+        raw = None
         if isinstance(results, DTColumns):
             self.columns_dt = results
         elif isinstance(results, str):
@@ -35,6 +36,11 @@ class TaoResults(Tao):
                 "Assuming user provided the results in correct format.")
             assert isinstance(results, list), "results is not a list."
             self.columns_dt = DTColumns.from_json(results)
+            raw = results
+            # (the caller's dicts: results.py:47-50, before any check)
+            from ..lvis_amodal.results import merge_categories_like_reference
+            merge_categories_like_reference(
+                raw, {int(a): int(b) for a, b in self.gt.columns.cat_merged.tolist()})
         self.max_dets = max_dets
         if len(self.columns_dt) == 0 and not _share:
             raise IndexError("list index out of range")  # results.py:61
@@ -66,6 +72,12 @@ class TaoResults(Tao):
                 "At least one track had annotations with different scores; "
                 "using average of individual annotation scores as track "
                 "scores.")
+        if raw is not None:
+            # the caller's dicts, rewritten as the reference rewrites them
+            # (results.py:47-98) -- after the checks above, which raise at the
+            # reference's places before it would have touched the kept boxes
+            from ..lvis_amodal.results import rewrite_like_reference
+            rewrite_like_reference(raw, self.columns_dt, max_dets, tao=True)
 
     def _flatten(self, max_dets):
         """Cell tables on the device; inputs the reference rejects go through

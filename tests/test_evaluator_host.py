@@ -231,3 +231,27 @@ def test_restrict_to_params_is_the_references_prepare_filter():
         restrict_to_params(gt, dt, "image", imgs, [10 ** 9], True)
     with pytest.raises(NotImplementedError):
         restrict_to_params(gt, dt, "image", imgs, cats[:1], False)
+
+
+@pytest.mark.parametrize("name", ["f1", "f2", "f4"])
+def test_list_inputs_are_rewritten_in_place_like_the_reference(name):
+    """A list of prediction dicts is the caller's object and the reference
+    rewrites it (L/results.py:39-65: segmentation, area, id of the boxes that
+    survive the per-image cut; T/results.py:47-98: merged categories on every
+    dict, then the same, then averaged scores where a track's kept boxes
+    differ).  Goldens: the lists after the reference's constructors ran
+    (tests/golden/make_golden_mutation.py; F2 holds > 300 boxes in an image,
+    merged categories and tracks with non-uniform scores)."""
+    import gzip
+    import json
+    want = json.load(gzip.open(path(name, "mutated.json.gz"), "rt"))
+    _, predj = load_inputs(name)
+    LVISResults(LVIS(path(name, "gt.json")), predj)
+    assert json.loads(json.dumps(predj)) == want["lvis"]
+    _, predj = load_inputs(name)
+    # (what the CLI does first: tools/eval_on_tao_amodal.py:44-66 on the list)
+    new_ids, _ = flatten.make_track_ids_unique(DTColumns.from_json(predj))
+    for p, t in zip(predj, new_ids.tolist()):
+        p["track_id"] = t
+    TaoResults(Tao(path(name, "gt.json")), predj)
+    assert json.loads(json.dumps(predj, default=float)) == want["tao"]
