@@ -754,3 +754,77 @@ def test_cells_whose_detections_overlap_two_ground_truths(detail):
     assert at == len(want["iou"]) and multi > 100
     got = _engine().evaluate_flat(f, detail=detail)
     _compare_with_oracle(f, got, detail=detail)
+
+
+@pytest.mark.parametrize("world,own", [(1, 0), (3, -1), (3, 1), (8, 7), (8, 0)])
+def test_exchange_positions_and_place_vs_numpy(world, own):
+    """taoamd_exchange_scores / _positions / _place (the by-video plan's owner
+    side, round 5) against the numpy statement the gloo tests run with
+    (tests/test_dist_gloo.py: stable -score sort of the sources' concatenation
+    in rank order, L/eval.py:353-361): runs of equal scores across and inside
+    sources, empty runs, an empty source, the rank's own rows read outside the
+    wire buffer (own >= 0) or every source on the wire (own < 0), one and four
+    combo words."""
+    import torch
+    from test_dist_gloo import OracleBackend
+    from tao_amodal_amd import dist as tdist
+    be, ref = tdist.HipBackend(), OracleBackend({})
+    rng = np.random.default_rng(7 * world + own + 2)
+    Kb = 9
+    for nw in (1, 4):
+        rc = rng.integers(0, 40, (world, Kb))
+        rc[:, 3] = 0                                  # a category nobody sends
+        if world > 2:
+            rc[1] = 0                                 # a source without records
+        src_base = np.zeros(world + 1, np.int64)
+        np.cumsum(rc.sum(1), out=src_base[1:])
+        run_off = np.zeros((world, Kb + 1), np.int64)
+        np.cumsum(rc, axis=1, out=run_off[:, 1:])
+        cat_base = np.zeros(Kb + 1, np.int64)
+        np.cumsum(rc.sum(0), out=cat_base[1:])
+        n = int(rc.sum())
+        # scores: few distinct values (ties across and inside sources), each
+        # source's run descending
+        scores = np.zeros(n)
+        for s in range(world):
+            for kb in range(Kb):
+                a, b = src_base[s] + run_off[s, kb], src_base[s] + run_off[s, kb + 1]
+                scores[a:b] = -np.sort(-rng.integers(0, 6, b - a) / 5.0)
+        rows = rng.integers(-2 ** 62, 2 ** 62, (n, nw, 2))
+        own_lo, own_hi = (int(src_base[own]), int(src_base[own + 1])) if own >= 0 else (0, 0)
+        keep = np.ones(n, bool)
+        keep[own_lo:own_hi] = False
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a))  # noqa: E731
+        h_wire_s, h_own_s = t(scores[keep].view(np.int64)), t(scores[own_lo:own_hi].view(np.int64))
+        h_wire_r, h_own_r = t(rows[keep]), t(rows[own_lo:own_hi])
+        pad = lambda x, shape: x if x.numel() else torch.zeros(shape, dtype=torch.int64)  # noqa: E731
+        args_h = (t(src_base), t(run_off), t(cat_base))
+        want_pos = torch.zeros(max(n, 1), dtype=torch.int32)
+        ref.positions(n, world, Kb, h_wire_s, h_own_s, own, *args_h, want_pos)
+        want_rows = torch.zeros((max(n, 1), nw, 2), dtype=torch.int64)
+        ref.place(n, world, nw, h_wire_r, h_own_r, own, args_h[0], want_pos, want_rows)
+        assert sorted(want_pos[:n].tolist()) == list(range(n))
+        dev = "cuda:0"
+        d = [x.to(dev) for x in args_h]
+        got_pos = torch.full((max(n, 1),), -1, dtype=torch.int32, device=dev)
+        be.positions(n, world, Kb, pad(h_wire_s, (1,)).to(dev), pad(h_own_s, (1,)).to(dev), own,
+                     d[0], d[1], d[2], got_pos)
+        got_rows = torch.zeros((max(n, 1), nw, 2), dtype=torch.int64, device=dev)
+        be.place(n, world, nw, pad(h_wire_r, (1, nw, 2)).to(dev), pad(h_own_r, (1, nw, 2)).to(dev),
+                 own, d[0], got_pos, got_rows)
+        torch.cuda.synchronize()
+        assert np.array_equal(got_pos.cpu().numpy()[:n], want_pos.numpy()[:n]), (world, own, nw)
+        assert np.array_equal(got_rows.cpu().numpy()[:n], want_rows.numpy()[:n]), (world, own, nw)
+    # the scores at their sorted place
+    n = 1000
+    dst = torch.from_numpy(rng.permutation(n).astype(np.int32)).to("cuda:0")
+    sc = torch.from_numpy(rng.random(n)).to("cuda:0")
+    out = torch.zeros(n, dtype=torch.int64, device="cuda:0")
+    from tao_amodal_amd import _lib
+    _lib.check(_lib.load().taoamd_exchange_scores(
+        n, dst.data_ptr(), sc.data_ptr(), out.data_ptr(),
+        torch.cuda.current_stream().cuda_stream), "taoamd_exchange_scores")
+    torch.cuda.synchronize()
+    want = np.zeros(n, np.int64)
+    want[dst.cpu().numpy()] = sc.cpu().numpy().view(np.int64)
+    assert np.array_equal(out.cpu().numpy(), want)
