@@ -241,6 +241,20 @@ def test_sharded_path_on_one_gpu_equals_plain_path():
                 ng = want["num_gt"][k0:k1] > 0
                 ref = want["precision"][:, :, k0:k1].transpose(2, 3, 0, 1)
                 assert np.array_equal(val[ng], ref[ng])
+        # the by-video plan's exchange primitive on RCCL (its list form and the
+        # asynchronous handle only run with more than one rank otherwise):
+        # pieces are views into larger buffers, an empty piece travels too
+        src = torch.arange(40, dtype=torch.int64, device="cuda:0").reshape(10, 2, 2)
+        dst = torch.zeros_like(src)
+        work = tdist.exchange_pieces([dst[3:9]], [src[1:7]])
+        side = torch.cuda.Stream("cuda:0")
+        with torch.cuda.stream(side):
+            work.wait()                       # the side stream waits, the host does not
+            got = dst.clone()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        assert torch.equal(got[3:9], src[1:7]) and int(got[:3].abs().sum()) == 0
+        tdist.exchange_pieces([dst[:0]], [src[:0]]).wait()
         plan = tdist.CategoryPlan(engine.DeviceProblem(fl_, "cuda:0"),
                                   engine.DeviceProblem(ft_, "cuda:0"), 0, 1,
                                   torch.device("cuda", 0))
