@@ -301,9 +301,8 @@ class ShardedEval:
         self.phases = []
         for j in range(B):
             e0, e1 = edges[j], edges[j + 1]
+            # (the phase's categories: sub-block j = [e0, e1) of every owner's block)
             self.phases.append({
-                # the phase's categories: sub-block j of every owner's block
-                "cat_ranges": [(min(r * Kb + e0, K), min(r * Kb + e1, K)) for r in range(world)],
                 "send": [(int(cs[r * Kb + e0]), int(cs[r * Kb + e1])) if r != rank else (0, 0)
                          for r in range(world)],
                 "recv": [(int(wire_base[s_] + run_off[s_, e0]), int(wire_base[s_] + run_off[s_, e1]))
