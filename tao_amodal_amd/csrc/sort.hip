@@ -1293,6 +1293,35 @@ __device__ __forceinline__ void ss_split_chunk4(const SsArgs &a, const SsChunk &
     // mostly were: 32 of them)
     int32_t rel[R];
     double sc[R];
+#ifndef SS_SAMPLE_SCATTERED
+    // Round 5: the samples are taken as WHOLE 64-byte lines -- eight consecutive
+    // scores at a jittered, line-aligned place of every window of 8 * stride
+    // elements, eight neighbouring lanes a line -- instead of one score out of
+    // every `stride` (~11): at one score per 88 bytes every 64-byte sector of
+    // the score array was fetched to look at an eighth of it (VERDICT r4 #6:
+    // 153 MB for ~1 MB of samples at 21 M rows).  Which elements are sampled
+    // only steers how evenly the buckets come out, never the order: the
+    // elements of a line are neighbours in the input order (one or two cells,
+    // a cell's scores independent draws), and a bucket that does come out too
+    // large takes the 16-register network or the counting path as before.
+    const int32_t win = 8 * stride;                   // elements per sampled line
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int j = (r * 4 + wave) * WAVE + lane;   // four interleaved quarters of 64-sample blocks
+        const int g = j >> 3, e = j & 7;
+        // one of the lines that lie INSIDE window g (aligned in memory; a
+        // window too short to hold one: its first eight elements), so no two
+        // windows ever sample the same element
+        const int32_t w0 = c.begin + g * win;
+        const int32_t a0 = (w0 + 7) & ~7;
+        const int32_t lines = (w0 + win - a0) >> 3;
+        const int32_t at = lines > 0
+            ? a0 + 8 * (int32_t)(ss_mix((uint32_t)g * 0x9e3779b9u ^ (uint32_t)c.begin) %
+                                 (uint32_t)lines) - c.begin
+            : g * win;
+        rel[r] = j < m ? at + e : 0;
+    }
+#else
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const int j = (lane * R + r) * 4 + wave;  // my quarter: samples j = wave (mod 4)
@@ -1300,11 +1329,16 @@ __device__ __forceinline__ void ss_split_chunk4(const SsArgs &a, const SsChunk &
                                                        (uint32_t)c.begin) % (uint32_t)stride)
                        : 0;
     }
+#endif
 #pragma unroll
     for (int r = 0; r < R; r++) sc[r] = a.score[c.begin + rel[r]];
 #pragma unroll
     for (int r = 0; r < R; r++) {
+#ifndef SS_SAMPLE_SCATTERED
+        const int j = (r * 4 + wave) * WAVE + lane;
+#else
         const int j = (lane * R + r) * 4 + wave;
+#endif
         p[r] = j < m ? ss_pack(desc_key(sc[r]), 0, 64 - SS_SPLIT_KEY_BITS, rel[r])
                      : __longlong_as_double((long long)SS_PAD);
     }
