@@ -226,7 +226,9 @@ def kernel_models(dp, ws):
              "seg_split_kernel": K * 256,
              "seg_kmerge_kernel": (n_dt + 255) // 256 * 256,
              "acc_finalize_kernel": ((K * A + 63) // 64) * ((T * R + 63) // 64) * 256,
-             "acc_sweep_kernel": ((n_dt // 2048) + K + 1) * nw * 256,
+             # (eight runs cut at category boundaries: accumulate.hip, XCD-aware order)
+             "acc_sweep_kernel": 8 * (((n_dt // 2048) + K + 1) // 8
+                                      + int(seg.max() if len(seg) else 0) // 2048 + 3) * nw * 256,
              "acc_raise_kernel": (K * A * T + 3) // 4 * 256,
              "acc_cj_kernel": (K * A * R + 255) // 256 * 256,
              "ss_scatter_kernel": nt_ * 256,
