@@ -42,6 +42,18 @@ def test_fused_chunked_and_onepass_sweeps_agree(sweep_mode):
     tp.test_fused_and_chunked_sweeps_agree()
 
 
+@pytest.mark.parametrize("name", ["f1", "f2", "f4"])
+def test_cli_text_and_class_state_under_every_sweep_mode(sweep_mode, name, tmp_path):
+    """The drop-in CLI (both levels on two threads) and the class API's state
+    -- eval_imgs / ious views, dt_pointers -- with the sweep forced onto each
+    path: the reference's text byte for byte, its tensors and pointers."""
+    import test_gpu_cli as tc
+    tc.test_cli_text_is_identical_to_the_reference(name, tmp_path)
+    if name in ("f1", "f2"):
+        tc.test_class_api_state_matches_reference(name)
+        tc.test_tao_class_api_state_matches_reference(name)
+
+
 @pytest.mark.parametrize("case", ["many", "unsorted_rec"])
 @pytest.mark.parametrize("name", ["f1", "f4"])
 def test_edited_constants_under_every_sweep_mode(sweep_mode, name, case):
