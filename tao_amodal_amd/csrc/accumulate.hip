@@ -1068,9 +1068,13 @@ __global__ __launch_bounds__(FW * WAVE) void acc_fused_kernel(AccArgs a, RecThr 
 // ===========================================================================
 #define SC_SPIN_LIMIT (1 << 18)     // a fraction of a second of polling
 #define SWEEP_NB 8                   // blocks of 64 rows per wavefront of the one-pass sweep
+#ifndef SWEEP_SW
 #define SWEEP_SW 4                   // wavefronts (chunks) per super-chunk: 16 and 8 were
                                      // measured slower (big workgroups hold their CU's wave
-                                     // slots until the slowest wavefront is done)
+                                     // slots until the slowest wavefront is done); round 5,
+                                     // -DSWEEP_SW=2 / 3 / 6 at 21 M rows: 0.287 / 0.270 /
+                                     // 0.297 against 0.264 ms
+#endif
 #define SC_FLAG_AGG 1ull
 #define SC_FLAG_PRE 2ull
 __device__ __forceinline__ uint64_t sc_status(uint32_t gen, uint64_t flag, uint32_t v)
