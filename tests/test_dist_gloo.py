@@ -185,7 +185,7 @@ def _unit_parts(world, empty=None):
     return parts
 
 
-def _worker(rank, world, port, out, empty=None):
+def _worker(rank, world, port, out, empty=None, phases=None):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path[:0] = [root, os.path.join(root, "tests")]
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -205,7 +205,8 @@ def _worker(rank, world, port, out, empty=None):
         dp = engine.DeviceProblem(flat, "cpu")
         ws = engine.Workspace(dp)
         be = OracleCategoryBackend({id(dp): flat})
-        ev = tdist.ShardedEval(dp, ws, rank, world, be)
+        ev = tdist.ShardedEval(dp, ws, rank, world, be, phases=phases)
+        assert phases is None or len(ev.phases) == min(phases, ev.Kb)
         covered = np.zeros(dp.n_dt, int)
         for ph in ev.phases:            # the phases' launch plans cover every detection once
             if ph["groups"] is not None:
@@ -235,16 +236,19 @@ def _worker(rank, world, port, out, empty=None):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("world,empty", [(2, None), (3, None), (3, 1), (8, None), (8, 7)])
-def test_unit_partition_ranks_reproduce_the_whole_problem(tmp_path, world, empty):
+@pytest.mark.parametrize("world,empty,phases", [(2, None, None), (3, None, None), (3, 1, None),
+                                                (8, None, None), (8, 7, None),
+                                                (3, None, 1), (3, 2, 2), (2, None, 7)])
+def test_unit_partition_ranks_reproduce_the_whole_problem(tmp_path, world, empty, phases):
     """Every rank holds its own videos; the scores, then -- in category phases
     -- the rows meet at the category owners, every record's row is worked out
     from the scores alone, the rows are placed and swept; every rank ends with
     the tables a single process computes on the union.  World sizes 2, 3 and 8
     (8 owners of 3 categories each: one phase per category), also with a rank
     whose share holds no prediction (it takes part in every collective with
-    zero records)."""
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), empty), nprocs=world,
+    zero records), and with 1, 2 and 7 phases of the rows message instead of
+    the plan's four."""
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), empty, phases), nprocs=world,
              join=True)
     from tao_amodal_amd import flatten
     from tao_amodal_amd.columns import DTColumns, GTColumns
