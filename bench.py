@@ -563,6 +563,12 @@ def main():
 
     # ---- the timed region: reps x K steps between two barrier + synchronize
     _lib.kernel_timings()                  # forget anything recorded so far
+    # (look-backs of the one-pass sweep that give up anywhere in the region
+    # count into this word; the workspaces' own flags are per pass -- an
+    # unprepared pass, every pass of the multi-GPU plans, clears its own)
+    giveups = torch.zeros(1, dtype=torch.int32, device=dev)
+    _lib.check(_lib.load().taoamd_accumulate_giveup_counter(giveups.data_ptr()),
+               "taoamd_accumulate_giveup_counter")
     bracket()
     t0 = time.perf_counter()
     for i in range(timed_steps):
@@ -582,10 +588,18 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     in_step = _lib.kernel_timings() if rank == 0 else {}
-    # ---- the one-pass sweep's look-back: a wait that gave up anywhere in the
-    # timed region left its (sticky) flag in the workspace that was swept; the
-    # last pass is then swept again with the chunked kernels (what the CLI
-    # does) and the line says so
+    # ---- the one-pass sweep's look-back: waits that gave up anywhere in the
+    # timed region are counted in `giveups` (every pass, every plan); the flag
+    # of the workspace that was swept tells of the LAST pass (of all prepared
+    # passes on one GPU: nothing clears it there) -- that pass is then swept
+    # again with the chunked kernels (what the CLI does) and the line says so
+    _lib.check(_lib.load().taoamd_accumulate_giveup_counter(None),
+               "taoamd_accumulate_giveup_counter")
+    look_back_giveups = int(giveups.item())
+    if use_dist:
+        gsum = torch.tensor([look_back_giveups], dtype=torch.int64, device=dev)
+        dist.all_reduce(gsum)
+        look_back_giveups = int(gsum.item())
     if use_dist:
         plan.lvis.check()
         plan.tao.check()
@@ -880,6 +894,7 @@ def main():
                     "bit_exact": d["bit_exact_vs_oracle"],
                     "set_order_sample": g["set_order_sample"],
                     "look_back_timeouts": d.get("look_back_timeouts"),
+                    "look_back_giveups": d.get("look_back_giveups"),
                     "workload": d["config"]["workload"],
                     "leg_wall_s": round(time.perf_counter() - t0, 1)}
         except Exception as e:       # (the leg must not lose the bench line)
@@ -917,6 +932,7 @@ def main():
             "bit_exact_vs_oracle": verified,
             "decimal": decimal_leg,
             "look_back_timeouts": look_back_timeouts,
+            "look_back_giveups": look_back_giveups,
             "frame_order_guard": {
                 "exact_terms": bool(dpt.exact_terms),
                 "active": bool(dpt.guard_active()),

@@ -696,10 +696,20 @@ int taoamd_accumulate_compact_chunked(int64_t n_dt, int32_t n_cat, int32_t n_rng
  * taoamd_accumulate_prepared while this is the value it was built under.
  * _spin_limit: polls a look-back waits for one predecessor (0: the default,
  * 2^18; < 0: every look-back gives up at once -- fault injection for the
- * caller's recovery path). */
+ * caller's recovery path).
+ * _giveup_counter: a caller-owned DEVICE word (NULL: none) to which every
+ * look-back that gives up adds one, in every pass launched while it is
+ * registered, and which the library never clears -- the workspace's flag is per
+ * pass (an unprepared pass zeroes it when it starts), so a caller that runs
+ * many passes and synchronises once reads this word instead.
+ * max_segment, wherever an entry point of this family takes it: 0 = unknown;
+ * a positive value MUST be an upper bound of the longest category's rows -- it
+ * chooses the single-workgroup kernels and sizes the one-pass sweep's XCD-aware
+ * launch, and rows of a category longer than stated would not be swept. */
 int taoamd_accumulate_sweep_mode(int32_t mode);
 int taoamd_accumulate_plan_kind(int64_t n_dt, int32_t n_rng, int32_t max_segment);
 int taoamd_accumulate_spin_limit(int32_t polls);
+int taoamd_accumulate_giveup_counter(uint32_t *device_word);
 int taoamd_accumulate_prepare(int64_t n_dt, int32_t n_cat, int32_t n_rng,
                               const int32_t *cat_off, int32_t max_segment,
                               void *workspace, size_t workspace_bytes, void *stream);

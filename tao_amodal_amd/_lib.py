@@ -150,6 +150,7 @@ SIGNATURES = {
     "taoamd_accumulate_sweep_mode": (C.c_int, [_i32]),
     "taoamd_accumulate_plan_kind": (C.c_int, [_i64, _i32, _i32]),
     "taoamd_accumulate_spin_limit": (C.c_int, [_i32]),
+    "taoamd_accumulate_giveup_counter": (C.c_int, [_vp]),
     "taoamd_accumulate_prepare": (C.c_int, [_i64, _i32, _i32, _vp, _i32, _vp, _sz, _vp]),
     "taoamd_accumulate_prepared": (C.c_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _i32,
                                     _vp, _vp, _vp, _sz, _vp]),

@@ -92,6 +92,7 @@ struct AccArgs {
     uint64_t *sc_max;            // [SC][word][64] largest precision record of the SC
     uint8_t *sc_jhi;             // [SC][word][64] recall thresholds reached up to its end
     uint32_t *sc_error;          // set when a look-back gave up (never observed)
+    uint32_t *sc_giveups;        // caller's counter of such waits, never cleared here (may be null)
     int32_t *xcd_start;          // [9] first SC of each XCD's run (null: SC = workgroup number)
     int32_t sc_spin;             // polls a look-back waits for one predecessor; < 0: it gives
                                  // up at once (fault injection, taoamd_accumulate_spin_limit)
@@ -1226,7 +1227,10 @@ void acc_sweep_kernel(AccArgs a, RecThr rec)
                                        (uint32_t)(vf >> 34) == a.sc_gen && ft != 0 && ft == ff;
                     if (a.sc_spin >= 0 && __ballot(open && !ready) == 0) break;
                     if (spin >= a.sc_spin) {
-                        if (lane == 0) atomicOr(a.sc_error, 1u);
+                        if (lane == 0) {
+                            atomicOr(a.sc_error, 1u);
+                            if (a.sc_giveups) atomicAdd(a.sc_giveups, 1u);
+                        }
                         vt = vf = 0;
                         break;
                     }
@@ -1495,6 +1499,7 @@ enum { SWEEP_AUTO = -1, SWEEP_CHUNKED = 0, SWEEP_LOOKBACK = 1, SWEEP_TWOPASS = 2
 #define SWEEP_ONEPASS_MIN 6000000
 static std::atomic<int> g_sweep_set{SWEEP_AUTO};
 static std::atomic<int> g_sweep_spin{0};       // 0: SC_SPIN_LIMIT
+static std::atomic<uint32_t *> g_sweep_giveups{nullptr};   // taoamd_accumulate_giveup_counter
 static int sweep_mode(int64_t n_dt)
 {
     static const int env = [] {
@@ -1544,6 +1549,17 @@ extern "C" int taoamd_accumulate_plan_kind(int64_t n_dt, int32_t n_rng, int32_t 
 extern "C" int taoamd_accumulate_spin_limit(int32_t polls)
 {
     g_sweep_spin.store(polls, std::memory_order_relaxed);
+    return TAOAMD_OK;
+}
+
+// A caller-owned device word that counts the look-backs that gave up, over
+// every pass launched while it is registered (nullptr: none).  The workspace's
+// own flag is per pass -- an unprepared pass clears it when it starts --, so a
+// caller that runs many passes and synchronises once (bench.py's timed region
+// through the multi-GPU plans) reads this instead.
+extern "C" int taoamd_accumulate_giveup_counter(uint32_t *device_word)
+{
+    g_sweep_giveups.store(device_word, std::memory_order_relaxed);
     return TAOAMD_OK;
 }
 // (rows, whatever their width: at 2.9 M track-level rows of four words -- the
@@ -1623,6 +1639,7 @@ static int accumulate_compact(int64_t n_dt, int32_t n_cat, int32_t n_rng,
     a.inline_scans = 0;
     a.sc_rows = 0; a.sc_gen = 0; a.sc_stat = a.sc_max = nullptr; a.sc_jhi = nullptr;
     a.sc_error = nullptr;
+    a.sc_giveups = g_sweep_giveups.load(std::memory_order_relaxed);
     a.xcd_start = nullptr;
     {
         const int sp = g_sweep_spin.load(std::memory_order_relaxed);

@@ -389,6 +389,14 @@ class ShardedEval:
     def _pieces(self, buf, ranges):
         return [buf[a:b] for a, b in ranges]
 
+    def _own(self, buf):
+        """The rank's own block inside a send-side buffer (it never travels).
+        A rank without a detection in its own or any later owner's block has
+        `own_at` == the buffer's length: the empty slice there has a NULL
+        data pointer, which the C entries refuse whenever records arrive --
+        the buffer's base stands in (no element of an empty block is read)."""
+        return buf[self.own_at:] if self.own_at < buf.shape[0] else buf
+
     def _exchange_scores(self, send=None, recv=None):
         """Message #1 (also what carries the detections' ids for
         eval['dt_pointers']: owner_rows)."""
@@ -425,7 +433,7 @@ class ShardedEval:
             with (torch.cuda.stream(side) if side is not None else _null()):
                 scores_in.wait()
                 be.positions(self.n_recv, self.world, self.Kb, self.recv_score,
-                             self.send_score[self.own_at:], self.rank, self.src_base,
+                             self._own(self.send_score), self.rank, self.src_base,
                              self.run_off, self.cat_base, self.pos)
         be.track_iou(dp, ws)
         if cur is not None:
@@ -444,7 +452,7 @@ class ShardedEval:
             if self._side is not None:
                 torch.cuda.current_stream(dp.device).wait_stream(self._side)
             be.place(self.n_recv, self.world, dp.n_words, self.recv_rows,
-                     ws.rows[self.own_at:], self.rank, self.src_base, self.pos, self.rows)
+                     self._own(ws.rows), self.rank, self.src_base, self.pos, self.rows)
         self._sweep()
         self._publish()
 

@@ -1058,15 +1058,23 @@ def time_stages(dpl, wsl, dpt, wst, reps=10):
     return out
 
 
-def run_guarded(dp, ws, flat=None, upto=None, read_count=True):
+def run_guarded(dp, ws, flat=None, upto=None, read_count=True, head=True):
     """One evaluator pass; returns the number of pairs the frame-order guard
     recomputed (synchronises at the end to read it, unless read_count=False:
-    guarded_pairs() gives it later)."""
+    guarded_pairs() gives it later).  `head=False`: a further pass over the
+    SAME detections under other evaluation constants (blocks of thresholds /
+    ranges, evaluation/_core.py) -- the score order and the IoU matrix of the
+    pass before it stand (neither depends on a threshold or a range); the
+    range masks, the guard's near list (it is taken against the thresholds;
+    pairs it patched earlier keep the reference-order value) and the match
+    are what is repeated."""
     if _lib.TIMING:
         _lib.kernel_timing_label(dp.kind)
     stage_ranges(dp, ws)
-    stage_sort(dp, ws)
-    stage_track_iou_guarded(dp, ws)
+    if head:
+        stage_sort(dp, ws)
+        stage_track_iou(dp, ws)
+    stage_iou_guard(dp, ws)
     apply_iou_guard(dp, ws, flat)
     stage_match(dp, ws)
     if upto != "match":

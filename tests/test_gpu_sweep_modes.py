@@ -208,7 +208,18 @@ def test_the_flag_is_raised_and_the_chunked_entry_point_recovers(failing_look_ba
     lib = _lib.load()
     cat_off, m, i, ng = _rows(3, SIZES, 6)
     want_p, want_r = _oracle_tables(cat_off, m, i, ng)
-    got_p, got_r, flag = _device_tables(cat_off, m, i, ng, "paired", 0)
+    # a caller-owned counter of the waits that gave up: not cleared by a pass
+    counter = torch.zeros(1, dtype=torch.int32, device="cuda:0")
+    _lib.check(lib.taoamd_accumulate_giveup_counter(counter.data_ptr()), "giveup_counter")
+    try:
+        got_p, got_r, flag = _device_tables(cat_off, m, i, ng, "paired", 0)
+        first = int(counter.item())
+        _device_tables(cat_off, m, i, ng, "paired", 0)
+        assert first > 0 and int(counter.item()) == 2 * first
+    finally:
+        _lib.check(lib.taoamd_accumulate_giveup_counter(None), "giveup_counter")
+    _device_tables(cat_off, m, i, ng, "paired", 0)
+    assert int(counter.item()) == 2 * first          # (deregistered)
     assert flag == 1                      # every look-back gave up at once
     assert not np.array_equal(got_p, want_p)
     # the same rows through taoamd_accumulate_chunked
