@@ -32,6 +32,8 @@ def _stream():
 
 
 _RAW_TABLES = {}     # id(host table) -> (weakref, {device: tensor})
+import threading as _threading
+_RAW_TABLES_LOCK = _threading.Lock()
 
 
 def _to_device(v, device):
@@ -43,13 +45,15 @@ def _to_device(v, device):
         return torch.from_numpy(np.ascontiguousarray(v)).to(device)
     import weakref
     key = id(v.source)
-    ent = _RAW_TABLES.get(key)
-    if ent is None or ent[0]() is not v.source:
-        ent = (weakref.ref(v.source, lambda _r, k=key: _RAW_TABLES.pop(k, None)), {})
-        _RAW_TABLES[key] = ent
     dev = torch.device(device)
-    if dev not in ent[1]:
-        ent[1][dev] = torch.from_numpy(np.ascontiguousarray(v.source)).to(dev)
+    with _RAW_TABLES_LOCK:
+        ent = _RAW_TABLES.get(key)
+        if ent is None or ent[0]() is not v.source:
+            ent = (weakref.ref(v.source, lambda _r, k=key: _RAW_TABLES.pop(k, None)), {})
+            _RAW_TABLES[key] = ent
+        if dev not in ent[1]:
+            # (under the lock: the CLI builds both levels' problems side by side)
+            ent[1][dev] = torch.from_numpy(np.ascontiguousarray(v.source)).to(dev)
     if len(v.index) == 0:
         return torch.zeros((0,) + tuple(v.source.shape[1:]), dtype=ent[1][dev].dtype,
                            device=dev)
@@ -875,6 +879,10 @@ TRACK_AFTER_SORT = _os.environ.get("TAOAMD_TRACK_AFTER_SORT", "0") != "0"
 # scatter and the bucket sort instead and slows those down: 1.54 against 1.52
 # ms.  The step is bound by the sum of its kernels' work, not by the chain.
 TRACK_AFTER_SPLIT = _os.environ.get("TAOAMD_TRACK_AFTER_SPLIT", "0") != "0"
+# ... or when the image level's MATCH is done: the 3D IoU (bound by the LDS
+# array) then runs beside the sweep (bound by VALU issue, no LDS to speak of) --
+# the one pairing of the step's long kernels that does not share its bound
+TRACK_AFTER_MATCH = _os.environ.get("TAOAMD_TRACK_AFTER_MATCH", "0") != "0"
 
 
 class Overlap:
@@ -944,6 +952,12 @@ class Overlap:
                        "taoamd_stream_wait_event")
             _lib.check(lib.taoamd_stream_wait_event(s_aux_t.cuda_stream, self.split_done),
                        "taoamd_stream_wait_event")
+        elif TRACK_AFTER_MATCH:
+            ev = torch.cuda.Event()
+            run_forked(dpl, wsl, s_aux_l, sort_aside=SORT_ASIDE, match_done=ev)
+            # (the image level's sweep is launched by run_forked right behind the
+            # event: the track level's kernels queue beside it)
+            st.wait_event(ev)
         elif TRACK_AFTER_SORT:
             # A/B schedule: the track level starts when the image level's sort is
             # done -- its 3D IoU then runs beside the match and the sweep instead
@@ -991,7 +1005,7 @@ def _probed(name, fn, dp, ws):
 
 
 def run_forked(dp, ws, aux, head_only=False, sort_aside=False, no_match=False,
-               sort_done=None):
+               sort_done=None, match_done=None):
     """One evaluator pass on the current stream, its independent head stages
     on the stream `aux` (forked from and joined to the current stream):
     image level  ranges || sort -> match -> accumulate,
@@ -1032,6 +1046,8 @@ def run_forked(dp, ws, aux, head_only=False, sort_aside=False, no_match=False,
     if no_match:
         return
     _probed("match", stage_match, dp, ws)
+    if match_done is not None:
+        match_done.record(cur)
     if not head_only:
         stage_accumulate(dp, ws)
 

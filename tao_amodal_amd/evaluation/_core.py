@@ -21,6 +21,21 @@ def masked_mean(s):
     return np.mean(sel)
 
 
+def summaries(jobs):
+    """``[(key, thunk), ...] -> [(key, thunk()), ...]`` in the order given: the
+    masked means of a summary are independent of each other and numpy's
+    slicing, comparing and adding run without the interpreter lock, so they go
+    to a few threads (46 means over 58 + 194 MB of tables: 0.08 s one after the
+    other); the caller fills its result dict from the list, in the reference's
+    order of insertion (a key written twice keeps the LAST value:
+    lvis_amodal/eval.py:497-499)."""
+    if len(jobs) < 4:
+        return [(k, f()) for k, f in jobs]
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        return list(zip([k for k, _ in jobs], pool.map(lambda kf: kf[1](), jobs)))
+
+
 TIMING = {}   # wall-clock seconds per stage, filled when TAOAMD_TIMING is set
 
 

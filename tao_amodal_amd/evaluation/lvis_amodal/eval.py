@@ -13,7 +13,7 @@ import numpy as np
 from ... import flatten
 from .._core import (N_REC, N_THR, CellView, GpuRun, LazyIous, LazyPointers,
                      EvalConstants, restrict_to_params,
-                     masked_mean, now, timed)
+                     masked_mean, now, summaries, timed)
 from .lvis import LVIS
 from .results import LVISResults
 
@@ -242,27 +242,29 @@ class LVISEval:
         if not self.eval:
             raise RuntimeError("Please run accumulate() first.")
         max_dets = self.params.max_dets
-        R = self.results
+        S = self._summarize
+        jobs = []
         for suffix, rng in (("", "all"), ("-HO", "highly-occluded"),
                             ("-PO", "partially-occluded"),
                             ("-HP", "highly-and-partially-occluded"),
                             ("-HV", "highly-visible"), ("-OOF", "out-of-frame")):
-            R["AP" + suffix] = self._summarize("ap", visibility_rng=rng)
-            R["AP50" + suffix] = self._summarize("ap", iou_thr=0.50,
-                                                 visibility_rng=rng)
-            R["AP75" + suffix] = self._summarize("ap", iou_thr=0.75,
-                                                 visibility_rng=rng)
-        R["APr"] = self._summarize("ap", freq_group_idx=0)
-        R["APc"] = self._summarize("ap", freq_group_idx=1)
-        R["APf"] = self._summarize("ap", freq_group_idx=2)
-        R["AR@{}".format(max_dets)] = self._summarize("ar")
+            jobs.append(("AP" + suffix, lambda rng=rng: S("ap", visibility_rng=rng)))
+            jobs.append(("AP50" + suffix,
+                         lambda rng=rng: S("ap", iou_thr=0.50, visibility_rng=rng)))
+            jobs.append(("AP75" + suffix,
+                         lambda rng=rng: S("ap", iou_thr=0.75, visibility_rng=rng)))
+        for name, g in (("APr", 0), ("APc", 1), ("APf", 2)):
+            jobs.append((name, lambda g=g: S("ap", freq_group_idx=g)))
+        jobs.append(("AR@{}".format(max_dets), lambda: S("ar")))
         # the key keeps only the first letter of the label, so the three
         # "highly-*" ranges share "ARh@300" and the last one wins
         # (reference eval.py:497-499)
         for rng in ["highly-occluded", "partially-occluded", "highly-visible",
                     "highly-and-partially-occluded", "out-of-frame"]:
-            R["AR{}@{}".format(rng[0], max_dets)] = self._summarize(
-                "ar", visibility_rng=rng)
+            jobs.append(("AR{}@{}".format(rng[0], max_dets),
+                         lambda rng=rng: S("ar", visibility_rng=rng)))
+        for key, value in summaries(jobs):
+            self.results[key] = value
 
     def run(self):
         self.evaluate()

@@ -11,7 +11,7 @@ import numpy as np
 
 from .._core import (N_REC, N_THR, CellView, GpuRun, LazyIous, LazyPointers,
                      EvalConstants,
-                     masked_mean, now, timed)
+                     masked_mean, now, summaries, timed)
 from .results import TaoResults
 from .tao import Tao
 
@@ -219,23 +219,25 @@ class TaoEval:
         if not self.eval:
             raise RuntimeError("Please run accumulate() first.")
         max_dets = self.params.max_dets
-        R = self.results
+        S = self._summarize
         hp = "highly-and-partially-occluded"
-        R["AP"] = self._summarize("ap")
-        R["AP50"] = self._summarize("ap", iou_thr=0.50)
-        R["AP75"] = self._summarize("ap", iou_thr=0.75)
-        R["AP-HP"] = self._summarize("ap", area_rng=hp)
-        R["AP50-HP"] = self._summarize("ap", area_rng=hp, iou_thr=0.50)
-        R["AP75-HP"] = self._summarize("ap", area_rng=hp, iou_thr=0.75)
+        jobs = [("AP", lambda: S("ap")),
+                ("AP50", lambda: S("ap", iou_thr=0.50)),
+                ("AP75", lambda: S("ap", iou_thr=0.75)),
+                ("AP-HP", lambda: S("ap", area_rng=hp)),
+                ("AP50-HP", lambda: S("ap", area_rng=hp, iou_thr=0.50)),
+                ("AP75-HP", lambda: S("ap", area_rng=hp, iou_thr=0.75))]
         for rng in ["small", "medium", "large"]:
-            R[("AP", "area", rng, max_dets)] = self._summarize("ap", area_rng=rng)
+            jobs.append((("AP", "area", rng, max_dets), lambda rng=rng: S("ap", area_rng=rng)))
         for rng in ["short", "medium", "long"]:
-            R[("AP", "time", rng, max_dets)] = self._summarize("ap", time_rng=rng)
-        R["AR@{}".format(max_dets)] = self._summarize("ar")
+            jobs.append((("AP", "time", rng, max_dets), lambda rng=rng: S("ap", time_rng=rng)))
+        jobs.append(("AR@{}".format(max_dets), lambda: S("ar")))
         for rng in ["small", "medium", "large"]:
-            R[("AR", "area", rng, max_dets)] = self._summarize("ar", area_rng=rng)
+            jobs.append((("AR", "area", rng, max_dets), lambda rng=rng: S("ar", area_rng=rng)))
         for rng in ["short", "medium", "long"]:
-            R[("AR", "time", rng, max_dets)] = self._summarize("ar", time_rng=rng)
+            jobs.append((("AR", "time", rng, max_dets), lambda rng=rng: S("ar", time_rng=rng)))
+        for key, value in summaries(jobs):
+            self.results[key] = value
 
     def run(self, show_progress=False):
         self.evaluate(show_progress=show_progress)
