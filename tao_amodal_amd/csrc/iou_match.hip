@@ -388,11 +388,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const int32_t nG = __builtin_amdgcn_readfirstlane(run.w);
     if (nD == 0) return;
     const int n_combo = a.n_rng * N_THR;
-    const int combo = word * WAVE + lane;
-    const bool active = combo < n_combo;
-    const int r = active ? combo / N_THR : 0;
-    const int t = active ? combo - r * N_THR : 0;
-    const double thr0 = thr.v[t];
+    // (lane = combo -- its range, its threshold, the ignore mask of its range's
+    // GTs -- is the view of the SEQUENTIAL loop at the end, which few runs
+    // reach: worked out there, round 6; 90 of the kernel's 427 VALU
+    // instructions per wavefront were spent on it in every run)
 
     // ---- lane = detection of the run
     int32_t t_flags = 0, t_rng = 0, gb = 0, dloc = 0, Gc = 0;
@@ -463,11 +462,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         ghid = a.gt_flags[g0 + lane] & TAOAMD_GT_ID_HIDDEN;
         if (FUSED) s_gt[wave][lane] = reinterpret_cast<const double4 *>(a.gt_box)[g0 + lane];
     }
-    uint64_t IG = 0;
-    for (int q = 0; q < a.n_rng; q++) {
-        const uint64_t m = __ballot(lane < nG && ((grng >> q) & 1u));
-        IG = (q == r) ? m : IG;
-    }
     const uint64_t HID = __ballot(ghid);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -494,7 +488,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             if (FUSED) {
                 const double4 A = s_gt[wave][gb + k];
                 v = box_iou(B.x, B.y, B.z, B.w, A.x, A.y, A.z, A.w);
-                if (a.ious_out != nullptr && word == 0)
+                if (!FAST && a.ious_out != nullptr && word == 0)
                     a.ious_out[t_ioff + (int64_t)dloc * Gc + k] = v;
             } else {
                 v = vmem[k];
@@ -581,7 +575,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             if (cand == c) M = (prev >> 4) == cell_no ? (int)(prev & 15u) : 0;
         }
         const uint32_t m10 = qpass > M ? ((1u << qpass) - 1) & ~((1u << M) - 1) : 0u;
-        if (simple) {
+        if (FAST) {
+            // One combo word, at most six ranges (the image level): range q's ten
+            // bits are (igr_q ? m10 : 0) | (dig_q ? X : 0) at bit 10 q, i.e.
+            //     ignored = m10 * S(mygrng) | X * S(t_rng),  matched = m10 * S(all)
+            // with S(g) = sum of 2^(10 q) over the set bits q of g -- products of
+            // a ten-bit value with bits ten apart: no two partial products
+            // overlap, nothing carries.  S(g) itself is (g * C) & S(all) for
+            // C = sum of 2^(9 i): bit j of g lands at 9 i + j, which is a
+            // multiple of ten only for i = j.  A dozen VALU instructions where
+            // the loop over the ranges below, with its run-time 64-bit shifts,
+            // took 144 (round 6).
+            static_assert(N_THR == 10, "bit layout of the fast word");
+            constexpr uint64_t S_ALL = 1ull | 1ull << 10 | 1ull << 20 | 1ull << 30 |
+                                       1ull << 40 | 1ull << 50;
+            constexpr uint64_t C9 = 1ull | 1ull << 9 | 1ull << 18 | 1ull << 27 |
+                                    1ull << 36 | 1ull << 45;
+            const uint32_t all10 = (1u << N_THR) - 1;
+            const uint32_t rmask = 0xffffffffu >> (32 - a.n_rng);       // (uniform)
+            const uint64_t sall = ((uint64_t)rmask * C9) & S_ALL;
+            const uint64_t sg = ((uint64_t)(mygrng & rmask) * C9) & S_ALL;
+            const uint64_t sd = ((uint64_t)((uint32_t)t_rng & rmask) * C9) & S_ALL;
+            const uint32_t X = myghid ? all10 : (~m10 & all10);
+            if (simple) {
+                my_m = myghid ? 0ull : (uint64_t)m10 * sall;
+                my_i = (uint64_t)m10 * sg | (uint64_t)X * sd;
+            }
+        } else if (simple) {
             const uint32_t all10 = (1u << N_THR) - 1;
             const int r_lo = (word * WAVE) / N_THR;
             const int r_hi = min(a.n_rng - 1, (word * WAVE + WAVE - 1) / N_THR);
@@ -605,6 +625,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     // (first GT of the cell | GT count | flags) to the scalar unit; the masks
     // are narrowed to the cell's <= GRP_GCAP GTs so the inner loop is 32-bit.
     const uint64_t todo = __ballot(lane < nD && !simple);
+    if (todo == 0) {                  // (wave-uniform: the common case)
+        if (lane < nD) store_row(a, t_row, word, my_m, my_i);
+        return;
+    }
+    const int combo = word * WAVE + lane;
+    const bool active = combo < n_combo;
+    const int r = active ? combo / N_THR : 0;
+    const int t = active ? combo - r * N_THR : 0;
+    const double thr0 = thr.v[t];
+    uint64_t IG = 0;
+    for (int q = 0; q < a.n_rng; q++) {
+        const uint64_t m = __ballot(lane < nG && ((grng >> q) & 1u));
+        IG = (q == r) ? m : IG;
+    }
     const int32_t meta = (gb & 0xff) | ((Gc & 0xff) << 8) | ((t_flags & 0xff) << 16);
     uint64_t taken = 0;
     for (uint64_t rest = todo; rest != 0; rest &= rest - 1) {
@@ -915,7 +949,9 @@ extern "C" int taoamd_match(int64_t n_cells, const int32_t *cell_dt_off,
     hipStream_t s = (hipStream_t)stream;
     if (planned && n_groups > 0) {
         const unsigned gb = (unsigned)(((int64_t)n_groups * a.n_words + 3) / 4);
-        const bool fast = fused && a.dt_meta && a.dst && !a.dt_rng && !a.ious_out && !a.match_gt;
+        // (one combo word of at most six ranges: the fast kernel's word assembly)
+        const bool fast = fused && a.dt_meta && a.dst && !a.dt_rng && !a.ious_out && !a.match_gt &&
+                          a.n_words == 1 && n_rng <= 6;
         if (fast) TAO_TIMED("match_group_kernel", s, (match_group_kernel<true, true><<<gb, 256, 0, s>>>(a, match_thr())));
         else if (fused) TAO_TIMED("match_group_kernel", s, match_group_kernel<true><<<gb, 256, 0, s>>>(a, match_thr()));
         else TAO_TIMED("match_group_kernel", s, match_group_kernel<false><<<gb, 256, 0, s>>>(a, match_thr()));

@@ -1156,15 +1156,38 @@ __device__ __forceinline__ void ss_bitonic_packed(double (&p)[R], int lane)
                 const double o = ss_shfl_xor_f64(p[0], m);
                 p[0] = ((o < p[0]) == lower) ? o : p[0];
             }
-            // my register r meets the partner lane's register R - 1 - r
+            // my register r meets the partner lane's register R - 1 - r.
+            // Round 6: the lower lanes keep the minimum, the upper lanes the
+            // maximum -- v_min_f64 / v_max_f64 under the two halves of the exec
+            // mask, ONE instruction per register and lane (the words are
+            // distinct positive normal numbers: an operand comes back bit for
+            // bit) where compare + two selects were three; the kernel is bound
+            // by VALU issue (1424 instructions per bucket, 88 % of its cycles).
+            // Four registers at a time: the partners' words are live together.
+            if (R > 1) {
+                constexpr int G = R / 2 < 2 ? 1 : 2;
 #pragma unroll
-            for (int r = 0; r < R / 2; r++) {
-                const double o1 = ss_shfl_xor_f64(p[R - 1 - r], m);
-                const double o2 = ss_shfl_xor_f64(p[r], m);
-                // (take the partner's if it is the smaller one and I am the lower
-                // lane, or the larger one and I am the upper: compare + select)
-                p[r] = ((o1 < p[r]) == lower) ? o1 : p[r];
-                p[R - 1 - r] = ((o2 < p[R - 1 - r]) == lower) ? o2 : p[R - 1 - r];
+                for (int r0 = 0; r0 < R / 2; r0 += G) {
+                    double o1[G], o2[G];
+#pragma unroll
+                    for (int g = 0; g < G; g++) {
+                        o1[g] = ss_shfl_xor_f64(p[R - 1 - (r0 + g)], m);
+                        o2[g] = ss_shfl_xor_f64(p[r0 + g], m);
+                    }
+                    if (lower) {
+#pragma unroll
+                        for (int g = 0; g < G; g++) {
+                            p[r0 + g] = ss_fmin(p[r0 + g], o1[g]);
+                            p[R - 1 - (r0 + g)] = ss_fmin(p[R - 1 - (r0 + g)], o2[g]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int g = 0; g < G; g++) {
+                            p[r0 + g] = ss_fmax(p[r0 + g], o1[g]);
+                            p[R - 1 - (r0 + g)] = ss_fmax(p[R - 1 - (r0 + g)], o2[g]);
+                        }
+                    }
+                }
             }
         }
 #pragma unroll
@@ -1173,10 +1196,19 @@ __device__ __forceinline__ void ss_bitonic_packed(double (&p)[R], int lane)
             if (j >= R) {
                 const int m = j / R;
                 const bool lower = (lane & m) == 0;
+                constexpr int G = R < 4 ? R : 4;
 #pragma unroll
-                for (int r = 0; r < R; r++) {
-                    const double o = ss_shfl_xor_f64(p[r], m);
-                    p[r] = ((o < p[r]) == lower) ? o : p[r];
+                for (int r0 = 0; r0 < R; r0 += G) {
+                    double o[G];
+#pragma unroll
+                    for (int g = 0; g < G; g++) o[g] = ss_shfl_xor_f64(p[r0 + g], m);
+                    if (lower) {
+#pragma unroll
+                        for (int g = 0; g < G; g++) p[r0 + g] = ss_fmin(p[r0 + g], o[g]);
+                    } else {
+#pragma unroll
+                        for (int g = 0; g < G; g++) p[r0 + g] = ss_fmax(p[r0 + g], o[g]);
+                    }
                 }
             } else {
 #pragma unroll
