@@ -197,14 +197,21 @@ int taoamd_rle_iou(int64_t n_cells, const int32_t *cell_dt_off,
  * taoamd_track_iou is the plan-less form: one lane per track pair walks the two
  * CSR lists with a two-pointer merge (slow; any input).
  *
- * taoamd_track_iou_planned is the fast form.  It reads the tracks from the
- * PADDED frame table built by taoamd_track_pad and follows a launch plan built
- * by taoamd_track_iou_plan_host, one wavefront per task:
+ * taoamd_track_iou_planned is the fast form.  It follows a launch plan built
+ * by taoamd_track_iou_plan_host, one workgroup per task:
  *   tasks      int32[n_tasks][4] {first row, rows (<= 32), first pair, pairs (<= 64)}
  *   task_rows  int32  the tasks' tracks: t for detection track t, n_dt + t for
  *              GT track t (= the row of trk_meta)
  *   task_pairs int32  detection row | GT row << 8 (rows local to the task)
  *   task_out   int64  index of the pair's result in `iou`
+ * and reads the tracks' frames from the tasks' FRAME STREAM (taoamd_track_stream):
+ *   frames     double[n_pieces * 8][4]  pieces of 8 consecutive timeline
+ *              positions (one 256-byte piece = 8 boxes x, y, w, h; the far box
+ *              where the track has no frame), in the order the tasks consume
+ *              them: task by task, chunk by chunk of the task's timeline, the
+ *              rows whose span reaches into the chunk in row order; piece 0 is
+ *              eight far boxes
+ *   task_base  int32[n_tasks]  a task's first piece
  * A task stages its tracks' frames in LDS chunk by chunk of the timeline and
  * adds the per-frame terms in ascending timeline order, one lane per pair.
  * Both forms give bit-identical results. */
@@ -217,9 +224,10 @@ int taoamd_track_iou(int64_t n_cells, const int32_t *cell_dt_off,
                      int64_t *pair_frames, void *stream);
 int taoamd_track_iou_planned(int64_t n_tasks, const int32_t *tasks,
                              const int32_t *task_rows, const int32_t *task_pairs,
-                             const int64_t *task_out, const double *padded,
-                             const int32_t *trk_meta, int32_t mode, double *iou,
-                             int64_t *pair_frames, void *stream);
+                             const int64_t *task_out, const double *frames,
+                             const int32_t *task_base, const int32_t *trk_meta,
+                             int32_t mode, double *iou, int64_t *pair_frames,
+                             void *stream);
 
 /* The same IoUs when EVERY detection and ground-truth track has exactly one
  * frame (frame k of the lists = the frame of track k): a pair is one box IoU
@@ -251,6 +259,23 @@ int taoamd_track_pad(int64_t n_trk, int64_t n_frames, const int32_t *frame_off,
                      const int32_t *frame_pos, const double *frame_box,
                      const int32_t *meta, int64_t slot_first, int64_t n_slots,
                      double *padded, int32_t *inexact, void *stream);
+
+/* Frame stream of a launch plan (once per problem): the padded table's frames
+ * rearranged into the order taoamd_track_iou_planned's tasks read them, so that
+ * what a task requests for one chunk of its timeline is ONE contiguous stretch
+ * of memory instead of 32 pieces scattered over the padded table.  A task's
+ * chunks are the 8-position windows [8 c, 8 c + 8) from its earliest first to
+ * its latest last position; row r of the task (rows in task_rows order, with
+ * first <= last) owns a piece in every chunk its span first .. last reaches
+ * into.  task_base[t] (int32, device, filled by the caller) = 1 + the pieces
+ * of the tasks before t, where a task's pieces = the sum over its rows of
+ * (last >> 3) - (first >> 3) + 1; `frames` holds 1 + the pieces of all tasks,
+ * 256 bytes each.  Reads tasks, task_rows, trk_meta and the padded table
+ * (which may be released afterwards). */
+int taoamd_track_stream(int64_t n_tasks, const int32_t *tasks,
+                        const int32_t *task_rows, const int32_t *trk_meta,
+                        const int32_t *task_base, const double *padded,
+                        double *frames, void *stream);
 
 /* Guard of the documented frame-order deviation (frames are added in timeline
  * order; the reference adds them in CPython set order, T/eval.py:83-94): lists

@@ -54,8 +54,9 @@ SIGNATURES = {
                                    _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
     "taoamd_track_iou_single": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32,
                                           _vp, _vp, _vp]),
-    "taoamd_track_iou_planned": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp,
+    "taoamd_track_iou_planned": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                            _i32, _vp, _vp, _vp]),
+    "taoamd_track_stream": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "taoamd_track_pad": (C.c_int, [_i64, _i64, _vp, _vp, _vp, _vp, _i64, _i64,
                                    _vp, _vp, _vp]),
     "taoamd_track_iou_near": (C.c_int, [_i64, _vp, _vp, _i64, _vp, _i32, _i32,

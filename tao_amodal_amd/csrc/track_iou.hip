@@ -268,72 +268,72 @@ __device__ __forceinline__ void tt_barrier()
 // stager was the longer of the two chains).
 template <int S>
 __device__ __forceinline__ void tt_stager(
-    const double4 *__restrict__ padded, double (*rows)[TT_ROWS * TT_RS],
-    const int4 *meta, uint32_t (*rmask)[TT_SLOTS], uint32_t (*flags)[2][2],
-    int32_t p_first, int n_chunks, int lane)
+    const double4 *__restrict__ frames, int64_t sbase, double (*rows)[TT_ROWS * TT_RS],
+    const int4 *meta, int32_t p_first, int n_chunks, int lane)
 {
     constexpr int NR = (TT_ROUNDS - S + 1) / 2;      // my rounds
     const int grp = lane / TT_P, j = lane % TT_P;
     // lane (grp, j) serves position j of the rows grp, TT_GROUPS + grp, ...
-    int32_t F[NR], L[NR], M[NR];
-    uint32_t isdt = 0;
+    int32_t F[NR], L[NR];
+    uint32_t bit[NR];
 #pragma unroll
     for (int i = 0; i < NR; i++) {
         const int4 m = meta[TT_GROUPS * (S + 2 * i) + grp];
         F[i] = m.x;
         L[i] = m.y;
-        M[i] = m.z;
-        isdt |= (uint32_t)(m.w & 1) << i;
+        bit[i] = 1u << (TT_GROUPS * (S + 2 * i) + grp);
     }
+    // lanes 0 .. TT_SLOTS - 1: first / last of row = lane, for the chunk's
+    // mask of present rows (one ballot per chunk, the same in both stagers)
+    static_assert(TT_SLOTS <= 32, "one 32-bit mask of a task's rows");
+    const int4 mrow = meta[lane & (TT_SLOTS - 1)];
+    const bool row_has = lane < TT_SLOTS && mrow.y >= mrow.x;
+    int64_t cursor = sbase;           // first slot of the next chunk to be requested (uniform)
     // TT_SETS register sets: the loads of chunk k + TT_SETS are issued when
     // chunk k has been staged.  Every round loads (lanes out of range read
     // slot 0), so the number of loads in flight is known at compile time
     // and a chunk waits for ITS loads only (s_waitcnt vmcnt(n > 0)).
     double4 B[TT_SETS][NR];
-    uint32_t wiped[2] = {~0u, ~0u};   // bit i: my round i's row holds far boxes in buffer b
 
     auto issue = [&](double4 *Bx, int32_t pc) {
-        const int32_t p = pc + j;
+        // rows whose span reaches into the chunk own a piece of TT_P slots in
+        // the chunk's stretch of the stream, in row order
+        const uint32_t pm = (uint32_t)__ballot(row_has && mrow.x < pc + TT_P && mrow.y >= pc);
 #pragma unroll
         for (int i = 0; i < NR; i++) {
-            const bool in = p >= F[i] && p <= L[i];
+            const bool in = (pm & bit[i]) != 0;
+            const int64_t slot = cursor + (__popc(pm & (bit[i] - 1u)) * TT_P + j);
 #ifdef TT_ABLATE_LOADS     // (timing experiment: every load hits slot 0)
-            Bx[i] = padded[in ? 0 : 0];
+            Bx[i] = frames[in ? 0 : 0];
+#elif defined(TT_ABLATE_CACHED)   // (timing experiment: the same requests inside 1 MB)
+            Bx[i] = frames[in ? (slot & 0x7fff) : 0];
 #else
-            Bx[i] = padded[in ? M[i] + p : 0];      // slot 0: the far box
+            Bx[i] = frames[in ? slot : 0];          // slots 0 .. TT_P - 1: far boxes
 #endif
         }
+        cursor += __popc(pm) * TT_P;
     };
     auto stage = [&](const double4 *Bx, int32_t pc, int b) {
-        uint64_t any = 0, anydt = 0;
-        uint32_t wp = wiped[b];
+        // A row is parked only where its span reaches into the chunk -- the one
+        // case in which the adder reads it (it branches on the same test).
 #pragma unroll
         for (int i = 0; i < NR; i++) {
             const int r = TT_GROUPS * (S + 2 * i) + grp;
             const bool ov = F[i] < pc + TT_P && L[i] >= pc;   // same for the row's lanes
-            const bool act = ov || !((wp >> i) & 1u);
-            if (__ballot(act) == 0) continue;
+            if (__ballot(ov) == 0) continue;
             const double4 bx = Bx[i];
-            const bool present = bx.x != TT_FAR;
-            const uint64_t ball = __ballot(present);
-            any |= ball;
-            anydt |= __ballot(present && ((isdt >> i) & 1u));
-            if (act) {
+            const uint64_t ball = __ballot(bx.x != TT_FAR);
+            if (ov) {
                 double *rb = rows[b] + r * TT_RS + j;
                 rb[0] = bx.x;
                 rb[TT_P] = bx.y;
                 rb[2 * TT_P] = bx.x + bx.z;
                 rb[3 * TT_P] = bx.y + bx.w;
                 rb[4 * TT_P] = bx.z * bx.w;
-                if (j == 0)
-                    rmask[b][r] = (uint32_t)(ball >> (TT_P * grp)) & ((1u << TT_P) - 1);
+                if (j == 0)     // positions of the chunk that hold a frame: the row's padding
+                    *reinterpret_cast<uint32_t *>(rb + 5 * TT_P) =
+                        (uint32_t)(ball >> (TT_P * grp)) & ((1u << TT_P) - 1);
             }
-            wp = ov ? wp & ~(1u << i) : wp | (1u << i);
-        }
-        wiped[b] = wp;
-        if (lane == 0) {
-            flags[b][S][0] = any != 0;
-            flags[b][S][1] = anydt != 0;
         }
     };
     // chunk c lives in register set c % TT_SETS and in LDS buffer c & 1
@@ -362,13 +362,12 @@ template <int MODE>
 __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(MODE == 2 ? 4 : 6, MODE == 2 ? 4 : 6))) void track_iou_task_kernel(
     const int4 *__restrict__ tasks, const int32_t *__restrict__ task_rows,
     const int32_t *__restrict__ task_pairs, const int64_t *__restrict__ task_out,
-    const double4 *__restrict__ padded, const int4 *__restrict__ trk_meta,
+    const double4 *__restrict__ frames, const int32_t *__restrict__ task_base,
+    const int4 *__restrict__ trk_meta,
     double *__restrict__ iou, unsigned long long *__restrict__ pair_frames)
 {
     __shared__ __align__(16) double rows[2][TT_ROWS * TT_RS];
     __shared__ int4 meta[TT_SLOTS];
-    __shared__ uint32_t rmask[2][TT_SLOTS];   // positions of the chunk that hold a frame
-    __shared__ uint32_t flags[2][2][2];       // per stager {any frame, any detection frame} of the chunk
     __shared__ int32_t span[2];               // first chunk start, last position
 
     const int lane = threadIdx.x & 63;
@@ -386,9 +385,11 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
             if (m.y >= m.x) {
                 p_lo = m.x;
                 p_hi = m.y;
+            } else {
+                m.x = INT32_MAX;       // a track without frames: in no chunk
+                m.y = -1;
             }
             meta[lane] = m;
-            rmask[0][lane] = rmask[1][lane] = 0;
         }
 #pragma unroll
         for (int s = 32; s > 0; s >>= 1) {
@@ -399,71 +400,79 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
             span[0] = p_lo & ~(TT_P - 1);
             span[1] = p_hi;
         }
-    } else {
-        // the other two wavefronts put far boxes into both buffers meanwhile
-        for (int s = (wave - 1) * 64 + lane; s < 2 * TT_ROWS * TT_P; s += 128) {
-            const int b = s / (TT_ROWS * TT_P), t = s % (TT_ROWS * TT_P);
-            double *rb = rows[b] + (t / TT_P) * TT_RS + (t % TT_P);
-            rb[0] = rb[TT_P] = rb[2 * TT_P] = rb[3 * TT_P] = TT_FAR;
-            rb[4 * TT_P] = 0.0;
-        }
     }
     __syncthreads();
     const int32_t p_first = span[0], p_hi = span[1];
     const int n_chunks = p_hi < 0 ? 0 : (p_hi - p_first) / TT_P + 1;
 
     if (stager) {
+        const int64_t sbase = (int64_t)task_base[blockIdx.x] * TT_P;
         if (wave == 0)
-            tt_stager<0>(padded, rows, meta, rmask, flags, p_first, n_chunks, lane);
+            tt_stager<0>(frames, sbase, rows, meta, p_first, n_chunks, lane);
         else
-            tt_stager<1>(padded, rows, meta, rmask, flags, p_first, n_chunks, lane);
+            tt_stager<1>(frames, sbase, rows, meta, p_first, n_chunks, lane);
         return;
     }
 
     // ---- adder
     int32_t pr = 0;
-    int64_t out = 0;
-    if (lane < n_pairs) {
-        pr = task_pairs[tk.z + lane];
-        out = task_out[tk.z + lane];
-    }
+    if (lane < n_pairs) pr = task_pairs[tk.z + lane];
     const int rowd = pr & 0xFF, rowg = (pr >> 8) & 0xFF;
+    // first / last position of my pair's two tracks: which of them reaches into
+    // a chunk follows from registers (a lane without a pair: neither, ever)
+    int32_t Fd = INT32_MAX, Ld = -1, Fg = INT32_MAX, Lg = -1;
+    if (lane < n_pairs) {
+        const int4 md = meta[rowd], mg = meta[rowg];
+        Fd = md.x;
+        Ld = md.y;
+        Fg = mg.x;
+        Lg = mg.y;
+    }
+    const int offd = rowd * (TT_RS * 8), offg = rowg * (TT_RS * 8);     // bytes
     double u = 0.0, i = 0.0;
     unsigned long long common = 0;
-    auto add = [&](int b) {
+    auto add = [&](int b, int32_t pc) {
 #ifdef TT_ABLATE_ADDER     // (timing experiment: the adder only keeps the barriers)
         return;
 #endif
-        const bool any = flags[b][0][0] | flags[b][1][0];
-        const bool anydt = flags[b][0][1] | flags[b][1][1];
-        if (!any || lane >= n_pairs) return;
-        const double *__restrict__ dr = rows[b] + rowd * TT_RS;
-        const double *__restrict__ gr = rows[b] + rowg * TT_RS;
-        const uint32_t dm = rmask[b][rowd], gm = rmask[b][rowg];
+        // Round 6: the stagers park a row exactly where its span first .. last
+        // reaches into the chunk, and the adder branches on the same test --
+        // from four registers, where it used to wait for two LDS round trips
+        // (the chunk's flags, then its rows' frame masks) before it could ask
+        // for the first box: the adder's chain of dependent waits, not its
+        // arithmetic, was a third of the kernel (a build without the general
+        // step: -8 %; without the adder's skeleton: -40 %).  A chunk that lies
+        // in a hole of a track finds far boxes there, whose terms are exact
+        // zeros / the other box's area: the same bits as not reading it.
+        const bool dp = Fd < pc + TT_P && Ld >= pc;
+        const bool gp = Fg < pc + TT_P && Lg >= pc;
+        if (__ballot(dp || gp) == 0) return;
+        // (row offsets in two registers; the buffer's base folds into the LDS
+        // instructions' immediate offsets)
+        const char *rbase = reinterpret_cast<const char *>(rows[b]);
+        const double *__restrict__ dr = reinterpret_cast<const double *>(rbase + offd);
+        const double *__restrict__ gr = reinterpret_cast<const double *>(rbase + offg);
         if (MODE == 0) {
-            // Round 4: the adder's LDS reads are what a chunk costs (ten 16-byte
-            // reads per lane and position pair: 40 KB per chunk and task, seven
-            // tasks on a CU's 128 B / clock), and two thirds of a task's
-            // (pair, chunk) steps find at most ONE of the pair's tracks in the
-            // chunk.  Such a step adds that track's areas alone -- against far
-            // boxes (x = 1e300, area 0) the general formula gives i_ = 0 and
-            // u_ = (a + 0) - 0 = a, the same bits -- and a step without either
-            // track adds zeros, i.e. nothing.  Lanes branch on the rows' frame
-            // masks of the chunk: fewer lanes, fewer LDS reads.
-            const bool both = dm != 0 && gm != 0;
-            if (anydt && !both && (dm | gm) != 0) {
+            // At most ONE of the pair's tracks in the chunk (two thirds of a
+            // task's (pair, chunk) steps): that track's areas alone -- against
+            // far boxes (x = 1e300, area 0) the general formula gives i_ = 0
+            // and u_ = (a + 0) - 0 = a, the same bits.  Lanes branch: fewer
+            // lanes, fewer LDS reads (round 4).
+            if (dp != gp) {
                 const double2 *__restrict__ a2 =
-                    reinterpret_cast<const double2 *>((dm != 0 ? dr : gr) + 4 * TT_P);
+                    reinterpret_cast<const double2 *>(rbase + (dp ? offd : offg) + 4 * TT_P * 8);
 #pragma unroll
                 for (int pp = 0; pp < TT_P / 2; pp++) {
                     const double2 ar = a2[pp];
                     u += ar.x;
                     u += ar.y;
                 }
-            } else if (anydt && both) {
+            } else if (dp) {
                 // two positions per 16-byte LDS read of every field
                 const double2 *__restrict__ d2 = reinterpret_cast<const double2 *>(dr);
                 const double2 *__restrict__ g2 = reinterpret_cast<const double2 *>(gr);
+                const uint32_t dm = *reinterpret_cast<const uint32_t *>(dr + 5 * TT_P);
+                const uint32_t gm = *reinterpret_cast<const uint32_t *>(gr + 5 * TT_P);
 #pragma unroll
                 for (int pp = 0; pp < TT_P / 2; pp++) {
                     const double2 dx1 = d2[pp], gx1 = g2[pp];
@@ -488,12 +497,14 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
                         i += i_;
                     }
                 }
-            } else if (!anydt && gm != 0) {
-#pragma unroll
-                for (int pp = 0; pp < TT_P; pp++) u += gr[4 * TT_P + pp];
+                common += __popc(dm & gm);
             }
         } else {
             // avg_iou / imagenetvid: u = sum of per-frame scores, i = frames
+            // (a row that does not reach into the chunk was not parked: its
+            // frame mask counts as empty, what is read of it is not used)
+            const uint32_t dm = dp ? *reinterpret_cast<const uint32_t *>(dr + 5 * TT_P) : 0u;
+            const uint32_t gm = gp ? *reinterpret_cast<const uint32_t *>(gr + 5 * TT_P) : 0u;
 #pragma unroll
             for (int pp = 0; pp < TT_P; pp++) {
                 const bool both = ((dm & gm) >> pp) & 1u, either = ((dm | gm) >> pp) & 1u;
@@ -510,19 +521,19 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
                 u += tx;
                 i += either ? 1.0 : 0.0;
             }
+            common += __popc(dm & gm);
         }
-        common += __popc(dm & gm);
     };
     tt_barrier();
     for (int k = 0; k < n_chunks; k += 2) {
-        add(0);
+        add(0, p_first + k * TT_P);
         tt_barrier();
         if (k + 1 >= n_chunks) break;
-        add(1);
+        add(1, p_first + (k + 1) * TT_P);
         tt_barrier();
     }
-    if (lane < n_pairs)
-        iou[out] = MODE == 0 ? (u > 0 ? i / u : 0.0) : u / i;
+    if (lane < n_pairs)       // (the place is fetched here: two registers less across the loop)
+        iou[task_out[tk.z + lane]] = MODE == 0 ? (u > 0 ? i / u : 0.0) : u / i;
     if (pair_frames != nullptr) {
         for (int s_ = WAVE / 2; s_ > 0; s_ >>= 1)
             common += __shfl_down(common, s_, WAVE);
@@ -644,6 +655,52 @@ __global__ __launch_bounds__(64) void track_iou_setorder_kernel(
     }
 }
 
+// Padded table -> the tasks' frame stream (taoamd_track_stream).  A workgroup
+// per task walks the task's chunks exactly as tt_stager::issue does: thread
+// (row, position) of a row whose span reaches into the chunk writes its slot
+// of the row's piece -- the frame's box, or the far box outside first .. last
+// (holes inside the span hold far boxes in the padded table already).
+__global__ __launch_bounds__(TT_SLOTS * TT_P) void track_stream_kernel(
+    const int4 *__restrict__ tasks, const int32_t *__restrict__ task_rows,
+    const int4 *__restrict__ trk_meta, const int32_t *__restrict__ task_base,
+    const double4 *__restrict__ padded, double4 *__restrict__ out)
+{
+    __shared__ int4 meta[TT_SLOTS];
+    const int4 tk = tasks[blockIdx.x];
+    const int tid = threadIdx.x;
+    if (tid < TT_SLOTS)
+        meta[tid] = tid < tk.y ? trk_meta[task_rows[tk.x + tid]] : make_int4(INT32_MAX, -1, 0, 0);
+    if (blockIdx.x == 0 && tid < TT_P) out[tid] = make_double4(TT_FAR, TT_FAR, 0.0, 0.0);
+    __syncthreads();
+    int32_t p_lo = INT32_MAX, p_hi = -1;
+    for (int r = 0; r < TT_SLOTS; r++) {
+        const int4 m = meta[r];
+        if (m.y >= m.x) {
+            p_lo = min(p_lo, m.x);
+            p_hi = max(p_hi, m.y);
+        }
+    }
+    if (p_hi < 0) return;
+    const int r = tid / TT_P, j = tid % TT_P;
+    const int4 mine = meta[r];
+    const bool has = mine.y >= mine.x;
+    int64_t cursor = (int64_t)task_base[blockIdx.x] * TT_P;
+    for (int32_t pc = p_lo & ~(TT_P - 1); pc <= p_hi; pc += TT_P) {
+        uint32_t pm = 0;
+        for (int q = 0; q < TT_SLOTS; q++) {
+            const int4 m = meta[q];
+            if (m.y >= m.x && m.x < pc + TT_P && m.y >= pc) pm |= 1u << q;
+        }
+        if (has && ((pm >> r) & 1u)) {
+            const int32_t p = pc + j;
+            const bool in = p >= mine.x && p <= mine.y;
+            out[cursor + (__popc(pm & ((1u << r) - 1u)) * TT_P + j)] =
+                in ? padded[(int64_t)mine.z + p] : make_double4(TT_FAR, TT_FAR, 0.0, 0.0);
+        }
+        cursor += __popc(pm) * TT_P;
+    }
+}
+
 __global__ void track_pad_fill_kernel(int64_t n, double4 *__restrict__ padded)
 {
     const int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -701,7 +758,8 @@ extern "C" int taoamd_track_iou_planned(int64_t n_tasks, const int32_t *tasks,
                                         const int32_t *task_rows,
                                         const int32_t *task_pairs,
                                         const int64_t *task_out,
-                                        const double *padded,
+                                        const double *frames,
+                                        const int32_t *task_base,
                                         const int32_t *trk_meta, int32_t mode,
                                         double *iou, int64_t *pair_frames,
                                         void *stream)
@@ -710,14 +768,15 @@ extern "C" int taoamd_track_iou_planned(int64_t n_tasks, const int32_t *tasks,
     if (mode < 0 || mode > 2 || n_tasks < 0) return TAOAMD_ERR_ARG;
     if (pair_frames) TAO_HIP(hipMemsetAsync(pair_frames, 0, 8, s));
     if (n_tasks == 0) return TAOAMD_OK;
-    if (!tasks || !task_rows || !task_pairs || !task_out || !padded || !trk_meta || !iou)
+    if (!tasks || !task_rows || !task_pairs || !task_out || !frames || !task_base ||
+        !trk_meta || !iou)
         return TAOAMD_ERR_ARG;
     unsigned long long *pf = (unsigned long long *)pair_frames;
 #define TT_LAUNCH(M)                                                           \
     TAO_TIMED("track_iou_task_kernel", s,                                      \
               track_iou_task_kernel<M><<<(unsigned)n_tasks, 192, 0, s>>>(       \
                   (const int4 *)tasks, task_rows, task_pairs, task_out,        \
-                  (const double4 *)padded, (const int4 *)trk_meta, iou, pf))
+                  (const double4 *)frames, task_base, (const int4 *)trk_meta, iou, pf))
     if (mode == 0) TT_LAUNCH(0);
     else if (mode == 1) TT_LAUNCH(1);
     else TT_LAUNCH(2);
@@ -748,6 +807,24 @@ extern "C" int taoamd_track_pad(int64_t n_trk, int64_t n_frames,
             n_frames, n_trk, frame_off, frame_pos, (const double4 *)frame_box,
             (const int4 *)meta, (double4 *)padded, inexact));
     }
+    TAO_LAUNCH_CHECK();
+    return TAOAMD_OK;
+}
+
+extern "C" int taoamd_track_stream(int64_t n_tasks, const int32_t *tasks,
+                                   const int32_t *task_rows, const int32_t *trk_meta,
+                                   const int32_t *task_base, const double *padded,
+                                   double *frames, void *stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (n_tasks < 0) return TAOAMD_ERR_ARG;
+    if (n_tasks == 0) return TAOAMD_OK;
+    if (!tasks || !task_rows || !trk_meta || !task_base || !padded || !frames)
+        return TAOAMD_ERR_ARG;
+    TAO_TIMED("track_stream_kernel", s,
+              track_stream_kernel<<<(unsigned)n_tasks, TT_SLOTS * TT_P, 0, s>>>(
+                  (const int4 *)tasks, task_rows, (const int4 *)trk_meta, task_base,
+                  (const double4 *)padded, (double4 *)frames));
     TAO_LAUNCH_CHECK();
     return TAOAMD_OK;
 }

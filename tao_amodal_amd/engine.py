@@ -312,8 +312,8 @@ class DeviceProblem:
     def _plan_track_iou(self, flat):
         """Padded frame table + launch plan of taoamd_track_iou_planned."""
         lib = _lib.load()
-        for k in ("tasks", "task_rows", "task_pairs", "task_out", "padded",
-                  "trk_meta"):
+        for k in ("tasks", "task_rows", "task_pairs", "task_out", "frames",
+                  "task_base", "trk_meta"):
             self.t[k] = None
         if self.device.type != "cuda":     # host-side plumbing tests: no kernels
             return
@@ -345,8 +345,7 @@ class DeviceProblem:
         self.t["task_out"] = torch.from_numpy(out).to(dev)
         self.t["trk_meta"] = torch.from_numpy(
             np.ascontiguousarray(meta, dtype=np.int32)).to(dev)
-        self.t["padded"] = torch.empty((n_slots, 4), dtype=torch.float64,
-                                       device=dev)
+        padded = torch.empty((n_slots, 4), dtype=torch.float64, device=dev)
         n_dt = len(flat.dt_frame_off) - 1
         inexact = torch.zeros(1, dtype=torch.int32, device=dev)
         with torch.cuda.device(dev):
@@ -359,8 +358,29 @@ class DeviceProblem:
                     _ptr(self.t[side + "_frame_pos"]),
                     _ptr(self.t[side + "_frame_box"]),
                     self.t["trk_meta"].data_ptr() + 16 * row0, slot0, slots,
-                    _ptr(self.t["padded"]), _ptr(inexact), _stream()),
+                    _ptr(padded), _ptr(inexact), _stream()),
                     "taoamd_track_pad")
+            # the frames in the order the tasks read them (taoamd_track_stream):
+            # a row owns a 256-byte piece in every 8-position chunk its span
+            # reaches into; a task's pieces lie chunk by chunk, rows in order
+            has = meta[:, 1] >= meta[:, 0]
+            trk_pieces = np.where(has, (meta[:, 1] >> 3) - (meta[:, 0] >> 3) + 1, 0)
+            task_pieces = np.add.reduceat(trk_pieces[rows].astype(np.int64),
+                                          tasks[:, 0].astype(np.int64))
+            base = 1 + np.cumsum(task_pieces) - task_pieces
+            n_pieces = 1 + int(task_pieces.sum())
+            if n_pieces >= 2 ** 31 - 1:
+                for k in ("tasks", "task_rows", "task_pairs", "task_out", "trk_meta"):
+                    self.t[k] = None        # (the plan-less kernel takes over)
+                return
+            self.t["task_base"] = torch.from_numpy(base.astype(np.int32)).to(dev)
+            self.t["frames"] = torch.empty((n_pieces * 8, 4), dtype=torch.float64,
+                                           device=dev)
+            _lib.check(lib.taoamd_track_stream(
+                self.n_tasks, _ptr(self.t["tasks"]), _ptr(self.t["task_rows"]),
+                _ptr(self.t["trk_meta"]), _ptr(self.t["task_base"]), _ptr(padded),
+                _ptr(self.t["frames"]), _stream()), "taoamd_track_stream")
+            del padded
         # integer boxes: frame sums are exact in any order, nothing to guard
         # (products < 2^40, tracks of at most 2^12 frames: every sum < 2^53)
         longest = int((meta[:, 1] - meta[:, 0]).max()) + 1 if len(meta) else 0
@@ -600,8 +620,8 @@ def stage_track_iou(dp, ws):
     if t["tasks"] is not None:
         _lib.check(lib.taoamd_track_iou_planned(
             dp.n_tasks, _ptr(t["tasks"]), _ptr(t["task_rows"]),
-            _ptr(t["task_pairs"]), _ptr(t["task_out"]), _ptr(t["padded"]),
-            _ptr(t["trk_meta"]), dp.iou_mode, _ptr(ws.iou),
+            _ptr(t["task_pairs"]), _ptr(t["task_out"]), _ptr(t["frames"]),
+            _ptr(t["task_base"]), _ptr(t["trk_meta"]), dp.iou_mode, _ptr(ws.iou),
             _ptr(ws.pair_frames), s), "taoamd_track_iou_planned")
         return
     _lib.check(lib.taoamd_track_iou(
