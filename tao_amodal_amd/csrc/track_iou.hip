@@ -447,6 +447,9 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
         const bool dp = Fd < pc + TT_P && Ld >= pc;
         const bool gp = Fg < pc + TT_P && Lg >= pc;
         if (__ballot(dp || gp) == 0) return;
+#ifdef TT_ABLATE_ADD_BODY  // (timing experiment: 1 = no area-only step, 2 = no general step, 3 = neither)
+        if (TT_ABLATE_ADD_BODY == 3) return;
+#endif
         // (row offsets in two registers; the buffer's base folds into the LDS
         // instructions' immediate offsets)
         const char *rbase = reinterpret_cast<const char *>(rows[b]);
@@ -458,7 +461,11 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
             // far boxes (x = 1e300, area 0) the general formula gives i_ = 0
             // and u_ = (a + 0) - 0 = a, the same bits.  Lanes branch: fewer
             // lanes, fewer LDS reads (round 4).
+#ifdef TT_ABLATE_ADD_BODY
+            if (dp != gp && !(TT_ABLATE_ADD_BODY & 1)) {
+#else
             if (dp != gp) {
+#endif
                 const double2 *__restrict__ a2 =
                     reinterpret_cast<const double2 *>(rbase + (dp ? offd : offg) + 4 * TT_P * 8);
 #pragma unroll
@@ -467,7 +474,11 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
                     u += ar.x;
                     u += ar.y;
                 }
+#ifdef TT_ABLATE_ADD_BODY
+            } else if (dp && gp && !(TT_ABLATE_ADD_BODY & 2)) {
+#else
             } else if (dp) {
+#endif
                 // two positions per 16-byte LDS read of every field
                 const double2 *__restrict__ d2 = reinterpret_cast<const double2 *>(dr);
                 const double2 *__restrict__ g2 = reinterpret_cast<const double2 *>(gr);
