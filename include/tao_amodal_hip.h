@@ -83,6 +83,7 @@ extern "C" {
 #define TAOAMD_ERR_ARG 2         /* bad argument */
 #define TAOAMD_ERR_TOO_LARGE 3   /* a cell exceeds a kernel limit */
 #define TAOAMD_ERR_WORKSPACE 4   /* workspace too small */
+#define TAOAMD_JSON_FALLBACK 16  /* taoamd_json_pred_open: the host reader should take the file */
 
 const char *taoamd_strerror(int status);
 /* text of the last failing HIP call on this thread ("" if none) */
@@ -831,6 +832,38 @@ int taoamd_exchange_place(int64_t n_recv, int32_t world, int32_t n_words,
                           const uint64_t *rows, const uint64_t *own_rows,
                           int32_t own_rank, const int64_t *src_base,
                           const int32_t *pos, uint64_t *out, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * The prediction file read on the device (csrc/json_ingest.hip): replaces the
+ * reference's json.load of prediction.json (lvis_amodal/results.py:29-30,
+ * tools/eval_on_tao_amodal.py:127-128) for the six keys of a prediction.
+ *
+ * taoamd_json_pred_open copies the file's text into HBM, finds the list's
+ * objects (string state, bracket depth and object count of 16 KB blocks, three
+ * prefix sums) and checks the list's shape.  *status: TAOAMD_OK (a handle is
+ * returned); TAOAMD_JSON_FALLBACK -- the file holds something this reader leaves
+ * to the host's (a backslash, an element that is not an object, text around the
+ * list, an empty file): call the host reader (include/tao_amodal_ingest.h),
+ * whose results and error messages are the contract; TAOAMD_ERR_ARG -- the file
+ * cannot be opened (err says so); TAOAMD_ERR_HIP.
+ *
+ * taoamd_json_pred_read converts the objects (one thread each; decimal ->
+ * double correctly rounded, csrc/decfloat.hpp) and copies the columns into the
+ * caller's HOST arrays of taoamd_json_pred_count() rows (bbox: 4 doubles a row).
+ * Objects it leaves to the host reader -- literals, numbers of more than 19
+ * digits, ids that are not plain integers, missing keys, unexpected syntax --
+ * are listed: flag[k] = the object's number, flag_at[k] = the byte offset of its
+ * '{' in the file, for the first flag_cap of *n_flagged; their rows are not
+ * written (taoamd_pred_patch of the host library fills them or reports the
+ * error).  More than flag_cap: use the host reader for the file. */
+void *taoamd_json_pred_open(const char *path, int32_t *status, char *err, size_t errlen,
+                            void *stream);
+int64_t taoamd_json_pred_count(void *handle);
+int taoamd_json_pred_read(void *handle, int64_t *image_id, int64_t *category_id,
+                          double *bbox, double *score, int64_t *track_id,
+                          int64_t *video_id, int64_t *flag, int64_t *flag_at,
+                          int32_t flag_cap, int32_t *n_flagged);
+void taoamd_json_pred_close(void *handle);
 
 #ifdef __cplusplus
 }

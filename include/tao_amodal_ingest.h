@@ -50,6 +50,14 @@ int taoamd_pred_convert(void *handle, int64_t *image_id, int64_t *category_id,
                         double *bbox, double *score, int64_t *track_id,
                         int64_t *video_id, char *err, size_t errlen);
 void taoamd_pred_scan_free(void *handle);
+/* Rows the device-side reader (taoamd_json_pred_read, include/tao_amodal_hip.h)
+ * left to this one: object idx[k] of the file's list, whose '{' is byte at[k]
+ * of the file, is read into row idx[k] of the columns.  0 = ok, 1 = the file
+ * cannot be read, 2 = malformed record (message of the first one in err). */
+int taoamd_pred_patch(const char *path, int64_t n, const int64_t *idx, const int64_t *at,
+                      int64_t *image_id, int64_t *category_id, double *bbox,
+                      double *score, int64_t *track_id, int64_t *video_id, char *err,
+                      size_t errlen);
 int64_t taoamd_pred_count(void *handle);
 /* copies the columns into caller memory: n int64 / 4n double / n double / ... */
 int taoamd_pred_copy(void *handle, int64_t *image_id, int64_t *category_id,

@@ -14,6 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("TAOAMD_LIBRARY") or os.path.join(HERE, "libtao_amodal_hip.so")
 
 OK = 0
+ERR_HIP, ERR_ARG, JSON_FALLBACK = 1, 2, 16
 N_THR, N_REC = 10, 101
 LVIS_RNG, TAO_RNG = 6, 20
 MAX_GT_PER_CELL = 3072
@@ -57,6 +58,11 @@ SIGNATURES = {
     "taoamd_track_iou_planned": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                            _i32, _vp, _vp, _vp]),
     "taoamd_track_stream": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "taoamd_json_pred_open": (_vp, [C.c_char_p, _vp, C.c_char_p, _sz, _vp]),
+    "taoamd_json_pred_count": (_i64, [_vp]),
+    "taoamd_json_pred_read": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                        _i32, _vp]),
+    "taoamd_json_pred_close": (None, [_vp]),
     "taoamd_track_pad": (C.c_int, [_i64, _i64, _vp, _vp, _vp, _vp, _i64, _i64,
                                    _vp, _vp, _vp]),
     "taoamd_track_iou_near": (C.c_int, [_i64, _vp, _vp, _i64, _vp, _i32, _i32,

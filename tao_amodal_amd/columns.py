@@ -361,6 +361,10 @@ class DTColumns:
         if not os.path.exists(so):
             return None
         lib = C.CDLL(so)
+        if n_parts == 1:
+            out = cls._from_file_device(path, lib)
+            if out is not None:
+                return out
         lib.taoamd_pred_scan.restype = C.c_void_p
         lib.taoamd_pred_scan.argtypes = [C.c_char_p, C.c_int64, C.c_int64, C.c_char_p,
                                          C.c_size_t]
@@ -410,6 +414,84 @@ class DTColumns:
                                  daemon=True).start()
             else:
                 lib.taoamd_pred_scan_free(h)
+        return out
+
+    # files from this size on are read on the device (csrc/json_ingest.hip)
+    DEVICE_INGEST_MIN_BYTES = 32 << 20
+    DEVICE_INGEST_FLAG_CAP = 4096
+
+    @classmethod
+    def _from_file_device(cls, path, host_lib):
+        """The prediction file read on the GPU (taoamd_json_pred_open / _read:
+        the text copied into HBM, the list's objects found and converted there).
+        Returns None when the host reader should take the file: a small file,
+        no GPU, ``TAOAMD_DEVICE_INGEST=0``, or a file holding anything the
+        device reader leaves to the host's (a backslash, elements that are not
+        objects, more unusual objects than it lists).  Objects it lists --
+        literals, ids that are not plain integers, missing keys -- are read by
+        the host reader's parse_object and patched in, with its errors."""
+        import ctypes as C
+        import sys
+        if os.environ.get("TAOAMD_DEVICE_INGEST", "1") == "0":
+            return None
+        # (a fresh process whose torch is still being imported on another
+        # thread keeps the host reader: loading the kernel library would wait
+        # for that import, the host's threads are done before it is)
+        if "torch" not in sys.modules:
+            return None
+        try:
+            if os.path.getsize(path) < cls.DEVICE_INGEST_MIN_BYTES:
+                return None
+        except OSError:
+            return None                 # (the host reader reports the missing file)
+        from . import _lib
+        try:
+            hip = _lib.load()
+        except OSError:
+            return None
+        err = C.create_string_buffer(512)
+        status = C.c_int32(0)
+        h = hip.taoamd_json_pred_open(os.fsencode(path), C.byref(status), err, 512, None)
+        if not h:
+            if status.value == _lib.JSON_FALLBACK or status.value == _lib.ERR_ARG:
+                return None
+            raise RuntimeError("taoamd_json_pred_open: %s (%s)"
+                               % (err.value.decode(), hip.taoamd_last_error().decode()))
+        try:
+            n = hip.taoamd_json_pred_count(h)
+            i64, f64 = np.int64, np.float64
+            out = cls(image_id=np.empty(n, i64), category_id=np.empty(n, i64),
+                      bbox=np.empty((n, 4), f64), score=np.empty(n, f64),
+                      track_id=np.empty(n, i64), video_id=np.empty(n, i64))
+            cap = cls.DEVICE_INGEST_FLAG_CAP
+            flag, flag_at = np.zeros(cap, i64), np.zeros(cap, i64)
+            n_flag = C.c_int32(0)
+            _lib.check(hip.taoamd_json_pred_read(
+                h, out.image_id.ctypes.data, out.category_id.ctypes.data,
+                out.bbox.ctypes.data, out.score.ctypes.data, out.track_id.ctypes.data,
+                out.video_id.ctypes.data, flag.ctypes.data, flag_at.ctypes.data, cap,
+                C.byref(n_flag)), "taoamd_json_pred_read")
+        finally:
+            hip.taoamd_json_pred_close(h)
+        if n_flag.value > cap:
+            return None
+        if n_flag.value:
+            k = n_flag.value
+            order = np.argsort(flag[:k], kind="stable")
+            idx = np.ascontiguousarray(flag[:k][order])
+            at = np.ascontiguousarray(flag_at[:k][order])
+            host_lib.taoamd_pred_patch.argtypes = [C.c_char_p, C.c_int64] + [C.c_void_p] * 8 \
+                + [C.c_char_p, C.c_size_t]
+            rc = host_lib.taoamd_pred_patch(
+                os.fsencode(path), k, idx.ctypes.data, at.ctypes.data,
+                out.image_id.ctypes.data, out.category_id.ctypes.data, out.bbox.ctypes.data,
+                out.score.ctypes.data, out.track_id.ctypes.data, out.video_id.ctypes.data,
+                err, 512)
+            if rc:
+                # (the host reader scans the file again and raises what it finds:
+                # its message for the list's first malformed record)
+                return None
+        out.first, out.total = 0, n
         return out
 
     @classmethod

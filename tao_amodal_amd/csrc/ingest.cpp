@@ -970,6 +970,49 @@ int taoamd_pred_convert(void *h, int64_t *image_id, int64_t *category_id, double
 
 void taoamd_pred_scan_free(void *h) { delete (PredScan *)h; }
 
+// Rows the device-side reader (csrc/json_ingest.hip) left to this one: object
+// idx[k] of the list starts at byte at[k] of the file; it is read by
+// parse_object -- the text of its value, its errors -- into row idx[k] of the
+// columns.  0 = ok, 2 = malformed record (the FIRST such object's message in
+// err, as taoamd_pred_convert reports it).
+int taoamd_pred_patch(const char *path, int64_t n, const int64_t *idx, const int64_t *at,
+                      int64_t *image_id, int64_t *category_id, double *bbox, double *score,
+                      int64_t *track_id, int64_t *video_id, char *err, size_t errlen)
+{
+    if (n <= 0) return 0;
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) return 1;
+    struct stat st;
+    fstat(fd, &st);
+    const size_t len = (size_t)st.st_size;
+    const char *buf = (const char *)mmap(nullptr, len, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (buf == MAP_FAILED) return 1;
+    const ColView v{image_id, category_id, track_id, video_id, bbox, score};
+    int64_t bad = -1;
+    std::string bad_msg;
+    for (int64_t k = 0; k < n; k++) {
+        std::string er;
+        bool ok = at[k] >= 0 && (size_t)at[k] < len && buf[at[k]] == '{';
+        if (ok) {
+            Cursor cur{buf + at[k], buf + len};
+            cur.skip();                               // the object's extent
+            ok = !cur.fail && parse_object(buf + at[k], cur.p, idx[k], v, er);
+            if (cur.fail) er = cur.why;
+        } else er = "list element is not an object";
+        if (!ok && (bad < 0 || idx[k] < bad)) {
+            bad = idx[k];
+            bad_msg = "prediction " + std::to_string(idx[k]) + ": " + er;
+        }
+    }
+    munmap((void *)buf, len);
+    if (bad >= 0) {
+        if (err && errlen) snprintf(err, errlen, "%s", bad_msg.c_str());
+        return 2;
+    }
+    return 0;
+}
+
 int64_t taoamd_pred_count(void *h) { return (int64_t)((Columns *)h)->image_id.size(); }
 
 // position of the share's first element in the whole list, and the list's length

@@ -1,0 +1,167 @@
+"""The prediction file read on the device (csrc/json_ingest.hip) against the
+host reader (csrc/ingest.cpp, itself pinned to json.load in tests/
+test_ingest.py): the same columns bit for bit, the same errors, and the host
+reader taking over wherever the device reader does not decide."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tao_amodal_amd.columns import DTColumns
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = DTColumns.FIELDS
+
+
+@pytest.fixture(autouse=True)
+def small_files_too(monkeypatch):
+    import torch  # noqa: F401  (the device path needs the runtime torch loaded)
+    monkeypatch.setattr(DTColumns, "DEVICE_INGEST_MIN_BYTES", 0)
+
+
+def host(path):
+    os.environ["TAOAMD_DEVICE_INGEST"] = "0"
+    try:
+        return DTColumns.from_file_native(path)
+    finally:
+        del os.environ["TAOAMD_DEVICE_INGEST"]
+
+
+def device(path):
+    import ctypes as C
+    so = os.path.join(os.path.dirname(os.path.abspath(DTColumns.__module__.replace(".", "/"))), "x")
+    from tao_amodal_amd import columns
+    lib = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(columns.__file__)),
+                              "libtao_amodal_ingest.so"))
+    return DTColumns._from_file_device(path, lib)
+
+
+def same(a, b):
+    assert len(a) == len(b)
+    for f in FIELDS:
+        x, y = np.asarray(getattr(a, f)), np.asarray(getattr(b, f))
+        assert x.dtype == y.dtype and x.shape == y.shape, f
+        assert (x.view(np.uint64) == y.view(np.uint64)).all(), f
+
+
+def synth_columns(n, seed=0):
+    rng = np.random.default_rng(seed)
+    return DTColumns(
+        image_id=rng.integers(1, 10 ** 6, n), category_id=rng.integers(1, 1204, n),
+        bbox=np.concatenate([rng.uniform(-64, 1216, (n, 2)), rng.uniform(1, 400, (n, 2))], 1),
+        score=rng.random(n), track_id=rng.integers(0, 10 ** 5, n),
+        video_id=rng.integers(0, 2000, n))
+
+
+def test_native_writer_file_equals_host_reader(tmp_path):
+    p = str(tmp_path / "pred.json")
+    c = synth_columns(300000, 1)
+    c.write_json(p)
+    d = device(p)
+    assert d is not None
+    same(d, host(p))
+    same(d, c)
+
+
+def test_integer_boxes_and_json_dumps_spellings(tmp_path):
+    rng = np.random.default_rng(2)
+    rows = []
+    for k in range(20000):
+        r = {"image_id": int(rng.integers(1, 10 ** 9)), "category_id": int(rng.integers(1, 1204)),
+             "bbox": [int(x) for x in rng.integers(-50, 1300, 4)] if k % 3 == 0
+             else [float(x) for x in rng.uniform(-50, 1300, 4)],
+             "score": float(rng.random()) * (1e-7 if k % 11 == 0 else 1.0),
+             "track_id": int(rng.integers(0, 10 ** 12)), "video_id": int(rng.integers(0, 3000))}
+        if k % 5 == 0:
+            del r["track_id"]
+        if k % 7 == 0:
+            r["extra"] = {"a": [1, 2, {"b": "x}]"}], "c": "str[ing{"}
+            r["segmentation"] = [[1.5, 2.5, 3.5]]
+        rows.append(r)
+    for indent in (None, 1):
+        p = str(tmp_path / ("pred%s.json" % indent))
+        with open(p, "w") as f:
+            json.dump(rows, f, indent=indent)
+        d = device(p)
+        assert d is not None
+        same(d, host(p))
+
+
+def test_objects_left_to_the_host_reader(tmp_path):
+    base = '{"image_id": %d, "category_id": 3, "bbox": [1, 2.5, 3e1, 4], "score": %s, "track_id": %s, "video_id": 1}'
+    objs = [base % (k, "0.5", str(k)) for k in range(5000)]
+    objs[7] = base % (7, "NaN", "7")
+    objs[8] = base % (8, "true", "8")
+    objs[9] = base % (9, "0.25", "9.0")                 # an id spelt as a float
+    objs[10] = base % (10, "0.1234567890123456789012", "10")      # 22 digits
+    objs[11] = base % (11, "-Infinity", "11")
+    objs[12] = base % (12, "1e400", "12")
+    p = str(tmp_path / "pred.json")
+    with open(p, "w") as f:
+        f.write("[" + ",\n".join(objs) + "]\n")
+    d = device(p)
+    assert d is not None
+    same(d, host(p))
+    assert np.isnan(d.score[7]) and d.score[8] == 1.0 and d.track_id[9] == 9
+
+
+def test_what_goes_to_the_host_reader_as_a_whole(tmp_path):
+    ok = '{"image_id": 1, "category_id": 3, "bbox": [1, 2, 3, 4], "score": 0.5}'
+    cases = {
+        "backslash": "[" + ok + ', {"image_id": 2, "category_id": 3, "bbox": [1,2,3,4], "score": 1, "n\\u0061me": 3}]',
+        "not_a_list": '{"a": ' + ok + "}",
+        "number_in_list": "[" + ok + ", 5]",
+        "string_in_list": "[" + ok + ', "x"]',
+        "nested_list": "[" + ok + ", [" + ok + "]]",
+        "text_after": "[" + ok + "] x",
+        "two_lists": "[" + ok + "] [" + ok + "]",
+        "unterminated": "[" + ok + ", " + ok,
+        "empty": "",
+    }
+    for name, text in cases.items():
+        p = str(tmp_path / (name + ".json"))
+        with open(p, "w") as f:
+            f.write(text)
+        assert device(p) is None, name
+
+
+def test_errors_are_the_host_readers(tmp_path):
+    ok = '{"image_id": 1, "category_id": 3, "bbox": [1, 2, 3, 4], "score": 0.5}'
+    bad = {
+        "missing_key": '{"image_id": 1, "category_id": 3, "bbox": [1, 2, 3, 4]}',
+        "short_box": '{"image_id": 1, "category_id": 3, "bbox": [1, 2, 3], "score": 0.5}',
+        "garbage": '{"image_id": 1x, "category_id": 3, "bbox": [1, 2, 3, 4], "score": 0.5}',
+    }
+    for name, obj in bad.items():
+        p = str(tmp_path / (name + ".json"))
+        with open(p, "w") as f:
+            f.write("[" + ", ".join([ok] * 50 + [obj] + [ok] * 50) + "]")
+        assert device(p) is None, name            # (the host reader then raises its own error)
+        with pytest.raises((KeyError, ValueError)):
+            DTColumns.from_file_native(p)
+
+
+def test_empty_list_and_white_space(tmp_path):
+    p = str(tmp_path / "e.json")
+    with open(p, "w") as f:
+        f.write("  [ \n ]  \n")
+    d = device(p)
+    assert d is not None and len(d) == 0
+    p = str(tmp_path / "w.json")
+    with open(p, "w") as f:
+        f.write(' [ {"image_id" : 4 ,\n "category_id":\t2, "bbox" : [ 1 , 2 , 3 , 4 ] , "score" : 1 } , ]')
+    d = device(p)
+    # (a trailing comma: the host reader accepts what stands between objects leniently)
+    h = host(p)
+    assert d is not None
+    same(d, h)
+
+
+def test_from_file_native_takes_the_device_path(tmp_path):
+    p = str(tmp_path / "pred.json")
+    c = synth_columns(50000, 5)
+    c.write_json(p)
+    same(DTColumns.from_file_native(p), c)
+    same(DTColumns.from_json(p), c)
