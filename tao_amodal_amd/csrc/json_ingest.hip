@@ -502,6 +502,15 @@ extern "C" void *taoamd_json_pred_open(const char *path, int32_t *status, char *
     auto now = [] { return std::chrono::duration<double>(
                         std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = now();
+    {
+        // no GPU in this process: the host reader's file
+        int n_dev = 0;
+        if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev < 1) {
+            (void)hipGetLastError();
+            *status = TAOAMD_JSON_FALLBACK;
+            return nullptr;
+        }
+    }
     const int fd = open(path, O_RDONLY);
     if (fd < 0) {
         js_msg(err, errlen, std::string("cannot open ") + path);

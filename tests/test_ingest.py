@@ -405,3 +405,66 @@ def test_numbers_equal_pythons_float_bit_for_bit(tmp_path):
     for k, sh in ((1, 2), (2, 3), (3, 4)):
         assert np.array_equal(d.bbox[:, k].view(np.uint64), np.roll(want, -sh).view(np.uint64))
     assert len(d.score) == n
+
+
+def test_rows_patched_for_the_device_reader(tmp_path):
+    """taoamd_pred_patch: the objects the device-side reader (csrc/
+    json_ingest.hip) leaves to this one, read at their byte offsets into their
+    rows -- the same values as the whole-file read, the same error text."""
+    import ctypes as C
+    from tao_amodal_amd import columns
+    base = '{"image_id": %d, "category_id": 3, "bbox": [1, 2.5, 3e1, 4], "score": %s, "track_id": %s}'
+    objs = [base % (k, "0.5", str(k)) for k in range(200)]
+    objs[7] = base % (7, "NaN", "7")
+    objs[9] = base % (9, "true", "9.0")
+    objs[150] = base % (150, "0.1234567890123456789012", "150")
+    text = "[" + ",\n ".join(objs) + "]"
+    p = str(tmp_path / "p.json")
+    with open(p, "w") as f:
+        f.write(text)
+    whole = DTColumns.from_file_native(p)
+    lib = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(columns.__file__)),
+                              "libtao_amodal_ingest.so"))
+    lib.taoamd_pred_patch.argtypes = [C.c_char_p, C.c_int64] + [C.c_void_p] * 8 + [C.c_char_p,
+                                                                                   C.c_size_t]
+    n = len(objs)
+    cols = DTColumns(image_id=np.zeros(n, np.int64), category_id=np.zeros(n, np.int64),
+                     bbox=np.zeros((n, 4)), score=np.zeros(n), track_id=np.zeros(n, np.int64),
+                     video_id=np.zeros(n, np.int64))
+    idx = np.array([7, 9, 150], dtype=np.int64)
+    at, pos = [], 0
+    for k in range(n):
+        pos = text.index("{", pos)
+        at.append(pos)
+        pos += 1
+    at = np.array([at[k] for k in idx], dtype=np.int64)
+    err = C.create_string_buffer(512)
+    rc = lib.taoamd_pred_patch(os.fsencode(p), 3, idx.ctypes.data, at.ctypes.data,
+                               cols.image_id.ctypes.data, cols.category_id.ctypes.data,
+                               cols.bbox.ctypes.data, cols.score.ctypes.data,
+                               cols.track_id.ctypes.data, cols.video_id.ctypes.data, err, 512)
+    assert rc == 0, err.value
+    for f in DTColumns.FIELDS:
+        a, b = np.asarray(getattr(cols, f))[idx], np.asarray(getattr(whole, f))[idx]
+        assert (a.view(np.uint64) == b.view(np.uint64)).all(), f
+    # a malformed object: the first one's message, by position in the list
+    at_bad = np.array([at[0] + 1, at[1]], dtype=np.int64)
+    rc = lib.taoamd_pred_patch(os.fsencode(p), 2, idx[:2].ctypes.data, at_bad.ctypes.data,
+                               cols.image_id.ctypes.data, cols.category_id.ctypes.data,
+                               cols.bbox.ctypes.data, cols.score.ctypes.data,
+                               cols.track_id.ctypes.data, cols.video_id.ctypes.data, err, 512)
+    assert rc == 2 and err.value.startswith(b"prediction 7: ")
+
+
+def test_device_reader_steps_aside_without_a_gpu(tmp_path, monkeypatch):
+    """No GPU in the process (this suite): DTColumns.from_file_native reads with
+    the host library whatever the file's size."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    monkeypatch.setattr(DTColumns, "DEVICE_INGEST_MIN_BYTES", 0)
+    p = str(tmp_path / "p.json")
+    with open(p, "w") as f:
+        f.write('[{"image_id": 4, "category_id": 2, "bbox": [1, 2, 3, 4], "score": 0.25}]')
+    d = DTColumns.from_file_native(p)
+    assert len(d) == 1 and d.score[0] == 0.25 and d.track_id[0] == -1
