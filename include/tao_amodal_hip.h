@@ -847,18 +847,24 @@ int taoamd_exchange_place(int64_t n_recv, int32_t world, int32_t n_words,
  * whose results and error messages are the contract; TAOAMD_ERR_ARG -- the file
  * cannot be opened (err says so); TAOAMD_ERR_HIP.
  *
- * taoamd_json_pred_read converts the objects (one thread each; decimal ->
- * double correctly rounded, csrc/decfloat.hpp) and copies the columns into the
- * caller's HOST arrays of taoamd_json_pred_count() rows (bbox: 4 doubles a row).
- * Objects it leaves to the host reader -- literals, numbers of more than 19
+ * taoamd_json_pred_convert converts the objects (one thread each; decimal ->
+ * double correctly rounded, csrc/decfloat.hpp) into the caller's DEVICE arrays of
+ * taoamd_json_pred_count() rows (bbox: 4 doubles a row) and returns when they
+ * are written; taoamd_json_pred_read does the same into HOST arrays.
+ * Objects left to the host reader -- literals, numbers of more than 19
  * digits, ids that are not plain integers, missing keys, unexpected syntax --
- * are listed: flag[k] = the object's number, flag_at[k] = the byte offset of its
- * '{' in the file, for the first flag_cap of *n_flagged; their rows are not
- * written (taoamd_pred_patch of the host library fills them or reports the
- * error).  More than flag_cap: use the host reader for the file. */
+ * are listed (HOST arrays): flag[k] = the object's number, flag_at[k] = the byte
+ * offset of its '{' in the file, for the first flag_cap of *n_flagged; their
+ * rows are not written (taoamd_pred_patch of the host library fills them in
+ * host arrays or reports the error).  More than flag_cap: use the host reader
+ * for the file. */
 void *taoamd_json_pred_open(const char *path, int32_t *status, char *err, size_t errlen,
                             void *stream);
 int64_t taoamd_json_pred_count(void *handle);
+int taoamd_json_pred_convert(void *handle, int64_t *image_id, int64_t *category_id,
+                             double *bbox, double *score, int64_t *track_id,
+                             int64_t *video_id, int64_t *flag, int64_t *flag_at,
+                             int32_t flag_cap, int32_t *n_flagged);
 int taoamd_json_pred_read(void *handle, int64_t *image_id, int64_t *category_id,
                           double *bbox, double *score, int64_t *track_id,
                           int64_t *video_id, int64_t *flag, int64_t *flag_at,

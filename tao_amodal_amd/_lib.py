@@ -62,6 +62,8 @@ SIGNATURES = {
     "taoamd_json_pred_count": (_i64, [_vp]),
     "taoamd_json_pred_read": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                         _i32, _vp]),
+    "taoamd_json_pred_convert": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                           _i32, _vp]),
     "taoamd_json_pred_close": (None, [_vp]),
     "taoamd_track_pad": (C.c_int, [_i64, _i64, _vp, _vp, _vp, _vp, _i64, _i64,
                                    _vp, _vp, _vp]),

@@ -334,6 +334,19 @@ class GTColumns:
                 "categories": cats}
 
 
+def fingerprint(v):
+    """A cheap digest of an array's CONTENT -- ~1000 evenly spaced elements and
+    both ends -- so that the usual in-place edits of an uploaded column between
+    two evaluations (scores rescaled, boxes shifted, ids remapped: ADVICE r3)
+    are seen as well as a rebound column; an edit of single elements between
+    the samples still needs flatten_dev.forget_columns(dt)."""
+    if not isinstance(v, np.ndarray) or v.size == 0:
+        return 0
+    flat = v.reshape(-1) if v.flags.c_contiguous else np.ascontiguousarray(v).reshape(-1)
+    step = max(1, flat.size // 1024)
+    return hash((flat[::step].tobytes(), flat[-1:].tobytes()))
+
+
 class DTColumns:
     """Prediction list as arrays (file order preserved)."""
 
@@ -457,40 +470,57 @@ class DTColumns:
                 return None
             raise RuntimeError("taoamd_json_pred_open: %s (%s)"
                                % (err.value.decode(), hip.taoamd_last_error().decode()))
+        import torch
         try:
             n = hip.taoamd_json_pred_count(h)
-            i64, f64 = np.int64, np.float64
-            out = cls(image_id=np.empty(n, i64), category_id=np.empty(n, i64),
-                      bbox=np.empty((n, 4), f64), score=np.empty(n, f64),
-                      track_id=np.empty(n, i64), video_id=np.empty(n, i64))
-            cap = cls.DEVICE_INGEST_FLAG_CAP
-            flag, flag_at = np.zeros(cap, i64), np.zeros(cap, i64)
-            n_flag = C.c_int32(0)
-            _lib.check(hip.taoamd_json_pred_read(
-                h, out.image_id.ctypes.data, out.category_id.ctypes.data,
-                out.bbox.ctypes.data, out.score.ctypes.data, out.track_id.ctypes.data,
-                out.video_id.ctypes.data, flag.ctypes.data, flag_at.ctypes.data, cap,
-                C.byref(n_flag)), "taoamd_json_pred_read")
+            dev = torch.device("cuda", torch.cuda.current_device())
+            i64, f64 = torch.int64, torch.float64
+            with torch.cuda.device(dev):
+                t = {"image_id": torch.empty(n, dtype=i64, device=dev),
+                     "category_id": torch.empty(n, dtype=i64, device=dev),
+                     "bbox": torch.empty((n, 4), dtype=f64, device=dev),
+                     "score": torch.empty(n, dtype=f64, device=dev),
+                     "track_id": torch.empty(n, dtype=i64, device=dev),
+                     "video_id": torch.empty(n, dtype=i64, device=dev)}
+                torch.cuda.current_stream().synchronize()
+                cap = cls.DEVICE_INGEST_FLAG_CAP
+                flag, flag_at = np.zeros(cap, np.int64), np.zeros(cap, np.int64)
+                n_flag = C.c_int32(0)
+                _lib.check(hip.taoamd_json_pred_convert(
+                    h, t["image_id"].data_ptr(), t["category_id"].data_ptr(),
+                    t["bbox"].data_ptr(), t["score"].data_ptr(), t["track_id"].data_ptr(),
+                    t["video_id"].data_ptr(), flag.ctypes.data, flag_at.ctypes.data, cap,
+                    C.byref(n_flag)), "taoamd_json_pred_convert")
         finally:
-            hip.taoamd_json_pred_close(h)
+            # (the text, the tables and the mapping are released off the
+            # caller's path: 0.04 s at 30 M predictions)
+            import threading
+            threading.Thread(target=hip.taoamd_json_pred_close, args=(h,),
+                             daemon=True).start()
         if n_flag.value > cap:
             return None
-        if n_flag.value:
-            k = n_flag.value
-            order = np.argsort(flag[:k], kind="stable")
-            idx = np.ascontiguousarray(flag[:k][order])
-            at = np.ascontiguousarray(flag_at[:k][order])
-            host_lib.taoamd_pred_patch.argtypes = [C.c_char_p, C.c_int64] + [C.c_void_p] * 8 \
-                + [C.c_char_p, C.c_size_t]
-            rc = host_lib.taoamd_pred_patch(
-                os.fsencode(path), k, idx.ctypes.data, at.ctypes.data,
-                out.image_id.ctypes.data, out.category_id.ctypes.data, out.bbox.ctypes.data,
-                out.score.ctypes.data, out.track_id.ctypes.data, out.video_id.ctypes.data,
-                err, 512)
-            if rc:
-                # (the host reader scans the file again and raises what it finds:
-                # its message for the list's first malformed record)
-                return None
+        if n_flag.value == 0:
+            # the columns stay where they were made: the table builds read
+            # them there, the host arrays arrive in the background
+            return DeviceDTColumns(n, t, dev)
+        # some objects are the host reader's: plain host columns, patched
+        out = cls(**{f: t[f].cpu().numpy() for f in cls.FIELDS})
+        del t
+        k = n_flag.value
+        order = np.argsort(flag[:k], kind="stable")
+        idx = np.ascontiguousarray(flag[:k][order])
+        at = np.ascontiguousarray(flag_at[:k][order])
+        host_lib.taoamd_pred_patch.argtypes = [C.c_char_p, C.c_int64] + [C.c_void_p] * 8 \
+            + [C.c_char_p, C.c_size_t]
+        rc = host_lib.taoamd_pred_patch(
+            os.fsencode(path), k, idx.ctypes.data, at.ctypes.data,
+            out.image_id.ctypes.data, out.category_id.ctypes.data, out.bbox.ctypes.data,
+            out.score.ctypes.data, out.track_id.ctypes.data, out.video_id.ctypes.data,
+            err, 512)
+        if rc:
+            # (the host reader scans the file again and raises what it finds:
+            # its message for the list's first malformed record)
+            return None
         out.first, out.total = 0, n
         return out
 
@@ -556,3 +586,92 @@ class DTColumns:
     def concat(cls, parts):
         return cls(**{f: np.concatenate([getattr(p, f) for p in parts])
                       for f in cls.FIELDS})
+
+
+class DeviceDTColumns(DTColumns):
+    """Prediction columns made ON THE DEVICE (DTColumns._from_file_device): the
+    device tensors are there at once -- flatten_dev.raw_columns hands them to
+    the table builds instead of uploading host arrays -- and the host arrays
+    every other reader of a DTColumns sees arrive in the background, column by
+    column (image_id, track_id, video_id first: what the constructors of the
+    Results classes check on the host).  Reading a column waits for its copy;
+    assigning one (``dt.score = other``) replaces it and retires the device
+    copy, and an in-place edit of an arrived array is seen by its fingerprint,
+    as for uploaded columns."""
+
+    ORDER = ("image_id", "track_id", "video_id", "category_id", "score", "bbox")
+
+    def __init__(self, n, tensors, device):
+        import threading
+        d = self.__dict__
+        d["_n"], d["_dev"], d["_device"] = n, dict(tensors), device
+        d["_host"], d["_fp"], d["_error"] = {}, {}, None
+        d["_ready"] = {f: threading.Event() for f in self.FIELDS}
+        d["first"], d["total"] = 0, n
+        threading.Thread(target=self._download, daemon=True).start()
+
+    def _download(self):
+        try:
+            import torch
+            with torch.cuda.device(self._device):
+                side = torch.cuda.Stream(device=self._device)
+                with torch.cuda.stream(side):
+                    for f in self.ORDER:
+                        t = self._dev.get(f)
+                        if self._ready[f].is_set() or t is None:
+                            continue            # (assigned meanwhile)
+                        arr = np.empty(tuple(t.shape), dtype=np.float64
+                                       if t.dtype == torch.float64 else np.int64)
+                        torch.from_numpy(arr).copy_(t)
+                        side.synchronize()
+                        if not self._ready[f].is_set():
+                            self._fp[f] = fingerprint(arr)
+                            self._host[f] = arr
+                            self._ready[f].set()
+        except BaseException as e:      # (a reader of the columns re-raises it)
+            self.__dict__["_error"] = e
+            for ev in self._ready.values():
+                ev.set()
+
+    def __len__(self):
+        return self._n
+
+    def _get(self, f):
+        self._ready[f].wait()
+        if self._error is not None and f not in self._host:
+            raise RuntimeError("prediction columns could not be copied from the "
+                               "device") from self._error
+        return self._host[f]
+
+    def _set(self, f, v):
+        if self._ready[f].is_set() and v is self._host.get(f):
+            return                      # (the same array handed back)
+        self._host[f] = v
+        self._dev.pop(f, None)
+        self._fp.pop(f, None)
+        self._ready[f].set()
+
+    def device_columns(self, device, names):
+        """{name: tensor} of the columns as they were made, when they still
+        are what the host arrays hold (None: upload the host arrays)."""
+        import torch
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        if device.type != "cuda" or idx != self._device.index:
+            return None
+        out = {}
+        for f in names:
+            t = self._dev.get(f)
+            if t is None:
+                return None
+            if self._ready[f].is_set() and (self._error is not None
+                                            or fingerprint(self._host[f]) != self._fp.get(f)):
+                self._dev.pop(f, None)
+                return None
+            out[f] = t
+        return out
+
+
+for _f in DTColumns.FIELDS:
+    setattr(DeviceDTColumns, _f, property(lambda self, _f=_f: self._get(_f),
+                                          lambda self, v, _f=_f: self._set(_f, v)))
+del _f

@@ -408,13 +408,14 @@ struct JsHandle {
     int fd = -1;
     const char *map = nullptr;
     size_t len = 0;
-    uint8_t *d_text = nullptr;
+    uint8_t *d_text = nullptr, *d_cols = nullptr;
     int64_t *d_starts = nullptr;
     int64_t n = 0;
     hipStream_t s = nullptr;
     ~JsHandle()
     {
         if (d_text) (void)hipFree(d_text);
+        if (d_cols) (void)hipFree(d_cols);
         if (d_starts) (void)hipFree(d_starts);
         if (map && len) munmap((void *)map, len);
     }
@@ -467,6 +468,41 @@ hipError_t parallel_copy(const std::vector<Piece> &parts, hipMemcpyKind kind, in
     for (auto &t : pool) t.join();
     return (hipError_t)failed.load();
 }
+
+// Pages of a host range touched by helper threads while something else runs:
+// a mapped file's pages are mapped on first read, a fresh array's on first
+// write (huge pages where the system hands them out on request) -- faults the
+// runtime's staging memcpy would otherwise take one by one on the copying thread.
+struct Toucher {
+    std::vector<std::thread> pool;
+    void read(const char *p, size_t bytes, int n)
+    {
+        for (int w = 0; w < n; w++)
+            pool.emplace_back([=]() {
+                volatile char sink = 0;
+                const size_t a = bytes * w / n, b = bytes * (w + 1) / n;
+                for (size_t q = a; q < b; q += 4096) sink += p[q];
+                (void)sink;
+            });
+    }
+    void write(char *p, size_t bytes, int n)
+    {
+        const uintptr_t a0 = ((uintptr_t)p + ((size_t)2 << 20) - 1) & ~(((uintptr_t)2 << 20) - 1);
+        const uintptr_t b0 = ((uintptr_t)p + bytes) & ~(((uintptr_t)2 << 20) - 1);
+        if (b0 > a0) madvise((void *)a0, b0 - a0, MADV_HUGEPAGE);
+        for (int w = 0; w < n; w++)
+            pool.emplace_back([=]() {
+                const size_t a = bytes * w / n, b = bytes * (w + 1) / n;
+                for (size_t q = a; q < b; q += 4096) p[q] = 0;
+            });
+    }
+    void join()
+    {
+        for (auto &t : pool) t.join();
+        pool.clear();
+    }
+    ~Toucher() { join(); }
+};
 
 int copy_threads()
 {
@@ -547,8 +583,11 @@ extern "C" void *taoamd_json_pred_open(const char *path, int32_t *status, char *
     // mapped on first touch: the copying threads' own faults)
     {
         madvise((void *)h->map, h->len, MADV_WILLNEED);
+        Toucher ahead;
+        ahead.read(h->map, h->len, 4);
         const hipError_t ce = parallel_copy({Piece{(char *)h->d_text, h->map, h->len}},
                                             hipMemcpyHostToDevice, copy_threads());
+        ahead.join();
         if (ce != hipSuccess) {
             taoamd::set_error(ce, "hipMemcpyAsync(text)");
             js_msg(err, errlen, "HIP: copy of the text");
@@ -615,13 +654,15 @@ extern "C" void *taoamd_json_pred_open(const char *path, int32_t *status, char *
 
 extern "C" int64_t taoamd_json_pred_count(void *h) { return h ? ((JsHandle *)h)->n : 0; }
 
-// The columns into HOST arrays of taoamd_json_pred_count() rows; flag[0 ..
+// The objects converted into the caller's DEVICE arrays of
+// taoamd_json_pred_count() rows (bbox: 4 doubles a row); flag[0 ..
 // min(*n_flagged, flag_cap)) = the objects left to the host reader (their rows
-// are not written), flag_at[] their byte offsets in the file.
-extern "C" int taoamd_json_pred_read(void *handle, int64_t *image_id, int64_t *category_id,
-                                     double *bbox, double *score, int64_t *track_id,
-                                     int64_t *video_id, int64_t *flag, int64_t *flag_at,
-                                     int32_t flag_cap, int32_t *n_flagged)
+// are not written), flag_at[] their byte offsets in the file (HOST arrays).
+// Returns when the kernel is done.
+extern "C" int taoamd_json_pred_convert(void *handle, int64_t *image_id, int64_t *category_id,
+                                        double *bbox, double *score, int64_t *track_id,
+                                        int64_t *video_id, int64_t *flag, int64_t *flag_at,
+                                        int32_t flag_cap, int32_t *n_flagged)
 {
     JsHandle *h = (JsHandle *)handle;
     if (!h || !n_flagged || flag_cap < 0 || (flag_cap > 0 && (!flag || !flag_at)))
@@ -635,26 +676,24 @@ extern "C" int taoamd_json_pred_read(void *handle, int64_t *image_id, int64_t *c
     auto now = [] { return std::chrono::duration<double>(
                         std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = now();
-    uint8_t *buf = nullptr;
-    const size_t col = (size_t)n * 8;
-    TAO_HIP(hipMalloc(&buf, 9 * col + (size_t)(2 * flag_cap + 1) * 8 + 64));
-    if (timing) fprintf(stderr, "taoamd ingest (device): hipMalloc of the columns %.3f s\n", now() - t0);
+    int64_t *d_flag = nullptr;
+    TAO_HIP(hipMalloc(&d_flag, (size_t)(2 * flag_cap + 1) * 8 + 64));
     struct Free {
         void *p;
         ~Free() { (void)hipFree(p); }
-    } free_buf{buf};
+    } free_flag{d_flag};
     JsParseArgs a{};
     a.text = h->d_text;
     a.len = (int64_t)h->len;
     a.n = n;
     a.starts = h->d_starts;
-    a.c.bbox = (double *)buf;                          // (32-byte rows first: aligned)
-    a.c.score = (double *)(buf + 4 * col);
-    a.c.image_id = (int64_t *)(buf + 5 * col);
-    a.c.category_id = (int64_t *)(buf + 6 * col);
-    a.c.track_id = (int64_t *)(buf + 7 * col);
-    a.c.video_id = (int64_t *)(buf + 8 * col);
-    a.flag = (int64_t *)(buf + 9 * col);
+    a.c.bbox = bbox;
+    a.c.score = score;
+    a.c.image_id = image_id;
+    a.c.category_id = category_id;
+    a.c.track_id = track_id;
+    a.c.video_id = video_id;
+    a.flag = d_flag;
     a.flag_at = a.flag + flag_cap;
     a.n_flag = (int32_t *)(a.flag_at + flag_cap);
     a.flag_cap = flag_cap;
@@ -662,27 +701,8 @@ extern "C" int taoamd_json_pred_read(void *handle, int64_t *image_id, int64_t *c
     js_parse_kernel<<<(unsigned)((n + 255) / 256), 256, 0, h->s>>>(a);
     TAO_LAUNCH_CHECK();
     int32_t nf = 0;
-    // the caller's fresh arrays are touched here for the first time: huge pages
-    // where the system hands them out on request (csrc/ingest.cpp, pred_convert)
-    auto huge = [](void *p, size_t bytes) {
-        const uintptr_t a0 = ((uintptr_t)p + ((size_t)2 << 20) - 1) & ~(((uintptr_t)2 << 20) - 1);
-        const uintptr_t b0 = ((uintptr_t)p + bytes) & ~(((uintptr_t)2 << 20) - 1);
-        if (b0 > a0) madvise((void *)a0, b0 - a0, MADV_HUGEPAGE);
-    };
-    huge(bbox, 4 * col);
-    for (void *p : {(void *)score, (void *)image_id, (void *)category_id, (void *)track_id,
-                    (void *)video_id})
-        huge(p, col);
     TAO_HIP(hipMemcpyAsync(&nf, a.n_flag, 4, hipMemcpyDeviceToHost, h->s));
     TAO_HIP(hipStreamSynchronize(h->s));
-    const double t1 = now();
-    TAO_HIP(parallel_copy({Piece{(char *)bbox, (const char *)a.c.bbox, 4 * col},
-                           Piece{(char *)score, (const char *)a.c.score, col},
-                           Piece{(char *)image_id, (const char *)a.c.image_id, col},
-                           Piece{(char *)category_id, (const char *)a.c.category_id, col},
-                           Piece{(char *)track_id, (const char *)a.c.track_id, col},
-                           Piece{(char *)video_id, (const char *)a.c.video_id, col}},
-                          hipMemcpyDeviceToHost, copy_threads()));
     *n_flagged = nf;
     const int32_t k = nf < flag_cap ? nf : flag_cap;
     if (k > 0) {
@@ -690,8 +710,50 @@ extern "C" int taoamd_json_pred_read(void *handle, int64_t *image_id, int64_t *c
         TAO_HIP(hipMemcpy(flag_at, a.flag_at, (size_t)k * 8, hipMemcpyDeviceToHost));
     }
     if (timing)
-        fprintf(stderr, "taoamd ingest (device): %lld objects converted %.3f s, copied %.3f s, %d "
-                        "left to the host reader\n", (long long)n, t1 - t0, now() - t1, (int)nf);
+        fprintf(stderr, "taoamd ingest (device): %lld objects converted %.3f s, %d left to the "
+                        "host reader\n", (long long)n, now() - t0, (int)nf);
+    return TAOAMD_OK;
+}
+
+// The same into HOST arrays (device columns of the call's own, copied out:
+// the destination's fresh pages are touched by helper threads beside the
+// kernel).
+extern "C" int taoamd_json_pred_read(void *handle, int64_t *image_id, int64_t *category_id,
+                                     double *bbox, double *score, int64_t *track_id,
+                                     int64_t *video_id, int64_t *flag, int64_t *flag_at,
+                                     int32_t flag_cap, int32_t *n_flagged)
+{
+    JsHandle *h = (JsHandle *)handle;
+    if (!h || !n_flagged) return TAOAMD_ERR_ARG;
+    *n_flagged = 0;
+    const int64_t n = h->n;
+    if (n == 0) return TAOAMD_OK;
+    if (!image_id || !category_id || !bbox || !score || !track_id || !video_id)
+        return TAOAMD_ERR_ARG;
+    const size_t col = (size_t)n * 8;
+    if (h->d_cols) return TAOAMD_ERR_ARG;               // (one read per handle)
+    TAO_HIP(hipMalloc(&h->d_cols, 9 * col + 64));
+    uint8_t *buf = h->d_cols;
+    double *d_bbox = (double *)buf;                    // (32-byte rows first: aligned)
+    double *d_score = (double *)(buf + 4 * col);
+    int64_t *d_img = (int64_t *)(buf + 5 * col), *d_cat = (int64_t *)(buf + 6 * col);
+    int64_t *d_trk = (int64_t *)(buf + 7 * col), *d_vid = (int64_t *)(buf + 8 * col);
+    Toucher ahead;                 // (beside the kernel)
+    ahead.write((char *)bbox, 4 * col, 2);
+    for (void *p : {(void *)score, (void *)image_id, (void *)category_id, (void *)track_id,
+                    (void *)video_id})
+        ahead.write((char *)p, col, 1);
+    const int rc = taoamd_json_pred_convert(handle, d_img, d_cat, d_bbox, d_score, d_trk, d_vid,
+                                            flag, flag_at, flag_cap, n_flagged);
+    ahead.join();
+    if (rc != TAOAMD_OK) return rc;
+    TAO_HIP(parallel_copy({Piece{(char *)bbox, (const char *)d_bbox, 4 * col},
+                           Piece{(char *)score, (const char *)d_score, col},
+                           Piece{(char *)image_id, (const char *)d_img, col},
+                           Piece{(char *)category_id, (const char *)d_cat, col},
+                           Piece{(char *)track_id, (const char *)d_trk, col},
+                           Piece{(char *)video_id, (const char *)d_vid, col}},
+                          hipMemcpyDeviceToHost, copy_threads()));
     return TAOAMD_OK;
 }
 

@@ -88,17 +88,7 @@ def _column_key(dt):
     return tuple(key)
 
 
-def _fingerprint(v):
-    """A cheap digest of an array's CONTENT -- ~1000 evenly spaced elements and
-    both ends -- so that the usual in-place edits of an uploaded column between
-    two evaluations (scores rescaled, boxes shifted, ids remapped: ADVICE r3)
-    are seen as well as a rebound column; an edit of single elements between
-    the samples still needs forget_columns(dt)."""
-    if not isinstance(v, np.ndarray) or v.size == 0:
-        return 0
-    flat = v.reshape(-1) if v.flags.c_contiguous else np.ascontiguousarray(v).reshape(-1)
-    step = max(1, flat.size // 1024)
-    return hash((flat[::step].tobytes(), flat[-1:].tobytes()))
+from .columns import fingerprint as _fingerprint   # noqa: E402
 
 
 def forget_columns(dt):
@@ -116,6 +106,14 @@ def raw_columns(dt, device):
 
 def _raw_columns(dt, device):
     dev = torch.device(device)
+    born = getattr(dt, "device_columns", None)
+    if born is not None and getattr(dt, "area", None) is None:
+        # columns the device-side reader made (columns.DeviceDTColumns): there
+        # already, unless the caller has replaced or edited one since
+        cols = born(dev, ("image_id", "category_id", "score", "bbox", "video_id"))
+        if cols is not None:
+            cols["area"] = None
+            return cols
     key = id(dt)
     cols_key = _column_key(dt)
     ent = _RAW.get(key)

@@ -165,3 +165,37 @@ def test_from_file_native_takes_the_device_path(tmp_path):
     c.write_json(p)
     same(DTColumns.from_file_native(p), c)
     same(DTColumns.from_json(p), c)
+
+
+def test_columns_stay_on_the_device_and_arrive_on_the_host(tmp_path):
+    """DeviceDTColumns: the table builds get the tensors the reader made (no
+    upload), every other reader the host arrays; a rebound or edited column
+    retires its device copy."""
+    import torch
+    from tao_amodal_amd import flatten_dev
+    from tao_amodal_amd.columns import DeviceDTColumns
+    p = str(tmp_path / "pred.json")
+    c = synth_columns(80000, 9)
+    c.write_json(p)
+    d = DTColumns.from_file_native(p)
+    assert isinstance(d, DeviceDTColumns) and len(d) == 80000
+    raw = flatten_dev.raw_columns(d, "cuda")
+    assert raw["score"].is_cuda and raw["area"] is None
+    assert raw["score"].data_ptr() == d._dev["score"].data_ptr()       # not a copy
+    same(d, c)                                     # (waits for the host arrays)
+    assert flatten_dev.raw_columns(d, "cuda")["bbox"].data_ptr() == d._dev["bbox"].data_ptr()
+    assert (raw["bbox"].cpu().numpy() == c.bbox).all()
+    # an in-place edit of an arrived column is seen; the others keep their copy
+    d.score[:] = 0.5
+    raw2 = flatten_dev.raw_columns(d, "cuda")
+    assert "score" not in d._dev and float(raw2["score"][0]) == 0.5
+    # a rebound column, and one handed back as it is
+    e = DTColumns.from_file_native(p)
+    e.track_id = e.track_id
+    assert "track_id" in e._dev
+    e.image_id = e.image_id + 1
+    assert "image_id" not in e._dev and int(e.image_id[0]) == int(c.image_id[0]) + 1
+    raw3 = flatten_dev.raw_columns(e, "cuda")
+    assert int(raw3["image_id"][0]) == int(c.image_id[0]) + 1
+    t = e.take(np.arange(10))
+    assert type(t) is DTColumns and (t.score == c.score[:10]).all()
