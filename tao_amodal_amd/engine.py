@@ -113,13 +113,33 @@ def track_meta(flat):
     int32 table, the slot range of either side and the table size."""
     metas, sides, n_slots = [], {}, 1
     for side in ("dt", "gt"):
-        off = np.asarray(flat[side + "_frame_off"], dtype=np.int64)
-        pos = np.asarray(flat[side + "_frame_pos"], dtype=np.int64)
-        has = off[1:] > off[:-1]
-        first = np.ones(len(off) - 1, dtype=np.int64)
-        last = np.zeros(len(off) - 1, dtype=np.int64)
-        first[has] = pos[off[:-1][has]]
-        last[has] = pos[off[1:][has] - 1]
+        dev = getattr(flat, "dev", {})
+        if side + "_frame_off" in dev and side + "_frame_pos" in dev \
+                and not dict.__contains__(flat, side + "_frame_pos"):
+            # device-built tables: the tracks' first / last positions are
+            # gathered where the frame lists are (21 M positions at the
+            # validation scale: 0.04 s to bring them to the host for this)
+            off_t, pos_t = dev[side + "_frame_off"].long(), dev[side + "_frame_pos"]
+            has_t = off_t[1:] > off_t[:-1]
+            top = max(int(pos_t.numel()) - 1, 0)
+            if pos_t.numel():
+                first_t = torch.where(has_t, pos_t[off_t[:-1].clamp(max=top)].long(),
+                                      torch.ones_like(off_t[1:]))
+                last_t = torch.where(has_t, pos_t[(off_t[1:] - 1).clamp(min=0, max=top)].long(),
+                                     torch.zeros_like(off_t[1:]))
+            else:
+                first_t, last_t = torch.ones_like(off_t[1:]), torch.zeros_like(off_t[1:])
+            both = torch.stack([first_t, last_t]).cpu().numpy()
+            first, last = both[0], both[1]
+            has = last >= first
+        else:
+            off = np.asarray(flat[side + "_frame_off"], dtype=np.int64)
+            pos = np.asarray(flat[side + "_frame_pos"], dtype=np.int64)
+            has = off[1:] > off[:-1]
+            first = np.ones(len(off) - 1, dtype=np.int64)
+            last = np.zeros(len(off) - 1, dtype=np.int64)
+            first[has] = pos[off[:-1][has]]
+            last[has] = pos[off[1:][has] - 1]
         span = np.where(has, last - first + 1, 0)
         base = n_slots + np.cumsum(span) - span
         metas.append(np.stack([first, last, base - first,
@@ -318,7 +338,9 @@ class DeviceProblem:
         if self.device.type != "cuda":     # host-side plumbing tests: no kernels
             return
         meta, sides, n_slots = track_meta(flat)
-        n_frames = len(flat.dt_frame_pos) + len(flat.gt_frame_pos)
+        n_frames = sum(int(getattr(flat, "dev", {})[k].numel())
+                       if k in getattr(flat, "dev", {}) and not dict.__contains__(flat, k)
+                       else len(flat[k]) for k in ("dt_frame_pos", "gt_frame_pos"))
         self.n_slots = n_slots
         # tracks that are mostly holes would blow the table up: such inputs
         # take the two-pointer merge kernel instead (no plan)
@@ -346,14 +368,16 @@ class DeviceProblem:
         self.t["trk_meta"] = torch.from_numpy(
             np.ascontiguousarray(meta, dtype=np.int32)).to(dev)
         padded = torch.empty((n_slots, 4), dtype=torch.float64, device=dev)
-        n_dt = len(flat.dt_frame_off) - 1
+        # (sizes from the device tensors: a device-built table would bring its
+        # frame lists to the host to answer len())
+        n_dt = int(self.t["dt_frame_off"].numel()) - 1
         inexact = torch.zeros(1, dtype=torch.int32, device=dev)
         with torch.cuda.device(dev):
             for side, row0 in (("dt", 0), ("gt", n_dt)):
                 slot0, slots = sides[side]
-                n_trk = len(flat[side + "_frame_off"]) - 1
+                n_trk = int(self.t[side + "_frame_off"].numel()) - 1
                 _lib.check(lib.taoamd_track_pad(
-                    n_trk, len(flat[side + "_frame_pos"]),
+                    n_trk, int(self.t[side + "_frame_pos"].numel()),
                     _ptr(self.t[side + "_frame_off"]),
                     _ptr(self.t[side + "_frame_pos"]),
                     _ptr(self.t[side + "_frame_box"]),

@@ -71,7 +71,7 @@ def _tao_gt_ready(gt, visit_universe=None):
 _READY = {"lvis": _lvis_gt_ready, "tao": _tao_gt_ready}
 
 
-def prepare_gt(gt, kinds=("lvis", "tao")):
+def prepare_gt(gt, kinds=("lvis", "tao"), wait=True):
     """Build the ground-truth halves of the cell tables ahead of time -- the
     CLI calls this while the prediction file is still being parsed (0.5 s of
     numpy at 3 M annotations that otherwise sits between the parse and the
@@ -79,22 +79,25 @@ def prepare_gt(gt, kinds=("lvis", "tao")):
     the same columns and dropped there (single use: a caller who edits the
     columns afterwards never meets a stale table).  Errors are not raised
     here: the build that needs the bundle runs into them at the place the
-    reference does."""
+    reference does.  ``wait=False``: the halves are built on threads of their
+    own and the call returns at once; the table build that needs one waits for
+    it (round 6: the track level's half beside its constructor and the
+    track-id check instead of in front of them)."""
     def build(kind):
         try:
             return _READY[kind](gt)
         except Exception:
             return None
-    if len(kinds) > 1:
-        # (numpy's sorts, searches and gathers run without the GIL: the two
-        # levels' halves side by side)
-        from concurrent.futures import ThreadPoolExecutor
-        with ThreadPoolExecutor(max_workers=len(kinds)) as pool:
-            built = list(pool.map(build, kinds))
-    else:
-        built = [build(k) for k in kinds]
-    made = {k: b for k, b in zip(kinds, built) if b is not None}
+    # (numpy's sorts, searches and gathers run without the GIL: the two
+    # levels' halves side by side)
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(max_workers=max(len(kinds), 1))
+    made = {k: pool.submit(build, k) for k in kinds}
+    pool.shutdown(wait=False)
     vars(gt)["_prepared_gt"] = (_gt_key(gt), made)
+    if wait:
+        for f in made.values():
+            f.result()
 
 
 def _gt_ready(gt, kind):
@@ -104,6 +107,8 @@ def _gt_ready(gt, kind):
         R = made.pop(kind, None)
         if not made:
             vars(gt).pop("_prepared_gt", None)
+        if R is not None:
+            R = R.result()              # (a half still being built: wait for it)
         if R is not None and key == _gt_key(gt):
             return R
     return _READY[kind](gt)

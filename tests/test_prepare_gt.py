@@ -25,7 +25,7 @@ def test_bundles_equal_a_fresh_build_and_are_single_use():
     flatten_dev.prepare_gt(gt)
     for kind in ("lvis", "tao"):
         key, made = vars(gt)["_prepared_gt"]
-        stored = made[kind]
+        stored = made[kind].result()
         got = flatten_dev._gt_ready(gt, kind)
         assert got is stored
         again = flatten_dev._gt_ready(gt, kind)     # gone: built afresh
@@ -41,7 +41,7 @@ def test_bundles_equal_a_fresh_build_and_are_single_use():
 def test_a_rebound_column_is_not_served_from_the_bundle():
     gt, _ = synth(seed=4, V=5, F=12, C=9, dets_per_frame=6, n_present=4)
     flatten_dev.prepare_gt(gt)
-    stored = vars(gt)["_prepared_gt"][1]["lvis"]
+    stored = vars(gt)["_prepared_gt"][1]["lvis"].result()
     gt.ann_area = gt.ann_area.copy()
     gt.ann_area[:] = 0.0                    # every ground truth filtered out
     got = flatten_dev._gt_ready(gt, "lvis")
@@ -54,10 +54,21 @@ def test_errors_wait_for_the_build_that_needs_the_bundle():
     gt.ann_trk = gt.ann_trk.copy()
     gt.ann_trk[0] = 10 ** 9                 # annotation of a track that is not listed
     flatten_dev.prepare_gt(gt)              # silent
-    assert "tao" not in vars(gt)["_prepared_gt"][1]
+    assert vars(gt)["_prepared_gt"][1]["tao"].result() is None
     try:
         flatten_dev._gt_ready(gt, "tao")
     except KeyError as e:
         assert e.args[0] == 10 ** 9
     else:
         raise AssertionError("KeyError expected")
+
+
+def test_halves_built_in_the_background_are_waited_for():
+    gt, _ = synth(seed=4, V=5, F=12, C=9, dets_per_frame=6, n_present=4)
+    flatten_dev.prepare_gt(gt, wait=False)          # returns at once
+    for kind in ("tao", "lvis"):
+        fut = vars(gt)["_prepared_gt"][1][kind]
+        got = flatten_dev._gt_ready(gt, kind)       # waits for the half
+        assert fut.done() and got is fut.result()
+        _same(got, flatten_dev._READY[kind](gt))
+    assert "_prepared_gt" not in vars(gt)

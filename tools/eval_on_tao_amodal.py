@@ -460,7 +460,13 @@ def main(argv=None):
                 with timed("parse:annotation"):
                     lvis_gt = read_annotation()
             gt_dataset = annotation          # the track level shares the columns
-            if cold or not dt_future.done():
+            if not cold:
+                # a running process: the halves of the cell tables that depend on
+                # the annotation file alone start on threads of their own now;
+                # each level's table build picks its half up (or waits for it)
+                from tao_amodal_amd import prepare
+                prepare.prepare_gt(lvis_gt.columns, wait=False)
+            elif cold or not dt_future.done():
                 # the annotation file is the smaller one: its halves of the
                 # cell tables are built while the predictions are still read
                 # (a fresh process: while the helper creates the HIP context.
