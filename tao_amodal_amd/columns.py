@@ -24,6 +24,11 @@ import numpy as np
 
 FREQ_MISSING, FREQ_OTHER = ord("?"), 0xFF
 
+# A fresh process: {"event": threading.Event set when the HIP runtime has been
+# started ahead of torch's import, "ok": it succeeded} -- set by the drop-in CLI
+# (tools/eval_on_tao_amodal.py, _early_hip_init); DTColumns._from_file_device
+EARLY_HIP = {}
+
 
 def _ingest_lib():
     import ctypes as C
@@ -447,21 +452,39 @@ class DTColumns:
         import sys
         if os.environ.get("TAOAMD_DEVICE_INGEST", "1") == "0":
             return None
-        # (a fresh process whose torch is still being imported on another
-        # thread keeps the host reader: loading the kernel library would wait
-        # for that import, the host's threads are done before it is)
-        if "torch" not in sys.modules:
-            return None
         try:
             if os.path.getsize(path) < cls.DEVICE_INGEST_MIN_BYTES:
                 return None
         except OSError:
             return None                 # (the host reader reports the missing file)
         from . import _lib
-        try:
-            hip = _lib.load()
-        except OSError:
-            return None
+        fresh = EARLY_HIP.get("event") is not None and not EARLY_HIP.get("torch_loaded")
+        if not fresh and "torch" not in sys.modules:
+            return None                 # (no torch, nobody starting the runtime: the host reader)
+        if fresh:
+            # A fresh process whose torch is still being imported on another
+            # thread: _lib.load() would wait for that import.  The drop-in CLI
+            # starts the HIP runtime beside it (EARLY_HIP: torch's own copy of
+            # the runtime, loaded first, so the kernel library binds to it) --
+            # then the library is loaded here without torch and the columns come
+            # back as host arrays; nobody started the runtime: the host reader.
+            ev = EARLY_HIP.get("event")
+            if ev is None:
+                return None
+            ev.wait()
+            if not EARLY_HIP.get("ok") or not os.path.exists(_lib.SO_PATH):
+                return None
+            hip = C.CDLL(_lib.SO_PATH)
+            for name in ("taoamd_json_pred_open", "taoamd_json_pred_count",
+                         "taoamd_json_pred_read", "taoamd_json_pred_close",
+                         "taoamd_last_error"):
+                fn = getattr(hip, name)
+                fn.restype, fn.argtypes = _lib.SIGNATURES[name]
+        else:
+            try:
+                hip = _lib.load()
+            except OSError:
+                return None
         err = C.create_string_buffer(512)
         status = C.c_int32(0)
         h = hip.taoamd_json_pred_open(os.fsencode(path), C.byref(status), err, 512, None)
@@ -470,27 +493,46 @@ class DTColumns:
                 return None
             raise RuntimeError("taoamd_json_pred_open: %s (%s)"
                                % (err.value.decode(), hip.taoamd_last_error().decode()))
-        import torch
+        cap = cls.DEVICE_INGEST_FLAG_CAP
+        flag, flag_at = np.zeros(cap, np.int64), np.zeros(cap, np.int64)
+        n_flag = C.c_int32(0)
+        out = t = dev = None
         try:
             n = hip.taoamd_json_pred_count(h)
-            dev = torch.device("cuda", torch.cuda.current_device())
-            i64, f64 = torch.int64, torch.float64
-            with torch.cuda.device(dev):
-                t = {"image_id": torch.empty(n, dtype=i64, device=dev),
-                     "category_id": torch.empty(n, dtype=i64, device=dev),
-                     "bbox": torch.empty((n, 4), dtype=f64, device=dev),
-                     "score": torch.empty(n, dtype=f64, device=dev),
-                     "track_id": torch.empty(n, dtype=i64, device=dev),
-                     "video_id": torch.empty(n, dtype=i64, device=dev)}
-                torch.cuda.current_stream().synchronize()
-                cap = cls.DEVICE_INGEST_FLAG_CAP
-                flag, flag_at = np.zeros(cap, np.int64), np.zeros(cap, np.int64)
-                n_flag = C.c_int32(0)
-                _lib.check(hip.taoamd_json_pred_convert(
-                    h, t["image_id"].data_ptr(), t["category_id"].data_ptr(),
-                    t["bbox"].data_ptr(), t["score"].data_ptr(), t["track_id"].data_ptr(),
-                    t["video_id"].data_ptr(), flag.ctypes.data, flag_at.ctypes.data, cap,
-                    C.byref(n_flag)), "taoamd_json_pred_convert")
+            if fresh:
+                i64, f64 = np.int64, np.float64
+                out = cls(image_id=np.empty(n, i64), category_id=np.empty(n, i64),
+                          bbox=np.empty((n, 4), f64), score=np.empty(n, f64),
+                          track_id=np.empty(n, i64), video_id=np.empty(n, i64))
+                rc = hip.taoamd_json_pred_read(
+                    h, out.image_id.ctypes.data, out.category_id.ctypes.data,
+                    out.bbox.ctypes.data, out.score.ctypes.data, out.track_id.ctypes.data,
+                    out.video_id.ctypes.data, flag.ctypes.data, flag_at.ctypes.data, cap,
+                    C.byref(n_flag))
+                if rc:
+                    raise RuntimeError("taoamd_json_pred_read: status %d (%s)"
+                                       % (rc, hip.taoamd_last_error().decode()))
+            else:
+                import torch
+                dev = torch.device("cuda", torch.cuda.current_device())
+                i64, f64 = torch.int64, torch.float64
+                with torch.cuda.device(dev):
+                    try:
+                        t = {"image_id": torch.empty(n, dtype=i64, device=dev),
+                             "category_id": torch.empty(n, dtype=i64, device=dev),
+                             "bbox": torch.empty((n, 4), dtype=f64, device=dev),
+                             "score": torch.empty(n, dtype=f64, device=dev),
+                             "track_id": torch.empty(n, dtype=i64, device=dev),
+                             "video_id": torch.empty(n, dtype=i64, device=dev)}
+                    except torch.cuda.OutOfMemoryError:
+                        return None     # (no room for the columns: the host reader)
+                    torch.cuda.current_stream().synchronize()
+                    _lib.check(hip.taoamd_json_pred_convert(
+                        h, t["image_id"].data_ptr(), t["category_id"].data_ptr(),
+                        t["bbox"].data_ptr(), t["score"].data_ptr(),
+                        t["track_id"].data_ptr(), t["video_id"].data_ptr(),
+                        flag.ctypes.data, flag_at.ctypes.data, cap, C.byref(n_flag)),
+                        "taoamd_json_pred_convert")
         finally:
             # (the text, the tables and the mapping are released off the
             # caller's path: 0.04 s at 30 M predictions)
@@ -500,12 +542,16 @@ class DTColumns:
         if n_flag.value > cap:
             return None
         if n_flag.value == 0:
+            if out is not None:
+                out.first, out.total = 0, n
+                return out
             # the columns stay where they were made: the table builds read
             # them there, the host arrays arrive in the background
             return DeviceDTColumns(n, t, dev)
         # some objects are the host reader's: plain host columns, patched
-        out = cls(**{f: t[f].cpu().numpy() for f in cls.FIELDS})
-        del t
+        if out is None:
+            out = cls(**{f: t[f].cpu().numpy() for f in cls.FIELDS})
+            del t
         k = n_flag.value
         order = np.argsort(flag[:k], kind="stable")
         idx = np.ascontiguousarray(flag[:k][order])

@@ -513,6 +513,23 @@ int copy_threads()
 
 }  // namespace
 
+// (no room for the text or a table in HBM: the host reader's file, not an error)
+#define JS_ALLOC(call)                                                 \
+    do {                                                               \
+        hipError_t e_ = (call);                                        \
+        if (e_ == hipErrorOutOfMemory || e_ == hipErrorMemoryAllocation) { \
+            (void)hipGetLastError();                                   \
+            *status = TAOAMD_JSON_FALLBACK;                            \
+            return nullptr;                                            \
+        }                                                              \
+        if (e_ != hipSuccess) {                                        \
+            taoamd::set_error(e_, #call);                              \
+            js_msg(err, errlen, std::string("HIP: ") + #call);         \
+            *status = TAOAMD_ERR_HIP;                                  \
+            return nullptr;                                            \
+        }                                                              \
+    } while (0)
+
 #define JS_HIP(call)                                                   \
     do {                                                               \
         hipError_t e_ = (call);                                        \
@@ -577,7 +594,7 @@ extern "C" void *taoamd_json_pred_open(const char *path, int32_t *status, char *
     const int32_t n_blk = (int32_t)n_blk64;
     const size_t padded = (size_t)n_blk * JS_BLK;
     const double tm0 = now();
-    JS_HIP(hipMalloc(&h->d_text, padded + 64));
+    JS_ALLOC(hipMalloc(&h->d_text, padded + 64));
     if (timing) fprintf(stderr, "taoamd ingest (device): hipMalloc of the text %.3f s\n", now() - tm0);
     // the text travels in slices, by several threads (the file's pages are
     // mapped on first touch: the copying threads' own faults)
@@ -599,7 +616,7 @@ extern "C" void *taoamd_json_pred_open(const char *path, int32_t *status, char *
     const double t1 = now();
     // per-block tables: parity, depth change, object count, their prefix sums
     int32_t *tab = nullptr;
-    JS_HIP(hipMalloc(&tab, ((size_t)n_blk * 6 + 8) * sizeof(int32_t)));
+    JS_ALLOC(hipMalloc(&tab, ((size_t)n_blk * 6 + 8) * sizeof(int32_t)));
     struct Free {
         void *p;
         ~Free() { (void)hipFree(p); }
@@ -639,7 +656,7 @@ extern "C" void *taoamd_json_pred_open(const char *path, int32_t *status, char *
     }
     h->n = res[0];
     if (h->n > 0) {
-        JS_HIP(hipMalloc(&h->d_starts, (size_t)h->n * 8));
+        JS_ALLOC(hipMalloc(&h->d_starts, (size_t)h->n * 8));
         a.starts = h->d_starts;
         js_walk_kernel<2><<<n_blk, JS_T, 0, h->s>>>(a);
         JS_HIP(hipGetLastError());

@@ -318,8 +318,16 @@ def _early_hip_init():
         hip.hipSetDevice(0)
         hip.hipFree(None)               # creates the primary context
         _EARLY["hip_s"] = time.perf_counter() - t
+        _EARLY["ok"] = True
     except Exception:
         pass
+    finally:
+        # (the prediction reader waits for this before it loads the kernel
+        # library without torch: columns.DTColumns._from_file_device)
+        from tao_amodal_amd import columns
+        columns.EARLY_HIP["ok"] = bool(_EARLY.get("ok"))
+        if columns.EARLY_HIP.get("event") is not None:
+            columns.EARLY_HIP["event"].set()
 
 
 def _warm_device(pred_path=None):
@@ -438,8 +446,20 @@ def main(argv=None):
                 from tao_amodal_amd import flatten as fl
                 lib = fl._host_lib()
                 q = lib.taoamd_host_threads() - 1 if lib else 0
+                early = not os.environ.get("TAOAMD_NO_EARLY_HIP")
                 if q >= 7:
                     teams = (q - q // 3, q // 3)        # (predictions, annotations)
+                    if early and os.environ.get("TAOAMD_DEVICE_INGEST", "1") != "0":
+                        # the prediction file is read on the device once the HIP
+                        # runtime is up (started below, beside the import): the
+                        # cores go to the annotation reader
+                        teams = (q // 3, q - q // 3)
+                if early:
+                    # (before the readers start: the prediction reader waits for
+                    # the runtime, then loads the kernel library without torch)
+                    from tao_amodal_amd import columns as _columns
+                    _columns.EARLY_HIP["event"] = threading.Event()
+                    threading.Thread(target=_early_hip_init, daemon=True).start()
             dt_future = pool.submit(capped, teams[0], DTColumns.from_json, args.track_result)
 
             def read_annotation():
@@ -448,10 +468,10 @@ def main(argv=None):
                 return gt
             if cold:
                 gt_future = pool.submit(capped, teams[1], read_annotation)
-                if not os.environ.get("TAOAMD_NO_EARLY_HIP"):
-                    threading.Thread(target=_early_hip_init, daemon=True).start()
                 with timed("parse:import_torch"):
                     import torch  # noqa: F401
+                from tao_amodal_amd import columns as _columns
+                _columns.EARLY_HIP["torch_loaded"] = True
                 threading.Thread(target=_warm_device, args=(args.track_result,),
                                  daemon=True).start()
                 with timed("parse:annotation"):
