@@ -783,9 +783,12 @@ extern "C" int taoamd_track_iou_planned(int64_t n_tasks, const int32_t *tasks,
         !trk_meta || !iou)
         return TAOAMD_ERR_ARG;
     unsigned long long *pf = (unsigned long long *)pair_frames;
+    // (TAOAMD_TT_LDS_PAD: unused dynamic LDS per task, i.e. fewer tasks per CU --
+    // a schedule experiment: room for the other level's workgroups beside this kernel)
+    static const unsigned lds_pad = getenv("TAOAMD_TT_LDS_PAD") ? (unsigned)atoi(getenv("TAOAMD_TT_LDS_PAD")) : 0u;
 #define TT_LAUNCH(M)                                                           \
     TAO_TIMED("track_iou_task_kernel", s,                                      \
-              track_iou_task_kernel<M><<<(unsigned)n_tasks, 192, 0, s>>>(       \
+              track_iou_task_kernel<M><<<(unsigned)n_tasks, 192, lds_pad, s>>>( \
                   (const int4 *)tasks, task_rows, task_pairs, task_out,        \
                   (const double4 *)frames, task_base, (const int4 *)trk_meta, iou, pf))
     if (mode == 0) TT_LAUNCH(0);
