@@ -338,6 +338,27 @@ def pmc_traffic(kernel, variant, grid, workload):
     return None
 
 
+def hbm_delivers():
+    """What HBM was MEASURED to deliver on an MI355X (tools/hbm_rates.hip, the
+    newest profiles/*_hbm_rates.txt): context for the 8 TB/s the roofline
+    fractions are taken against, never their denominator."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_rates.txt")))
+    if not files:
+        return None
+    best = {}
+    for line in open(files[-1]):
+        m = re.match(r"(read|write|copy)\s.*\s([0-9.]+) TB/s", line)
+        if m:
+            best[m.group(1)] = max(best.get(m.group(1), 0.0), float(m.group(2)) * 1000.0)
+    if not best:
+        return None
+    return dict({k + "_GBs": v for k, v in best.items()},
+                source=os.path.relpath(files[-1], ROOT) + " (tools/hbm_rates.hip: best of "
+                "1-8 KB pieces in sequence / shuffled, 2 GiB working sets)")
+
+
 def wallclock_leg(gt, dt):
     """tools/eval_on_tao_amodal.py (the plugin surface) on the workload written
     out as prediction.json / annotation JSON: total seconds and the parse /
@@ -920,6 +941,7 @@ def main():
             "timed_region_s": round(elapsed, 4),
             "roofline": roof, "roofline_other": roof_other,
             "step_roofline": step_roof,
+            "hbm_delivers": hbm_delivers(),
             "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all,
             "kernels_ms": kernels_ms,
             "kernels_alone_ms": {k: round(t / c, 4) for k, (t, c) in alone.items()},
