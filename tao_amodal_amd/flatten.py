@@ -642,18 +642,14 @@ def video_images(gt):
     return gt.img_id[by_vid]
 
 
-def tao_gt_side(gt, visit_universe=None):
-    """Ground-truth half of the track-level tables (T/tao.py:108-254): merged
-    categories, sorted unique ids and dataset rows (dict semantics: last one
-    wins), the per-video timeline, the CPython-set visiting order of the
-    images, and the ground-truth tracks (selected annotations grouped by
-    track in first-appearance order, frame order inside).
-
-    ``visit_universe``: when ``gt`` is one rank's share of a larger ground
-    truth (by-video partition), the image ids of the WHOLE ground truth in
-    video_images() order -- the iteration order of a CPython set depends on
-    everything in it, so the visiting order must come from the full set."""
-    # ---- category merge (GT annotations + tracks + predictions)
+def tao_gt_universe(gt, visit_universe=None):
+    """The part of tao_gt_side that does not look at the annotations or the
+    tracks: the category merge map, sorted unique ids and dataset rows of
+    videos / categories / images, the per-video timeline and the CPython-set
+    visiting order of the images.  What the prediction side of the track-level
+    tables needs first -- the drop-in CLI builds it ahead of the (three times
+    longer) annotation part, which the device build only meets at its
+    federated filter (flatten_dev.flatten_tao_device)."""
     merge_src = gt.cat_merged[:, 0] if len(gt.cat_merged) else \
         np.zeros(0, np.int64)
     merge_dst = gt.cat_merged[:, 1] if len(gt.cat_merged) else \
@@ -664,13 +660,6 @@ def tao_gt_side(gt, visit_universe=None):
     keep_last = np.r_[ms[1:] != ms[:-1], True] if len(ms) else np.zeros(0, bool)
     ms, md = ms[keep_last], md[keep_last]
 
-    def merged(c):
-        j = _lookup(ms, c)
-        return np.where(j >= 0, md[np.maximum(j, 0)], c) if len(ms) else c
-
-    ann_cat = merged(gt.ann_cat)
-    trk_cat = merged(gt.trk_cat)
-
     vid_ids = np.unique(gt.vid_id)
     cat_ids = np.unique(gt.cat_id)
     img_ids = np.unique(gt.img_id)
@@ -679,20 +668,6 @@ def tao_gt_side(gt, visit_universe=None):
     vid_row[_lookup(vid_ids, gt.vid_id)] = np.arange(len(gt.vid_id))
     img_row = np.full(len(img_ids), -1, dtype=np.int64)
     img_row[_lookup(img_ids, gt.img_id)] = np.arange(len(gt.img_id))
-    # T/tao.py:148-149
-    trow = np.full(len(gt.trk_id), -1, dtype=np.int64)
-    t_sorted = np.argsort(gt.trk_id, kind="stable")
-    t_keys = gt.trk_id[t_sorted]
-    # dict semantics: last track with an id wins
-    t_last = np.r_[t_keys[1:] != t_keys[:-1], True] if len(t_keys) else \
-        np.zeros(0, bool)
-    t_keys_u, t_rows_u = t_keys[t_last], t_sorted[t_last]
-    a_trow = _lookup(t_keys_u, gt.ann_trk)
-    if (a_trow < 0).any():
-        raise KeyError(int(gt.ann_trk[np.flatnonzero(a_trow < 0)[0]]))
-    a_trow = t_rows_u[a_trow]
-    assert np.array_equal(ann_cat, trk_cat[a_trow]), \
-        "annotation/track category mismatch"
 
     # ---- per-video timeline position of every image: (frame_index, id)
     img_vid_idx = _lookup(vid_ids, gt.img_vid[img_row])
@@ -716,7 +691,50 @@ def tao_gt_side(gt, visit_universe=None):
     visit_rank = np.full(len(img_ids), -1, dtype=np.int64)
     mine = np.flatnonzero((at >= 0) & np.isin(visit, own_images))
     visit_rank[at[mine]] = np.arange(len(mine))
+    A = Flat()
+    for k, v in list(locals().items()):
+        if k not in ("A", "gt", "visit_universe") and not k.startswith("_"):
+            A[k] = v
+    return A
 
+
+def tao_gt_side(gt, visit_universe=None, universe=None):
+    """Ground-truth half of the track-level tables (T/tao.py:108-254): merged
+    categories, sorted unique ids and dataset rows (dict semantics: last one
+    wins), the per-video timeline, the CPython-set visiting order of the
+    images, and the ground-truth tracks (selected annotations grouped by
+    track in first-appearance order, frame order inside).
+
+    ``visit_universe``: when ``gt`` is one rank's share of a larger ground
+    truth (by-video partition), the image ids of the WHOLE ground truth in
+    video_images() order -- the iteration order of a CPython set depends on
+    everything in it, so the visiting order must come from the full set.
+    ``universe``: tao_gt_universe(gt, visit_universe) built ahead of time."""
+    A = universe if universe is not None else tao_gt_universe(gt, visit_universe)
+    ms, md = A.ms, A.md
+    vid_ids, cat_ids, img_ids, img_row = A.vid_ids, A.cat_ids, A.img_ids, A.img_row
+    visit_rank = A.visit_rank
+
+    def merged(c):
+        j = _lookup(ms, c)
+        return np.where(j >= 0, md[np.maximum(j, 0)], c) if len(ms) else c
+
+    ann_cat = merged(gt.ann_cat)
+    trk_cat = merged(gt.trk_cat)
+    # T/tao.py:148-149
+    trow = np.full(len(gt.trk_id), -1, dtype=np.int64)
+    t_sorted = np.argsort(gt.trk_id, kind="stable")
+    t_keys = gt.trk_id[t_sorted]
+    # dict semantics: last track with an id wins
+    t_last = np.r_[t_keys[1:] != t_keys[:-1], True] if len(t_keys) else \
+        np.zeros(0, bool)
+    t_keys_u, t_rows_u = t_keys[t_last], t_sorted[t_last]
+    a_trow = _lookup(t_keys_u, gt.ann_trk)
+    if (a_trow < 0).any():
+        raise KeyError(int(gt.ann_trk[np.flatnonzero(a_trow < 0)[0]]))
+    a_trow = t_rows_u[a_trow]
+    assert np.array_equal(ann_cat, trk_cat[a_trow]), \
+        "annotation/track category mismatch"
 
     a_img = _lookup(img_ids, gt.ann_img)
     g_sel = _tao_select(visit_rank, a_img, _lookup(cat_ids, ann_cat), gt.ann_area,
@@ -743,8 +761,10 @@ def tao_gt_side(gt, visit_universe=None):
     if (g_vid < 0).any():
         raise KeyError("track refers to an unknown video")
     T = Flat()
+    T.update(A)
     for k, v in list(locals().items()):
-        if k not in ("T", "gt", "merged") and not k.startswith("_"):
+        if k not in ("T", "A", "gt", "merged", "universe", "visit_universe") \
+                and not k.startswith("_"):
             T[k] = v
     return T
 

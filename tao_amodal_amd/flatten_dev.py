@@ -205,7 +205,7 @@ def _cells_from_runs(lib, dev, n_keep, dt_key, gkeys_sorted, keys_g):
 # ---------------------------------------------------------------------------
 # ground-truth halves, buildable before the predictions are there: prepare.py
 # (no torch there -- the CLI builds them while torch is still being imported)
-from .prepare import (_gt_key, _gt_ready, _lvis_gt_ready, _READY,   # noqa: E402,F401
+from .prepare import (_gt_key, _gt_ready, _gt_universe, _lvis_gt_ready, _READY,   # noqa: E402,F401
                       _tao_gt_ready, prepare_gt)
 
 
@@ -343,9 +343,17 @@ def flatten_tao_device(gt, dt, device="cuda", max_dets=MAX_DETS,
     dev = torch.device(device)
     # (a rank's share of the annotation file takes its visiting order from the
     # whole set: never prepared ahead)
-    ready = _gt_ready(gt, "tao") if visit_universe is None \
-        else _tao_gt_ready(gt, visit_universe)
-    T, keys_g, gkeys, img_frame = ready.T, ready.keys_g, ready.gkeys, ready.img_frame
+    # Round 6: when the ground-truth half is being built in the background in
+    # two stages (prepare_gt), the prediction side starts with the first --
+    # ids, timeline, visiting order -- and meets the annotation part (`ready`)
+    # at the federated filter, by when it is there.
+    ready = None
+    T = _gt_universe(gt) if visit_universe is None else None
+    if T is None:
+        ready = _gt_ready(gt, "tao") if visit_universe is None \
+            else _tao_gt_ready(gt, visit_universe)
+        T = ready.T
+    img_frame = gt.img_frame[T.img_row]
     vid_ids, cat_ids, img_ids = T.vid_ids, T.cat_ids, T.img_ids
     U, K, NI, n = len(vid_ids), len(cat_ids), len(img_ids), len(dt)
     tid_host = np.ascontiguousarray(dt.track_id, dtype=np.int64)
@@ -502,6 +510,10 @@ def flatten_tao_device(gt, dt, device="cuda", max_dets=MAX_DETS,
             _ptr(sel_frames), _ptr(sel_first_p), _stream()), "taoamd_flat_track_sel")
 
         # ---- federated filter, track order
+        if ready is None:
+            ready = _gt_ready(gt, "tao")     # (the annotation part: waits for it)
+            T = ready.T
+        keys_g, gkeys = ready.keys_g, ready.gkeys
         key, flags = new(R, torch.int32), new(R, torch.uint8)
         n_keep_t = new(1, torch.int32)
         _lib.check(lib.taoamd_flat_track_filter(

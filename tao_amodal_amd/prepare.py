@@ -43,9 +43,10 @@ def _lvis_gt_ready(gt):
     return R
 
 
-def _tao_gt_ready(gt, visit_universe=None):
-    """The same for the track level."""
-    T = flatten.tao_gt_side(gt, visit_universe)
+def _tao_gt_ready(gt, visit_universe=None, universe=None):
+    """The same for the track level (``universe``: flatten.tao_gt_universe built
+    ahead of the annotation part)."""
+    T = flatten.tao_gt_side(gt, visit_universe, universe)
     U = len(T.vid_ids)
     keys_g = T.g_cat * U + T.g_vid
     og = flatten.sort_key_score(keys_g)
@@ -91,19 +92,52 @@ def prepare_gt(gt, kinds=("lvis", "tao"), wait=True):
     # (numpy's sorts, searches and gathers run without the GIL: the two
     # levels' halves side by side)
     from concurrent.futures import ThreadPoolExecutor
-    pool = ThreadPoolExecutor(max_workers=max(len(kinds), 1))
-    made = {k: pool.submit(build, k) for k in kinds}
+    pool = ThreadPoolExecutor(max_workers=max(len(kinds), 1) + 1)
+    made, parts = {}, {}
+    for k in kinds:
+        if k == "tao":
+            # in two stages: what the prediction side of the device build needs
+            # first (ids, timeline, visiting order: no annotation looked at),
+            # then the three times longer annotation part, which that build
+            # only meets at its federated filter
+            def universe():
+                try:
+                    return flatten.tao_gt_universe(gt)
+                except Exception:
+                    return None
+            parts["tao_universe"] = ua = pool.submit(universe)
+
+            def rest(ua=ua):
+                try:
+                    return _tao_gt_ready(gt, universe=ua.result())
+                except Exception:
+                    return None
+            made[k] = pool.submit(rest)
+        else:
+            made[k] = pool.submit(build, k)
     pool.shutdown(wait=False)
-    vars(gt)["_prepared_gt"] = (_gt_key(gt), made)
+    vars(gt)["_prepared_gt"] = (_gt_key(gt), made, parts)
     if wait:
         for f in made.values():
             f.result()
 
 
+def _gt_universe(gt):
+    """flatten.tao_gt_universe(gt) if prepare_gt started it on these columns
+    (None otherwise: the caller takes the whole half from _gt_ready)."""
+    slot = vars(gt).get("_prepared_gt")
+    if slot is None:
+        return None
+    key, _made, parts = slot
+    fut = parts.pop("tao_universe", None)
+    A = fut.result() if fut is not None else None
+    return A if A is not None and key == _gt_key(gt) else None
+
+
 def _gt_ready(gt, kind):
     slot = vars(gt).get("_prepared_gt")
     if slot is not None:
-        key, made = slot
+        key, made, _parts = slot
         R = made.pop(kind, None)
         if not made:
             vars(gt).pop("_prepared_gt", None)

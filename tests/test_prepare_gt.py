@@ -24,7 +24,7 @@ def test_bundles_equal_a_fresh_build_and_are_single_use():
     gt, _ = synth(seed=4, V=5, F=12, C=9, dets_per_frame=6, n_present=4)
     flatten_dev.prepare_gt(gt)
     for kind in ("lvis", "tao"):
-        key, made = vars(gt)["_prepared_gt"]
+        key, made, _parts = vars(gt)["_prepared_gt"]
         stored = made[kind].result()
         got = flatten_dev._gt_ready(gt, kind)
         assert got is stored
@@ -72,3 +72,28 @@ def test_halves_built_in_the_background_are_waited_for():
         assert fut.done() and got is fut.result()
         _same(got, flatten_dev._READY[kind](gt))
     assert "_prepared_gt" not in vars(gt)
+
+
+def test_the_track_level_half_in_two_stages():
+    """prepare_gt builds the track level's half as tao_gt_universe (no
+    annotation looked at) and the rest on top of it: the same tables as in one
+    piece, the first stage handed out ahead of the whole."""
+    gt, _ = synth(seed=4, V=5, F=12, C=9, dets_per_frame=6, n_present=4)
+    whole = flatten.tao_gt_side(gt)
+    A = flatten.tao_gt_universe(gt)
+    staged = flatten.tao_gt_side(gt, universe=A)
+    assert set(whole.keys()) == set(staged.keys())
+    for k in whole:
+        assert np.array_equal(np.asarray(whole[k]), np.asarray(staged[k])), k
+    flatten_dev.prepare_gt(gt, wait=False)
+    U = flatten_dev._gt_universe(gt)
+    assert U is not None and np.array_equal(U.visit_rank, A.visit_rank)
+    assert flatten_dev._gt_universe(gt) is None            # single use
+    R = flatten_dev._gt_ready(gt, "tao")
+    _same(R, flatten_dev._tao_gt_ready(gt))
+    flatten_dev._gt_ready(gt, "lvis")
+    assert "_prepared_gt" not in vars(gt)
+    # a rebound column: the universe of the old columns is not handed out
+    flatten_dev.prepare_gt(gt, wait=False)
+    gt.img_frame = gt.img_frame.copy()
+    assert flatten_dev._gt_universe(gt) is None
