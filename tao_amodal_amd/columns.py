@@ -697,6 +697,25 @@ class DeviceDTColumns(DTColumns):
         self._fp.pop(f, None)
         self._ready[f].set()
 
+    def track_clash_free(self):
+        """Whether every track id occurs with ONE video id (what
+        make_track_ids_unique asks first, tools/eval_on_tao_amodal.py:44-58),
+        answered where the columns were made: a table of the id's video, every
+        row against it.  None: not answerable here (a column replaced, ids
+        negative or in too wide a range) -- the host statement decides."""
+        import torch
+        cols = self.device_columns(self._device, ("track_id", "video_id"))
+        if cols is None or self._n == 0:
+            return None
+        tid, vid = cols["track_id"], cols["video_id"]
+        with torch.cuda.device(self._device):
+            lo, hi = int(tid.min()), int(tid.max())
+            if lo < 0 or hi >= (1 << 26):
+                return None
+            table = torch.empty(hi + 1, dtype=torch.int64, device=self._device)
+            table[tid] = vid                    # (some row's video per id)
+            return not bool((table[tid] != vid).any())
+
     def device_columns(self, device, names):
         """{name: tensor} of the columns as they were made, when they still
         are what the host arrays hold (None: upload the host arrays)."""

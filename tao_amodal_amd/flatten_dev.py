@@ -356,9 +356,19 @@ def flatten_tao_device(gt, dt, device="cuda", max_dets=MAX_DETS,
     img_frame = gt.img_frame[T.img_row]
     vid_ids, cat_ids, img_ids = T.vid_ids, T.cat_ids, T.img_ids
     U, K, NI, n = len(vid_ids), len(cat_ids), len(img_ids), len(dt)
-    tid_host = np.ascontiguousarray(dt.track_id, dtype=np.int64)
+    # (columns made on the device bring their track ids along: no wait for the
+    # host array, no upload)
+    born = getattr(dt, "device_columns", None)
+    tid_dev = born(dev, ("track_id",)) if born is not None else None
+    if tid_dev is not None:
+        tid_dev = tid_dev["track_id"]
+        with torch.cuda.device(dev):
+            tid_lo, tid_hi = int(tid_dev.min()), int(tid_dev.max())
+    else:
+        tid_host = np.ascontiguousarray(dt.track_id, dtype=np.int64)
+        tid_lo, tid_hi = int(tid_host.min()), int(tid_host.max())
     if U == 0 or K == 0 or K * U >= 2 ** 31 - 1 or n >= 2 ** 31 - 1 or \
-            int(tid_host.min()) < 0 or int(tid_host.max()) >= 2 ** 62:
+            tid_lo < 0 or tid_hi >= 2 ** 62:
         raise Unsupported("keys do not fit")
 
     def reject():
@@ -376,7 +386,8 @@ def flatten_tao_device(gt, dt, device="cuda", max_dets=MAX_DETS,
             hold.append(torch.from_numpy(np.ascontiguousarray(a, dtype=t)).to(dev))
             return hold[-1]
         new = lambda m, t: torch.empty(max(int(m), 1), dtype=t, device=dev)
-        tid = up(tid_host, np.int64)        # (not cached: make_track_ids_unique rewrites it)
+        # (not cached: make_track_ids_unique rewrites it)
+        tid = tid_dev if tid_dev is not None else up(tid_host, np.int64)
         d_img, d_cat0 = new(n, torch.int32), new(n, torch.int32)
         d_area = new(n, torch.float64)
         img_count, img_start = new(NI + 1, torch.int32), new(NI + 1, torch.int32)
@@ -420,7 +431,7 @@ def flatten_tao_device(gt, dt, device="cuda", max_dets=MAX_DETS,
 
         # ---- tracks: runs of the boxes sorted by track id
         lo, hi = new(n, torch.int32), None
-        wide = int(tid_host.max()) >= 2 ** 31
+        wide = tid_hi >= 2 ** 31
         if wide:
             hi = new(n, torch.int32)
         _lib.check(lib.taoamd_flat_split64(n, _ptr(tid), None, _ptr(lo), None,

@@ -199,3 +199,25 @@ def test_columns_stay_on_the_device_and_arrive_on_the_host(tmp_path):
     assert int(raw3["image_id"][0]) == int(c.image_id[0]) + 1
     t = e.take(np.arange(10))
     assert type(t) is DTColumns and (t.score == c.score[:10]).all()
+
+
+def test_track_clash_answered_on_the_device(tmp_path):
+    from tao_amodal_amd.columns import DeviceDTColumns
+    from tao_amodal_amd import flatten
+    c = synth_columns(60000, 11)
+    c.track_id = c.track_id % 500                   # (every id on ~120 rows)
+    c.video_id = c.track_id % 7                     # one video per track id
+    p = str(tmp_path / "a.json")
+    c.write_json(p)
+    d = DTColumns.from_file_native(p)
+    assert isinstance(d, DeviceDTColumns) and d.track_clash_free() is True
+    assert flatten.make_track_ids_unique(d)[1] == 0
+    c.video_id = c.video_id.copy()
+    c.video_id[123] += 1                            # that id now has two videos
+    p = str(tmp_path / "b.json")
+    c.write_json(p)
+    d = DTColumns.from_file_native(p)
+    assert d.track_clash_free() is False
+    assert flatten.make_track_ids_unique(d)[1] == 1
+    d.track_id = d.track_id.copy()                  # a replaced column: the host decides
+    assert d.track_clash_free() is None

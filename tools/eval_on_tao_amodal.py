@@ -72,6 +72,12 @@ def create_small_table(small_dict):
 
 def make_track_ids_unique(dt):
     """reference tools/eval_on_tao_amodal.py:44-66, on columns (in place)."""
+    ask = getattr(dt, "track_clash_free", None)
+    if ask is not None and ask():
+        # columns made on the device (columns.DeviceDTColumns): the usual answer
+        # -- no id is shared between videos, nothing to renumber -- comes from
+        # there, without waiting for the host arrays
+        return 0
     dt.track_id, n = flatten.make_track_ids_unique(dt)
     return n
 
