@@ -453,7 +453,9 @@ class DTColumns:
         if os.environ.get("TAOAMD_DEVICE_INGEST", "1") == "0":
             return None
         try:
-            if os.path.getsize(path) < cls.DEVICE_INGEST_MIN_BYTES:
+            least = int(os.environ.get("TAOAMD_DEVICE_INGEST_MIN_BYTES",
+                                       cls.DEVICE_INGEST_MIN_BYTES))
+            if os.path.getsize(path) < least:
                 return None
         except OSError:
             return None                 # (the host reader reports the missing file)

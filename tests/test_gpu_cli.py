@@ -199,3 +199,37 @@ def test_cli_serial_switch_gives_the_same_text(tmp_path, monkeypatch):
     assert buf.getvalue() == open(path("f5", "cli_stdout.txt")).read()
     got = log.read_text().replace(os.path.join(path("f5", "")), "<DIR>/")
     assert got == open(path("f5", "cli_log.txt")).read()
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_cli_text_with_the_prediction_file_read_on_the_device(name, tmp_path, monkeypatch):
+    """The reference's text again with the device-side reader taking files of
+    any size (csrc/json_ingest.hip; by default from 32 MB on): columns that
+    stay on the device through both levels' table builds, or the host reader
+    where the device reader steps aside."""
+    monkeypatch.setenv("TAOAMD_DEVICE_INGEST_MIN_BYTES", "0")
+    log = tmp_path / "out" / "eval.log"
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        _cli().main(["--track_result", path(name, "pred.json"), "--annotation",
+                     path(name, "gt.json"), "--output_log", str(log)])
+    assert buf.getvalue() == open(path(name, "cli_stdout.txt")).read()
+    want = open(path(name, "cli_log.txt")).read()
+    got = log.read_text().replace(os.path.join(path(name, "")), "<DIR>/")
+    assert got == want
+
+
+def test_cli_as_a_fresh_process_reads_on_the_device(tmp_path):
+    """A fresh process: the reader waits for the early HIP start, loads the
+    kernel library without torch and returns host arrays -- same text."""
+    import subprocess
+    import sys
+    name = FIXTURES[0]
+    env = dict(os.environ, TAOAMD_DEVICE_INGEST_MIN_BYTES="0", TAOAMD_INGEST_TIMING="1")
+    r = subprocess.run(
+        [sys.executable, os.path.join(ROOT, "tools", "eval_on_tao_amodal.py"),
+         "--track_result", path(name, "pred.json"), "--annotation", path(name, "gt.json"),
+         "--output_log", str(tmp_path / "eval.log")], env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout == open(path(name, "cli_stdout.txt")).read()
+    assert "taoamd ingest (device)" in r.stderr
