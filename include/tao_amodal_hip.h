@@ -845,7 +845,10 @@ int taoamd_exchange_place(int64_t n_recv, int32_t world, int32_t n_words,
  * to the host's (a backslash, an element that is not an object, text around the
  * list, an empty file): call the host reader (include/tao_amodal_ingest.h),
  * whose results and error messages are the contract; TAOAMD_ERR_ARG -- the file
- * cannot be opened (err says so); TAOAMD_ERR_HIP.
+ * cannot be opened (err says so); TAOAMD_ERR_HIP.  `work` (optional, device
+ * memory of taoamd_json_pred_workspace(file size) bytes, the caller's until
+ * taoamd_json_pred_close): the text, the tables and the objects' offsets live
+ * there instead of in memory the call allocates -- for callers with a pool.
  *
  * taoamd_json_pred_convert converts the objects (one thread each; decimal ->
  * double correctly rounded, csrc/decfloat.hpp) into the caller's DEVICE arrays of
@@ -858,8 +861,9 @@ int taoamd_exchange_place(int64_t n_recv, int32_t world, int32_t n_words,
  * rows are not written (taoamd_pred_patch of the host library fills them in
  * host arrays or reports the error).  More than flag_cap: use the host reader
  * for the file. */
-void *taoamd_json_pred_open(const char *path, int32_t *status, char *err, size_t errlen,
-                            void *stream);
+size_t taoamd_json_pred_workspace(size_t file_bytes);
+void *taoamd_json_pred_open(const char *path, void *work, size_t work_bytes,
+                            int32_t *status, char *err, size_t errlen, void *stream);
 int64_t taoamd_json_pred_count(void *handle);
 int taoamd_json_pred_convert(void *handle, int64_t *image_id, int64_t *category_id,
                              double *bbox, double *score, int64_t *track_id,

@@ -58,7 +58,8 @@ SIGNATURES = {
     "taoamd_track_iou_planned": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                            _i32, _vp, _vp, _vp]),
     "taoamd_track_stream": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "taoamd_json_pred_open": (_vp, [C.c_char_p, _vp, C.c_char_p, _sz, _vp]),
+    "taoamd_json_pred_workspace": (_sz, [_sz]),
+    "taoamd_json_pred_open": (_vp, [C.c_char_p, _vp, _sz, _vp, C.c_char_p, _sz, _vp]),
     "taoamd_json_pred_count": (_i64, [_vp]),
     "taoamd_json_pred_read": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                         _i32, _vp]),

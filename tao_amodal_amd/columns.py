@@ -477,7 +477,8 @@ class DTColumns:
             if not EARLY_HIP.get("ok") or not os.path.exists(_lib.SO_PATH):
                 return None
             hip = C.CDLL(_lib.SO_PATH)
-            for name in ("taoamd_json_pred_open", "taoamd_json_pred_count",
+            for name in ("taoamd_json_pred_open", "taoamd_json_pred_workspace",
+                         "taoamd_json_pred_count",
                          "taoamd_json_pred_read", "taoamd_json_pred_close",
                          "taoamd_last_error"):
                 fn = getattr(hip, name)
@@ -489,7 +490,23 @@ class DTColumns:
                 return None
         err = C.create_string_buffer(512)
         status = C.c_int32(0)
-        h = hip.taoamd_json_pred_open(os.fsencode(path), C.byref(status), err, 512, None)
+        work, work_ptr, work_bytes = None, None, 0
+        if not fresh:
+            # text, tables and object offsets in memory of torch's caching
+            # allocator (the CLI's warm-up keeps a block of the file's size
+            # there): a raw hipMalloc / hipFree of gigabytes takes 0.1 s and more
+            # in a process whose allocator already holds most of what it uses
+            import torch
+            try:
+                work_bytes = int(hip.taoamd_json_pred_workspace(os.path.getsize(path)))
+                work = torch.empty(work_bytes, dtype=torch.uint8,
+                                   device=torch.device("cuda", torch.cuda.current_device()))
+                torch.cuda.current_stream().synchronize()
+                work_ptr = work.data_ptr()
+            except (torch.cuda.OutOfMemoryError, OSError):
+                work, work_ptr, work_bytes = None, None, 0
+        h = hip.taoamd_json_pred_open(os.fsencode(path), work_ptr, work_bytes,
+                                      C.byref(status), err, 512, None)
         if not h:
             if status.value == _lib.JSON_FALLBACK or status.value == _lib.ERR_ARG:
                 return None
@@ -539,8 +556,11 @@ class DTColumns:
             # (the text, the tables and the mapping are released off the
             # caller's path: 0.04 s at 30 M predictions)
             import threading
-            threading.Thread(target=hip.taoamd_json_pred_close, args=(h,),
-                             daemon=True).start()
+
+            def release(h=h, work=work):
+                hip.taoamd_json_pred_close(h)
+                del work                # (the workspace goes back to its pool after the handle)
+            threading.Thread(target=release, daemon=True).start()
         if n_flag.value > cap:
             return None
         if n_flag.value == 0:

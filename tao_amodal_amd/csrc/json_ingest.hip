@@ -409,14 +409,27 @@ struct JsHandle {
     const char *map = nullptr;
     size_t len = 0;
     uint8_t *d_text = nullptr, *d_cols = nullptr;
-    int64_t *d_starts = nullptr;
+    int64_t *d_starts = nullptr, *d_flag = nullptr;
+    bool own_text = true, own_starts = true;      // false: inside the caller's workspace
+    uint8_t *work = nullptr;                      // the caller's workspace, what is left of it
+    size_t work_left = 0;
     int64_t n = 0;
     hipStream_t s = nullptr;
+    // n bytes of the caller's workspace (256-byte aligned), nullptr when it has not got them
+    uint8_t *carve(size_t n_bytes)
+    {
+        const size_t need = (n_bytes + 255) & ~(size_t)255;
+        if (!work || work_left < need) return nullptr;
+        uint8_t *p = work;
+        work += need;
+        work_left -= need;
+        return p;
+    }
     ~JsHandle()
     {
-        if (d_text) (void)hipFree(d_text);
+        if (d_text && own_text) (void)hipFree(d_text);
         if (d_cols) (void)hipFree(d_cols);
-        if (d_starts) (void)hipFree(d_starts);
+        if (d_starts && own_starts) (void)hipFree(d_starts);
         if (map && len) munmap((void *)map, len);
     }
 };
@@ -543,14 +556,33 @@ int copy_threads()
 
 // status: 0 ok; TAOAMD_ERR_HIP; TAOAMD_ERR_ARG (cannot open: err says why);
 // TAOAMD_JSON_FALLBACK = the host reader should take the file
-extern "C" void *taoamd_json_pred_open(const char *path, int32_t *status, char *err,
-                                       size_t errlen, void *stream)
+// Device memory the reader wants for a file of file_bytes (text, per-block
+// tables, scratch, the objects' offsets for up to one object per 32 bytes): a
+// caller that allocates from a pool (torch's caching allocator) hands it to
+// taoamd_json_pred_open and spares the call its hipMalloc / hipFree -- in a
+// process whose allocator holds most of the device those take 0.1 s and more.
+extern "C" size_t taoamd_json_pred_workspace(size_t file_bytes)
+{
+    const size_t n_blk = (file_bytes + JS_BLK - 1) / JS_BLK;
+    return n_blk * JS_BLK + 256 + ((n_blk * 6 + 8) * 4 + 256) + (((size_t)2 << 16) + 256) +
+           (file_bytes / 32 + 1) * 8 + 1024;
+}
+
+extern "C" void *taoamd_json_pred_open(const char *path, void *work, size_t work_bytes,
+                                       int32_t *status, char *err, size_t errlen, void *stream)
 {
     int32_t dummy;
     if (!status) status = &dummy;
     *status = TAOAMD_OK;
     std::unique_ptr<JsHandle> h(new JsHandle);
     h->s = (hipStream_t)stream;
+    if (work && work_bytes) {
+        const uintptr_t a0 = ((uintptr_t)work + 255) & ~(uintptr_t)255;
+        if (a0 - (uintptr_t)work < work_bytes) {
+            h->work = (uint8_t *)a0;
+            h->work_left = work_bytes - (a0 - (uintptr_t)work);
+        }
+    }
     const bool timing = getenv("TAOAMD_INGEST_TIMING") != nullptr;
     auto now = [] { return std::chrono::duration<double>(
                         std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -593,9 +625,9 @@ extern "C" void *taoamd_json_pred_open(const char *path, int32_t *status, char *
     }
     const int32_t n_blk = (int32_t)n_blk64;
     const size_t padded = (size_t)n_blk * JS_BLK;
-    const double tm0 = now();
-    JS_ALLOC(hipMalloc(&h->d_text, padded + 64));
-    if (timing) fprintf(stderr, "taoamd ingest (device): hipMalloc of the text %.3f s\n", now() - tm0);
+    h->d_text = h->carve(padded + 64);
+    h->own_text = h->d_text == nullptr;
+    if (h->own_text) JS_ALLOC(hipMalloc(&h->d_text, padded + 64));
     // the text travels in slices, by several threads (the file's pages are
     // mapped on first touch: the copying threads' own faults)
     {
@@ -615,12 +647,16 @@ extern "C" void *taoamd_json_pred_open(const char *path, int32_t *status, char *
     JS_HIP(hipMemsetAsync(h->d_text + h->len, ' ', padded + 64 - h->len, h->s));
     const double t1 = now();
     // per-block tables: parity, depth change, object count, their prefix sums
-    int32_t *tab = nullptr;
-    JS_ALLOC(hipMalloc(&tab, ((size_t)n_blk * 6 + 8) * sizeof(int32_t)));
+    int32_t *tab = (int32_t *)h->carve(((size_t)n_blk * 6 + 8) * sizeof(int32_t));
     struct Free {
         void *p;
-        ~Free() { (void)hipFree(p); }
-    } free_tab{tab};
+        ~Free() { if (p) (void)hipFree(p); }
+    } free_tab{nullptr};
+    if (!tab) {
+        JS_ALLOC(hipMalloc(&tab, ((size_t)n_blk * 6 + 8) * sizeof(int32_t)));
+        free_tab.p = tab;
+    }
+    h->d_flag = (int64_t *)h->carve((size_t)2 << 16);
     int32_t *par = tab, *delta = par + n_blk, *count = delta + n_blk;
     int32_t *par_ex = count + n_blk, *depth_ex = par_ex + n_blk + 1,
             *count_ex = depth_ex + n_blk + 1;
@@ -656,7 +692,9 @@ extern "C" void *taoamd_json_pred_open(const char *path, int32_t *status, char *
     }
     h->n = res[0];
     if (h->n > 0) {
-        JS_ALLOC(hipMalloc(&h->d_starts, (size_t)h->n * 8));
+        h->d_starts = (int64_t *)h->carve((size_t)h->n * 8);
+        h->own_starts = h->d_starts == nullptr;
+        if (h->own_starts) JS_ALLOC(hipMalloc(&h->d_starts, (size_t)h->n * 8));
         a.starts = h->d_starts;
         js_walk_kernel<2><<<n_blk, JS_T, 0, h->s>>>(a);
         JS_HIP(hipGetLastError());
@@ -693,12 +731,15 @@ extern "C" int taoamd_json_pred_convert(void *handle, int64_t *image_id, int64_t
     auto now = [] { return std::chrono::duration<double>(
                         std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = now();
-    int64_t *d_flag = nullptr;
-    TAO_HIP(hipMalloc(&d_flag, (size_t)(2 * flag_cap + 1) * 8 + 64));
+    int64_t *d_flag = (size_t)(2 * flag_cap + 1) * 8 + 64 <= ((size_t)2 << 16) ? h->d_flag : nullptr;
     struct Free {
         void *p;
-        ~Free() { (void)hipFree(p); }
-    } free_flag{d_flag};
+        ~Free() { if (p) (void)hipFree(p); }
+    } free_flag{nullptr};
+    if (!d_flag) {
+        TAO_HIP(hipMalloc(&d_flag, (size_t)(2 * flag_cap + 1) * 8 + 64));
+        free_flag.p = d_flag;
+    }
     JsParseArgs a{};
     a.text = h->d_text;
     a.len = (int64_t)h->len;
