@@ -497,6 +497,8 @@ class DTColumns:
             # there): a raw hipMalloc / hipFree of gigabytes takes 0.1 s and more
             # in a process whose allocator already holds most of what it uses
             import torch
+            if not torch.cuda.is_available():
+                return None             # (no GPU in this process: the host reader)
             try:
                 work_bytes = int(hip.taoamd_json_pred_workspace(os.path.getsize(path)))
                 work = torch.empty(work_bytes, dtype=torch.uint8,
