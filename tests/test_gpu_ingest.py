@@ -221,3 +221,102 @@ def test_track_clash_answered_on_the_device(tmp_path):
     assert flatten.make_track_ids_unique(d)[1] == 1
     d.track_id = d.track_id.copy()                  # a replaced column: the host decides
     assert d.track_clash_free() is None
+
+
+def test_random_files_agree_with_the_host_reader_or_go_to_it(tmp_path):
+    """Fuzz: prediction lists with random spellings, spacing, key order, extra
+    and missing keys, literals and broken syntax.  The device reader either
+    steps aside (None) or returns exactly what the host reader returns; where
+    the host reader raises, the device reader must have stepped aside."""
+    import random
+    rng = random.Random(20240807)
+
+    def number(kind):
+        r = rng.random()
+        if kind == "id":
+            if r < 0.85:
+                return str(rng.randint(0, 10 ** rng.randint(1, 17)))
+            if r < 0.9:
+                return "-" + str(rng.randint(0, 1000))
+            if r < 0.95:
+                return "%d.0" % rng.randint(0, 1000)
+            return rng.choice(["1e3", "12.5", "007", "true", "null"])
+        if r < 0.5:
+            return repr(rng.uniform(-100, 2000))
+        if r < 0.65:
+            return str(rng.randint(-50, 2000))
+        if r < 0.8:
+            return "%.*f" % (rng.randint(1, 6), rng.uniform(0, 1))
+        if r < 0.9:
+            return repr(rng.uniform(0, 1) * 10.0 ** rng.randint(-12, 12))
+        return rng.choice(["NaN", "Infinity", "-Infinity", "true", "false", "null", "1e400",
+                           "0.12345678901234567890123", "1.", ".5", "1e", "0x10", "-0.0", "0",
+                           "-0", "5e-324", "1E+2"])
+
+    def ws():
+        return rng.choice(["", "", "", " ", "\n", "\t", "  ", " \r\n "])
+
+    def obj(plain=False):
+        fields = [("image_id", number("id")), ("category_id", number("id")),
+                  ("score", number("f")),
+                  ("bbox", "[" + ws() + ("," + ws()).join(number("f") for _ in range(
+                      4 if plain else rng.choice([4, 4, 4, 4, 4, 4, 3, 5, 0]))) + ws() + "]")]
+        if rng.random() < 0.7:
+            fields.append(("track_id", number("id")))
+        if rng.random() < 0.7:
+            fields.append(("video_id", number("id")))
+        if rng.random() < 0.2:
+            fields.append((rng.choice(["extra", "segmentation", "area", "name"]),
+                           rng.choice(['"text"', '{"a": [1, {"b": "}]"}], "c": null}', "[[1, 2], []]",
+                                       "12", "null", '"br{ace[s"', "true"])))
+        if rng.random() < 0.05 and not plain:
+            fields.pop(rng.randrange(len(fields)))               # a missing key
+        if rng.random() < 0.05:
+            fields.append(rng.choice(fields))                    # a key twice: the last one wins
+        rng.shuffle(fields)
+        sep = rng.choice([",", ", ", " ,\n"]) if plain or rng.random() < 0.98 else " "
+        body = sep.join('"%s"%s:%s%s' % (k, ws(), ws(), v) for k, v in fields)
+        return "{" + ws() + body + ws() + "}"
+
+    agreed = stepped_aside = 0
+    for case in range(300):
+        n = rng.choice([0, 1, 2, 5, 40, 300])
+        # (most files hold only plain objects: the device reader's own path)
+        plain = rng.random() < 0.6
+        if plain:
+            st = rng.getstate()
+        objs = []
+        for _ in range(n):
+            o = obj(plain)
+            if plain:
+                # keep drawing until the host reader would accept the object as plain
+                for _try in range(20):
+                    if not any(t in o for t in ("NaN", "Infinity", "true", "false", "null", "e400",
+                                                "1.,", ".5", "1e,", "0x", "007", "8901234567890123",
+                                                '1e"', "1e ", "1e]", "1e}")) \
+                            and all(k in o for k in ('"image_id"', '"category_id"', '"score"',
+                                                     '"bbox"')):
+                        break
+                    o = obj(plain)
+            objs.append(o)
+        text = ws() + "[" + ws() + ("," + ws()).join(objs) + ws() + "]" + ws()
+        if rng.random() < 0.03:
+            text = text.replace("]", "", 1)
+        p = str(tmp_path / ("f%d.json" % case))
+        with open(p, "w") as f:
+            f.write(text)
+        try:
+            want = host(p)
+        except Exception:
+            want = None
+        got = device(p)
+        if want is None:
+            assert got is None, (case, text[:300])
+            stepped_aside += 1
+            continue
+        if got is None:
+            stepped_aside += 1
+            continue
+        same(got, want)
+        agreed += 1
+    assert agreed >= 100 and stepped_aside >= 20, (agreed, stepped_aside)
