@@ -266,7 +266,7 @@ __device__ __forceinline__ void tt_barrier()
 // chunk took 2250 cycles for ~200 stager and ~160 adder instructions, two
 // wavefronts per SIMD, i.e. one dependent instruction every ~10 cycles: the
 // stager was the longer of the two chains).
-template <int S>
+template <int S, bool MASKS>
 __device__ __forceinline__ void tt_stager(
     const double4 *__restrict__ frames, int64_t sbase, double (*rows)[TT_ROWS * TT_RS],
     const int4 *meta, int32_t p_first, int n_chunks, int lane)
@@ -322,7 +322,8 @@ __device__ __forceinline__ void tt_stager(
             const bool ov = F[i] < pc + TT_P && L[i] >= pc;   // same for the row's lanes
             if (__ballot(ov) == 0) continue;
             const double4 bx = Bx[i];
-            const uint64_t ball = __ballot(bx.x != TT_FAR);
+            uint64_t ball = 0;
+            if (MASKS) ball = __ballot(bx.x != TT_FAR);
             if (ov) {
                 double *rb = rows[b] + r * TT_RS + j;
                 rb[0] = bx.x;
@@ -330,7 +331,7 @@ __device__ __forceinline__ void tt_stager(
                 rb[2 * TT_P] = bx.x + bx.z;
                 rb[3 * TT_P] = bx.y + bx.w;
                 rb[4 * TT_P] = bx.z * bx.w;
-                if (j == 0)     // positions of the chunk that hold a frame: the row's padding
+                if (MASKS && j == 0)     // positions of the chunk that hold a frame: the row's padding
                     *reinterpret_cast<uint32_t *>(rb + 5 * TT_P) =
                         (uint32_t)(ball >> (TT_P * grp)) & ((1u << TT_P) - 1);
             }
@@ -358,7 +359,12 @@ __device__ __forceinline__ void tt_stager(
 
 // (six wavefronts per SIMD: 78 instead of 84 VGPRs, no spill, and seven tasks
 // of 21.5 KB LDS per CU instead of six: 0.329 -> 0.314 ms at 2000 videos)
-template <int MODE>
+// COUNT: the pairs' common frames are counted (pair_frames).  The 3D IoU's
+// arithmetic needs no frame masks -- far boxes make absent frames exact -- so a
+// pass that does not count (every pass after a problem's first: the count is a
+// constant of the problem) keeps them out of the stagers and the adder: 5 % of
+// the kernel.
+template <int MODE, bool COUNT = true>
 __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(MODE == 2 ? 4 : 6, MODE == 2 ? 4 : 6))) void track_iou_task_kernel(
     const int4 *__restrict__ tasks, const int32_t *__restrict__ task_rows,
     const int32_t *__restrict__ task_pairs, const int64_t *__restrict__ task_out,
@@ -407,10 +413,11 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
 
     if (stager) {
         const int64_t sbase = (int64_t)task_base[blockIdx.x] * TT_P;
+        constexpr bool MASKS = MODE != 0 || COUNT;
         if (wave == 0)
-            tt_stager<0>(frames, sbase, rows, meta, p_first, n_chunks, lane);
+            tt_stager<0, MASKS>(frames, sbase, rows, meta, p_first, n_chunks, lane);
         else
-            tt_stager<1>(frames, sbase, rows, meta, p_first, n_chunks, lane);
+            tt_stager<1, MASKS>(frames, sbase, rows, meta, p_first, n_chunks, lane);
         return;
     }
 
@@ -482,8 +489,11 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
                 // two positions per 16-byte LDS read of every field
                 const double2 *__restrict__ d2 = reinterpret_cast<const double2 *>(dr);
                 const double2 *__restrict__ g2 = reinterpret_cast<const double2 *>(gr);
-                const uint32_t dm = *reinterpret_cast<const uint32_t *>(dr + 5 * TT_P);
-                const uint32_t gm = *reinterpret_cast<const uint32_t *>(gr + 5 * TT_P);
+                uint32_t dm = 0, gm = 0;
+                if (COUNT) {
+                    dm = *reinterpret_cast<const uint32_t *>(dr + 5 * TT_P);
+                    gm = *reinterpret_cast<const uint32_t *>(gr + 5 * TT_P);
+                }
 #pragma unroll
                 for (int pp = 0; pp < TT_P / 2; pp++) {
                     const double2 dx1 = d2[pp], gx1 = g2[pp];
@@ -508,7 +518,7 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
                         i += i_;
                     }
                 }
-                common += __popc(dm & gm);
+                if (COUNT) common += __popc(dm & gm);
             }
         } else {
             // avg_iou / imagenetvid: u = sum of per-frame scores, i = frames
@@ -545,7 +555,7 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(MODE == 2 ?
     }
     if (lane < n_pairs)       // (the place is fetched here: two registers less across the loop)
         iou[task_out[tk.z + lane]] = MODE == 0 ? (u > 0 ? i / u : 0.0) : u / i;
-    if (pair_frames != nullptr) {
+    if (COUNT && pair_frames != nullptr) {
         for (int s_ = WAVE / 2; s_ > 0; s_ >>= 1)
             common += __shfl_down(common, s_, WAVE);
         if (lane == 0 && common) atomicAdd(pair_frames, common);
@@ -791,7 +801,12 @@ extern "C" int taoamd_track_iou_planned(int64_t n_tasks, const int32_t *tasks,
               track_iou_task_kernel<M><<<(unsigned)n_tasks, 192, lds_pad, s>>>( \
                   (const int4 *)tasks, task_rows, task_pairs, task_out,        \
                   (const double4 *)frames, task_base, (const int4 *)trk_meta, iou, pf))
-    if (mode == 0) TT_LAUNCH(0);
+    if (mode == 0 && pf == nullptr)
+        TAO_TIMED("track_iou_task_kernel", s,
+                  (track_iou_task_kernel<0, false><<<(unsigned)n_tasks, 192, lds_pad, s>>>(
+                      (const int4 *)tasks, task_rows, task_pairs, task_out,
+                      (const double4 *)frames, task_base, (const int4 *)trk_meta, iou, pf)));
+    else if (mode == 0) TT_LAUNCH(0);
     else if (mode == 1) TT_LAUNCH(1);
     else TT_LAUNCH(2);
 #undef TT_LAUNCH
