@@ -274,56 +274,62 @@ __device__ __forceinline__ void tt_stager(
     constexpr int NR = (TT_ROUNDS - S + 1) / 2;      // my rounds
     const int grp = lane / TT_P, j = lane % TT_P;
     // lane (grp, j) serves position j of the rows grp, TT_GROUPS + grp, ...
-    int32_t F[NR], L[NR];
     uint32_t bit[NR];
 #pragma unroll
-    for (int i = 0; i < NR; i++) {
-        const int4 m = meta[TT_GROUPS * (S + 2 * i) + grp];
-        F[i] = m.x;
-        L[i] = m.y;
-        bit[i] = 1u << (TT_GROUPS * (S + 2 * i) + grp);
-    }
+    for (int i = 0; i < NR; i++) bit[i] = 1u << (TT_GROUPS * (S + 2 * i) + grp);
     // lanes 0 .. TT_SLOTS - 1: first / last of row = lane, for the chunk's
     // mask of present rows (one ballot per chunk, the same in both stagers)
     static_assert(TT_SLOTS <= 32, "one 32-bit mask of a task's rows");
     const int4 mrow = meta[lane & (TT_SLOTS - 1)];
     const bool row_has = lane < TT_SLOTS && mrow.y >= mrow.x;
-    int64_t cursor = sbase;           // first slot of the next chunk to be requested (uniform)
     // TT_SETS register sets: the loads of chunk k + TT_SETS are issued when
     // chunk k has been staged.  Every round loads (lanes out of range read
     // slot 0), so the number of loads in flight is known at compile time
     // and a chunk waits for ITS loads only (s_waitcnt vmcnt(n > 0)).
     double4 B[TT_SETS][NR];
+    // Round 6 (the stagers' instruction chain is the kernel's critical one):
+    // the mask of the rows present in a chunk is worked out ONCE, when the
+    // chunk's loads are issued, and kept with its register set -- staging tests
+    // "any row of this round" on the scalar unit and a lane's own bit with one
+    // AND; the loads take a 32-bit byte offset from the task's own stretch of
+    // the stream (a lane without a piece reads the stretch's first bytes: what
+    // it loads is never parked), no 64-bit address arithmetic per lane.
+    uint32_t pmv[TT_SETS];
+    const char *const tbase = reinterpret_cast<const char *>(frames + sbase);
+    uint32_t cur = 0;                 // bytes of the task's stretch requested so far (uniform)
+    const uint32_t joff = (uint32_t)j * 32u;
 
-    auto issue = [&](double4 *Bx, int32_t pc) {
+    auto issue = [&](double4 *Bx, uint32_t &pm_set, int32_t pc) {
         // rows whose span reaches into the chunk own a piece of TT_P slots in
         // the chunk's stretch of the stream, in row order
-        const uint32_t pm = (uint32_t)__ballot(row_has && mrow.x < pc + TT_P && mrow.y >= pc);
+        const uint32_t pm = (uint32_t)__builtin_amdgcn_ballot_w64(
+            row_has && mrow.x < pc + TT_P && mrow.y >= pc);
+        pm_set = pm;
 #pragma unroll
         for (int i = 0; i < NR; i++) {
-            const bool in = (pm & bit[i]) != 0;
-            const int64_t slot = cursor + (__popc(pm & (bit[i] - 1u)) * TT_P + j);
-#ifdef TT_ABLATE_LOADS     // (timing experiment: every load hits slot 0)
-            Bx[i] = frames[in ? 0 : 0];
+            const uint32_t off = cur + ((uint32_t)__popc(pm & (bit[i] - 1u)) << 8) + joff;
+#ifdef TT_ABLATE_LOADS     // (timing experiment: every load hits the stretch's first bytes)
+            Bx[i] = *reinterpret_cast<const double4 *>(tbase + ((pm & bit[i]) ? 0u : 0u));
 #elif defined(TT_ABLATE_CACHED)   // (timing experiment: the same requests inside 1 MB)
-            Bx[i] = frames[in ? (slot & 0x7fff) : 0];
+            Bx[i] = *reinterpret_cast<const double4 *>(tbase + ((pm & bit[i]) ? (off & 0xfffe0u) : 0u));
 #else
-            Bx[i] = frames[in ? slot : 0];          // slots 0 .. TT_P - 1: far boxes
+            Bx[i] = *reinterpret_cast<const double4 *>(tbase + ((pm & bit[i]) ? off : 0u));
 #endif
         }
-        cursor += __popc(pm) * TT_P;
+        cur += (uint32_t)__popc(pm) << 8;
     };
-    auto stage = [&](const double4 *Bx, int32_t pc, int b) {
+    auto stage = [&](const double4 *Bx, uint32_t pm, int b) {
         // A row is parked only where its span reaches into the chunk -- the one
         // case in which the adder reads it (it branches on the same test).
 #pragma unroll
         for (int i = 0; i < NR; i++) {
+            constexpr uint32_t ALL = (1u << TT_GROUPS) - 1u;
+            if ((pm & (ALL << (TT_GROUPS * (S + 2 * i)))) == 0) continue;     // (scalar)
             const int r = TT_GROUPS * (S + 2 * i) + grp;
-            const bool ov = F[i] < pc + TT_P && L[i] >= pc;   // same for the row's lanes
-            if (__ballot(ov) == 0) continue;
+            const bool ov = (pm & bit[i]) != 0;               // same for the row's lanes
             const double4 bx = Bx[i];
             uint64_t ball = 0;
-            if (MASKS) ball = __ballot(bx.x != TT_FAR);
+            if (MASKS) ball = __builtin_amdgcn_ballot_w64(bx.x != TT_FAR);
             if (ov) {
                 double *rb = rows[b] + r * TT_RS + j;
                 rb[0] = bx.x;
@@ -339,9 +345,9 @@ __device__ __forceinline__ void tt_stager(
     };
     // chunk c lives in register set c % TT_SETS and in LDS buffer c & 1
 #pragma unroll
-    for (int c = 0; c < TT_SETS; c++) issue(B[c], p_first + c * TT_P);
-    if (n_chunks > 0) stage(B[0], p_first, 0);
-    issue(B[0], p_first + TT_SETS * TT_P);
+    for (int c = 0; c < TT_SETS; c++) issue(B[c], pmv[c], p_first + c * TT_P);
+    if (n_chunks > 0) stage(B[0], pmv[0], 0);
+    issue(B[0], pmv[0], p_first + TT_SETS * TT_P);
     tt_barrier();
     for (int k = 0; k < n_chunks; k += TT_SETS) {
 #pragma unroll
@@ -350,8 +356,8 @@ __device__ __forceinline__ void tt_stager(
             // chunk k + a
             const int c = k + a;
             if (c - 1 >= n_chunks) break;
-            if (c < n_chunks) stage(B[a % TT_SETS], p_first + c * TT_P, a & 1);
-            issue(B[a % TT_SETS], p_first + (c + TT_SETS) * TT_P);
+            if (c < n_chunks) stage(B[a % TT_SETS], pmv[a % TT_SETS], a & 1);
+            issue(B[a % TT_SETS], pmv[a % TT_SETS], p_first + (c + TT_SETS) * TT_P);
             tt_barrier();
         }
     }

@@ -393,7 +393,8 @@ class DeviceProblem:
                                           tasks[:, 0].astype(np.int64))
             base = 1 + np.cumsum(task_pieces) - task_pieces
             n_pieces = 1 + int(task_pieces.sum())
-            if n_pieces >= 2 ** 31 - 1:
+            # (a task's stretch is addressed by 32-bit byte offsets)
+            if n_pieces >= 2 ** 31 - 1 or int(task_pieces.max()) * 256 >= 2 ** 32:
                 for k in ("tasks", "task_rows", "task_pairs", "task_out", "trk_meta"):
                     self.t[k] = None        # (the plan-less kernel takes over)
                 return
