@@ -271,7 +271,8 @@ int taoamd_track_pad(int64_t n_trk, int64_t n_frames, const int32_t *frame_off,
  * into.  task_base[t] (int32, device, filled by the caller) = 1 + the pieces
  * of the tasks before t, where a task's pieces = the sum over its rows of
  * (last >> 3) - (first >> 3) + 1; `frames` holds 1 + the pieces of all tasks,
- * 256 bytes each.  Reads tasks, task_rows, trk_meta and the padded table
+ * 256 bytes each, and a margin of 64 more pieces' bytes behind them (read, never
+ * used, by taoamd_track_iou_planned).  Reads tasks, task_rows, trk_meta and the padded table
  * (which may be released afterwards). */
 int taoamd_track_stream(int64_t n_tasks, const int32_t *tasks,
                         const int32_t *task_rows, const int32_t *trk_meta,

@@ -281,7 +281,8 @@ __device__ __forceinline__ void tt_stager(
     // mask of present rows (one ballot per chunk, the same in both stagers)
     static_assert(TT_SLOTS <= 32, "one 32-bit mask of a task's rows");
     const int4 mrow = meta[lane & (TT_SLOTS - 1)];
-    const bool row_has = lane < TT_SLOTS && mrow.y >= mrow.x;
+    // (rows with frames, as a mask: a track without frames has first = INT32_MAX, last = -1)
+    const uint32_t has_rows = (uint32_t)__builtin_amdgcn_ballot_w64(lane < TT_SLOTS && mrow.y >= mrow.x);
     // TT_SETS register sets: the loads of chunk k + TT_SETS are issued when
     // chunk k has been staged.  Every round loads (lanes out of range read
     // slot 0), so the number of loads in flight is known at compile time
@@ -302,18 +303,22 @@ __device__ __forceinline__ void tt_stager(
     auto issue = [&](double4 *Bx, uint32_t &pm_set, int32_t pc) {
         // rows whose span reaches into the chunk own a piece of TT_P slots in
         // the chunk's stretch of the stream, in row order
-        const uint32_t pm = (uint32_t)__builtin_amdgcn_ballot_w64(
-            row_has && mrow.x < pc + TT_P && mrow.y >= pc);
+        const uint32_t pm = (uint32_t)(__builtin_amdgcn_ballot_w64(mrow.x < pc + TT_P) &
+                                       __builtin_amdgcn_ballot_w64(mrow.y >= pc)) & has_rows;
         pm_set = pm;
 #pragma unroll
         for (int i = 0; i < NR; i++) {
+            // (a lane whose row has no piece in the chunk computes the place of
+            // the next present row's piece, or of the bytes behind the chunk's
+            // stretch -- the stream ends in a margin: what it loads is never
+            // parked, and no select is spent on it)
             const uint32_t off = cur + ((uint32_t)__popc(pm & (bit[i] - 1u)) << 8) + joff;
 #ifdef TT_ABLATE_LOADS     // (timing experiment: every load hits the stretch's first bytes)
-            Bx[i] = *reinterpret_cast<const double4 *>(tbase + ((pm & bit[i]) ? 0u : 0u));
+            Bx[i] = *reinterpret_cast<const double4 *>(tbase + (off & 0u));
 #elif defined(TT_ABLATE_CACHED)   // (timing experiment: the same requests inside 1 MB)
-            Bx[i] = *reinterpret_cast<const double4 *>(tbase + ((pm & bit[i]) ? (off & 0xfffe0u) : 0u));
+            Bx[i] = *reinterpret_cast<const double4 *>(tbase + (off & 0xfffe0u));
 #else
-            Bx[i] = *reinterpret_cast<const double4 *>(tbase + ((pm & bit[i]) ? off : 0u));
+            Bx[i] = *reinterpret_cast<const double4 *>(tbase + off);
 #endif
         }
         cur += (uint32_t)__popc(pm) << 8;

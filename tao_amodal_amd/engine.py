@@ -399,7 +399,9 @@ class DeviceProblem:
                     self.t[k] = None        # (the plan-less kernel takes over)
                 return
             self.t["task_base"] = torch.from_numpy(base.astype(np.int32)).to(dev)
-            self.t["frames"] = torch.empty((n_pieces * 8, 4), dtype=torch.float64,
+            # (+ a margin behind the last piece: a stager lane whose row has no
+            # piece in a chunk loads from behind the chunk's stretch)
+            self.t["frames"] = torch.empty(((n_pieces + 64) * 8, 4), dtype=torch.float64,
                                            device=dev)
             _lib.check(lib.taoamd_track_stream(
                 self.n_tasks, _ptr(self.t["tasks"]), _ptr(self.t["task_rows"]),
