@@ -316,7 +316,8 @@ __device__ __forceinline__ void tt_stager(
 #ifdef TT_ABLATE_LOADS     // (timing experiment: every load hits the stretch's first bytes)
             Bx[i] = *reinterpret_cast<const double4 *>(tbase + (off & 0u));
 #elif defined(TT_ABLATE_CACHED)   // (timing experiment: the same requests inside 1 MB)
-            Bx[i] = *reinterpret_cast<const double4 *>(tbase + (off & 0xfffe0u));
+            Bx[i] = *reinterpret_cast<const double4 *>(
+                reinterpret_cast<const char *>(frames) + (((uint32_t)(sbase * 32) + off) & 0xfffe0u));
 #else
             Bx[i] = *reinterpret_cast<const double4 *>(tbase + off);
 #endif
