@@ -52,3 +52,19 @@ cum=0
 for lo_,hi_ in [(0,0),(1,8),(9,16),(17,24),(25,32),(33,48),(49,64)]:
     n = sum(v for k,v in hist.items() if lo_<=k<=hi_)
     print(f'both-lanes {lo_:2d}-{hi_:2d}: {n:7d} {100*n/tot:5.1f}%')
+
+# rounds of 8 rows the stagers work through per (task, chunk): groups of the task's rows (in
+# plan order) that hold a present row, against ceil(present rows / 8) if present rows were compacted
+r_now = r_cmp = n_tc = 0
+for (r0, nr, p0, npair) in tasks:
+    rr = rows[r0:r0 + nr]
+    f, l = first[rr] // P, last[rr] // P
+    lo = (first[rr].min() & ~7) // P
+    hi = last[rr].max() // P
+    c = np.arange(lo, hi + 1)[:, None]
+    pres = (f[None, :] <= c) & (l[None, :] >= c)            # [chunks, rows]
+    pad = np.zeros((pres.shape[0], 32), bool); pad[:, :nr] = pres
+    r_now += pad.reshape(-1, 4, 8).any(2).sum()
+    r_cmp += np.ceil(pres.sum(1) / 8).sum()
+    n_tc += pres.shape[0]
+print('rounds per (task, chunk): %.2f as planned, %.2f with the present rows compacted' % (r_now / n_tc, r_cmp / n_tc))
