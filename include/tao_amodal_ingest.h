@@ -136,6 +136,11 @@ int taoamd_host_pyset_self_and(int64_t n, const int64_t *ids, int64_t *out,
 int taoamd_host_track_clash(int64_t n, const int64_t *track_id, const int64_t *video_id,
                             int64_t *n_clash);
 
+/* *n_bad = how many of the n boxes (x, y, w, h) have x < 0, y < 0, w <= 0 or
+ * h <= 0: the count of the reference's "annotations had negative values in
+ * coordinates" warning (tao_amodal/tao.py:143-158).  Returns 0. */
+int taoamd_host_count_bad_boxes(int64_t n, const double *bbox, int64_t *n_bad);
+
 /* OpenMP threads the host-side entry points of this library start: the
  * logical CPUs of the process capped by its affinity mask and by the control
  * group's CPU quota (csrc/host_threads.hpp; TAOAMD_HOST_THREADS overrides). */

@@ -1490,4 +1490,24 @@ int taoamd_host_track_clash(int64_t n, const int64_t *tid, const int64_t *vid, i
     return 0;
 }
 
+// Boxes (x, y, w, h) with x < 0, y < 0, w <= 0 or h <= 0 -- the count behind the
+// reference's "annotations had negative values in coordinates" warning
+// (tao_amodal/tao.py:143-158) -- in one pass on all threads (numpy: four strided
+// comparisons and three temporaries, 0.03 s for 1.5 M annotations).  NaN
+// compares false, as in numpy.
+int taoamd_host_count_bad_boxes(int64_t n, const double *bbox, int64_t *n_bad)
+{
+    taoamd::ThreadScope threads;
+    if (n < 0 || (n && !bbox) || !n_bad) return 1;
+    const int T = std::max(1, std::min(32, taoamd::team_threads()));
+    int64_t c = 0;
+#pragma omp parallel for schedule(static) num_threads(T) reduction(+ : c)
+    for (int64_t i = 0; i < n; i++) {
+        const double *b = bbox + 4 * i;
+        c += (b[0] < 0) | (b[1] < 0) | (b[2] <= 0) | (b[3] <= 0);
+    }
+    *n_bad = c;
+    return 0;
+}
+
 }  // extern "C"

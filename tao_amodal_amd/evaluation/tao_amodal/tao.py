@@ -12,6 +12,7 @@ from collections import defaultdict
 import numpy as np
 
 from ...columns import GTColumns
+from ...flatten import count_bad_boxes
 
 
 class Tao:
@@ -81,10 +82,7 @@ class Tao:
         c = self.columns
         if len(c.cat_merged) == 0:
             logging.error("Did not merge any categories.")
-        b = c.ann_bbox
-        neg = int(np.count_nonzero((b[:, 0] < 0) | (b[:, 1] < 0)
-                                   | (b[:, 2] <= 0) | (b[:, 3] <= 0))) \
-            if len(b) else 0
+        neg = count_bad_boxes(c.ann_bbox)
         if neg:
             self.logger.warning(f"{neg} annotations had negative values in "
                                 f"coordinates!")

@@ -75,6 +75,7 @@ def _host_lib():
                 "taoamd_host_seq_mean": [i64, vp, vp, vp],
                 "taoamd_host_pyset_self_and": [i64, vp, vp, vp],
                 "taoamd_host_track_clash": [i64, vp, vp, vp],
+                "taoamd_host_count_bad_boxes": [i64, vp, vp],
                 "taoamd_host_threads": [],
                 "taoamd_host_thread_cap": [C.c_int32],
             }
@@ -108,6 +109,24 @@ def take(src, idx):
             if rc == 0:
                 return out
     return src[idx]
+
+
+def count_bad_boxes(bbox):
+    """How many (x, y, w, h) rows have ``x < 0``, ``y < 0``, ``w <= 0`` or
+    ``h <= 0`` (the reference's warning, tao_amodal/tao.py:143-158): one pass of
+    the host library's threads for large tables, numpy otherwise."""
+    b = np.asarray(bbox)
+    n = len(b)
+    if n == 0:
+        return 0
+    lib = _host_lib() if n >= _NATIVE_MIN else False
+    if lib and b.dtype == np.float64 and b.ndim == 2 and b.shape[1] == 4 \
+            and b.flags.c_contiguous:
+        out = np.zeros(1, dtype=np.int64)
+        if lib.taoamd_host_count_bad_boxes(n, b.ctypes.data, out.ctypes.data) == 0:
+            return int(out[0])
+    return int(np.count_nonzero((b[:, 0] < 0) | (b[:, 1] < 0)
+                                | (b[:, 2] <= 0) | (b[:, 3] <= 0)))
 
 
 def sort_key_score(key, score=None):

@@ -26,7 +26,7 @@ def test_ingest_header_symbols_are_exported():
     text = open(os.path.join(ROOT, "include", "tao_amodal_ingest.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     declared = set(re.findall(r"\b(taoamd_[a-z_0-9]+)\s*\(", text))
-    assert len(declared) == 36, declared
+    assert len(declared) == 37, declared
     lib = ctypes.CDLL(os.path.join(ROOT, "tao_amodal_amd", "libtao_amodal_ingest.so"))
     for name in sorted(declared):
         assert hasattr(lib, name), name

@@ -255,3 +255,28 @@ def test_list_inputs_are_rewritten_in_place_like_the_reference(name):
         p["track_id"] = t
     TaoResults(Tao(path(name, "gt.json")), predj)
     assert json.loads(json.dumps(predj, default=float)) == want["tao"]
+
+
+def test_tao_counts_the_annotations_with_negative_coordinates(caplog):
+    """tao_amodal/tao.py:143-158: one warning with the number of annotations whose
+    box has x < 0, y < 0, w <= 0 or h <= 0; none when there is no such box."""
+    import copy
+    import logging
+    gtj, _ = load_inputs("f2")
+    gtj = copy.deepcopy(gtj)
+    for a in gtj["annotations"]:
+        a["bbox"] = [0.0, 0.0, 2.5, 1.0]
+    with caplog.at_level(logging.INFO, logger="tao.tao"):
+        Tao(copy.deepcopy(gtj))
+    assert not [r for r in caplog.records if "negative values" in r.getMessage()]
+    bad = copy.deepcopy(gtj)
+    boxes = ([-1.0, 2.0, 3.0, 4.0], [1.0, -0.5, 3.0, 4.0], [1.0, 2.0, 0.0, 4.0],
+             [1.0, 2.0, 3.0, -4.0], [0.0, 0.0, 1.0, 1.0])
+    for a, b in zip(bad["annotations"], boxes):
+        a["bbox"] = list(b)
+    caplog.clear()
+    with caplog.at_level(logging.INFO, logger="tao.tao"):
+        Tao(bad)
+    said = [r.getMessage() for r in caplog.records]
+    at = said.index("4 annotations had negative values in coordinates!")
+    assert said[at - 1] == "Creating index." and said[at + 1] == "Index created."

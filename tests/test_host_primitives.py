@@ -136,3 +136,27 @@ def test_track_clash_detection(both_paths):
     neg = tid - 3500
     (a, na), (b, nb) = both_paths(lambda: flatten.make_track_ids_unique(cols(neg, v2)))
     assert na == nb > 0 and np.array_equal(a, b)
+
+
+def test_count_bad_boxes_is_the_numpy_statement():
+    """tao_amodal/tao.py:143-158: x < 0 or y < 0 or w <= 0 or h <= 0, NaN never."""
+    from tao_amodal_amd import flatten
+    rng = np.random.default_rng(5)
+    for n in (0, 1, 7, 49999, 50000, 200003):
+        b = rng.integers(-2, 6, size=(n, 4)).astype(np.float64)
+        if n > 5:
+            b[3] = [np.nan, 1, 1, 1]
+            b[4] = [1, 1, np.nan, 0]
+            b[5] = [0, 0, 1e-300, 5e-324]
+
+        def want(x):
+            return int(np.count_nonzero((x[:, 0] < 0) | (x[:, 1] < 0)
+                                        | (x[:, 2] <= 0) | (x[:, 3] <= 0))) if n else 0
+        assert flatten.count_bad_boxes(b) == want(b)
+        # another dtype, a view that is not contiguous: the numpy statement
+        f = b.astype(np.float32)
+        assert flatten.count_bad_boxes(f) == want(f)
+        if n:
+            wide = np.zeros((n, 6))
+            wide[:, :4] = b
+            assert flatten.count_bad_boxes(wide[:, :4]) == want(b)
