@@ -217,6 +217,11 @@ def kernel_models(dp, ws):
     variants = {"match_group_kernel": "<true>" if fused else "<false>",
                 "match_kernel": "<true>" if fused else "<false>",
                 "match_big_kernel": "<true>" if fused else "<false>"}
+    if dp.kind == "tao":
+        # the timed passes launch the instance that does not count the pairs'
+        # common frames (a workspace's first pass does: engine.stage_track_iou)
+        variants["track_iou_task_kernel"] = "<%d, %s>" % (
+            dp.iou_mode, "false" if dp.iou_mode == 0 else "true")
     grids = {"seg_tile_kernel": dp.n_tiles * 256,
              "match_group_kernel": (dp.n_groups + 3) // 4 * 256,
              "lvis_ranges_kernel": (max(n_gt, n_dt) + 255) // 256 * 256,
