@@ -297,12 +297,14 @@ __device__ __forceinline__ uint32_t xor_lane(uint32_t x, int lane)
 // cycles -- and the transposes were 0.12 ms of chip time at 21 M rows):
 //   S = 32  the two words change places between the wave's halves: ONE
 //           v_permlane32_swap (lower lanes' hi <-> upper lanes' lo);
-//   S = 16, 8  whole bytes move: the partner's word (v_permlane16_swap /
-//           DPP row_ror:8) and ONE v_perm_b32 with a per-lane selector;
+//   S = 16  half words move: see transpose64 (one v_permlane16_swap for both
+//           words, four v_perm_b32 with constant selectors);
+//   S = 8   whole bytes move: the partner's word (DPP row_ror:8) and ONE
+//           v_perm_b32 with a per-lane selector;
 //   S = 4, 2, 1  the partner's word rotated so that the bits it hands over
 //           sit where they go (v_alignbit, per-lane amount) and ONE v_bfi.
 struct TransposeConsts {
-    uint32_t sel16, sel8;          // v_perm_b32 selectors
+    uint32_t sel8;                 // v_perm_b32 selector
     uint32_t keep4, keep2, keep1;  // bits of my own word that stay
     uint32_t rot4, rot2, rot1;     // right-rotation of the partner's word
 };
@@ -311,7 +313,6 @@ __device__ __forceinline__ TransposeConsts transpose_consts(int lane)
     TransposeConsts c;
     // lower lane of a pair keeps the low part and takes the partner's low part
     // into its high part; the upper lane the other way round
-    c.sel16 = (lane & 16) ? 0x03020706u : 0x05040100u;
     c.sel8 = (lane & 8) ? 0x03070105u : 0x06020400u;
     c.keep4 = (lane & 4) ? 0xf0f0f0f0u : 0x0f0f0f0fu;
     c.keep2 = (lane & 2) ? 0xccccccccu : 0x33333333u;
@@ -338,8 +339,21 @@ __device__ __forceinline__ uint64_t transpose64(uint64_t x, int lane, const Tran
         lo = r[0];
         hi = r[1];
     }
-    lo = __builtin_amdgcn_perm(xor_lane<16>(lo, lane), lo, c.sel16);
-    hi = __builtin_amdgcn_perm(xor_lane<16>(hi, lane), hi, c.sel16);
+    {
+        // S = 16 (round 6): the halves that change lanes gathered into ONE
+        // register first -- P = the low halves of (lo, hi), Q = the high ones;
+        // the lower lane of a pair keeps P and needs its partner's P, the upper
+        // one keeps Q and needs its partner's Q -- so that a single
+        // v_permlane16_swap (odd rows of P <-> even rows of Q) serves both
+        // words and both directions, and the two words are put together again
+        // with the same selectors in every lane: 5 instructions for the stage
+        // instead of 8 (a copy, a swap, a per-lane select and a v_perm a word).
+        const uint32_t p = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+        const uint32_t q = __builtin_amdgcn_perm(hi, lo, 0x07060302u);
+        auto r = __builtin_amdgcn_permlane16_swap(p, q, false, false);
+        lo = __builtin_amdgcn_perm(r[1], r[0], 0x05040100u);
+        hi = __builtin_amdgcn_perm(r[1], r[0], 0x07060302u);
+    }
     lo = __builtin_amdgcn_perm(xor_lane<8>(lo, lane), lo, c.sel8);
     hi = __builtin_amdgcn_perm(xor_lane<8>(hi, lane), hi, c.sel8);
     lo = transpose_bits<4>(lo, lane, c.keep4, c.rot4);
@@ -353,6 +367,40 @@ __device__ __forceinline__ uint64_t transpose64(uint64_t x, int lane, const Tran
 __device__ __forceinline__ uint64_t transpose64(uint64_t x, int lane)
 {
     return transpose64(x, lane, transpose_consts(lane));
+}
+
+// The one-pass sweep's form of load_chunk: the TP word and the word of the rows
+// that COUNT (not ignored: TP | FP) of every row -- the sweep needs the
+// transposes of exactly these two (T and T | F; the FP count of a lane is the
+// difference of their popcounts).  A FULL chunk of the common layout (all but a
+// category's last) is fetched from one uniform base address with one 32-bit
+// offset per lane (global_load_dwordx4 v, v_off, s[base]) and no in-range
+// selects: ~190 VALU instructions of address arithmetic, selects and and-nots
+// a chunk become ~50.
+template <int ACC_BLK_N>
+__device__ __forceinline__ void load_chunk_tv(const AccArgs &a, int64_t start, int word, int len,
+                                              int lane, uint64_t (&tpw)[ACC_BLK_N],
+                                              uint64_t (&vw)[ACC_BLK_N])
+{
+    if (a.wide && a.order == nullptr && len == ACC_BLK_N * WAVE) {
+        const char *base = reinterpret_cast<const char *>(a.matched + 2 * (start * a.n_words + word));
+        const uint32_t lane_off = (uint32_t)lane * (uint32_t)a.n_words * 16u;
+        const uint32_t blk_off = (uint32_t)WAVE * (uint32_t)a.n_words * 16u;
+        ulonglong2 v[ACC_BLK_N];
+#pragma unroll
+        for (int blk = 0; blk < ACC_BLK_N; blk++)
+            v[blk] = *reinterpret_cast<const ulonglong2 *>(base + ((uint32_t)blk * blk_off + lane_off));
+#pragma unroll
+        for (int blk = 0; blk < ACC_BLK_N; blk++) {
+            tpw[blk] = v[blk].x & ~v[blk].y;
+            vw[blk] = ~v[blk].y;
+        }
+        return;
+    }
+    uint64_t fpw[ACC_BLK_N];
+    load_chunk(a, start, word, len, lane, tpw, fpw);
+#pragma unroll
+    for (int blk = 0; blk < ACC_BLK_N; blk++) vw[blk] = tpw[blk] | fpw[blk];
 }
 
 #define ACC_BLK (ACC_CH / WAVE)   // 64-row blocks per chunk
@@ -1160,8 +1208,8 @@ void acc_sweep_kernel(AccArgs a, RecThr rec)
     const int len = (int)max((int64_t)0, min((int64_t)(NB * WAVE), cat_end - start));
     const bool swept = k >= a.k_begin && k < a.k_end;       // (uniform)
     // ---- rows of my chunk: every load ahead of anything else
-    uint64_t tpw[NB], fpw[NB];
-    load_chunk(a, start, word, len, lane, tpw, fpw);
+    uint64_t tpw[NB], vw[NB];
+    load_chunk_tv(a, start, word, len, lane, tpw, vw);
     const int r_lo = (word * WAVE) / N_THR;
     const int r_hi = min(a.n_rng - 1, (word * WAVE + WAVE - 1) / N_THR);
     if (MODE != 2) {
@@ -1173,19 +1221,20 @@ void acc_sweep_kernel(AccArgs a, RecThr rec)
             (&s_cj[0][0])[i] = src[i];
     }
     uint64_t T[NB], TF[NB];
-    uint32_t tp_own = 0, fp_own = 0;
+    uint32_t tp_own = 0, n_own = 0;
 #pragma unroll
     for (int blk = 0; blk < NB; blk++) {
-        uint64_t t_ = 0, f_ = 0;
+        uint64_t t_ = 0, v_ = 0;
         if (blk * WAVE < len) {
             t_ = transpose64(tpw[blk], lane);
-            f_ = transpose64(fpw[blk], lane);
+            v_ = transpose64(vw[blk], lane);
         }
         T[blk] = t_;
-        TF[blk] = t_ | f_;
+        TF[blk] = v_;
         tp_own += (uint32_t)__popcll(t_);
-        fp_own += (uint32_t)__popcll(f_);
+        n_own += (uint32_t)__popcll(v_);
     }
+    const uint32_t fp_own = n_own - tp_own;       // (TP and FP rows are disjoint)
     s_tp[wave][lane] = tp_own;
     s_fp[wave][lane] = fp_own;
     __syncthreads();
