@@ -1115,6 +1115,14 @@ __global__ __launch_bounds__(FW * WAVE) void acc_fused_kernel(AccArgs a, RecThr 
 //
 // The walk itself (emit_block) is the chunked path's, statement by statement.
 // ===========================================================================
+// -DSW_ABLATE=<bits> (timing experiments, results wrong): 1 no walk, 2 no
+// transposes, 4 no look-back, 8 leave behind the rows' counts, 16 leave behind
+// the counts of the earlier chunks.  Round 6, 21.4 M rows, one box: whole kernel
+// 0.260 ms; rows fetched and counted without transposes 0.069 (5.0 TB/s), with
+// them 0.103; up to the earlier chunks' counts 0.113; everything but the walk
+// 0.160 (0.159 without the transposes too: behind the first barrier they are
+// hidden); without the look-back 0.245.  So the walk is 0.10 ms of the kernel
+// and the bookkeeping between the counts and the walk's end 0.05.
 #define SC_SPIN_LIMIT (1 << 18)     // a fraction of a second of polling
 #define SWEEP_NB 8                   // blocks of 64 rows per wavefront of the one-pass sweep
 #ifndef SWEEP_SW
@@ -1226,8 +1234,13 @@ void acc_sweep_kernel(AccArgs a, RecThr rec)
     for (int blk = 0; blk < NB; blk++) {
         uint64_t t_ = 0, v_ = 0;
         if (blk * WAVE < len) {
+#if defined(SW_ABLATE) && (SW_ABLATE & 2)     // (timing experiment: no transposes)
+            t_ = tpw[blk];
+            v_ = vw[blk];
+#else
             t_ = transpose64(tpw[blk], lane);
             v_ = transpose64(vw[blk], lane);
+#endif
         }
         T[blk] = t_;
         TF[blk] = v_;
@@ -1235,6 +1248,10 @@ void acc_sweep_kernel(AccArgs a, RecThr rec)
         n_own += (uint32_t)__popcll(v_);
     }
     const uint32_t fp_own = n_own - tp_own;       // (TP and FP rows are disjoint)
+#if defined(SW_ABLATE) && (SW_ABLATE & 8)     // (timing experiment: rows fetched and counted, nothing else)
+    if (tp_own + n_own == (uint32_t)a.sc_spin) a.sc_max[0] = n_own;
+    return;
+#endif
     s_tp[wave][lane] = tp_own;
     s_fp[wave][lane] = fp_own;
     __syncthreads();
@@ -1264,6 +1281,9 @@ void acc_sweep_kernel(AccArgs a, RecThr rec)
             // prefix.  A pair is usable when both words are of this call and of
             // one kind (the publisher replaces AGG by PRE word by word)
             bool open = jsc > 0;
+#if defined(SW_ABLATE) && (SW_ABLATE & 4)     // (timing experiment: no look-back)
+            open = false;
+#endif
             const int64_t stride = 2 * (int64_t)a.n_words * WAVE;
             const uint64_t *p = st - stride;
             for (int32_t jj = jsc - 1; jj >= 0 && __ballot(open) != 0; jj--, p -= stride) {
@@ -1308,6 +1328,10 @@ void acc_sweep_kernel(AccArgs a, RecThr rec)
     __syncthreads();
     tp0 += s_pre[0][lane];
     fp0 += s_pre[1][lane];
+#if defined(SW_ABLATE) && (SW_ABLATE & 16)    // (timing experiment: ... and the counts before the chunk)
+    if (tp0 + fp0 == (uint32_t)a.sc_spin) a.sc_max[0] = T[0] ^ TF[NB - 1];
+    return;
+#endif
     // ---- my lane's combo
     const int combo = word * WAVE + lane;
     const bool active = combo < a.n_rng * N_THR;
@@ -1350,7 +1374,11 @@ void acc_sweep_kernel(AccArgs a, RecThr rec)
 #pragma unroll
     for (int blk = NB - 1; blk >= 0; blk--) {
         if (blk * WAVE >= len) continue;
+#if defined(SW_ABLATE) && (SW_ABLATE & 1)     // (timing experiment: no walk)
+        run ^= T[blk] + TF[blk];
+#else
         emit_block<1>(live ? T[blk] : 0, live ? TF[blk] : 0, tp, n, run, jcur, cnext, out, cj);
+#endif
     }
     if (live && is_first && jcur > 0 && len > 0) {
         const uint64_t v = run;
