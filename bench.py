@@ -373,6 +373,7 @@ def wallclock_leg(gt, dt):
     import io
     import shutil
     import tempfile
+    import threading
     d = tempfile.mkdtemp(prefix="taoamd_wall_", dir="/tmp")
     try:
         gt_p, pr_p = os.path.join(d, "gt.json"), os.path.join(d, "pred.json")
@@ -390,6 +391,12 @@ def wallclock_leg(gt, dt):
         from tao_amodal_amd.evaluation._core import TIMING
         TIMING.clear()
         text = io.StringIO()
+        # (what the bench's earlier legs left behind -- the oracle's tables, the
+        # writers' buffers: gigabytes in reference cycles -- is collected HERE:
+        # the interpreter's collector would otherwise run, and unmap them, in
+        # the middle of the timed call: 0.55 s became 0.75-1.4 s, measured)
+        import gc
+        gc.collect()
         t0 = time.perf_counter()
         with contextlib.redirect_stdout(text), contextlib.redirect_stderr(io.StringIO()):
             cli.main(["--track_result", pr_p, "--annotation", gt_p, "--output_log",
@@ -397,7 +404,15 @@ def wallclock_leg(gt, dt):
         total = time.perf_counter() - t0
         lines = text.getvalue().splitlines()
         # the same command as a user runs it: a fresh interpreter (imports, HIP
-        # context, loading the libraries) -- the files are in the page cache
+        # context, loading the libraries) -- the files are in the page cache.
+        # (The call above leaves helper threads behind -- the columns' host
+        # copies, the reader's release -- and its own garbage: both are let go
+        # first, a fresh process competes with neither.)
+        for th in threading.enumerate():
+            if th is not threading.current_thread() and \
+                    not th.name.startswith(("ThreadPoolExecutor", "pydev")):   # (idle pool workers stay)
+                th.join(timeout=2.0)
+        gc.collect()
         t0 = time.perf_counter()
         r = subprocess.run(
             [sys.executable, os.path.join(ROOT, "tools", "eval_on_tao_amodal.py"),
@@ -416,7 +431,8 @@ def wallclock_leg(gt, dt):
                 "split": {k: round(v, 3) for k, v in TIMING.items()},
                 "files": sizes, "write_files_s_not_counted": round(t_write, 2),
                 "what": "tools/eval_on_tao_amodal.py in this process on the same "
-                        "workload as JSON files: both evaluators, printed tables",
+                        "workload as JSON files: both evaluators, printed tables "
+                        "(gc.collect() of the bench's own earlier garbage first)",
                 "first_line": lines[0] if lines else None}
     except Exception as e:      # (a full /tmp must not lose the bench line)
         return {"error": "%s: %s" % (type(e).__name__, e)}
