@@ -35,7 +35,11 @@ class Rejected(Exception):
 class DeviceFlat(Flat):
     """Flat whose per-detection tables live on the device (``dev``); reading
     one as an attribute downloads it once (views, tests, the oracle).  ``lazy``
-    holds host-side thunks for tables only the class API's views read."""
+    holds host-side thunks for tables only the class API's views read (called
+    with the table set itself: a thunk that closed over it would tie the set,
+    its device tensors and the prediction columns into a reference cycle that
+    only the interpreter's cycle collector undoes -- gigabytes a call, freed
+    at some later call's expense)."""
 
     def __init__(self):
         super().__init__()
@@ -46,7 +50,7 @@ class DeviceFlat(Flat):
         if dict.__contains__(self, k):
             return dict.__getitem__(self, k)
         if k in self.lazy:
-            v = self.lazy[k]()
+            v = self.lazy[k](self)
         elif k in self.dev:
             v = self.dev[k].cpu().numpy()
         else:
@@ -300,7 +304,7 @@ def flatten_lvis_device(gt, dt, device="cuda", max_dets=MAX_DETS):
                  dt_flags=dt_flags[:n_keep], dt_cat=dt_cat[:n_keep],
                  dt_cell=dt_cell, dt_row=dt_row[:n_keep])
 
-    def dt_id():
+    def dt_id(f):
         # id = 1 + position in the post-truncation list (L/results.py:73-84):
         # only the class API's views read it
         keep = flatten.limit_dets_per_image(dt, max_dets)
@@ -632,7 +636,7 @@ def flatten_tao_device(gt, dt, device="cuda", max_dets=MAX_DETS,
                  dt_frame_off=frame_off[:n_keep + 1],
                  dt_frame_pos=frame_pos[:n_frames], dt_frame_box=frame_box[:n_frames])
 
-    def track_scores():
+    def track_scores(f):
         # tracks with at least one box left after the top-max_dets cut
         live = (trk_first[:n_trk] >= 0).cpu().numpy()
         ids = tr.run_key[:n_trk].cpu().numpy()[live]
@@ -640,7 +644,7 @@ def flatten_tao_device(gt, dt, device="cuda", max_dets=MAX_DETS,
                         trk_score[:n_trk].cpu().numpy()[live].tolist()))
     f.lazy["track_scores"] = track_scores
 
-    def cell_span():
+    def cell_span(f):
         span = np.zeros(n_cells, dtype=np.int64)
         for off, pos, coff in ((f.dt_frame_off, f.dt_frame_pos, d_off),
                                (g_foff, g_fpos, g_off)):

@@ -82,6 +82,20 @@ def make_track_ids_unique(dt):
     return n
 
 
+# What a call's levels built -- tables, columns, evaluators: gigabytes of host
+# arrays -- is let go OFF the caller's path: the levels park their objects here
+# and main() hands the lot to a helper thread once the tables are printed
+# (unmapping them where they fall out of scope was 0.1-0.2 s of the call).
+_PARKED = []
+
+
+def _let_go(parked):
+    import time
+    time.sleep(0.05)            # (the caller leaves main() first)
+    while parked:
+        parked.pop()
+
+
 def evaluate_predictions_on_lvis(lvis_gt, track_result, dt_columns, iou_type,
                                  logger):
     logger.info("Evaluating {} on LVIS...".format(track_result))
@@ -99,6 +113,7 @@ def evaluate_predictions_on_lvis(lvis_gt, track_result, dt_columns, iou_type,
     logger.info("copypaste: " + ",".join(LVIS_METRICS))
     logger.info("copypaste: " + ",".join(
         "{0:.4f}".format(results[m]) for m in LVIS_METRICS))
+    _PARKED.extend((lvis_dt, lvis_eval))
     return results
 
 
@@ -131,6 +146,7 @@ def eval_tao_track(ann_path, gt_dataset, gt_columns, dt_columns, logger):
         logger.info("{}:{:.4f}".format(k, results[k]))
     logger.info("copypaste: " + ",".join(keys))
     logger.info("copypaste: " + ",".join("{:.4f}".format(results[k]) for k in keys))
+    _PARKED.extend((tao_gt, tao_dt, tao_eval))
     return results
 
 
@@ -175,6 +191,7 @@ class HeldLogs:
         self.thread = None
         for h, gate in self.gates:
             h.removeFilter(gate)
+        self.gates = []         # (owner <-> gates: no cycle left for the collector)
         if replay:
             for h, record in self.records:
                 h.acquire()
@@ -426,6 +443,7 @@ def main(argv=None):
     handler = logging.FileHandler(output_log, mode="w")
     logger.addHandler(handler)
     from tao_amodal_amd.evaluation._core import TIMING, timed
+    pool = lvis_gt = dt_columns = dt_future = gt_future = track = held = None
     try:
         from concurrent.futures import ThreadPoolExecutor
         pool = ThreadPoolExecutor(max_workers=2 if cold else 1)
@@ -533,10 +551,17 @@ def main(argv=None):
             eval_tao_track(annotation, gt_dataset, lvis_gt.columns, dt_columns,
                            logger)
     finally:
-        if "pool" in locals():
+        if pool is not None:
             pool.shutdown(wait=False)
         logger.removeHandler(handler)
         handler.close()
+        # (every name of this frame that holds a table goes with them)
+        parked = _PARKED[:]
+        del _PARKED[:]
+        parked.extend((lvis_gt, dt_columns, dt_future, gt_future, track, held))
+        lvis_gt = dt_columns = dt_future = gt_future = track = held = None
+        threading.Thread(target=_let_go, args=(parked,), daemon=True).start()
+        del parked
     if os.environ.get("TAOAMD_TIMING"):
         # wall-clock split (stderr only: stdout and the log file stay identical
         # to the reference's)
