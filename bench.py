@@ -750,13 +750,24 @@ def main():
         cands.sort(key=lambda c: -c["kernel_ms"])
         ranked = [c for c in cands if is_work(c)] or cands
         if cands:
-            roof = ranked[0]
+            # (the two longest launches of the default workload -- the 3D IoU
+            # and the image level's match -- lie within 1-2 % of each other and
+            # change places from box to box: among launches within 3 % of the
+            # longest the one with the LOWER fraction is named, so that the
+            # line names the same kernel run after run and errs low)
+            near = [c for c in ranked if c["kernel_ms"] >= 0.97 * ranked[0]["kernel_ms"]
+                    and c.get("frac") is not None]
+            roof = min(near, key=lambda c: c["frac"]) if near else ranked[0]
             roof["dominant_by"] = ("longest average launch inside the timed steps "
                                    "(launches that take more than 2x their time alone "
-                                   "-- queueing, not work -- excluded: %s)"
-                                   % ", ".join(c["kernel"] for c in cands[:6]
-                                               if not is_work(c)))
-            roof_other = ranked[1:5]
+                                   "-- queueing, not work -- excluded: %s; among "
+                                   "launches within 3 %% of the longest -- %s -- the "
+                                   "lower fraction)"
+                                   % (", ".join(c["kernel"] for c in cands[:6]
+                                                if not is_work(c)),
+                                      ", ".join("%s %.4f ms" % (c["kernel"], c["kernel_ms"])
+                                                for c in (near or ranked[:1]))))
+            roof_other = [c for c in ranked if c is not roof][:4]
         if not use_dist:
             b = step_algorithmic_bytes(dpl, dpt)
             ach = b / (ms_per_step * 1e-3) / 1e9
